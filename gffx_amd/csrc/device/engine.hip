@@ -1,0 +1,681 @@
+// engine.hip -- C-ABI (include/gffx_hip.h) of the gfx950 engine: index upload, query batches.
+//
+// HBM layout of an index (uploaded once, immutable):
+//   ent[R]        uint4 {start, end, pmax_end, root_fid}   16 B/root   (gather kernels)
+//   start/end/pmax/fid[R]  u32 SoA copies                  16 B/root   (sorted-strategy kernels)
+//   chr_meta[n_chr] uint4 {first, last+1, bin base, n_bins}
+//   bin_hi[sum(n_bins+1)] u32 bin directory over `start` (shift chosen so it stays L2-sized)
+// At GENCODE scale (63 k roots, 25 seqids) that is ~2 MB + ~0.8 MB of directory: resident in
+// every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and the results out.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <numeric>
+
+#include "gffx_device.hpp"
+#include "join_a_kernels.hpp"
+
+namespace gffx {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+static int device_count_quiet() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+template <typename T>
+static int dev_alloc(T **p, size_t n) {
+    *p = nullptr;
+    GFFX_HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return GFFX_OK;
+}
+
+}  // namespace gffx
+
+using namespace gffx;
+
+struct gffx_hip_index {
+    int device = 0;
+    uint32_t n_chr = 0;
+    uint32_t n_roots = 0;
+    uint32_t shift = 0;
+    uint4 *d_ent = nullptr;
+    uint32_t *d_start = nullptr, *d_end = nullptr, *d_pmax = nullptr, *d_fid = nullptr;
+    uint4 *d_chr_meta = nullptr;
+    uint32_t *d_bin_hi = nullptr;
+    std::vector<uint32_t> h_sorted_fids;
+    std::vector<uint32_t> h_chr_offsets;
+
+    IndexView view() const {
+        IndexView v;
+        v.ent = d_ent;
+        v.start = d_start;
+        v.end = d_end;
+        v.pmax = d_pmax;
+        v.fid = d_fid;
+        v.chr_meta = d_chr_meta;
+        v.bin_hi = d_bin_hi;
+        v.n_chr = n_chr;
+        v.shift = shift;
+        v.n_roots = n_roots;
+        return v;
+    }
+};
+
+struct ProfEvent {
+    int kernel;
+    hipEvent_t a, b;
+};
+
+struct gffx_hip_batch {
+    const gffx_hip_index *ix = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t max_q = 0, nq = 0;
+    // inputs
+    uint32_t *d_regions = nullptr;  // owned AoS upload buffer (3*max_q)
+    uint32_t *d_soa = nullptr;      // owned SoA upload buffer (3*max_q), lazily allocated
+    QueryView q{};
+    bool have_regions = false;
+    // outputs / workspace
+    uint32_t *d_counts = nullptr;
+    unsigned long long *d_block_sums = nullptr;
+    unsigned long long *d_status = nullptr;  // [0] total pairs, [1] error bits
+    unsigned long long *h_status = nullptr;  // pinned mirror
+    uint32_t *d_fids = nullptr, *d_triples = nullptr, *d_bitmap = nullptr;
+    unsigned long long *d_offsets = nullptr;
+    uint64_t cap_fids = 0, cap_triples = 0;
+    uint64_t reserve = 0;
+    // last run
+    int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
+    uint32_t flags = 0;
+    uint32_t n_blocks = 0;
+    uint64_t chunk = 0;
+    bool ran = false, waited = false;
+    uint64_t total = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfEvent> pending;
+    double k_ms[GFFX_K__COUNT] = {0};
+    uint64_t k_n[GFFX_K__COUNT] = {0};
+};
+
+// ------------------------------------------------------------------------------------ misc
+
+extern "C" int gffx_hip_abi_version(void) { return GFFX_HIP_ABI_VERSION; }
+extern "C" int gffx_hip_device_count(void) { return device_count_quiet(); }
+extern "C" const char *gffx_hip_last_error(void) { return g_last_error.c_str(); }
+extern "C" void gffx_hip_free_host(void *p) { free(p); }
+
+// ------------------------------------------------------------------------------------ index
+
+extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets,
+                                     const uint32_t *start, const uint32_t *end,
+                                     const uint32_t *root_fid, int device, gffx_hip_index **out) {
+    if (!out) return fail(GFFX_E_INVALID, "gffx_hip_index_create: out is NULL");
+    *out = nullptr;
+    if (!chr_offsets) return fail(GFFX_E_INVALID, "gffx_hip_index_create: chr_offsets is NULL");
+    for (uint32_t c = 0; c < n_chr; c++)
+        if (chr_offsets[c] > chr_offsets[c + 1])
+            return fail(GFFX_E_INVALID, "gffx_hip_index_create: chr_offsets not ascending at %u", c);
+    if (chr_offsets[0] != 0)
+        return fail(GFFX_E_INVALID, "gffx_hip_index_create: chr_offsets[0] must be 0");
+    const uint32_t R = chr_offsets[n_chr];
+    if (R && (!start || !end || !root_fid))
+        return fail(GFFX_E_INVALID, "gffx_hip_index_create: NULL interval arrays");
+    const int ndev = device_count_quiet();
+    if (ndev <= 0) return fail(GFFX_E_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
+    GFFX_HIP_TRY(hipSetDevice(device));
+
+    // sort every seqid stably by start (the tree does the same: utils/tree.rs:40), running max of end
+    std::vector<uint4> ent(R);
+    std::vector<uint32_t> order(R);
+    std::iota(order.begin(), order.end(), 0u);
+    std::vector<uint32_t> max_start(n_chr, 0);
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        std::stable_sort(order.begin() + lo, order.begin() + hi,
+                         [&](uint32_t a, uint32_t b) { return start[a] < start[b]; });
+        uint32_t pm = 0;
+        for (uint32_t i = lo; i < hi; i++) {
+            const uint32_t j = order[i];
+            pm = std::max(pm, end[j]);
+            ent[i] = make_uint4(start[j], end[j], pm, root_fid[j]);
+        }
+        if (hi > lo) max_start[c] = ent[hi - 1].x;
+    }
+    // bin directory: smallest shift whose total bin count stays within the budget
+    const uint64_t budget = std::max<uint64_t>(4ull * R, 1ull << 16);
+    uint32_t shift = 0;
+    for (;; shift++) {
+        uint64_t tot = 0;
+        for (uint32_t c = 0; c < n_chr; c++)
+            if (chr_offsets[c + 1] > chr_offsets[c]) tot += ((uint64_t)max_start[c] >> shift) + 2;
+        if (tot <= budget || shift == 31) break;
+    }
+    std::vector<uint4> meta(n_chr);
+    std::vector<uint32_t> bin_hi;
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        const uint32_t nb = hi > lo ? (max_start[c] >> shift) + 1 : 0;
+        meta[c] = make_uint4(lo, hi, (uint32_t)bin_hi.size(), nb);
+        uint32_t p = lo;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint64_t edge = (uint64_t)b << shift;
+            while (p < hi && ent[p].x < edge) p++;
+            bin_hi.push_back(p);
+        }
+        if (nb) bin_hi.push_back(hi);  // sentinel: nothing starts at or after nb << shift
+    }
+
+    std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
+    ix->device = device;
+    ix->n_chr = n_chr;
+    ix->n_roots = R;
+    ix->shift = shift;
+    ix->h_chr_offsets.assign(chr_offsets, chr_offsets + n_chr + 1);
+    ix->h_sorted_fids.resize(R);
+    std::vector<uint32_t> s(R), e(R), pm(R);
+    for (uint32_t i = 0; i < R; i++) {
+        s[i] = ent[i].x;
+        e[i] = ent[i].y;
+        pm[i] = ent[i].z;
+        ix->h_sorted_fids[i] = ent[i].w;
+    }
+    int rc;
+    if ((rc = dev_alloc(&ix->d_ent, R)) || (rc = dev_alloc(&ix->d_start, R)) ||
+        (rc = dev_alloc(&ix->d_end, R)) || (rc = dev_alloc(&ix->d_pmax, R)) ||
+        (rc = dev_alloc(&ix->d_fid, R)) || (rc = dev_alloc(&ix->d_chr_meta, n_chr)) ||
+        (rc = dev_alloc(&ix->d_bin_hi, bin_hi.size()))) {
+        gffx_hip_index_destroy(ix.release());
+        return rc;
+    }
+    if (R) {
+        GFFX_HIP_TRY(hipMemcpy(ix->d_ent, ent.data(), R * sizeof(uint4), hipMemcpyHostToDevice));
+        GFFX_HIP_TRY(hipMemcpy(ix->d_start, s.data(), R * 4, hipMemcpyHostToDevice));
+        GFFX_HIP_TRY(hipMemcpy(ix->d_end, e.data(), R * 4, hipMemcpyHostToDevice));
+        GFFX_HIP_TRY(hipMemcpy(ix->d_pmax, pm.data(), R * 4, hipMemcpyHostToDevice));
+        GFFX_HIP_TRY(hipMemcpy(ix->d_fid, ix->h_sorted_fids.data(), R * 4, hipMemcpyHostToDevice));
+    }
+    if (n_chr)
+        GFFX_HIP_TRY(hipMemcpy(ix->d_chr_meta, meta.data(), n_chr * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!bin_hi.empty())
+        GFFX_HIP_TRY(hipMemcpy(ix->d_bin_hi, bin_hi.data(), bin_hi.size() * 4, hipMemcpyHostToDevice));
+    *out = ix.release();
+    return GFFX_OK;
+}
+
+extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipFree(ix->d_ent);
+    (void)hipFree(ix->d_start);
+    (void)hipFree(ix->d_end);
+    (void)hipFree(ix->d_pmax);
+    (void)hipFree(ix->d_fid);
+    (void)hipFree(ix->d_chr_meta);
+    (void)hipFree(ix->d_bin_hi);
+    delete ix;
+}
+
+extern "C" uint32_t gffx_hip_index_n_chr(const gffx_hip_index *ix) { return ix ? ix->n_chr : 0; }
+extern "C" uint64_t gffx_hip_index_n_roots(const gffx_hip_index *ix) { return ix ? ix->n_roots : 0; }
+extern "C" int gffx_hip_index_device(const gffx_hip_index *ix) { return ix ? ix->device : -1; }
+extern "C" const uint32_t *gffx_hip_index_sorted_fids(const gffx_hip_index *ix) {
+    return ix ? ix->h_sorted_fids.data() : nullptr;
+}
+
+// ------------------------------------------------------------------------------------ batch
+
+extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_queries,
+                                     gffx_hip_batch **out) {
+    if (!out) return fail(GFFX_E_INVALID, "gffx_hip_batch_create: out is NULL");
+    *out = nullptr;
+    if (!ix) return fail(GFFX_E_INVALID, "gffx_hip_batch_create: index is NULL");
+    GFFX_HIP_TRY(hipSetDevice(ix->device));
+    std::unique_ptr<gffx_hip_batch> b(new gffx_hip_batch);
+    b->ix = ix;
+    b->max_q = max_queries;
+    int rc;
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(GFFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    if ((rc = dev_alloc(&b->d_counts, max_queries)) || (rc = dev_alloc(&b->d_block_sums, 4096)) ||
+        (rc = dev_alloc(&b->d_status, 2))) {
+        gffx_hip_batch_destroy(b.release());
+        return rc;
+    }
+    e = hipHostMalloc((void **)&b->h_status, 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        gffx_hip_batch_destroy(b.release());
+        return fail(GFFX_E_OOM, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    *out = b.release();
+    return GFFX_OK;
+}
+
+extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ix->device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    for (auto &p : b->pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    (void)hipFree(b->d_regions);
+    (void)hipFree(b->d_soa);
+    (void)hipFree(b->d_counts);
+    (void)hipFree(b->d_block_sums);
+    (void)hipFree(b->d_status);
+    (void)hipFree(b->d_fids);
+    (void)hipFree(b->d_triples);
+    (void)hipFree(b->d_bitmap);
+    (void)hipFree(b->d_offsets);
+    if (b->h_status) (void)hipHostFree(b->h_status);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+static int batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who) {
+    if (!b) return fail(GFFX_E_INVALID, "%s: batch is NULL", who);
+    if (nq > b->max_q)
+        return fail(GFFX_E_INVALID, "%s: %llu queries exceed the batch capacity %llu", who,
+                    (unsigned long long)nq, (unsigned long long)b->max_q);
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t *regions,
+                                               uint64_t nq) {
+    int rc = batch_check_nq(b, nq, "gffx_hip_batch_set_regions_host");
+    if (rc) return rc;
+    if (nq && !regions) return fail(GFFX_E_INVALID, "set_regions_host: regions is NULL");
+    GFFX_HIP_TRY(hipSetDevice(b->ix->device));
+    if (!b->d_regions && (rc = dev_alloc(&b->d_regions, 3 * b->max_q))) return rc;
+    if (nq)
+        GFFX_HIP_TRY(hipMemcpyAsync(b->d_regions, regions, nq * 12, hipMemcpyHostToDevice, b->stream));
+    b->q = QueryView{b->d_regions, nullptr, nullptr, nullptr};
+    b->nq = nq;
+    b->have_regions = true;
+    b->ran = b->waited = false;
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_set_regions_soa_host(gffx_hip_batch *b, const uint32_t *chr,
+                                                   const uint32_t *start, const uint32_t *end,
+                                                   uint64_t nq) {
+    int rc = batch_check_nq(b, nq, "gffx_hip_batch_set_regions_soa_host");
+    if (rc) return rc;
+    if (nq && (!chr || !start || !end)) return fail(GFFX_E_INVALID, "set_regions_soa_host: NULL array");
+    GFFX_HIP_TRY(hipSetDevice(b->ix->device));
+    if (!b->d_soa && (rc = dev_alloc(&b->d_soa, 3 * b->max_q))) return rc;
+    uint32_t *dc = b->d_soa, *ds = b->d_soa + b->max_q, *de = b->d_soa + 2 * b->max_q;
+    if (nq) {
+        GFFX_HIP_TRY(hipMemcpyAsync(dc, chr, nq * 4, hipMemcpyHostToDevice, b->stream));
+        GFFX_HIP_TRY(hipMemcpyAsync(ds, start, nq * 4, hipMemcpyHostToDevice, b->stream));
+        GFFX_HIP_TRY(hipMemcpyAsync(de, end, nq * 4, hipMemcpyHostToDevice, b->stream));
+    }
+    b->q = QueryView{nullptr, dc, ds, de};
+    b->nq = nq;
+    b->have_regions = true;
+    b->ran = b->waited = false;
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_set_regions_device(gffx_hip_batch *b, const uint32_t *d_chr,
+                                                 const uint32_t *d_start, const uint32_t *d_end,
+                                                 uint64_t nq) {
+    int rc = batch_check_nq(b, nq, "gffx_hip_batch_set_regions_device");
+    if (rc) return rc;
+    if (nq && (!d_chr || !d_start || !d_end))
+        return fail(GFFX_E_INVALID, "set_regions_device: NULL device array");
+    b->q = QueryView{nullptr, d_chr, d_start, d_end};
+    b->nq = nq;
+    b->have_regions = true;
+    b->ran = b->waited = false;
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_reserve_hits(gffx_hip_batch *b, uint64_t n_pairs) {
+    if (!b) return fail(GFFX_E_INVALID, "reserve_hits: batch is NULL");
+    b->reserve = n_pairs;
+    return GFFX_OK;
+}
+
+template <typename T>
+static int grow(T **p, uint64_t *cap, uint64_t want, size_t elems_per) {
+    if (*cap >= want && *p) return GFFX_OK;
+    if (*p) GFFX_HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    int rc = dev_alloc(p, want * elems_per);
+    if (rc) return rc;
+    *cap = want;
+    return GFFX_OK;
+}
+
+static void prof_begin(gffx_hip_batch *b, int kernel, ProfEvent *pe) {
+    pe->kernel = -1;
+    if (!b->profiling) return;
+    if (hipEventCreate(&pe->a) != hipSuccess || hipEventCreate(&pe->b) != hipSuccess) return;
+    pe->kernel = kernel;
+    (void)hipEventRecord(pe->a, b->stream);
+}
+static void prof_end(gffx_hip_batch *b, ProfEvent *pe) {
+    if (pe->kernel < 0) return;
+    (void)hipEventRecord(pe->b, b->stream);
+    b->pending.push_back(*pe);
+}
+static void prof_resolve(gffx_hip_batch *b) {
+    for (auto &p : b->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            b->k_ms[p.kernel] += ms;
+            b->k_n[p.kernel] += 1;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    b->pending.clear();
+}
+
+static JoinOut make_out(gffx_hip_batch *b) {
+    JoinOut o;
+    o.counts = b->d_counts;
+    o.block_sums = b->d_block_sums;
+    o.total = b->d_status;
+    o.err = reinterpret_cast<uint32_t *>(b->d_status + 1);
+    o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
+    o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
+    o.offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr;
+    o.bitmap = (b->flags & GFFX_OUT_ROOT_BITMAP) ? b->d_bitmap : nullptr;
+    uint64_t cap = UINT64_MAX;
+    if (o.fids) cap = std::min(cap, b->cap_fids);
+    if (o.triples) cap = std::min(cap, b->cap_triples);
+    o.capacity = cap;
+    return o;
+}
+
+template <int MODE, bool INV, bool AOS>
+static void launch_count(gffx_hip_batch *b, const JoinOut &o) {
+    hipLaunchKernelGGL((k_join_count<MODE, INV, AOS>), dim3(b->n_blocks), dim3(kJoinThreads), 0,
+                       b->stream, b->ix->view(), b->q, (unsigned long long)b->nq,
+                       (unsigned long long)b->chunk, o);
+}
+template <int MODE, bool INV, bool AOS>
+static void launch_emit(gffx_hip_batch *b, const JoinOut &o) {
+    hipLaunchKernelGGL((k_join_emit<MODE, INV, AOS>), dim3(b->n_blocks), dim3(kJoinThreads), 0,
+                       b->stream, b->ix->view(), b->q, (unsigned long long)b->nq,
+                       (unsigned long long)b->chunk, o);
+}
+
+template <bool EMIT>
+static void dispatch(gffx_hip_batch *b, const JoinOut &o) {
+    const bool aos = b->q.aos != nullptr;
+#define GFFX_CASE(M, I, A)                                  \
+    if (b->mode == M && (b->invert != 0) == I && aos == A) { \
+        if (EMIT)                                           \
+            launch_emit<M, I, A>(b, o);                     \
+        else                                                \
+            launch_count<M, I, A>(b, o);                    \
+        return;                                             \
+    }
+    GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
+    GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
+    GFFX_CASE(2, false, false) GFFX_CASE(2, false, true) GFFX_CASE(2, true, false) GFFX_CASE(2, true, true)
+#undef GFFX_CASE
+}
+
+static bool wants_pairs(uint32_t flags) {
+    return flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_ROOT_BITMAP | GFFX_OUT_OFFSETS);
+}
+
+static int enqueue_emit(gffx_hip_batch *b) {
+    if (b->flags & GFFX_OUT_ROOT_BITMAP)
+        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
+    const JoinOut o = make_out(b);
+    ProfEvent pe;
+    prof_begin(b, GFFX_K_JOIN_EMIT, &pe);
+    dispatch<true>(b, o);
+    prof_end(b, &pe);
+    GFFX_HIP_TRY(hipGetLastError());
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags,
+                                  int strategy) {
+    if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: batch is NULL");
+    if (!b->have_regions) return fail(GFFX_E_STATE, "gffx_hip_batch_run: no regions set");
+    if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad mode %d", mode);
+    if (strategy != GFFX_STRATEGY_AUTO && strategy != GFFX_STRATEGY_DIRECT)
+        return fail(GFFX_E_INVALID, "gffx_hip_batch_run: strategy %d not available", strategy);
+    GFFX_HIP_TRY(hipSetDevice(b->ix->device));
+    b->mode = mode;
+    b->invert = invert ? 1 : 0;
+    b->flags = out_flags | GFFX_OUT_COUNTS;
+    b->strategy = GFFX_STRATEGY_DIRECT;
+    b->ran = true;
+    b->waited = false;
+    b->total = 0;
+    GFFX_HIP_TRY(hipMemsetAsync(b->d_status, 0, 2 * sizeof(unsigned long long), b->stream));
+    const uint64_t nq = b->nq;
+    int rc;
+    if (b->flags & GFFX_OUT_OFFSETS) {
+        if (!b->d_offsets && (rc = dev_alloc(&b->d_offsets, b->max_q + 1))) return rc;
+        if (nq == 0) GFFX_HIP_TRY(hipMemsetAsync(b->d_offsets, 0, sizeof(unsigned long long), b->stream));
+    }
+    if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !b->d_bitmap &&
+        (rc = dev_alloc(&b->d_bitmap, ((size_t)b->ix->n_roots + 31) / 32 + 1)))
+        return rc;
+    if (nq == 0) {
+        if (b->flags & GFFX_OUT_ROOT_BITMAP)
+            GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
+        b->n_blocks = 0;
+        return GFFX_OK;
+    }
+    // contiguous chunk of queries per block, a multiple of the block size; <= 2048 blocks
+    const uint64_t tiles = (nq + kJoinThreads - 1) / kJoinThreads;
+    const uint64_t max_blocks = 2048;
+    const uint64_t tiles_per_block = (tiles + max_blocks - 1) / max_blocks;
+    b->chunk = tiles_per_block * kJoinThreads;
+    b->n_blocks = (uint32_t)((nq + b->chunk - 1) / b->chunk);
+    // initial capacity guess: reservation, else 2 pairs per query
+    const uint64_t want = std::max<uint64_t>(b->reserve ? b->reserve : 2 * nq, 1024);
+    if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want && (rc = grow(&b->d_fids, &b->cap_fids, want, 1)))
+        return rc;
+    if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want &&
+        (rc = grow(&b->d_triples, &b->cap_triples, want, 3)))
+        return rc;
+    {
+        const JoinOut o = make_out(b);
+        ProfEvent pe;
+        prof_begin(b, GFFX_K_JOIN_COUNT, &pe);
+        dispatch<false>(b, o);
+        prof_end(b, &pe);
+        GFFX_HIP_TRY(hipGetLastError());
+    }
+    if (wants_pairs(b->flags) && (rc = enqueue_emit(b))) return rc;
+    GFFX_HIP_TRY(hipMemcpyAsync(b->h_status, b->d_status, 2 * sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, b->stream));
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_sync(gffx_hip_batch *b) {
+    if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_sync: batch is NULL");
+    GFFX_HIP_TRY(hipSetDevice(b->ix->device));
+    GFFX_HIP_TRY(hipStreamSynchronize(b->stream));
+    prof_resolve(b);
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
+    if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_wait: batch is NULL");
+    if (!b->ran) return fail(GFFX_E_STATE, "gffx_hip_batch_wait: nothing was run");
+    int rc = gffx_hip_batch_sync(b);
+    if (rc) return rc;
+    if (b->nq == 0) {
+        b->total = 0;
+        b->waited = true;
+        return GFFX_OK;
+    }
+    if (b->h_status[1] & 1ull)
+        return fail(GFFX_E_CHR_RANGE, "a query's chr is >= the index's seqid count %u "
+                                      "(the reference panics here: commands/intersect.rs:117)",
+                    b->ix->n_chr);
+    b->total = b->h_status[0];
+    bool replay = false;
+    if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < b->total) {
+        if ((rc = grow(&b->d_fids, &b->cap_fids, b->total + b->total / 8, 1))) return rc;
+        replay = true;
+    }
+    if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < b->total) {
+        if ((rc = grow(&b->d_triples, &b->cap_triples, b->total + b->total / 8, 3))) return rc;
+        replay = true;
+    }
+    if (replay) {
+        if ((rc = enqueue_emit(b))) return rc;
+        if ((rc = gffx_hip_batch_sync(b))) return rc;
+    }
+    b->waited = true;
+    return GFFX_OK;
+}
+
+extern "C" uint64_t gffx_hip_batch_n_queries(const gffx_hip_batch *b) { return b ? b->nq : 0; }
+extern "C" uint64_t gffx_hip_batch_total_hits(const gffx_hip_batch *b) {
+    return (b && b->waited) ? b->total : 0;
+}
+
+static int need_waited(gffx_hip_batch *b, const char *who, uint32_t flag) {
+    if (!b) return fail(GFFX_E_INVALID, "%s: batch is NULL", who);
+    if (!b->waited) return fail(GFFX_E_STATE, "%s: call gffx_hip_batch_wait first", who);
+    if (flag && !(b->flags & flag)) return fail(GFFX_E_STATE, "%s: output was not requested in _run", who);
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_copy_counts(gffx_hip_batch *b, uint32_t *host) {
+    int rc = need_waited(b, "gffx_hip_batch_copy_counts", GFFX_OUT_COUNTS);
+    if (rc) return rc;
+    if (b->nq) GFFX_HIP_TRY(hipMemcpy(host, b->d_counts, b->nq * 4, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_copy_offsets(gffx_hip_batch *b, uint64_t *host) {
+    int rc = need_waited(b, "gffx_hip_batch_copy_offsets", GFFX_OUT_OFFSETS);
+    if (rc) return rc;
+    GFFX_HIP_TRY(hipMemcpy(host, b->d_offsets, (b->nq + 1) * 8, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_copy_fids(gffx_hip_batch *b, uint32_t *host) {
+    int rc = need_waited(b, "gffx_hip_batch_copy_fids", GFFX_OUT_FIDS);
+    if (rc) return rc;
+    if (b->total) GFFX_HIP_TRY(hipMemcpy(host, b->d_fids, b->total * 4, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_copy_triples(gffx_hip_batch *b, uint32_t *host) {
+    int rc = need_waited(b, "gffx_hip_batch_copy_triples", GFFX_OUT_TRIPLES);
+    if (rc) return rc;
+    if (b->total) GFFX_HIP_TRY(hipMemcpy(host, b->d_triples, b->total * 12, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_copy_root_bitmap(gffx_hip_batch *b, uint64_t *host, uint64_t n_words) {
+    int rc = need_waited(b, "gffx_hip_batch_copy_root_bitmap", GFFX_OUT_ROOT_BITMAP);
+    if (rc) return rc;
+    const uint64_t need = ((uint64_t)b->ix->n_roots + 63) / 64;
+    if (n_words < need) return fail(GFFX_E_INVALID, "copy_root_bitmap: need %llu words", (unsigned long long)need);
+    std::vector<uint32_t> tmp(2 * need + 2, 0);
+    const size_t w32 = ((size_t)b->ix->n_roots + 31) / 32;
+    if (w32) GFFX_HIP_TRY(hipMemcpy(tmp.data(), b->d_bitmap, w32 * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < need; i++) host[i] = (uint64_t)tmp[2 * i] | ((uint64_t)tmp[2 * i + 1] << 32);
+    return GFFX_OK;
+}
+extern "C" const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *b) { return b ? b->d_counts : nullptr; }
+extern "C" const uint32_t *gffx_hip_batch_device_fids(const gffx_hip_batch *b) {
+    return (b && (b->flags & GFFX_OUT_FIDS)) ? b->d_fids : nullptr;
+}
+extern "C" const uint32_t *gffx_hip_batch_device_triples(const gffx_hip_batch *b) {
+    return (b && (b->flags & GFFX_OUT_TRIPLES)) ? b->d_triples : nullptr;
+}
+
+extern "C" int gffx_hip_batch_set_profiling(gffx_hip_batch *b, int enabled) {
+    if (!b) return fail(GFFX_E_INVALID, "set_profiling: batch is NULL");
+    b->profiling = enabled != 0;
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_kernel_ms(gffx_hip_batch *b, int kernel_id, double *total_ms,
+                                        uint64_t *launches) {
+    if (!b || kernel_id < 0 || kernel_id >= GFFX_K__COUNT)
+        return fail(GFFX_E_INVALID, "kernel_ms: bad argument");
+    if (total_ms) *total_ms = b->k_ms[kernel_id];
+    if (launches) *launches = b->k_n[kernel_id];
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_reset_profile(gffx_hip_batch *b) {
+    if (!b) return fail(GFFX_E_INVALID, "reset_profile: batch is NULL");
+    for (int i = 0; i < GFFX_K__COUNT; i++) {
+        b->k_ms[i] = 0;
+        b->k_n[i] = 0;
+    }
+    return GFFX_OK;
+}
+
+// ------------------------------------------------------------------------------------ one-shot
+
+extern "C" int gffx_hip_query_features(const gffx_hip_index *ix, const uint32_t *regions,
+                                       uint64_t nq, int mode, int invert, uint32_t **triples_out,
+                                       uint64_t *n_triples) {
+    if (!triples_out || !n_triples) return fail(GFFX_E_INVALID, "gffx_hip_query_features: NULL output");
+    *triples_out = nullptr;
+    *n_triples = 0;
+    gffx_hip_batch *b = nullptr;
+    int rc = gffx_hip_batch_create(ix, nq, &b);
+    if (rc) return rc;
+    if ((rc = gffx_hip_batch_set_regions_host(b, regions, nq)) ||
+        (rc = gffx_hip_batch_run(b, mode, invert, GFFX_OUT_TRIPLES, GFFX_STRATEGY_AUTO)) ||
+        (rc = gffx_hip_batch_wait(b))) {
+        gffx_hip_batch_destroy(b);
+        return rc;
+    }
+    const uint64_t n = gffx_hip_batch_total_hits(b);
+    uint32_t *host = (uint32_t *)malloc(std::max<uint64_t>(n, 1) * 12);
+    if (!host) {
+        gffx_hip_batch_destroy(b);
+        return fail(GFFX_E_OOM, "gffx_hip_query_features: host allocation of %llu triples failed",
+                    (unsigned long long)n);
+    }
+    rc = gffx_hip_batch_copy_triples(b, host);
+    gffx_hip_batch_destroy(b);
+    if (rc) {
+        free(host);
+        return rc;
+    }
+    *triples_out = host;
+    *n_triples = n;
+    return GFFX_OK;
+}
+
+// ------------------------------------------------------------------------------------ Join B (placeholder until the device kernel lands)
+
+extern "C" int gffx_hip_lines_create(int, uint64_t, const uint32_t *, const uint32_t *,
+                                     const uint32_t *, gffx_hip_lines **out) {
+    if (out) *out = nullptr;
+    return fail(GFFX_E_STATE, "gffx_hip_lines_create: Join B is not built into this library yet");
+}
+extern "C" void gffx_hip_lines_destroy(gffx_hip_lines *) {}
+extern "C" int gffx_hip_lines_test(gffx_hip_lines *, const uint32_t *, uint64_t, uint32_t, int,
+                                   uint8_t *) {
+    return fail(GFFX_E_STATE, "gffx_hip_lines_test: Join B is not built into this library yet");
+}

@@ -1,0 +1,226 @@
+"""Python mirror of the reference's interface for the `intersect` hot path, over the C-ABI.
+
+Names and argument meaning follow the reference (Baohua-Chen/GFFx v0.4.0, src/):
+
+* ``OverlapMode``                     commands/intersect.rs:73-78
+* ``TreeIndexData``                   utils/tree_index.rs:12-16 (``chr_entries`` live in HBM)
+* ``query_features(index_data, regions, mode, invert, verbose)``
+                                      commands/intersect.rs:105-111
+* ``QueryBatch``                      the streaming form of the same call (device-resident
+                                      regions, reusable buffers, HIP-event kernel timing)
+
+Everything here is plumbing around ``libgffx_hip.so``; there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, lib, u32p, u64p
+
+
+class OverlapMode(enum.IntEnum):
+    Contained = 0
+    ContainsRegion = 1
+    Overlap = 2
+
+
+OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS = 1, 2, 4, 8, 16
+STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED = 0, 1, 2
+K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED = 0, 1, 2, 3, 4
+KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_sort",
+                K_LINES: "k_lines_exists", K_FUSED: "k_join_fused"}
+
+
+def device_count() -> int:
+    return lib().gffx_hip_device_count()
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(u32p)
+
+
+class TreeIndexData:
+    """Per-seqid root intervals resident in HBM + the seqid name maps (tree_index.rs:12-16)."""
+
+    def __init__(self, handle, num_to_seqid: Sequence[str]):
+        self._h = handle
+        self.num_to_seqid: List[str] = list(num_to_seqid)
+        # FxHashMap built by collect(): a later duplicate name wins (index_loader/core.rs:28-32)
+        self.seqid_to_num: Dict[str, int] = {n: i for i, n in enumerate(self.num_to_seqid)}
+
+    @classmethod
+    def from_roots(cls, chr_offsets, start, end, root_fid, names: Optional[Sequence[str]] = None,
+                   device: int = 0) -> "TreeIndexData":
+        co, s, e, f = _u32(chr_offsets), _u32(start), _u32(end), _u32(root_fid)
+        if co.ndim != 1 or len(co) < 1:
+            raise ValueError("chr_offsets must have n_chr+1 entries")
+        h = C.c_void_p()
+        check(lib().gffx_hip_index_create(len(co) - 1, _p(co), _p(s), _p(e), _p(f), device, C.byref(h)))
+        if names is None:
+            names = ["seq%d" % i for i in range(len(co) - 1)]
+        return cls(h, names)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().gffx_hip_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_chr(self) -> int:
+        return lib().gffx_hip_index_n_chr(self._h)
+
+    @property
+    def n_roots(self) -> int:
+        return lib().gffx_hip_index_n_roots(self._h)
+
+    @property
+    def device(self) -> int:
+        return lib().gffx_hip_index_device(self._h)
+
+    def sorted_fids(self) -> np.ndarray:
+        n = self.n_roots
+        ptr = lib().gffx_hip_index_sorted_fids(self._h)
+        return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
+
+
+class QueryBatch:
+    """Reusable query batch on one HIP stream (create once, run many)."""
+
+    def __init__(self, index: TreeIndexData, max_queries: int):
+        self.index = index
+        self._h = C.c_void_p()
+        check(lib().gffx_hip_batch_create(index._h, int(max_queries), C.byref(self._h)))
+        self._keep = None  # keeps host/device inputs alive until wait()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().gffx_hip_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs
+    def set_regions(self, regions) -> None:
+        """regions: (nq,3) u32 rows (chr, start, end) == the reference's &[(u32,u32,u32)]."""
+        r = _u32(regions).reshape(-1, 3)
+        self._keep = r
+        check(lib().gffx_hip_batch_set_regions_host(self._h, _p(r), r.shape[0]))
+
+    def set_regions_soa(self, chr_, start, end) -> None:
+        c, s, e = _u32(chr_), _u32(start), _u32(end)
+        self._keep = (c, s, e)
+        check(lib().gffx_hip_batch_set_regions_soa_host(self._h, _p(c), _p(s), _p(e), len(c)))
+
+    def set_regions_device(self, d_chr: int, d_start: int, d_end: int, nq: int, keep=None) -> None:
+        """Borrow three device arrays (raw pointers, e.g. torch.Tensor.data_ptr())."""
+        self._keep = keep
+        check(lib().gffx_hip_batch_set_regions_device(self._h, d_chr, d_start, d_end, int(nq)))
+
+    def reserve_hits(self, n_pairs: int) -> None:
+        check(lib().gffx_hip_batch_reserve_hits(self._h, int(n_pairs)))
+
+    # ---- run
+    def run(self, mode: int = OverlapMode.Overlap, invert: bool = False, out_flags: int = OUT_FIDS,
+            strategy: int = STRATEGY_AUTO) -> None:
+        check(lib().gffx_hip_batch_run(self._h, int(mode), int(bool(invert)), int(out_flags), int(strategy)))
+
+    def wait(self) -> None:
+        check(lib().gffx_hip_batch_wait(self._h))
+
+    def sync(self) -> None:
+        check(lib().gffx_hip_batch_sync(self._h))
+
+    # ---- results
+    @property
+    def n_queries(self) -> int:
+        return lib().gffx_hip_batch_n_queries(self._h)
+
+    @property
+    def total_hits(self) -> int:
+        return lib().gffx_hip_batch_total_hits(self._h)
+
+    def counts(self) -> np.ndarray:
+        out = np.empty(max(self.n_queries, 1), dtype=np.uint32)
+        check(lib().gffx_hip_batch_copy_counts(self._h, _p(out)))
+        return out[: self.n_queries]
+
+    def offsets(self) -> np.ndarray:
+        out = np.empty(self.n_queries + 1, dtype=np.uint64)
+        check(lib().gffx_hip_batch_copy_offsets(self._h, out.ctypes.data_as(u64p)))
+        return out
+
+    def fids(self) -> np.ndarray:
+        n = self.total_hits
+        out = np.empty(max(n, 1), dtype=np.uint32)
+        check(lib().gffx_hip_batch_copy_fids(self._h, _p(out)))
+        return out[:n]
+
+    def triples(self) -> np.ndarray:
+        n = self.total_hits
+        out = np.empty((max(n, 1), 3), dtype=np.uint32)
+        check(lib().gffx_hip_batch_copy_triples(self._h, _p(out)))
+        return out[:n]
+
+    def root_bitmap(self) -> np.ndarray:
+        """bool array over the index's roots in sorted order (see TreeIndexData.sorted_fids)."""
+        n = self.index.n_roots
+        words = np.zeros(max((n + 63) // 64, 1), dtype=np.uint64)
+        check(lib().gffx_hip_batch_copy_root_bitmap(self._h, words.ctypes.data_as(u64p), len(words)))
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:n]
+        return bits.astype(bool)
+
+    def unique_roots(self) -> np.ndarray:
+        """Sorted unique root_fids with >=1 kept pair (commands/intersect.rs:598-615)."""
+        return np.unique(self.index.sorted_fids()[self.root_bitmap()])
+
+    # ---- profiling (HIP events on the batch's stream)
+    def set_profiling(self, on: bool) -> None:
+        check(lib().gffx_hip_batch_set_profiling(self._h, int(bool(on))))
+
+    def reset_profile(self) -> None:
+        check(lib().gffx_hip_batch_reset_profile(self._h))
+
+    def kernel_ms(self, kernel_id: int) -> Tuple[float, int]:
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().gffx_hip_batch_kernel_ms(self._h, kernel_id, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+def query_features(index_data: TreeIndexData, regions, mode: int = OverlapMode.Overlap,
+                   invert: bool = False, verbose: bool = False) -> np.ndarray:
+    """commands/intersect.rs:105-169: (root_fid, iv.start, iv.end) per kept (region, root) pair.
+
+    Returns an (n,3) u32 array.  Pair order: regions in input order, ascending iv.start inside a
+    region (the reference's order is an FxHashMap walk, i.e. unspecified).  Raises GffxHipError
+    (GFFX_E_CHR_RANGE) where the reference panics on an out-of-range chr.
+    """
+    r = _u32(regions).reshape(-1, 3)
+    if verbose:
+        import sys
+        print("[DEBUG] Querying %d regions on device %d" % (r.shape[0], index_data.device), file=sys.stderr)
+    tp = u32p()
+    n = C.c_uint64()
+    check(lib().gffx_hip_query_features(index_data._h, _p(r), r.shape[0], int(mode), int(bool(invert)),
+                                        C.byref(tp), C.byref(n)))
+    out = np.ctypeslib.as_array(tp, shape=(max(n.value, 1), 3))[: n.value].copy()
+    lib().gffx_hip_free_host(tp)
+    return out

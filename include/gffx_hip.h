@@ -1,0 +1,178 @@
+/*
+ * gffx_hip.h -- C ABI of the MI355X (gfx950) engine for the `gffx intersect` hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  It is what a
+ * Rust `gffx-hip` FFI crate would bind with `extern "C"` (binding shown in INTEGRATION.md).
+ * Reference anchors are Baohua-Chen/GFFx v0.4.0, paths relative to its src/.
+ *
+ *   reference item (file:line)                          entry point here
+ *   --------------------------------------------------  ---------------------------------------
+ *   TreeIndexData / IntervalTree<u32> per seqid         gffx_hip_index_create / _destroy
+ *     (utils/tree_index.rs:12-16, utils/tree.rs:5-23)     (device-resident sorted SoA + AoS)
+ *   IntervalTree::query_interval (utils/tree.rs:98-121) \
+ *   query_features + OverlapMode predicates + invert     > gffx_hip_batch_run / _wait and the
+ *     (commands/intersect.rs:105-169, :73-78, :145-161) /   one-shot gffx_hip_query_features
+ *   unique-root collection (commands/intersect.rs:598-615)  GFFX_OUT_ROOT_BITMAP
+ *   gff_line_overlaps_queries, numeric part             gffx_hip_lines_* (Join B)
+ *     (commands/intersect.rs:500-521)
+ *
+ * Semantics (bit-exact with the reference):
+ *   a root interval iv of the query's seqid is a HIT iff  iv.start < q.end && iv.end > q.start
+ *   (strict, half-open; u32 compares; q.start >= q.end rows are legal and evaluated as-is);
+ *   keep = mode predicate(iv, q);  a (query, root) pair is emitted iff  invert ^ keep.
+ * Output order: pairs are grouped per query in INPUT order (CSR: offset[i] = sum of counts
+ * of queries < i), ascending iv.start inside a query.  The reference's own order is that of
+ * an FxHashMap walk and is unspecified; the multiset of pairs is the contract.
+ *
+ * Threading: an index is immutable after creation and may be shared by threads; a batch owns
+ * one HIP stream plus its buffers and must not be used from two threads at once.
+ * Errors: every function returns GFFX_OK (0) or a negative gffx_status; the message of the
+ * last failure on the calling thread is in gffx_hip_last_error().  Nothing throws or aborts
+ * across this boundary.  There is NO CPU fallback: without a HIP device every compute entry
+ * point fails with GFFX_E_NO_DEVICE.
+ */
+#ifndef GFFX_HIP_H
+#define GFFX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFFX_HIP_ABI_VERSION 1
+
+/* commands/intersect.rs:73-78 OverlapMode */
+enum gffx_mode { GFFX_MODE_CONTAINED = 0, GFFX_MODE_CONTAINS_REGION = 1, GFFX_MODE_OVERLAP = 2 };
+
+enum gffx_status {
+    GFFX_OK = 0,
+    GFFX_E_INVALID = -1,   /* bad argument */
+    GFFX_E_NO_DEVICE = -2, /* no HIP device / device index out of range */
+    GFFX_E_HIP = -3,       /* a HIP runtime call failed */
+    GFFX_E_OOM = -4,       /* host or device allocation failed */
+    GFFX_E_CHR_RANGE = -5, /* a query's chr >= n_chr (the reference panics: intersect.rs:117) */
+    GFFX_E_STATE = -6      /* call order violated (e.g. results read before _wait) */
+};
+
+/* what a batch run materialises on the device */
+enum gffx_out {
+    GFFX_OUT_COUNTS = 1,      /* u32 kept pairs per query, input order (always produced) */
+    GFFX_OUT_FIDS = 2,        /* u32 root_fid per kept pair, CSR order */
+    GFFX_OUT_TRIPLES = 4,     /* (root_fid, iv.start, iv.end) per kept pair == the reference's
+                                 Vec<(u32,u32,u32)> (intersect.rs:162) */
+    GFFX_OUT_ROOT_BITMAP = 8, /* one bit per root of the index: set iff the root is in >=1 kept pair */
+    GFFX_OUT_OFFSETS = 16     /* u64 exclusive prefix of the counts (nq+1 entries) */
+};
+
+enum gffx_strategy {
+    GFFX_STRATEGY_AUTO = 0,
+    GFFX_STRATEGY_DIRECT = 1, /* queries in input order; bin directory + gathers from the L2-resident index */
+    GFFX_STRATEGY_SORTED = 2  /* device radix sort by (chr,start); LDS-staged index tiles; coalesced SoA sweep */
+};
+
+enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
+    GFFX_K_JOIN_COUNT = 0,
+    GFFX_K_JOIN_EMIT = 1,
+    GFFX_K_SORT = 2,
+    GFFX_K_LINES = 3,
+    GFFX_K_FUSED = 4,
+    GFFX_K__COUNT = 8
+};
+
+typedef struct gffx_hip_index gffx_hip_index;
+typedef struct gffx_hip_batch gffx_hip_batch;
+typedef struct gffx_hip_lines gffx_hip_lines;
+
+int gffx_hip_abi_version(void);
+/* number of visible HIP devices (0 when none / no driver); never fails */
+int gffx_hip_device_count(void);
+/* thread-local, valid until the next failing call on this thread */
+const char *gffx_hip_last_error(void);
+
+/* ---- index: replaces TreeIndexData.chr_entries (utils/tree_index.rs:12-16) ----------------
+ * chr_offsets has n_chr+1 entries delimiting each seqid's root intervals in start/end/root_fid
+ * (0-based half-open coordinates as the builder stores them, index_builder/core.rs:108-109;
+ * any order inside a seqid -- the builder's file order is fine).  The library sorts each seqid
+ * stably by start, adds the running maximum of `end`, builds the bin directory and uploads
+ * everything to `device` once. */
+int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets, const uint32_t *start,
+                          const uint32_t *end, const uint32_t *root_fid, int device,
+                          gffx_hip_index **out);
+void gffx_hip_index_destroy(gffx_hip_index *);
+uint32_t gffx_hip_index_n_chr(const gffx_hip_index *);
+uint64_t gffx_hip_index_n_roots(const gffx_hip_index *);
+int gffx_hip_index_device(const gffx_hip_index *);
+/* root_fid of the i-th bit of the root bitmap (i < n_roots), host array owned by the index */
+const uint32_t *gffx_hip_index_sorted_fids(const gffx_hip_index *);
+
+/* ---- query batches: replaces query_features (commands/intersect.rs:105-169) --------------- */
+int gffx_hip_batch_create(const gffx_hip_index *, uint64_t max_queries, gffx_hip_batch **out);
+void gffx_hip_batch_destroy(gffx_hip_batch *);
+
+/* regions = nq AoS triples (chr, start, end): exactly the reference's &[(u32,u32,u32)]
+ * (intersect.rs:107).  Copied host -> device on the batch's stream. */
+int gffx_hip_batch_set_regions_host(gffx_hip_batch *, const uint32_t *regions, uint64_t nq);
+/* same, from three host arrays */
+int gffx_hip_batch_set_regions_soa_host(gffx_hip_batch *, const uint32_t *chr,
+                                        const uint32_t *start, const uint32_t *end, uint64_t nq);
+/* borrow three DEVICE arrays (SoA) already resident in HBM; they must stay valid until _wait */
+int gffx_hip_batch_set_regions_device(gffx_hip_batch *, const uint32_t *d_chr,
+                                      const uint32_t *d_start, const uint32_t *d_end, uint64_t nq);
+
+/* Enqueue one pass of Join A over the batch on its stream (asynchronous). */
+int gffx_hip_batch_run(gffx_hip_batch *, int mode, int invert, uint32_t out_flags, int strategy);
+/* Block until the pass finished; grows the output buffers and replays the emit step when the
+ * kept-pair count exceeded their capacity.  Returns GFFX_E_CHR_RANGE if a chr was out of range. */
+int gffx_hip_batch_wait(gffx_hip_batch *);
+/* Cheaper than _wait for pipelines: only checks that the stream drained (no capacity replay). */
+int gffx_hip_batch_sync(gffx_hip_batch *);
+
+uint64_t gffx_hip_batch_n_queries(const gffx_hip_batch *);
+/* valid after _wait */
+uint64_t gffx_hip_batch_total_hits(const gffx_hip_batch *);
+int gffx_hip_batch_copy_counts(gffx_hip_batch *, uint32_t *host /* nq */);
+int gffx_hip_batch_copy_offsets(gffx_hip_batch *, uint64_t *host /* nq+1 */);
+int gffx_hip_batch_copy_fids(gffx_hip_batch *, uint32_t *host /* total_hits */);
+int gffx_hip_batch_copy_triples(gffx_hip_batch *, uint32_t *host /* 3*total_hits */);
+/* n_words = ceil(n_roots/64); bit i <-> gffx_hip_index_sorted_fids()[i] */
+int gffx_hip_batch_copy_root_bitmap(gffx_hip_batch *, uint64_t *host, uint64_t n_words);
+/* device views of the same buffers (NULL if not produced), for zero-copy consumers */
+const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *);
+const uint32_t *gffx_hip_batch_device_fids(const gffx_hip_batch *);
+const uint32_t *gffx_hip_batch_device_triples(const gffx_hip_batch *);
+/* pre-size the pair buffers (pairs); avoids the capacity replay on the first run */
+int gffx_hip_batch_reserve_hits(gffx_hip_batch *, uint64_t n_pairs);
+
+/* HIP-event timing of the kernels on the batch's own stream.  While enabled every launch is
+ * bracketed by events; _kernel_ms returns the accumulated milliseconds and launch count of
+ * one kernel since the last _reset_profile (events are resolved by _wait/_sync). */
+int gffx_hip_batch_set_profiling(gffx_hip_batch *, int enabled);
+int gffx_hip_batch_kernel_ms(gffx_hip_batch *, int kernel_id, double *total_ms, uint64_t *launches);
+int gffx_hip_batch_reset_profile(gffx_hip_batch *);
+
+/* One-shot drop-in for query_features (commands/intersect.rs:105-111): host regions in, host
+ * triples out (malloc'd by the library, release with gffx_hip_free_host). */
+int gffx_hip_query_features(const gffx_hip_index *, const uint32_t *regions, uint64_t nq, int mode,
+                            int invert, uint32_t **triples_out, uint64_t *n_triples);
+void gffx_hip_free_host(void *);
+
+/* ---- Join B: the numeric core of gff_line_overlaps_queries (commands/intersect.rs:500-521) -
+ * A line table is the (seqid number, raw column-4 start, raw column-5 end) of GFF lines,
+ * in file order, uploaded once.  seq == UINT32_MAX marks a line that can never match (seqid
+ * without queries / unparsable columns).  _test evaluates, for every line, whether ANY region
+ * of the line's seqid satisfies the literal closed-interval predicate of the given mode
+ * (no invert: intersect.rs:232-240 has no such parameter) and writes one byte per line. */
+int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_t *seq, const uint32_t *start,
+                          const uint32_t *end, gffx_hip_lines **out);
+void gffx_hip_lines_destroy(gffx_hip_lines *);
+/* regions = AoS triples as above (all regions of the run, BED order: intersect.rs:621-633);
+ * n_seq = number of seqids; keep_host receives n_lines bytes (0/1). */
+int gffx_hip_lines_test(gffx_hip_lines *, const uint32_t *regions, uint64_t nq, uint32_t n_seq,
+                        int mode, uint8_t *keep_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFFX_HIP_H */

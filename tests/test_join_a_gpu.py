@@ -1,0 +1,173 @@
+"""Join A parity on the GPU: HIP engine (through the C-ABI) == oracle, bit for bit.
+
+Compared per stage (SURVEY.md section 8a "hit set"): per-query kept counts, the multiset of
+(root_fid, start, end) triples, the CSR grouping of pairs per query, and the unique-root set.
+"""
+import numpy as np
+import pytest
+
+from gffx_amd import engine, synth
+from gffx_amd.engine import OverlapMode
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+FLAGS = engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS
+STRATEGIES = [engine.STRATEGY_DIRECT]
+
+
+def _sorted_rows(t):
+    t = np.asarray(t, dtype=np.uint32).reshape(-1, 3)
+    return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+
+def _check(roots, regions, mode, invert, soa=False, strategy=engine.STRATEGY_AUTO):
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    want_t, want_c = oix.query_features(regions, int(mode), invert)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, max(len(regions), 1))
+    if soa:
+        b.set_regions_soa(regions[:, 0], regions[:, 1], regions[:, 2])
+    else:
+        b.set_regions(regions)
+    b.run(mode, invert, FLAGS, strategy)
+    b.wait()
+    assert b.total_hits == len(want_t)
+    got_c = b.counts()
+    assert np.array_equal(got_c, want_c)
+    got_t = b.triples()
+    assert np.array_equal(_sorted_rows(got_t), _sorted_rows(want_t))
+    assert np.array_equal(b.fids(), got_t[:, 0])
+    off = b.offsets()
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum(want_c.astype(np.uint64))]).astype(np.uint64))
+    # pairs of query i are exactly the oracle's pairs of query i (ascending start inside a query)
+    for qi in np.random.default_rng(0).choice(len(regions), size=min(200, len(regions)), replace=False):
+        seg = got_t[int(off[qi]):int(off[qi + 1])]
+        one_t, _ = oix.query_features(regions[qi:qi + 1], int(mode), invert)
+        assert np.array_equal(_sorted_rows(seg), _sorted_rows(one_t))
+        assert np.all(np.diff(seg[:, 1].astype(np.int64)) >= 0)
+    assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    b.close()
+    ix.close()
+    return len(want_t)
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("mode", list(OverlapMode))
+@pytest.mark.parametrize("invert", [False, True])
+def test_small_two_chromosomes_all_modes(mode, invert, strategy):
+    roots = synth.gencode_like_roots(300, seed=3, chroms=synth.SMALL2)
+    regions = synth.synth_bed(5000, seed=11, chroms=synth.SMALL2, width=(10, 200000), edge_frac=0.2, roots=roots)
+    n = _check(roots, regions, mode, invert, strategy=strategy)
+    if mode == OverlapMode.Overlap and invert:
+        assert n == 0
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("mode", list(OverlapMode))
+def test_gencode_scale_100k_queries(mode, strategy):
+    roots = synth.gencode_like_roots(63000, seed=42)
+    regions = synth.synth_bed(100_000, seed=1001, edge_frac=0.001, roots=roots)
+    n = _check(roots, regions, mode, False, soa=(mode == OverlapMode.Overlap), strategy=strategy)
+    assert n > 0 or mode != OverlapMode.Overlap
+
+
+def test_appendix_e_table_on_device():
+    # SURVEY.md App. E roots: seq0 {[100,200)->0, [150,400)->4}, seq1 {[0,50)->6}
+    ix = engine.TreeIndexData.from_roots([0, 2, 3], [100, 150, 0], [200, 400, 50], [0, 4, 6], ["chr1", "chr2"])
+
+    def q(c, s, e, m, inv=False):
+        return sorted(engine.query_features(ix, [[c, s, e]], m, inv)[:, 0].tolist())
+
+    assert q(0, 200, 250, OverlapMode.Overlap) == [4]
+    assert q(0, 200, 250, OverlapMode.Overlap, True) == []
+    assert q(0, 100, 200, OverlapMode.Contained) == [0]
+    assert q(0, 100, 200, OverlapMode.Contained, True) == [4]
+    assert q(0, 160, 170, OverlapMode.ContainsRegion) == [0, 4]
+    assert q(0, 200, 201, OverlapMode.Overlap) == [4]
+    assert q(1, 0, 1, OverlapMode.Overlap) == [6]
+    assert engine.query_features(ix, [[0, 100, 200]], OverlapMode.Contained).tolist() == [[0, 100, 200]]
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_edge_inputs(strategy):
+    roots = synth.gencode_like_roots(50, seed=5, chroms=synth.SMALL2)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    # empty batch
+    assert engine.query_features(ix, np.zeros((0, 3), np.uint32)).shape == (0, 3)
+    # out-of-range chr is an error (the reference panics: intersect.rs:117)
+    with pytest.raises(engine._ffi.GffxHipError) as ei:
+        engine.query_features(ix, [[2, 0, 10]])
+    assert ei.value.code == -5
+    # u32 extremes and degenerate rows
+    regions = np.array([[0, 0, 0], [0, 0, 0xFFFFFFFF], [1, 0xFFFFFFFF, 0], [0, 0xFFFFFFFF, 0xFFFFFFFF],
+                        [1, 5, 5], [0, 3_000_000, 10]], dtype=np.uint32)
+    for mode in OverlapMode:
+        for inv in (False, True):
+            _check(roots, regions, mode, inv, strategy=strategy)
+    # an index with an empty seqid and a seqid of identical intervals
+    roots2 = {"chr_offsets": np.array([0, 0, 4, 5], np.uint32), "start": np.array([7, 7, 7, 7, 0], np.uint32),
+              "end": np.array([9, 9, 9, 9, 1], np.uint32), "fid": np.array([1, 2, 3, 4, 5], np.uint32)}
+    regions2 = np.array([[0, 0, 100], [1, 8, 9], [1, 9, 10], [1, 6, 7], [1, 6, 8], [2, 0, 1], [2, 1, 2]], np.uint32)
+    for mode in OverlapMode:
+        _check(roots2, regions2, mode, False, strategy=strategy)
+    # u32-wide coordinates: starts near 2^32 exercise the bin directory's shift
+    roots3 = {"chr_offsets": np.array([0, 3], np.uint32),
+              "start": np.array([0, 0xFFFFFF00, 0x80000000], np.uint32),
+              "end": np.array([0xFFFFFFFF, 0xFFFFFFFF, 0x80000001], np.uint32),
+              "fid": np.array([10, 20, 30], np.uint32)}
+    regions3 = np.array([[0, 0, 1], [0, 0x80000000, 0x80000001], [0, 0xFFFFFF00, 0xFFFFFFFF],
+                         [0, 0xFFFFFFFE, 0xFFFFFFFF], [0, 0x7FFFFFFF, 0x80000000]], np.uint32)
+    for mode in OverlapMode:
+        _check(roots3, regions3, mode, False, strategy=strategy)
+    # empty index
+    ix0 = engine.TreeIndexData.from_roots([0], [], [], [])
+    assert engine.query_features(ix0, np.zeros((0, 3), np.uint32)).shape == (0, 3)
+
+
+def test_capacity_replay_and_reuse():
+    """More pairs than the initial buffer guess -> the emit step is replayed, results unchanged."""
+    k = 400  # 400 nested intervals, every query hits all of them
+    roots = {"chr_offsets": np.array([0, k], np.uint32), "start": np.arange(k, dtype=np.uint32),
+             "end": (10_000 - np.arange(k)).astype(np.uint32), "fid": np.arange(k, dtype=np.uint32) * 3}
+    regions = np.tile(np.array([[0, 1000, 2000]], np.uint32), (3000, 1))
+    _check(roots, regions, OverlapMode.Overlap, False)
+    ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    b = engine.QueryBatch(ix, 3000)
+    for n in (3000, 10, 0, 2999):  # the same batch object, different sizes
+        b.set_regions(regions[:n])
+        b.run(OverlapMode.Overlap, False, engine.OUT_FIDS)
+        b.wait()
+        assert b.total_hits == n * k
+        assert np.array_equal(b.counts(), np.full(n, k, np.uint32))
+
+
+@pytest.mark.parametrize("nq", [1_000_000])
+def test_full_size_c2_properties(nq):
+    """BASELINE config 2 size (1 M regions x 63 k roots): sampled oracle parity + size-independent
+    properties (sum of counts == pairs; invert complements the mode predicate inside the hit set)."""
+    roots = synth.gencode_like_roots(63000, seed=42)
+    regions = synth.synth_bed(nq, seed=1001)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, nq)
+    b.set_regions(regions)
+    res = {}
+    for mode in OverlapMode:
+        for inv in (False, True):
+            b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS)
+            b.wait()
+            c = b.counts()
+            assert int(c.sum(dtype=np.uint64)) == b.total_hits == int(b.offsets()[-1])
+            res[(int(mode), inv)] = c
+    ov = res[(2, False)]
+    assert np.array_equal(res[(0, False)] + res[(0, True)], ov)
+    assert np.array_equal(res[(1, False)] + res[(1, True)], ov)
+    assert res[(2, True)].sum() == 0
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    sel = np.random.default_rng(7).choice(nq, size=20000, replace=False)
+    for mode in OverlapMode:
+        _, want_c = oix.query_features(regions[sel], int(mode), False)
+        assert np.array_equal(res[(int(mode), False)][sel], want_c)
