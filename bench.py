@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
     ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
+    ap.add_argument("--presort", default="none", choices=["none", "chr_end", "bucket"],
+                    help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -108,6 +110,12 @@ def main():
         regions = np.ascontiguousarray(regions_all[rows])
     else:
         regions = regions_all
+    if args.presort == "chr_end":
+        regions = regions[np.lexsort((regions[:, 2], regions[:, 0]))]
+    elif args.presort == "bucket":  # (chr, end >> 21) buckets, input order inside a bucket
+        key = (regions[:, 0].astype(np.int64) << 11) | (regions[:, 2].astype(np.int64) >> 21)
+        regions = regions[np.argsort(key, kind="stable")]
+    regions = np.ascontiguousarray(regions)
     nq = len(regions)
 
     ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"],
@@ -215,6 +223,7 @@ def main():
                 "pairs_per_region": h_bar,
                 "outputs": "per-region counts + %s (CSR, input order)" % args.out,
                 "strategy": args.strategy,
+                "presort": args.presort,
                 "sharding": "chromosome buckets, LPT with splitting; index replicated; all-gather of hit counts per step"
                             if world > 1 else "none (1 GPU)",
             },

@@ -3,8 +3,8 @@
 // HBM layout of an index (uploaded once, immutable):
 //   ent[R]        uint4 {start, end, pmax_end, root_fid}   16 B/root   (gather kernels)
 //   start/end/pmax/fid[R]  u32 SoA copies                  16 B/root   (sorted-strategy kernels)
-//   chr_meta[n_chr] uint4 {first, last+1, bin base, n_bins}
-//   bin_hi[sum(n_bins+1)] u32 bin directory over `start` (shift chosen so it stays L2-sized)
+//   chr_lists[n_chr] uint2 {first list, n_lists};  list_meta[n_lists] uint4 {first, last+1, bin base, shift|n_bins}
+//   bins[sum(n_bins+1)] uint2 per-list bin directory over `start` (<= ~4 bins per entry: L2-sized)
 // At GENCODE scale (63 k roots, 25 seqids) that is ~2 MB + ~0.8 MB of directory: resident in
 // every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and the results out.
 #include <algorithm>
@@ -39,6 +39,16 @@ static int device_count_quiet() {
     return n;
 }
 
+// T of the list decomposition (gffx_device.hpp); GFFX_HIP_DECOMPOSE_T overrides for experiments
+static uint32_t gffx_decompose_T() {
+    const char *e = getenv("GFFX_HIP_DECOMPOSE_T");
+    if (e && *e) {
+        long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= (1 << 20)) return (uint32_t)v;
+    }
+    return 4;
+}
+
 template <typename T>
 static int dev_alloc(T **p, size_t n) {
     *p = nullptr;
@@ -54,11 +64,12 @@ struct gffx_hip_index {
     int device = 0;
     uint32_t n_chr = 0;
     uint32_t n_roots = 0;
-    uint32_t shift = 0;
     uint4 *d_ent = nullptr;
     uint32_t *d_start = nullptr, *d_end = nullptr, *d_pmax = nullptr, *d_fid = nullptr;
-    uint4 *d_chr_meta = nullptr;
-    uint32_t *d_bin_hi = nullptr;
+    uint2 *d_chr_lists = nullptr;
+    uint4 *d_list_meta = nullptr;
+    uint2 *d_bins = nullptr;
+    uint32_t n_lists = 0;
     std::vector<uint32_t> h_sorted_fids;
     std::vector<uint32_t> h_chr_offsets;
 
@@ -69,10 +80,11 @@ struct gffx_hip_index {
         v.end = d_end;
         v.pmax = d_pmax;
         v.fid = d_fid;
-        v.chr_meta = d_chr_meta;
-        v.bin_hi = d_bin_hi;
+        v.chr_lists = d_chr_lists;
+        v.list_meta = d_list_meta;
+        v.bins = d_bins;
         v.n_chr = n_chr;
-        v.shift = shift;
+        v.n_lists = n_lists;
         v.n_roots = n_roots;
         return v;
     }
@@ -95,8 +107,9 @@ struct gffx_hip_batch {
     // outputs / workspace
     uint32_t *d_counts = nullptr;
     unsigned long long *d_block_sums = nullptr;
-    unsigned long long *d_status = nullptr;  // [0] total pairs, [1] error bits
-    unsigned long long *h_status = nullptr;  // pinned mirror
+    unsigned long long *d_status = nullptr;     // [0] error bits
+    unsigned long long *h_status = nullptr;     // pinned: [0] error bits, [1..] block sums
+    static constexpr uint32_t kMaxBlocks = 2048;
     uint32_t *d_fids = nullptr, *d_triples = nullptr, *d_bitmap = nullptr;
     unsigned long long *d_offsets = nullptr;
     uint64_t cap_fids = 0, cap_triples = 0;
@@ -136,6 +149,8 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     if (chr_offsets[0] != 0)
         return fail(GFFX_E_INVALID, "gffx_hip_index_create: chr_offsets[0] must be 0");
     const uint32_t R = chr_offsets[n_chr];
+    if (R > kPosMask)
+        return fail(GFFX_E_INVALID, "gffx_hip_index_create: %u roots exceed the engine's limit of %u", R, kPosMask);
     if (R && (!start || !end || !root_fid))
         return fail(GFFX_E_INVALID, "gffx_hip_index_create: NULL interval arrays");
     const int ndev = device_count_quiet();
@@ -144,52 +159,74 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
     GFFX_HIP_TRY(hipSetDevice(device));
 
-    // sort every seqid stably by start (the tree does the same: utils/tree.rs:40), running max of end
-    std::vector<uint4> ent(R);
-    std::vector<uint32_t> order(R);
-    std::iota(order.begin(), order.end(), 0u);
-    std::vector<uint32_t> max_start(n_chr, 0);
+    // Per seqid: stable sort by start (the tree does the same: utils/tree.rs:40), then split into
+    // lists: an interval reaching past the start of its T-th successor moves to the next list
+    // (see gffx_device.hpp).  Every list gets the running max of `end` and a bin directory.
+    const uint32_t T = gffx_decompose_T();
+    const uint32_t kMaxLists = 8;
+    std::vector<uint4> ent;
+    ent.reserve(R);
+    std::vector<uint2> chr_lists(n_chr);
+    std::vector<uint4> list_meta;
+    std::vector<uint2> bins;
+    std::vector<uint32_t> order, cur, next;
     for (uint32_t c = 0; c < n_chr; c++) {
         const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
-        std::stable_sort(order.begin() + lo, order.begin() + hi,
+        order.resize(hi - lo);
+        std::iota(order.begin(), order.end(), lo);
+        std::stable_sort(order.begin(), order.end(),
                          [&](uint32_t a, uint32_t b) { return start[a] < start[b]; });
-        uint32_t pm = 0;
-        for (uint32_t i = lo; i < hi; i++) {
-            const uint32_t j = order[i];
-            pm = std::max(pm, end[j]);
-            ent[i] = make_uint4(start[j], end[j], pm, root_fid[j]);
+        chr_lists[c] = make_uint2((uint32_t)list_meta.size(), 0);
+        cur = order;
+        uint32_t n_l = 0;
+        while (!cur.empty()) {
+            next.clear();
+            std::vector<uint32_t> keep;
+            keep.reserve(cur.size());
+            const bool last = (n_l + 1 == kMaxLists) || cur.size() <= T;
+            for (size_t i = 0; i < cur.size(); i++) {
+                const bool reaches = !last && i + T < cur.size() && end[cur[i]] > start[cur[i + T]];
+                (reaches ? next : keep).push_back(cur[i]);
+            }
+            // emit the list
+            const uint32_t first = (uint32_t)ent.size();
+            uint32_t pm = 0;
+            for (uint32_t j : keep) {
+                pm = std::max(pm, end[j]);
+                ent.push_back(make_uint4(start[j], end[j], pm, root_fid[j]));
+            }
+            const uint32_t endp = (uint32_t)ent.size();
+            if (endp > first) {
+                const uint32_t max_start = ent[endp - 1].x;
+                const uint64_t budget = std::max<uint64_t>(4ull * (endp - first), 64);
+                uint32_t shift = 0;
+                while ((((uint64_t)max_start >> shift) + 1) > budget) shift++;
+                const uint32_t nb = (max_start >> shift) + 1;  // < 2^27 since budget <= 4*2^32/..: checked below
+                if (nb >= (1u << 27)) return fail(GFFX_E_INVALID, "index too large for the bin directory");
+                list_meta.push_back(make_uint4(first, endp, (uint32_t)bins.size(), (shift << kPosBits) | nb));
+                uint32_t p = first;
+                for (uint32_t b = 0; b < nb; b++) {
+                    const uint64_t edge = (uint64_t)b << shift, next_edge = (uint64_t)(b + 1) << shift;
+                    while (p < endp && ent[p].x < edge) p++;
+                    uint32_t q = p;
+                    while (q < endp && ent[q].x < next_edge) q++;
+                    bins.push_back(make_uint2(p | (std::min(q - p, kCntSat) << kPosBits),
+                                              p > first ? ent[p - 1].z : 0u));
+                }
+                // sentinel: nothing starts at or after nb << shift
+                bins.push_back(make_uint2(endp, ent[endp - 1].z));
+                n_l++;
+            }
+            cur.swap(next);
         }
-        if (hi > lo) max_start[c] = ent[hi - 1].x;
-    }
-    // bin directory: smallest shift whose total bin count stays within the budget
-    const uint64_t budget = std::max<uint64_t>(4ull * R, 1ull << 16);
-    uint32_t shift = 0;
-    for (;; shift++) {
-        uint64_t tot = 0;
-        for (uint32_t c = 0; c < n_chr; c++)
-            if (chr_offsets[c + 1] > chr_offsets[c]) tot += ((uint64_t)max_start[c] >> shift) + 2;
-        if (tot <= budget || shift == 31) break;
-    }
-    std::vector<uint4> meta(n_chr);
-    std::vector<uint32_t> bin_hi;
-    for (uint32_t c = 0; c < n_chr; c++) {
-        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
-        const uint32_t nb = hi > lo ? (max_start[c] >> shift) + 1 : 0;
-        meta[c] = make_uint4(lo, hi, (uint32_t)bin_hi.size(), nb);
-        uint32_t p = lo;
-        for (uint32_t b = 0; b < nb; b++) {
-            const uint64_t edge = (uint64_t)b << shift;
-            while (p < hi && ent[p].x < edge) p++;
-            bin_hi.push_back(p);
-        }
-        if (nb) bin_hi.push_back(hi);  // sentinel: nothing starts at or after nb << shift
+        chr_lists[c].y = n_l;
     }
 
     std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
     ix->device = device;
     ix->n_chr = n_chr;
     ix->n_roots = R;
-    ix->shift = shift;
+    ix->n_lists = (uint32_t)list_meta.size();
     ix->h_chr_offsets.assign(chr_offsets, chr_offsets + n_chr + 1);
     ix->h_sorted_fids.resize(R);
     std::vector<uint32_t> s(R), e(R), pm(R);
@@ -202,8 +239,9 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     int rc;
     if ((rc = dev_alloc(&ix->d_ent, R)) || (rc = dev_alloc(&ix->d_start, R)) ||
         (rc = dev_alloc(&ix->d_end, R)) || (rc = dev_alloc(&ix->d_pmax, R)) ||
-        (rc = dev_alloc(&ix->d_fid, R)) || (rc = dev_alloc(&ix->d_chr_meta, n_chr)) ||
-        (rc = dev_alloc(&ix->d_bin_hi, bin_hi.size()))) {
+        (rc = dev_alloc(&ix->d_fid, R)) || (rc = dev_alloc(&ix->d_chr_lists, n_chr)) ||
+        (rc = dev_alloc(&ix->d_list_meta, list_meta.size())) ||
+        (rc = dev_alloc(&ix->d_bins, bins.size()))) {
         gffx_hip_index_destroy(ix.release());
         return rc;
     }
@@ -215,9 +253,12 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         GFFX_HIP_TRY(hipMemcpy(ix->d_fid, ix->h_sorted_fids.data(), R * 4, hipMemcpyHostToDevice));
     }
     if (n_chr)
-        GFFX_HIP_TRY(hipMemcpy(ix->d_chr_meta, meta.data(), n_chr * sizeof(uint4), hipMemcpyHostToDevice));
-    if (!bin_hi.empty())
-        GFFX_HIP_TRY(hipMemcpy(ix->d_bin_hi, bin_hi.data(), bin_hi.size() * 4, hipMemcpyHostToDevice));
+        GFFX_HIP_TRY(hipMemcpy(ix->d_chr_lists, chr_lists.data(), n_chr * sizeof(uint2), hipMemcpyHostToDevice));
+    if (!list_meta.empty())
+        GFFX_HIP_TRY(hipMemcpy(ix->d_list_meta, list_meta.data(), list_meta.size() * sizeof(uint4),
+                               hipMemcpyHostToDevice));
+    if (!bins.empty())
+        GFFX_HIP_TRY(hipMemcpy(ix->d_bins, bins.data(), bins.size() * sizeof(uint2), hipMemcpyHostToDevice));
     *out = ix.release();
     return GFFX_OK;
 }
@@ -230,8 +271,9 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_end);
     (void)hipFree(ix->d_pmax);
     (void)hipFree(ix->d_fid);
-    (void)hipFree(ix->d_chr_meta);
-    (void)hipFree(ix->d_bin_hi);
+    (void)hipFree(ix->d_chr_lists);
+    (void)hipFree(ix->d_list_meta);
+    (void)hipFree(ix->d_bins);
     delete ix;
 }
 
@@ -256,12 +298,14 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
     int rc;
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(GFFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
-    if ((rc = dev_alloc(&b->d_counts, max_queries)) || (rc = dev_alloc(&b->d_block_sums, 4096)) ||
+    if ((rc = dev_alloc(&b->d_counts, max_queries)) || (rc = dev_alloc(&b->d_block_sums, gffx_hip_batch::kMaxBlocks)) ||
         (rc = dev_alloc(&b->d_status, 2))) {
         gffx_hip_batch_destroy(b.release());
         return rc;
     }
-    e = hipHostMalloc((void **)&b->h_status, 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    GFFX_HIP_TRY(hipMemset(b->d_status, 0, 2 * sizeof(unsigned long long)));
+    e = hipHostMalloc((void **)&b->h_status, (1 + gffx_hip_batch::kMaxBlocks) * sizeof(unsigned long long),
+                      hipHostMallocDefault);
     if (e != hipSuccess) {
         gffx_hip_batch_destroy(b.release());
         return fail(GFFX_E_OOM, "hipHostMalloc failed: %s", hipGetErrorString(e));
@@ -398,8 +442,7 @@ static JoinOut make_out(gffx_hip_batch *b) {
     JoinOut o;
     o.counts = b->d_counts;
     o.block_sums = b->d_block_sums;
-    o.total = b->d_status;
-    o.err = reinterpret_cast<uint32_t *>(b->d_status + 1);
+    o.err = reinterpret_cast<uint32_t *>(b->d_status);
     o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
     o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
     o.offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr;
@@ -411,15 +454,21 @@ static JoinOut make_out(gffx_hip_batch *b) {
     return o;
 }
 
-template <int MODE, bool INV, bool AOS>
+static uint32_t meta_bytes(const gffx_hip_index *ix) {
+    return ((ix->n_chr * 8u + 15u) & ~15u) + ix->n_lists * 16u;
+}
+
+template <int MODE, bool INV, bool AOS, bool ML>
 static void launch_count(gffx_hip_batch *b, const JoinOut &o) {
-    hipLaunchKernelGGL((k_join_count<MODE, INV, AOS>), dim3(b->n_blocks), dim3(kJoinThreads), 0,
+    const uint32_t lds = 32 + (ML ? meta_bytes(b->ix) : 0);
+    hipLaunchKernelGGL((k_join_count<MODE, INV, AOS, ML>), dim3(b->n_blocks), dim3(kJoinThreads), lds,
                        b->stream, b->ix->view(), b->q, (unsigned long long)b->nq,
                        (unsigned long long)b->chunk, o);
 }
-template <int MODE, bool INV, bool AOS>
+template <int MODE, bool INV, bool AOS, bool ML>
 static void launch_emit(gffx_hip_batch *b, const JoinOut &o) {
-    hipLaunchKernelGGL((k_join_emit<MODE, INV, AOS>), dim3(b->n_blocks), dim3(kJoinThreads), 0,
+    const uint32_t lds = 48 + (ML ? meta_bytes(b->ix) : 0);
+    hipLaunchKernelGGL((k_join_emit<MODE, INV, AOS, ML>), dim3(b->n_blocks), dim3(kJoinThreads), lds,
                        b->stream, b->ix->view(), b->q, (unsigned long long)b->nq,
                        (unsigned long long)b->chunk, o);
 }
@@ -427,18 +476,21 @@ static void launch_emit(gffx_hip_batch *b, const JoinOut &o) {
 template <bool EMIT>
 static void dispatch(gffx_hip_batch *b, const JoinOut &o) {
     const bool aos = b->q.aos != nullptr;
-#define GFFX_CASE(M, I, A)                                  \
-    if (b->mode == M && (b->invert != 0) == I && aos == A) { \
-        if (EMIT)                                           \
-            launch_emit<M, I, A>(b, o);                     \
-        else                                                \
-            launch_count<M, I, A>(b, o);                    \
-        return;                                             \
+    const bool ml = meta_bytes(b->ix) <= kMetaLdsBytes;
+#define GFFX_CASE2(M, I, A, L)                                          \
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) { \
+        if (EMIT)                                                       \
+            launch_emit<M, I, A, L>(b, o);                              \
+        else                                                            \
+            launch_count<M, I, A, L>(b, o);                             \
+        return;                                                         \
     }
+#define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
     GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
     GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
     GFFX_CASE(2, false, false) GFFX_CASE(2, false, true) GFFX_CASE(2, true, false) GFFX_CASE(2, true, true)
 #undef GFFX_CASE
+#undef GFFX_CASE2
 }
 
 static bool wants_pairs(uint32_t flags) {
@@ -472,7 +524,6 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     b->ran = true;
     b->waited = false;
     b->total = 0;
-    GFFX_HIP_TRY(hipMemsetAsync(b->d_status, 0, 2 * sizeof(unsigned long long), b->stream));
     const uint64_t nq = b->nq;
     int rc;
     if (b->flags & GFFX_OUT_OFFSETS) {
@@ -490,7 +541,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     }
     // contiguous chunk of queries per block, a multiple of the block size; <= 2048 blocks
     const uint64_t tiles = (nq + kJoinThreads - 1) / kJoinThreads;
-    const uint64_t max_blocks = 2048;
+    const uint64_t max_blocks = gffx_hip_batch::kMaxBlocks;
     const uint64_t tiles_per_block = (tiles + max_blocks - 1) / max_blocks;
     b->chunk = tiles_per_block * kJoinThreads;
     b->n_blocks = (uint32_t)((nq + b->chunk - 1) / b->chunk);
@@ -510,8 +561,8 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         GFFX_HIP_TRY(hipGetLastError());
     }
     if (wants_pairs(b->flags) && (rc = enqueue_emit(b))) return rc;
-    GFFX_HIP_TRY(hipMemcpyAsync(b->h_status, b->d_status, 2 * sizeof(unsigned long long),
-                                hipMemcpyDeviceToHost, b->stream));
+    // nothing else is enqueued per pass: the error word and the block sums are read back by
+    // _wait (blit copies and fills are ~3-5 us kernels of their own, a third of a 1 M-region pass)
     return GFFX_OK;
 }
 
@@ -533,11 +584,18 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         b->waited = true;
         return GFFX_OK;
     }
-    if (b->h_status[1] & 1ull)
+    GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    GFFX_HIP_TRY(hipMemcpy(b->h_status + 1, b->d_block_sums, b->n_blocks * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost));
+    if (b->h_status[0] & 1ull) {
+        // the flag is sticky on the device (kernels only ever set it): clear it for the next pass
+        GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
         return fail(GFFX_E_CHR_RANGE, "a query's chr is >= the index's seqid count %u "
                                       "(the reference panics here: commands/intersect.rs:117)",
                     b->ix->n_chr);
-    b->total = b->h_status[0];
+    }
+    b->total = 0;
+    for (uint32_t i = 0; i < b->n_blocks; i++) b->total += b->h_status[1 + i];
     bool replay = false;
     if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < b->total) {
         if ((rc = grow(&b->d_fids, &b->cap_fids, b->total + b->total / 8, 1))) return rc;

@@ -209,8 +209,8 @@ def query_features(index_data: TreeIndexData, regions, mode: int = OverlapMode.O
                    invert: bool = False, verbose: bool = False) -> np.ndarray:
     """commands/intersect.rs:105-169: (root_fid, iv.start, iv.end) per kept (region, root) pair.
 
-    Returns an (n,3) u32 array.  Pair order: regions in input order, ascending iv.start inside a
-    region (the reference's order is an FxHashMap walk, i.e. unspecified).  Raises GffxHipError
+    Returns an (n,3) u32 array.  Pair order: regions in input order, unspecified inside a region
+    (the reference's order is an FxHashMap walk plus a tree DFS, i.e. unspecified as well).  Raises GffxHipError
     (GFFX_E_CHR_RANGE) where the reference panics on an out-of-range chr.
     """
     r = _u32(regions).reshape(-1, 3)

@@ -21,8 +21,9 @@
  *   (strict, half-open; u32 compares; q.start >= q.end rows are legal and evaluated as-is);
  *   keep = mode predicate(iv, q);  a (query, root) pair is emitted iff  invert ^ keep.
  * Output order: pairs are grouped per query in INPUT order (CSR: offset[i] = sum of counts
- * of queries < i), ascending iv.start inside a query.  The reference's own order is that of
- * an FxHashMap walk and is unspecified; the multiset of pairs is the contract.
+ * of queries < i); inside a query the order is deterministic but unspecified (index list by
+ * list, descending iv.start inside a list).  The reference's own order is that of an FxHashMap
+ * walk plus a tree DFS and is unspecified as well; the multiset of pairs is the contract.
  *
  * Threading: an index is immutable after creation and may be shared by threads; a batch owns
  * one HIP stream plus its buffers and must not be used from two threads at once.

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd database (…_results.db) as text: per-kernel duration statistics
+(the `--kernel-trace --stats` view) and, when the run collected PMC counters, the per-kernel
+average of every counter.  Used to produce the files committed under profiles/.
+
+    python tools/rocpd_summary.py gpurun_out/prof/run_results.db > profiles/r01_xyz.txt
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    print("# source: %s" % path)
+    rows = cur.execute(
+        "select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
+        "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(scratch_size), "
+        "max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    print("## kernel trace stats (durations in us)")
+    print("%-8s %10s %9s %9s %9s %6s | %4s %4s %4s %6s %7s | %9s %5s | %s" % (
+        "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "vgpr", "agpr", "sgpr", "lds", "scratch", "grid_x", "wg_x", "kernel"))
+    for r in rows:
+        name, n, s, a, mn, mx, vg, ag, sg, lds, scr, gx, wx = r
+        print("%-8d %10.1f %9.2f %9.2f %9.2f %6.2f | %4s %4s %4s %6s %7s | %9s %5s | %s" % (
+            n, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot, vg, ag, sg, lds, scr, gx, wx, name))
+    try:
+        prow = cur.execute(
+            "select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+            "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
+    except sqlite3.Error:
+        prow = []
+    if prow:
+        print("\n## PMC counters (per dispatch average; summed over all instances of the counter's block)")
+        last = None
+        for k, c, n, a, s in prow:
+            if k != last:
+                print("\n%s" % k)
+                last = k
+            print("    %-40s dispatches=%-5d avg=%.1f" % (c, n, a))
+    try:
+        mc = cur.execute("select count(*), sum(size), avg(duration) from memory_copies").fetchone()
+        if mc and mc[0]:
+            print("\n## memory copies: n=%d bytes=%s avg_us=%.2f" % (mc[0], mc[1], (mc[2] or 0) / 1e3))
+    except sqlite3.Error:
+        pass
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
