@@ -1,0 +1,102 @@
+"""Chromosome-bucket sharding + the hit-count all-gather, on CPU (gloo, world size 2).
+
+The device join is replaced by the oracle here (tests may use it): what is under test is the
+N>1 plumbing -- the plan is a partition of the batch, every rank derives the same plan, and the
+all-gathered per-rank (regions, pairs) add up to the single-process answer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from gffx_amd import shard, synth
+
+
+def test_plan_is_a_balanced_partition():
+    rng = np.random.default_rng(0)
+    for n_ranks in (1, 2, 3, 4, 8):
+        for trial in range(20):
+            sizes = rng.integers(0, 5000, size=int(rng.integers(1, 40))).tolist()
+            if trial == 0:
+                sizes = [100000] + [10] * 5  # one dominant bucket must be split
+            plan = shard.plan_shards(sizes, n_ranks)
+            seen = [np.zeros(s, dtype=np.int32) for s in sizes]
+            loads = []
+            for r in range(n_ranks):
+                load = 0
+                for c, lo, hi in plan[r]:
+                    assert 0 <= lo < hi <= sizes[c]
+                    seen[c][lo:hi] += 1
+                    load += hi - lo
+                loads.append(load)
+            assert all((s == 1).all() for s in seen), "every row exactly once"
+            total = sum(sizes)
+            if total:
+                ideal = -(-total // n_ranks)
+                assert max(loads) <= ideal + max(1, int(0.02 * ideal)) + max(sizes) * (n_ranks == 1) or \
+                    max(loads) <= 1.25 * ideal + 64, (sizes, loads)
+            assert shard.plan_shards(sizes, n_ranks) == plan  # deterministic
+
+
+def test_grch38_like_batch_is_near_perfectly_balanced():
+    regions = synth.synth_bed(200_000, seed=5)
+    for n in (2, 4, 8):
+        rows = [shard.shard_rows(regions, 25, n, r) for r in range(n)]
+        allrows = np.concatenate(rows)
+        assert len(allrows) == len(regions) and len(np.unique(allrows)) == len(regions)
+        sizes = [len(r) for r in rows]
+        assert max(sizes) <= 1.03 * len(regions) / n
+    with pytest.raises(IndexError):
+        shard.bucket_regions(np.array([[30, 1, 2]], np.uint32), 25)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from oracle import binding as ob
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    roots = synth.gencode_like_roots(3000, seed=4)
+    regions = synth.synth_bed(40_000, seed=6, edge_frac=0.01, roots=roots)
+    rows = shard.shard_rows(regions, 25, world, rank)
+    oix = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    t, c = oix.query_features(regions[rows], 2, False)
+    got = shard.allgather_hit_counts(len(rows), len(t))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, got.tolist(), len(rows), len(t)))
+
+
+def test_two_rank_gloo_allgather_matches_single_process():
+    import torch.multiprocessing as mp
+
+    from oracle import binding as ob
+
+    ob.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][1] == res[1][1]  # every rank sees the same gathered table
+    table = np.array(res[0][1])
+    assert table[0].tolist() == [res[0][2], res[0][3]] and table[1].tolist() == [res[1][2], res[1][3]]
+    roots = synth.gencode_like_roots(3000, seed=4)
+    regions = synth.synth_bed(40_000, seed=6, edge_frac=0.01, roots=roots)
+    oix = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    t, _ = oix.query_features(regions, 2, False)
+    assert table[:, 0].sum() == len(regions) and table[:, 1].sum() == len(t)

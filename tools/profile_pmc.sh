@@ -2,7 +2,8 @@
 # Collect rocprofv3 evidence for bench.py on the GPU box (run through gpurun from the repo root):
 #   tools/profile_pmc.sh <tag> [bench.py args...]
 # Writes text summaries gpurun_out/<tag>_kernel_stats.txt and gpurun_out/<tag>_pmc.txt.
-# Counter passes are separate runs with --kernel-trace only (never combined with other traces).
+# Every rocprofv3 call sits under `timeout`: a TA_* counter set once aborted the profiler and hung
+# the box for the whole gpurun limit.  Counter passes are separate runs with --kernel-trace only (never combined with other traces).
 set -u
 TAG=$1; shift
 ARGS="--steps 20 --warmup 3 --no-cpu-baseline $*"
@@ -11,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
 python3 tools/rocpd_summary.py $OUT/trace/run_results.db > $R/gpurun_out/${TAG}_kernel_stats.txt 2>&1
 i=0
 for SET in \
@@ -21,10 +22,9 @@ for SET in \
   "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" \
   "FETCH_SIZE" \
-  "WRITE_SIZE" \
-  "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" ; do
+  "WRITE_SIZE" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$i -o run -- python3 bench.py $ARGS > $OUT/pmc$i.log 2>&1
+  timeout 180 rocprofv3 --kernel-trace --pmc $SET -d $OUT/pmc$i -o run -- python3 bench.py $ARGS > $OUT/pmc$i.log 2>&1
   python3 tools/rocpd_summary.py $OUT/pmc$i/run_results.db 2>&1 | sed -n '/PMC counters/,$p' > $OUT/pmc$i.txt
 done
 cat $OUT/pmc*.txt > $R/gpurun_out/${TAG}_pmc.txt
