@@ -724,16 +724,3 @@ extern "C" int gffx_hip_query_features(const gffx_hip_index *ix, const uint32_t 
     *n_triples = n;
     return GFFX_OK;
 }
-
-// ------------------------------------------------------------------------------------ Join B (placeholder until the device kernel lands)
-
-extern "C" int gffx_hip_lines_create(int, uint64_t, const uint32_t *, const uint32_t *,
-                                     const uint32_t *, gffx_hip_lines **out) {
-    if (out) *out = nullptr;
-    return fail(GFFX_E_STATE, "gffx_hip_lines_create: Join B is not built into this library yet");
-}
-extern "C" void gffx_hip_lines_destroy(gffx_hip_lines *) {}
-extern "C" int gffx_hip_lines_test(gffx_hip_lines *, const uint32_t *, uint64_t, uint32_t, int,
-                                   uint8_t *) {
-    return fail(GFFX_E_STATE, "gffx_hip_lines_test: Join B is not built into this library yet");
-}

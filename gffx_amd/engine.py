@@ -205,6 +205,41 @@ class QueryBatch:
         return ms.value, n.value
 
 
+class LineTable:
+    """(seqid number, raw column-4 start, raw column-5 end) of GFF lines, resident in HBM.
+
+    ``test(regions, n_seq, mode)`` is the numeric core of gff_line_overlaps_queries
+    (commands/intersect.rs:500-521) for every line at once: one bool per line."""
+
+    NO_SEQ = 0xFFFFFFFF
+
+    def __init__(self, seq, start, end, device: int = 0):
+        q, s, e = _u32(seq), _u32(start), _u32(end)
+        if not (len(q) == len(s) == len(e)):
+            raise ValueError("seq/start/end must have the same length")
+        self.n = len(q)
+        self._h = C.c_void_p()
+        check(lib().gffx_hip_lines_create(device, self.n, _p(q), _p(s), _p(e), C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().gffx_hip_lines_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def test(self, regions, n_seq: int, mode: int = OverlapMode.Overlap) -> np.ndarray:
+        r = _u32(regions).reshape(-1, 3)
+        keep = np.zeros(max(self.n, 1), dtype=np.uint8)
+        check(lib().gffx_hip_lines_test(self._h, _p(r), r.shape[0], int(n_seq), int(mode),
+                                        keep.ctypes.data_as(_ffi.u8p)))
+        return keep[: self.n].astype(bool)
+
+
 def query_features(index_data: TreeIndexData, regions, mode: int = OverlapMode.Overlap,
                    invert: bool = False, verbose: bool = False) -> np.ndarray:
     """commands/intersect.rs:105-169: (root_fid, iv.start, iv.end) per kept (region, root) pair.
