@@ -1,0 +1,132 @@
+// capi.cpp -- extern "C" shims of include/gffx_host.h over the C++ host side.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#include "../../../include/gffx_host.h"
+#include "gffx.hpp"
+
+using namespace gffx;
+
+namespace {
+int guard(char *err, size_t errlen, const std::function<void()> &f) {
+    try {
+        f();
+        return 0;
+    } catch (const std::exception &e) {
+        if (err && errlen) {
+            std::strncpy(err, e.what(), errlen - 1);
+            err[errlen - 1] = 0;
+        }
+        return -1;
+    }
+}
+template <typename T>
+T *dup_vec(const std::vector<T> &v) {
+    T *p = static_cast<T *>(std::malloc(std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+}  // namespace
+
+extern "C" int gffx_host_build_index(const char *gff, const char *attr_key, const char *skip_types, int verbose,
+                                     char *err, size_t errlen) {
+    return guard(err, errlen, [&] { build_index(gff, attr_key, skip_types, verbose != 0); });
+}
+
+extern "C" int gffx_host_load_tree_index(const char *gff, uint32_t *n_chr, uint32_t **chr_offsets,
+                                         uint32_t **start, uint32_t **end, uint32_t **root_fid, char **names,
+                                         char *err, size_t errlen) {
+    return guard(err, errlen, [&] {
+        TreeIndexData t = TreeIndexData::load_tree_index(gff);
+        *n_chr = static_cast<uint32_t>(t.chr_offsets.size() - 1);
+        *chr_offsets = dup_vec(t.chr_offsets);
+        *start = dup_vec(t.start);
+        *end = dup_vec(t.end);
+        *root_fid = dup_vec(t.root_fid);
+        std::string joined;
+        for (size_t i = 0; i < t.num_to_seqid.size(); ++i) {
+            if (i) joined.push_back('\n');
+            joined += t.num_to_seqid[i];
+        }
+        *names = static_cast<char *>(std::malloc(joined.size() + 1));
+        std::memcpy(*names, joined.c_str(), joined.size() + 1);
+    });
+}
+
+extern "C" int gffx_host_parse_bed_file(const char *gff, const char *bed, uint32_t **regions,
+                                        uint64_t *n_regions, char *err, size_t errlen) {
+    return guard(err, errlen, [&] {
+        const auto sqs = index_loader::load_sqs(gff);
+        const auto r = commands::intersect::parse_bed_file(bed, sqs.second);
+        std::vector<uint32_t> flat;
+        flat.reserve(r.size() * 3);
+        for (const auto &[c, s, e] : r) {
+            flat.push_back(c);
+            flat.push_back(s);
+            flat.push_back(e);
+        }
+        *regions = dup_vec(flat);
+        *n_regions = r.size();
+    });
+}
+
+extern "C" int gffx_host_parse_region(const char *gff, const char *region, uint32_t out[3], char *err,
+                                      size_t errlen) {
+    return guard(err, errlen, [&] {
+        const auto sqs = index_loader::load_sqs(gff);
+        CommonArgs c;
+        const auto [chr, s, e] = commands::intersect::parse_region(region, sqs.second, c);
+        out[0] = chr;
+        out[1] = s;
+        out[2] = e;
+    });
+}
+
+extern "C" int gffx_host_roots_to_offsets(const char *gff, const uint32_t *roots, uint64_t n, uint64_t *offsets,
+                                          char *err, size_t errlen) {
+    return guard(err, errlen, [&] {
+        const index_loader::GofMap gof = index_loader::load_gof(gff);
+        const auto blocks = gof.roots_to_offsets(std::vector<uint32_t>(roots, roots + n), 1);
+        for (uint64_t i = 0; i < n; ++i) {
+            offsets[2 * i] = std::get<1>(blocks[i]);
+            offsets[2 * i + 1] = std::get<2>(blocks[i]);
+        }
+    });
+}
+
+extern "C" int gffx_host_write_gff_output(const char *gff, const uint64_t *blocks, uint64_t n,
+                                          const char *out_path, char *err, size_t errlen) {
+    return guard(err, errlen, [&] {
+        std::vector<Block> b;
+        for (uint64_t i = 0; i < n; ++i)
+            b.emplace_back(static_cast<uint32_t>(blocks[3 * i]), blocks[3 * i + 1], blocks[3 * i + 2]);
+        write_gff_output(gff, b, std::string(out_path), false);
+    });
+}
+
+extern "C" int gffx_host_gff_type_allowed(const char *line, size_t len, const char *types) {
+    std::vector<std::string> allow;
+    const std::string t = types;
+    size_t a = 0;
+    while (true) {
+        const size_t c = t.find(',', a);
+        const std::string_view x =
+            trim_unicode_ws(std::string_view(t).substr(a, c == std::string::npos ? std::string::npos : c - a));
+        if (!x.empty()) allow.emplace_back(x);
+        if (c == std::string::npos) break;
+        a = c + 1;
+    }
+    return commands::intersect::gff_type_allowed(std::string_view(line, len), allow) ? 1 : 0;
+}
+
+extern "C" int gffx_host_split_line(const char *line, size_t len, size_t *seq_len, uint32_t *start, uint32_t *end) {
+    std::string_view seq;
+    if (!commands::intersect::split_line_for_join_b(std::string_view(line, len), seq, *start, *end)) return 0;
+    *seq_len = seq.size();
+    return 1;
+}
+
+extern "C" int gffx_host_cli(int argc, char **argv) { return cli_main(argc, argv); }
+extern "C" void gffx_host_free(void *p) { std::free(p); }

@@ -1,0 +1,151 @@
+// gffx.hpp -- host side of the `gffx intersect` path above the C-ABI, mirroring the reference's
+// module layout and names (Baohua-Chen/GFFx v0.4.0; file:line relative to its src/):
+//   gffx::CommonArgs, append_suffix, check_index_files_exist, write_gff_output   utils/common.rs
+//   gffx::build_index                                                            index_builder/core.rs
+//   gffx::index_loader::{load_sqs, GofMap, load_gof}                             index_loader/{core,gof}.rs
+//   gffx::TreeIndexData                                                          utils/tree_index.rs
+//   gffx::commands::intersect::{OverlapMode, IntersectArgs, parse_region, parse_bed_file,
+//        query_features, gff_type_allowed, write_gff_match_only_by_coords, run}  commands/intersect.rs
+// Compute (Join A, Join B) goes through include/gffx_hip.h only; there is no CPU join here.
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <string>
+#include <string_view>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/gffx_hip.h"
+#include "text.hpp"
+
+namespace gffx {
+
+constexpr uint64_t MISSING = UINT64_MAX;  // index_loader/gof.rs:7, commands/intersect.rs:18
+
+// ---- utils/common.rs -------------------------------------------------------------------------
+struct CommonArgs {  // common.rs:17-52
+    std::string input;                  // -i/--input
+    std::optional<std::string> output;  // -o/--output
+    bool entire_group = false;          // -e/--entire_group (underscore, common.rs:28)
+    std::optional<std::string> types;   // -T/--types
+    size_t threads = 12;                // -t/--threads
+    bool verbose = false;               // -v/--verbose
+    size_t effective_threads() const;   // common.rs:59-67
+};
+
+std::string append_suffix(const std::string &path, const std::string &suffix);  // common.rs:123-127
+bool check_index_files_exist(const std::string &gff);                           // common.rs:151-170
+
+using Block = std::tuple<uint32_t, uint64_t, uint64_t>;  // (root fid, start offset, end offset)
+
+// common.rs:188-287: drop sentinel blocks, sort, merge touching/overlapping, copy out.
+void write_gff_output(const std::string &gff_path, const std::vector<Block> &blocks,
+                      const std::optional<std::string> &output_path, bool verbose);
+
+// ---- index_builder/core.rs ---------------------------------------------------------------------
+// core.rs:41-242: one pass over the GFF -> <gff>.{fts,prt,a2f,atn,sqs,gof,rit,rix}
+void build_index(const std::string &gff, const std::string &attr_key, const std::string &skip_types,
+                 bool verbose);
+
+// ---- index_loader ------------------------------------------------------------------------------
+namespace index_loader {
+
+// core.rs:19-34: (id -> name, name -> id; a later duplicate name wins)
+std::pair<std::vector<std::string>, std::unordered_map<std::string, uint32_t>> load_sqs(const std::string &gff);
+
+struct GofEntry {  // gof.rs:10-15
+    uint32_t feature_id, seqid_num;
+    uint64_t start_offset, end_offset;
+};
+
+class GofMap {  // gof.rs:20-93
+  public:
+    std::vector<GofEntry> entries;
+    const std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> &index_cached() const;
+    std::vector<Block> roots_to_offsets(const std::vector<uint32_t> &roots, size_t threads) const;  // gof.rs:54-84
+
+  private:
+    mutable std::unordered_map<uint32_t, std::pair<uint64_t, uint64_t>> cache_;
+    mutable bool cached_ = false;
+};
+
+GofMap load_gof(const std::string &gff);  // gof.rs:95-128
+
+}  // namespace index_loader
+
+// ---- utils/tree_index.rs -------------------------------------------------------------------------
+// chr_entries (the per-seqid interval trees, tree_index.rs:13) live on the device as a
+// gffx_hip_index; the host keeps the flat interval arrays they were built from.
+struct TreeIndexData {
+    std::unordered_map<std::string, uint32_t> seqid_to_num;
+    std::vector<std::string> num_to_seqid;
+    std::vector<uint32_t> chr_offsets, start, end, root_fid;  // builder order inside a seqid
+    gffx_hip_index *device_index = nullptr;                   // created lazily by ensure_device()
+
+    TreeIndexData() = default;
+    TreeIndexData(const TreeIndexData &) = delete;
+    TreeIndexData &operator=(const TreeIndexData &) = delete;
+    TreeIndexData(TreeIndexData &&o) noexcept;
+    ~TreeIndexData();
+
+    // tree_index.rs:21-34.  The interval lists are rebuilt from .gof + the root lines of the
+    // GFF (1:1 with the builder's tree inputs, core.rs:170-186); .rit is not needed.
+    static TreeIndexData load_tree_index(const std::string &gff);
+    void ensure_device(int device);  // throws Error (incl. "no HIP device")
+};
+
+// ---- commands/intersect.rs -----------------------------------------------------------------------
+namespace commands {
+namespace intersect {
+
+enum class OverlapMode { Contained = 0, ContainsRegion = 1, Overlap = 2 };  // intersect.rs:73-78
+
+struct IntersectArgs {  // intersect.rs:43-70
+    CommonArgs common;
+    std::optional<std::string> region;  // -r/--region
+    std::optional<std::string> bed;     // -b/--bed
+    bool contained = false;             // -c/--contained
+    bool contains_region = false;       // -C/--contains-region
+    bool overlap = false;               // -O/--overlap
+    bool invert = false;                // -I/--invert
+    int device = 0;                     // --device (addition: which MI355X)
+};
+
+using Region = std::tuple<uint32_t, uint32_t, uint32_t>;  // (chr, start, end)
+
+Region parse_region(const std::string &region, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                    const CommonArgs &common);  // intersect.rs:172-198
+std::vector<Region> parse_bed_file(const std::string &bed_path,
+                                   const std::unordered_map<std::string, uint32_t> &seqid_map);  // :201-230
+
+// intersect.rs:105-169 on the device: one (root_fid, iv.start, iv.end) per kept pair.
+std::vector<Region> query_features(TreeIndexData &index_data, const std::vector<Region> &regions,
+                                   OverlapMode mode, bool invert, bool verbose, int device = 0);
+// What run() needs from Join A: the unique root fids (intersect.rs:598-615), via the root bitmap.
+std::vector<uint32_t> query_unique_roots(TreeIndexData &index_data, const std::vector<Region> &regions,
+                                         OverlapMode mode, bool invert, bool verbose, int device = 0);
+
+bool gff_type_allowed(std::string_view line, const std::vector<std::string> &allow);  // :80-102
+
+// The columns Join B needs from one raw line (no trailing '\n'): seqid text + raw start/end
+// (intersect.rs:446-494).  Returns false where the reference's function returns false early.
+bool split_line_for_join_b(std::string_view line, std::string_view &seq, uint32_t &start, uint32_t &end);
+
+// intersect.rs:232-438: per hit block, per line: type filter, Join B on the device, copy out
+// the kept lines in file order.
+void write_gff_match_only_by_coords(const std::string &gff_path, const std::vector<Block> &blocks,
+                                    const std::vector<Region> &regions, const std::vector<std::string> &num_to_seqid,
+                                    const std::optional<std::string> &types_filter,
+                                    const std::optional<std::string> &output_path, OverlapMode mode, bool verbose,
+                                    size_t threads, int device);
+
+void run(const IntersectArgs &args);  // intersect.rs:541-655
+
+}  // namespace intersect
+}  // namespace commands
+
+// main.rs: `gffx <index|intersect> ...`; returns the process exit code
+int cli_main(int argc, char **argv);
+
+}  // namespace gffx

@@ -1,0 +1,44 @@
+/*
+ * gffx_host.h -- C shims over the C++ host side (gffx_amd/csrc/host) so that the host logic of
+ * the intersect path -- index building, side-car loading, BED/region parsing, block lookup, the
+ * entire-group writer -- can be exercised without a GPU (tests/test_host_cpu.py).  None of these
+ * touch the device; the joins live behind include/gffx_hip.h.
+ * Every function returns 0, or -1 with a message in err (the text `gffx` prints after "Error: ").
+ * Arrays returned through pointers are malloc'd; release them with gffx_host_free.
+ */
+#ifndef GFFX_HOST_H
+#define GFFX_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* index_builder/core.rs:41-242 */
+int gffx_host_build_index(const char *gff, const char *attr_key, const char *skip_types, int verbose,
+                          char *err, size_t errlen);
+/* utils/tree_index.rs:21-34: names = '\n'-joined seqid names; interval arrays in builder order */
+int gffx_host_load_tree_index(const char *gff, uint32_t *n_chr, uint32_t **chr_offsets, uint32_t **start,
+                              uint32_t **end, uint32_t **root_fid, char **names, char *err, size_t errlen);
+/* commands/intersect.rs:201-230 / :172-198 (the seqid map comes from <gff>.sqs) */
+int gffx_host_parse_bed_file(const char *gff, const char *bed, uint32_t **regions, uint64_t *n_regions,
+                             char *err, size_t errlen);
+int gffx_host_parse_region(const char *gff, const char *region, uint32_t out[3], char *err, size_t errlen);
+/* index_loader/gof.rs:54-128: offsets[2*i], offsets[2*i+1] = block of roots[i] (UINT64_MAX = missing) */
+int gffx_host_roots_to_offsets(const char *gff, const uint32_t *roots, uint64_t n, uint64_t *offsets,
+                               char *err, size_t errlen);
+/* utils/common.rs:188-287: blocks = n x (fid, start, end) as u64 triples */
+int gffx_host_write_gff_output(const char *gff, const uint64_t *blocks, uint64_t n, const char *out_path,
+                               char *err, size_t errlen);
+/* commands/intersect.rs:80-102 with types = comma list; returns 0/1 */
+int gffx_host_gff_type_allowed(const char *line, size_t len, const char *types);
+/* commands/intersect.rs:446-494: returns 1 and fills seq offsets/len + raw start/end, else 0 */
+int gffx_host_split_line(const char *line, size_t len, size_t *seq_len, uint32_t *start, uint32_t *end);
+/* the `gffx` command line in-process (main.rs); returns the exit code */
+int gffx_host_cli(int argc, char **argv);
+void gffx_host_free(void *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

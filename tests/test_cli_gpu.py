@@ -1,0 +1,104 @@
+"""End-to-end `gffx intersect` on the GPU box: output bytes == the oracle's restatement of
+commands/intersect.rs::run, for the hand-derived table and for every mode x invert x -e x -T
+combination on synthetic GFFs with the quirks the reference has to survive."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from gffx_amd import synth
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GFFX = os.path.join(ROOT, "gffx_amd", "bin", "gffx")
+MODES = {"contained": 0, "contains_region": 1, "overlap": 2}
+MODE_FLAG = {"contained": "-c", "contains_region": "-C", "overlap": "-O"}
+
+
+def _cli(gff, args, out=None):
+    cmd = [GFFX, "intersect", "-i", gff]
+    if "region" in args:
+        cmd += ["-r", args["region"]]
+    if "bed" in args:
+        cmd += ["-b", args["bed"]]
+    if args.get("mode"):
+        cmd.append(MODE_FLAG[args["mode"]])
+    if args.get("invert"):
+        cmd.append("-I")
+    if args.get("entire_group"):
+        cmd.append("-e")
+    if args.get("types") is not None:
+        cmd += ["-T", args["types"]]
+    if out:
+        cmd += ["-o", out]
+    return subprocess.run(cmd, capture_output=True)
+
+
+def test_appendix_e_known_answers_through_the_cli(tmp_path, golden_dir):
+    fx = json.load(open(os.path.join(golden_dir, "appendix_e.json")))
+    gff = str(tmp_path / "t.gff")
+    shutil.copy(os.path.join(golden_dir, fx["gff"]), gff)
+    shutil.copy(os.path.join(golden_dir, "appendix_e.bed"), tmp_path / "appendix_e.bed")
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    data = open(gff, "rb").read()
+    by_key = {k: l + b"\n" for k, l in zip(fx["line_order"], data.split(b"\n")[:-1])}
+    for case in fx["cases"]:
+        a = dict(case["args"])
+        if "bed" in a:
+            a["bed"] = str(tmp_path / a["bed"])
+        r = _cli(gff, a)
+        if "error" in case:
+            assert r.returncode == case["exit"] and r.stderr.decode() == "Error: %s\n" % case["error"], case
+        else:
+            assert r.returncode == 0, (case, r.stderr)
+            assert r.stdout == b"".join(by_key[k] for k in case["stdout"]), case
+
+
+@pytest.mark.parametrize("seed,crlf", [(11, False), (12, True)])
+def test_all_flag_combinations_equal_the_oracle(tmp_path, seed, crlf):
+    roots = synth.gencode_like_roots(400, seed=seed, chroms=synth.SMALL2)
+    gff = str(tmp_path / "s.gff")
+    synth.write_gff3(gff, roots, seed=seed, quirks=True, crlf=crlf)
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    bed = str(tmp_path / "q.bed")
+    rows = synth.synth_bed(120, seed=seed + 1, chroms=synth.SMALL2, width=(20, 40000), edge_frac=0.25, roots=roots)
+    synth.write_bed(bed, rows, ["chr1", "chr2"], extra_lines=["# header\n", "chrUn\t1\t2\n"])
+    want_p, got_p = str(tmp_path / "want.gff"), str(tmp_path / "got.gff")
+    n_nonempty = 0
+    for mode in MODES:
+        for invert in (False, True):
+            for eg in (False, True):
+                for types in (None, "exon", "gene, CDS,,nonexistent"):
+                    rc, msg = ob.intersect_run(gff, want_p, bed=bed, mode=MODES[mode], invert=invert,
+                                               entire_group=eg, types=types)
+                    assert rc == 0, msg
+                    r = _cli(gff, dict(bed=bed, mode=mode, invert=invert, entire_group=eg, types=types), out=got_p)
+                    assert r.returncode == 0, r.stderr
+                    want = open(want_p, "rb").read()
+                    assert open(got_p, "rb").read() == want, (mode, invert, eg, types)
+                    n_nonempty += bool(want)
+    assert n_nonempty >= 12
+    # stdout path and the single-region form
+    rc, _ = ob.intersect_run(gff, want_p, region="chr1:100000-900000", mode=2)
+    r = _cli(gff, dict(region="chr1:100000-900000"))
+    assert rc == 0 and r.returncode == 0 and r.stdout == open(want_p, "rb").read() and r.stdout
+
+
+def test_config1_10k_feature_gff_region_query(tmp_path):
+    """BASELINE configs[0]: `gffx intersect --region chr1:1000000-2000000` on a ~10 k-feature GFF3."""
+    roots = synth.gencode_like_roots(600, seed=1, chroms=synth.SMALL2)
+    gff = str(tmp_path / "c1.gff")
+    n = synth.write_gff3(gff, roots, seed=1, tx_per_gene=2.5, exons_per_tx=3.0)
+    assert 8000 < n < 14000
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    want_p = str(tmp_path / "want.gff")
+    for eg in (False, True):
+        rc, msg = ob.intersect_run(gff, want_p, region="chr1:1000000-2000000", mode=2, entire_group=eg)
+        assert rc == 0, msg
+        r = _cli(gff, dict(region="chr1:1000000-2000000", entire_group=eg))
+        assert r.returncode == 0 and r.stdout == open(want_p, "rb").read() and len(r.stdout) > 1000

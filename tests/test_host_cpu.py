@@ -1,0 +1,219 @@
+"""Host logic of the intersect path (C++ above the C-ABI) against the oracle, on CPU:
+index building (side-car bytes), loaders, BED/region parsing, block lookup, the -e writer, the
+line splitter / type filter, and the command line's usage/error behaviour.  No join runs here."""
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from gffx_amd import synth
+from oracle import binding as ob
+from oracle import gffx_oracle_py as op
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GFFX = os.path.join(ROOT, "gffx_amd", "bin", "gffx")
+SUFFIXES = [".fts", ".prt", ".a2f", ".atn", ".sqs", ".gof", ".rit", ".rix"]
+u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def host():
+    L = C.CDLL(os.path.join(ROOT, "gffx_amd", "lib", "libgffx_host.so"))
+    L.gffx_host_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.gffx_host_load_tree_index.argtypes = [C.c_char_p, u32p, C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u32p),
+                                            C.POINTER(u32p), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    L.gffx_host_parse_bed_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(u32p), u64p, C.c_char_p, C.c_size_t]
+    L.gffx_host_parse_region.argtypes = [C.c_char_p, C.c_char_p, u32p, C.c_char_p, C.c_size_t]
+    L.gffx_host_roots_to_offsets.argtypes = [C.c_char_p, u32p, C.c_uint64, u64p, C.c_char_p, C.c_size_t]
+    L.gffx_host_write_gff_output.argtypes = [C.c_char_p, u64p, C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.gffx_host_gff_type_allowed.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    L.gffx_host_split_line.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t), u32p, u32p]
+    L.gffx_host_free.argtypes = [C.c_void_p]
+    return L
+
+
+def _err():
+    return C.create_string_buffer(2048)
+
+
+def _build(host, path, attr="gene_name", skip=ob.DEFAULT_SKIP):
+    e = _err()
+    rc = host.gffx_host_build_index(path.encode(), attr.encode(), skip.encode(), 0, e, len(e))
+    return rc, e.value.decode()
+
+
+def _sidecars(path):
+    return {s: open(path + s, "rb").read() for s in SUFFIXES}
+
+
+def _make_gff(tmp_path, seed, crlf=False, name="s.gff"):
+    roots = synth.gencode_like_roots(150, seed=seed, chroms=synth.SMALL2)
+    gff = str(tmp_path / name)
+    synth.write_gff3(gff, roots, seed=seed, quirks=True, crlf=crlf)
+    return gff, roots
+
+
+@pytest.mark.parametrize("seed,crlf", [(1, False), (2, True)])
+def test_build_index_bytes_equal_the_oracle(host, tmp_path, seed, crlf):
+    gff, _ = _make_gff(tmp_path, seed, crlf)
+    ob.build_index(gff)
+    want = _sidecars(gff)
+    for s in SUFFIXES:
+        os.remove(gff + s)
+    rc, msg = _build(host, gff)
+    assert rc == 0, msg
+    got = _sidecars(gff)
+    for s in SUFFIXES:
+        assert got[s] == want[s], s
+    # and through the command line (-a / -s given explicitly)
+    for s in SUFFIXES:
+        os.remove(gff + s)
+    r = subprocess.run([GFFX, "index", "-i", gff, "-a", "gene_name", "--skip-types", ob.DEFAULT_SKIP],
+                       capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert _sidecars(gff) == want
+
+
+def test_build_index_appendix_e_and_errors(host, tmp_path, golden_dir):
+    fx = json.load(open(os.path.join(golden_dir, "appendix_e.json")))
+    gff = str(tmp_path / "t.gff")
+    shutil.copy(os.path.join(golden_dir, fx["gff"]), gff)
+    assert _build(host, gff)[0] == 0
+    assert np.fromfile(gff + ".prt", "<u4").tolist() == fx["index"]["prt"]
+    assert np.fromfile(gff + ".a2f", "<u4").tolist() == fx["index"]["a2f"]
+    assert open(gff + ".sqs").read() == fx["index"]["sqs"] and open(gff + ".atn").read() == fx["index"]["atn"]
+    bad = str(tmp_path / "bad.gff")
+    for text, needle in [("chr1\tsrc\tgene\t1\t5\t.\t+\t.\n", "expected 9 columns"),
+                         ("chr1\tsrc\tgene\t1\t5\t.\t+\t.\tName=x\n", "Missing ID"),
+                         ("chr1\tsrc\tgene\tx\t5\t.\t+\t.\tID=a\n", "invalid digit"),
+                         ("chr1\tsrc\tgene\t1\t5\t.\t+\t.\tID=\xff\n", "utf-8")]:
+        open(bad, "w", encoding="latin-1").write(text)
+        rc, msg = _build(host, bad)
+        assert rc == -1 and needle in msg, (text, msg)
+        with pytest.raises(ob.OracleError):
+            ob.build_index(bad)
+    r = subprocess.run([GFFX, "index", "-i", bad], capture_output=True)
+    assert r.returncode == 1 and r.stderr.startswith(b"Error: ")
+
+
+def test_load_tree_index_parse_bed_and_offsets_equal_the_oracle(host, tmp_path):
+    gff, roots = _make_gff(tmp_path, 5)
+    assert _build(host, gff)[0] == 0
+    oix = ob.OracleIndex.load(gff)
+    co, S, E, F = oix.export()
+    n = C.c_uint32()
+    pco, ps, pe, pf, names = u32p(), u32p(), u32p(), u32p(), C.c_void_p()
+    e = _err()
+    assert host.gffx_host_load_tree_index(gff.encode(), C.byref(n), C.byref(pco), C.byref(ps), C.byref(pe),
+                                          C.byref(pf), C.byref(names), e, len(e)) == 0, e.value
+    assert n.value == oix.n_chr
+    gco = np.ctypeslib.as_array(pco, shape=(n.value + 1,)).copy()
+    assert np.array_equal(gco, co)
+    R = int(gco[-1])
+    for p, want in ((ps, S), (pe, E), (pf, F)):
+        assert np.array_equal(np.ctypeslib.as_array(p, shape=(max(R, 1),))[:R], want)
+    assert C.string_at(names).decode().split("\n") == oix.seq_names()
+    for p in (pco, ps, pe, pf, names):
+        host.gffx_host_free(p)
+
+    bed = str(tmp_path / "q.bed")
+    rows = synth.synth_bed(300, seed=3, chroms=synth.SMALL2, width=(1, 50000), edge_frac=0.3, roots=roots)
+    synth.write_bed(bed, rows, ["chr1", "chr2"],
+                    extra_lines=["#c\n", "\n", "chrUn\t5\t9\n", "chr1 7\n", "chr2   10 \t 20  extra\n", "chr1\t+5\t9\r\n"])
+    open(bed, "a").write("chr2\t7\t3")  # no trailing newline, start > end is kept
+    pr, nr = u32p(), C.c_uint64()
+    assert host.gffx_host_parse_bed_file(gff.encode(), bed.encode(), C.byref(pr), C.byref(nr), e, len(e)) == 0, e.value
+    got = np.ctypeslib.as_array(pr, shape=(max(nr.value, 1), 3))[: nr.value].copy()
+    host.gffx_host_free(pr)
+    assert np.array_equal(got, oix.parse_bed_file(bed))
+    assert got[-1].tolist() == [1, 7, 3] and [0, 5, 9] in got.tolist()
+    for badrow in ("chr1\tx\t5\n", "chr1\t5\t99999999999\n", "chr1\t-1\t5\n", "chr1\t1\t5\xff\n"):
+        open(bed, "w", encoding="latin-1").write(badrow)
+        assert host.gffx_host_parse_bed_file(gff.encode(), bed.encode(), C.byref(pr), C.byref(nr), e, len(e)) == -1
+        with pytest.raises(ob.OracleError):
+            oix.parse_bed_file(bed)
+
+    out3 = (C.c_uint32 * 3)()
+    assert host.gffx_host_parse_region(gff.encode(), b"chr2:10-20", out3, e, len(e)) == 0 and list(out3) == [1, 10, 20]
+    for region, msg in [("chr2", "Invalid region format, expected 'chr:start-end'"),
+                        ("chr2:5", "Invalid range format, expected 'start-end'"),
+                        ("chr2:a-5", "invalid digit found in string"),
+                        ("chrZ:1-5", "Sequence ID not found: chrZ"),
+                        ("chr2:5-5", "Region start must be less than end (5 >= 5)")]:
+        assert host.gffx_host_parse_region(gff.encode(), region.encode(), out3, e, len(e)) == -1
+        assert e.value.decode() == msg
+        with pytest.raises(ob.OracleError) as ei:
+            oix.parse_region(region)
+        assert str(ei.value) == msg
+
+    # roots -> blocks, then the -e writer == the oracle's whole run with -e
+    t, _ = oix.query_features(rows, 2, False)
+    uroots = np.unique(t[:, 0]).astype(np.uint32)
+    probe = np.concatenate([uroots, np.array([0xFFFFFFF0], np.uint32)])  # one fid that has no block
+    offs = np.zeros(2 * len(probe), dtype=np.uint64)
+    assert host.gffx_host_roots_to_offsets(gff.encode(), probe.ctypes.data_as(u32p), len(probe),
+                                           offs.ctypes.data_as(u64p), e, len(e)) == 0
+    assert offs[-1] == offs[-2] == np.uint64(2**64 - 1)
+    blocks = np.stack([probe.astype(np.uint64), offs[0::2], offs[1::2]], axis=1).copy()
+    outp = str(tmp_path / "e.gff")
+    assert host.gffx_host_write_gff_output(gff.encode(), blocks.ctypes.data_as(u64p), len(blocks), outp.encode(),
+                                           e, len(e)) == 0
+    synth.write_bed(bed, rows, ["chr1", "chr2"])
+    want = str(tmp_path / "want.gff")
+    rc, msg = ob.intersect_run(gff, want, bed=bed, mode=2, entire_group=True)
+    assert rc == 0, msg
+    assert open(outp, "rb").read() == open(want, "rb").read()
+
+
+def test_line_helpers_match_the_python_restatement(host):
+    lines = [b"chr1\tsrc\tgene\t101\t200\t.\t+\t.\tID=g1", b"chr1\tsrc\tgene\t101\t200", b"chr1\tsrc\tgene\t+1\t200\t.",
+             b"chr1\tsrc\tgene\t1\t4294967296\t.", b"\xff\tsrc\tgene\t1\t2\t.", b"a\tb\tc\t007\t9\t", b"", b"x\ty"]
+    for ln in lines:
+        sl, s, e = C.c_size_t(), C.c_uint32(), C.c_uint32()
+        got = host.gffx_host_split_line(ln, len(ln), C.byref(sl), C.byref(s), C.byref(e))
+        parts = ln.split(b"\t", 5)
+        ok = len(parts) >= 6 and op.parse_u32_ascii(parts[3]) is not None and op.parse_u32_ascii(parts[4]) is not None
+        if ok:
+            try:
+                parts[0].decode("utf-8")
+            except UnicodeDecodeError:
+                ok = False
+        assert bool(got) == ok, ln
+        if ok:
+            assert (sl.value, s.value, e.value) == (len(parts[0]), int(parts[3]), int(parts[4]))
+        for types in ("gene", " gene ,exon", "exon,,CDS", ""):
+            allow = {t.strip() for t in types.split(",")} - {""}
+            assert bool(host.gffx_host_gff_type_allowed(ln, len(ln), types.encode())) == op.gff_type_allowed(ln, allow)
+
+
+def test_cli_usage_errors_exit_2_and_runtime_errors_exit_1(tmp_path):
+    gff, _ = _make_gff(tmp_path, 7)
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    run = lambda *a: subprocess.run([GFFX, "intersect", *a], capture_output=True)  # noqa: E731
+    assert run("-i", gff).returncode == 2                                   # regions group is required
+    assert run("-i", gff, "-r", "chr1:1-5", "-b", "x.bed").returncode == 2  # ... and exclusive
+    assert run("-i", gff, "-r", "chr1:1-5", "-c", "-C").returncode == 2     # mode group
+    assert run("-r", "chr1:1-5").returncode == 2                            # --input required
+    assert run("-i", gff, "-r", "chr1:1-5", "--bogus").returncode == 2
+    assert subprocess.run([GFFX, "frobnicate"], capture_output=True).returncode == 2
+    r = run("-i", gff, "-r", "chr1:250-200")
+    assert r.returncode == 1 and r.stderr == b"Error: Region start must be less than end (250 >= 200)\n"
+    r = run("-i", gff, "--region=chrQ:1-2", "-ev")
+    assert r.returncode == 1 and b"Error: Sequence ID not found: chrQ" in r.stderr
+    r = run("-i", str(tmp_path / "missing.gff"), "-r", "chr1:1-2")
+    assert r.returncode == 1 and b"Failed to open SQS file" in r.stderr
+    assert subprocess.run([GFFX, "intersect", "--help"], capture_output=True).returncode == 0
+
+
+def test_cli_fails_loudly_without_a_gpu(tmp_path):
+    from gffx_amd import engine
+    if engine.device_count() > 0:
+        pytest.skip("only meaningful without a GPU")
+    gff, _ = _make_gff(tmp_path, 8)
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    r = subprocess.run([GFFX, "intersect", "-i", gff, "-r", "chr1:1-2000000"], capture_output=True)
+    assert r.returncode == 1 and b"no HIP device" in r.stderr and r.stdout == b""
