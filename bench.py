@@ -7,7 +7,8 @@ resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: 1 M synthetic BED 
 (seed 1001, chr ~ length, width U[100,10000], unsorted) x a GENCODE/GRCh38-shaped index
 (25 seqids, ~63 k root genes of a ~3.4 M-line annotation, seed 42), --overlap mode.
 For N>1 the global batch is N x 1 M regions, sharded by chromosome bucket over the ranks
-(gffx_amd.shard, LPT with splitting; index replicated), one RCCL all-gather of hit counts per step.
+(gffx_amd.shard, LPT with splitting; index replicated); the only collective is the RCCL
+all-gather of per-rank hit counts, once per job (--exchange per-step issues it after every step).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -41,6 +42,9 @@ def parse_args():
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
     ap.add_argument("--presort", default="none", choices=["none", "chr_end", "bucket"],
                     help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
+    ap.add_argument("--exchange", default="final", choices=["final", "per-step"],
+                    help="N>1: all-gather the per-rank hit counts once at the end of the timed region (default, "
+                         "north_star's 'final hit-count all-gather') or after every step (latency-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -90,11 +94,18 @@ def main():
     if not torch.cuda.is_available() or engine.device_count() < 1:
         print("bench.py: no MI355X visible; the engine has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GFFX_BENCH_BACKEND=gloo lets the N>1 plumbing be exercised on a 1-GPU box (all ranks share
+    # device 0); the driver's runs use nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("GFFX_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     mode = {"contained": 0, "contains_region": 1, "overlap": 2}[args.mode]
     strategy = {"auto": 0, "direct": 1, "sorted": 2}[args.strategy]
@@ -119,7 +130,7 @@ def main():
     nq = len(regions)
 
     ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"],
-                                         roots["names"], device=local_rank)
+                                         roots["names"], device=dev_index)
     # regions resident in HBM as SoA u32 (torch owns the memory; the engine borrows the pointers)
     t_regions = torch.from_numpy(np.ascontiguousarray(regions).view(np.int32))  # u32 bit patterns
     d_chr = t_regions[:, 0].contiguous().to(dev)
@@ -130,14 +141,16 @@ def main():
     batch.set_regions_device(d_chr.data_ptr(), d_start.data_ptr(), d_end.data_ptr(), nq,
                              keep=(d_chr, d_start, d_end))
 
+    coll_dev = dev if backend == "nccl" else None  # gloo gathers CPU tensors
+
     def step():
         batch.run(mode, False, out_flags, strategy)
 
     def exchange():
         # the path's one exchange step: all-gather of per-rank (queries, kept pairs)
-        if world > 1:
+        if world > 1 and args.exchange == "per-step":
             batch.wait()
-            return shard.allgather_hit_counts(nq, batch.total_hits, device=dev)
+            return shard.allgather_hit_counts(nq, batch.total_hits, device=coll_dev)
         return None
 
     # sizing pass (also the parity-relevant total), then warmup
@@ -159,14 +172,18 @@ def main():
     for _ in range(args.steps):
         step()
         exchange()
-    batch.sync()
+    if world > 1 and args.exchange == "final":
+        batch.wait()  # the job's one exchange step, inside the timed region
+        shard.allgather_hit_counts(nq, batch.total_hits, device=coll_dev)
+    else:
+        batch.sync()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        counts = shard.allgather_hit_counts(nq, pairs, device=dev)
+        counts = shard.allgather_hit_counts(nq, pairs, device=coll_dev)
         nq_total, pairs_total = int(counts[:, 0].sum()), int(counts[:, 1].sum())
     else:
         nq_total, pairs_total = nq, pairs
@@ -224,7 +241,8 @@ def main():
                 "outputs": "per-region counts + %s (CSR, input order)" % args.out,
                 "strategy": args.strategy,
                 "presort": args.presort,
-                "sharding": "chromosome buckets, LPT with splitting; index replicated; all-gather of hit counts per step"
+                "sharding": ("chromosome buckets, LPT with splitting; index replicated; all-gather of hit counts "
+                             + ("after every step" if args.exchange == "per-step" else "once, at the end of the timed region"))
                             if world > 1 else "none (1 GPU)",
             },
             "roofline": {
