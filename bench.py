@@ -110,6 +110,8 @@ def main():
     mode = {"contained": 0, "contains_region": 1, "overlap": 2}[args.mode]
     strategy = {"auto": 0, "direct": 1, "sorted": 2}[args.strategy]
     out_flags = {"counts": engine.OUT_COUNTS, "fids": engine.OUT_FIDS, "triples": engine.OUT_TRIPLES}[args.out]
+    if args.strategy == "sorted" and args.out != "counts":
+        out_flags |= engine.OUT_OFFSETS  # pairs are grouped by bucket: every region's segment is explicit
 
     # ---- synthetic inputs (identical on every rank; each rank keeps its shard)
     roots = synth.gencode_like_roots(63000, seed=42)

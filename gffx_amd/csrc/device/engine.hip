@@ -15,6 +15,7 @@
 
 #include "gffx_device.hpp"
 #include "join_a_kernels.hpp"
+#include "join_a_tile_kernels.hpp"
 
 namespace gffx {
 
@@ -70,6 +71,13 @@ struct gffx_hip_index {
     uint4 *d_list_meta = nullptr;
     uint2 *d_bins = nullptr;
     uint32_t n_lists = 0;
+    // sorted strategy: genome-window buckets and their LDS tiles (join_a_tile_kernels.hpp)
+    uint32_t *d_chr_bucket_base = nullptr;
+    uint32_t *d_tile_first = nullptr;
+    uint4 *d_tiles = nullptr;
+    uint8_t *d_bucket_in_lds = nullptr;
+    uint32_t n_buckets = 0, bucket_shift = 0;
+    bool sorted_ok = false;  // n_buckets <= kMaxBuckets
     std::vector<uint32_t> h_sorted_fids;
     std::vector<uint32_t> h_chr_offsets;
 
@@ -88,6 +96,8 @@ struct gffx_hip_index {
         v.n_roots = n_roots;
         return v;
     }
+    BucketPlanView bucket_view() const { return BucketPlanView{d_chr_bucket_base, n_chr, n_buckets, bucket_shift}; }
+    TileView tile_view() const { return TileView{d_tile_first, d_tiles, d_bucket_in_lds}; }
 };
 
 struct ProfEvent {
@@ -109,11 +119,18 @@ struct gffx_hip_batch {
     unsigned long long *d_block_sums = nullptr;
     unsigned long long *d_status = nullptr;     // [0] error bits
     unsigned long long *h_status = nullptr;     // pinned: [0] error bits, [1..] block sums
-    static constexpr uint32_t kMaxBlocks = 2048;
+    static constexpr uint32_t kMaxBlocks = 8192;
     uint32_t *d_fids = nullptr, *d_triples = nullptr, *d_bitmap = nullptr;
     unsigned long long *d_offsets = nullptr;
     uint64_t cap_fids = 0, cap_triples = 0;
     uint64_t reserve = 0;
+    // sorted strategy workspace (allocated on first use)
+    uint32_t *d_hist = nullptr, *d_cursor = nullptr, *d_bucket_start = nullptr, *d_work_start = nullptr;
+    uint32_t *d_n_work = nullptr, *d_counts_b = nullptr;
+    uint4 *d_records = nullptr;
+    unsigned long long *d_work_base = nullptr;
+    uint32_t max_work = 0;
+    uint64_t cap_sums = 0;  // entries in d_block_sums / h_status
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
     uint32_t flags = 0;
@@ -222,11 +239,60 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         chr_lists[c].y = n_l;
     }
 
+    // Sorted strategy: genome-window buckets (<= 2048 in total) and, per bucket and list, the
+    // entries a query ending inside the window can reach (see join_a_tile_kernels.hpp).
+    std::vector<uint32_t> chr_bucket_base(n_chr + 1, 0), tile_first;
+    std::vector<uint4> tiles;
+    std::vector<uint8_t> bucket_in_lds;
+    uint32_t bshift = 0;
+    {
+        std::vector<uint32_t> chr_max_start(n_chr, 0);
+        for (uint32_t c = 0; c < n_chr; c++)
+            for (uint32_t l = chr_lists[c].x; l < chr_lists[c].x + chr_lists[c].y; l++)
+                chr_max_start[c] = std::max(chr_max_start[c], ent[list_meta[l].y - 1].x);
+        for (;; bshift++) {
+            uint64_t tot = 0;
+            for (uint32_t c = 0; c < n_chr; c++)
+                tot += chr_lists[c].y ? ((uint64_t)chr_max_start[c] >> bshift) + 2 : 1;
+            if (tot <= 2048 || bshift == 31) break;
+        }
+        const uint64_t W = 1ull << bshift;
+        for (uint32_t c = 0; c < n_chr; c++) {
+            const uint32_t nb = chr_lists[c].y ? (chr_max_start[c] >> bshift) + 2 : 1;
+            chr_bucket_base[c + 1] = chr_bucket_base[c] + nb;
+            for (uint32_t b = 0; b < nb; b++) {
+                tile_first.push_back((uint32_t)tiles.size());
+                const uint64_t win_lo = (uint64_t)b << bshift, win_hi = (uint64_t)(b + 1) << bshift;
+                const uint64_t thr = win_lo > W ? win_lo - W : 0;
+                uint64_t total = 0;
+                for (uint32_t l = chr_lists[c].x; l < chr_lists[c].x + chr_lists[c].y; l++) {
+                    const uint32_t first = list_meta[l].x, endp = list_meta[l].y;
+                    uint32_t hi = endp;
+                    if (b + 1 < nb)  // the last bucket of a seqid also takes every query beyond it
+                        hi = (uint32_t)(std::lower_bound(ent.begin() + first, ent.begin() + endp, win_hi,
+                                                         [](const uint4 &e, uint64_t v) { return e.x < v; }) -
+                                        ent.begin());
+                    uint32_t lo = (uint32_t)(std::upper_bound(ent.begin() + first, ent.begin() + endp, thr,
+                                                              [](uint64_t v, const uint4 &e) { return v < e.z; }) -
+                                             ent.begin());  // first entry whose running max exceeds thr
+                    if (lo > hi) lo = hi;
+                    tiles.push_back(make_uint4(lo, hi, lo > first ? ent[lo - 1].z : 0u, first));
+                    total += hi - lo;
+                }
+                bucket_in_lds.push_back(total <= kTileEntries ? 1 : 0);
+            }
+        }
+        tile_first.push_back((uint32_t)tiles.size());
+    }
+
     std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
     ix->device = device;
     ix->n_chr = n_chr;
     ix->n_roots = R;
     ix->n_lists = (uint32_t)list_meta.size();
+    ix->n_buckets = chr_bucket_base[n_chr];
+    ix->bucket_shift = bshift;
+    ix->sorted_ok = ix->n_buckets <= kMaxBuckets;
     ix->h_chr_offsets.assign(chr_offsets, chr_offsets + n_chr + 1);
     ix->h_sorted_fids.resize(R);
     std::vector<uint32_t> s(R), e(R), pm(R);
@@ -241,7 +307,10 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         (rc = dev_alloc(&ix->d_end, R)) || (rc = dev_alloc(&ix->d_pmax, R)) ||
         (rc = dev_alloc(&ix->d_fid, R)) || (rc = dev_alloc(&ix->d_chr_lists, n_chr)) ||
         (rc = dev_alloc(&ix->d_list_meta, list_meta.size())) ||
-        (rc = dev_alloc(&ix->d_bins, bins.size()))) {
+        (rc = dev_alloc(&ix->d_bins, bins.size())) ||
+        (rc = dev_alloc(&ix->d_chr_bucket_base, chr_bucket_base.size())) ||
+        (rc = dev_alloc(&ix->d_tile_first, tile_first.size())) || (rc = dev_alloc(&ix->d_tiles, tiles.size())) ||
+        (rc = dev_alloc(&ix->d_bucket_in_lds, bucket_in_lds.size()))) {
         gffx_hip_index_destroy(ix.release());
         return rc;
     }
@@ -259,6 +328,12 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
                                hipMemcpyHostToDevice));
     if (!bins.empty())
         GFFX_HIP_TRY(hipMemcpy(ix->d_bins, bins.data(), bins.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    GFFX_HIP_TRY(hipMemcpy(ix->d_chr_bucket_base, chr_bucket_base.data(), chr_bucket_base.size() * 4, hipMemcpyHostToDevice));
+    GFFX_HIP_TRY(hipMemcpy(ix->d_tile_first, tile_first.data(), tile_first.size() * 4, hipMemcpyHostToDevice));
+    if (!tiles.empty())
+        GFFX_HIP_TRY(hipMemcpy(ix->d_tiles, tiles.data(), tiles.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!bucket_in_lds.empty())
+        GFFX_HIP_TRY(hipMemcpy(ix->d_bucket_in_lds, bucket_in_lds.data(), bucket_in_lds.size(), hipMemcpyHostToDevice));
     *out = ix.release();
     return GFFX_OK;
 }
@@ -274,6 +349,10 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_chr_lists);
     (void)hipFree(ix->d_list_meta);
     (void)hipFree(ix->d_bins);
+    (void)hipFree(ix->d_chr_bucket_base);
+    (void)hipFree(ix->d_tile_first);
+    (void)hipFree(ix->d_tiles);
+    (void)hipFree(ix->d_bucket_in_lds);
     delete ix;
 }
 
@@ -310,6 +389,7 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
         gffx_hip_batch_destroy(b.release());
         return fail(GFFX_E_OOM, "hipHostMalloc failed: %s", hipGetErrorString(e));
     }
+    b->cap_sums = gffx_hip_batch::kMaxBlocks;
     *out = b.release();
     return GFFX_OK;
 }
@@ -331,6 +411,14 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     (void)hipFree(b->d_triples);
     (void)hipFree(b->d_bitmap);
     (void)hipFree(b->d_offsets);
+    (void)hipFree(b->d_hist);
+    (void)hipFree(b->d_cursor);
+    (void)hipFree(b->d_bucket_start);
+    (void)hipFree(b->d_work_start);
+    (void)hipFree(b->d_n_work);
+    (void)hipFree(b->d_counts_b);
+    (void)hipFree(b->d_records);
+    (void)hipFree(b->d_work_base);
     if (b->h_status) (void)hipHostFree(b->h_status);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -509,18 +597,158 @@ static int enqueue_emit(gffx_hip_batch *b) {
     return GFFX_OK;
 }
 
+// ------------------------------------------------------------------------------------ sorted strategy
+
+static int sorted_prepare(gffx_hip_batch *b) {
+    const gffx_hip_index *ix = b->ix;
+    if (b->d_records) return GFFX_OK;
+    int rc;
+    const size_t nb = ix->n_buckets;
+    b->max_work = (uint32_t)(nb + b->max_q / kQueriesPerWork + 2);
+    if ((rc = dev_alloc(&b->d_hist, nb + 1)) || (rc = dev_alloc(&b->d_cursor, nb + 1)) ||
+        (rc = dev_alloc(&b->d_bucket_start, nb + 2)) || (rc = dev_alloc(&b->d_work_start, nb + 2)) ||
+        (rc = dev_alloc(&b->d_n_work, 1)) || (rc = dev_alloc(&b->d_counts_b, b->max_q)) ||
+        (rc = dev_alloc(&b->d_records, b->max_q)) || (rc = dev_alloc(&b->d_work_base, b->max_work)))
+        return rc;
+    GFFX_HIP_TRY(hipMemset(b->d_hist, 0, (nb + 1) * 4));
+    GFFX_HIP_TRY(hipMemset(b->d_cursor, 0, (nb + 1) * 4));
+    if (b->max_work > b->cap_sums) {  // one partial sum per work item
+        GFFX_HIP_TRY(hipFree(b->d_block_sums));
+        b->d_block_sums = nullptr;
+        if ((rc = dev_alloc(&b->d_block_sums, b->max_work))) return rc;
+        GFFX_HIP_TRY(hipHostFree(b->h_status));
+        b->h_status = nullptr;
+        GFFX_HIP_TRY(hipHostMalloc((void **)&b->h_status, (1 + (size_t)b->max_work) * sizeof(unsigned long long),
+                                   hipHostMallocDefault));
+        b->cap_sums = b->max_work;
+    }
+    return GFFX_OK;
+}
+
+static TileOut make_tile_out(gffx_hip_batch *b, bool prefix_ready) {
+    TileOut o;
+    o.work_base = prefix_ready ? b->d_work_base : nullptr;
+    o.counts_b = b->d_counts_b;
+    o.counts_in = getenv("GFFX_EXP_NOSCATTER") ? nullptr : b->d_counts;
+    o.block_sums = b->d_block_sums;
+    o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
+    o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
+    o.bitmap = (b->flags & GFFX_OUT_ROOT_BITMAP) ? b->d_bitmap : nullptr;
+    o.offsets_in = ((b->flags & GFFX_OUT_OFFSETS) && !getenv("GFFX_EXP_NOSCATTER")) ? b->d_offsets : nullptr;
+    uint64_t cap = UINT64_MAX;
+    if (o.fids) cap = std::min(cap, b->cap_fids);
+    if (o.triples) cap = std::min(cap, b->cap_triples);
+    o.capacity = cap;
+    return o;
+}
+
+template <bool EMIT, int MODE, bool INV, bool ML>
+static void launch_tile(gffx_hip_batch *b, uint32_t grid, const SortedWork &w, const TileOut &o) {
+    const uint32_t lds = kTileEntries * 16 + 224 + (ML ? meta_bytes(b->ix) : 0);
+    if (EMIT)
+        hipLaunchKernelGGL((k_tile_emit<MODE, INV, ML>), dim3(grid), dim3(kJoinThreads), lds, b->stream,
+                           b->ix->view(), b->ix->tile_view(), w, o);
+    else
+        hipLaunchKernelGGL((k_tile_count<MODE, INV, ML>), dim3(grid), dim3(kJoinThreads), lds, b->stream,
+                           b->ix->view(), b->ix->tile_view(), w, o);
+}
+
+template <bool EMIT>
+static void dispatch_tile(gffx_hip_batch *b, uint32_t grid, const SortedWork &w, const TileOut &o) {
+    const bool ml = meta_bytes(b->ix) <= kMetaLdsBytes;
+#define GFFX_CASE(M, I, L)                                    \
+    if (b->mode == M && (b->invert != 0) == I && ml == L) {   \
+        launch_tile<EMIT, M, I, L>(b, grid, w, o);            \
+        return;                                               \
+    }
+    GFFX_CASE(0, false, true) GFFX_CASE(0, false, false) GFFX_CASE(0, true, true) GFFX_CASE(0, true, false)
+    GFFX_CASE(1, false, true) GFFX_CASE(1, false, false) GFFX_CASE(1, true, true) GFFX_CASE(1, true, false)
+    GFFX_CASE(2, false, true) GFFX_CASE(2, false, false) GFFX_CASE(2, true, true) GFFX_CASE(2, true, false)
+#undef GFFX_CASE
+}
+
+static uint32_t sorted_grid(const gffx_hip_batch *b) {
+    return (uint32_t)(b->ix->n_buckets + b->nq / kQueriesPerWork + 1);
+}
+
+static int enqueue_tile_emit(gffx_hip_batch *b) {
+    if (b->flags & GFFX_OUT_ROOT_BITMAP)
+        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
+    const uint32_t grid = sorted_grid(b);
+    const bool big = grid > 4096;  // too many work items for every block to add up its predecessors
+    SortedWork w{b->d_records, b->d_bucket_start, b->d_work_start, b->d_n_work, b->ix->n_buckets};
+    ProfEvent pe;
+    prof_begin(b, GFFX_K_JOIN_EMIT, &pe);
+    if (big) hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, b->stream, b->d_n_work, b->d_block_sums, b->d_work_base);
+    dispatch_tile<true>(b, grid, w, make_tile_out(b, big));
+    prof_end(b, &pe);
+    GFFX_HIP_TRY(hipGetLastError());
+    return GFFX_OK;
+}
+
+static int run_sorted(gffx_hip_batch *b) {
+    int rc = sorted_prepare(b);
+    if (rc) return rc;
+    const gffx_hip_index *ix = b->ix;
+    const uint64_t nq = b->nq;
+    const bool aos = b->q.aos != nullptr;
+    const BucketPlanView bp = ix->bucket_view();
+    const uint32_t lds_b = (ix->n_buckets + ix->n_chr + 1) * 4;
+    ProfEvent pe;
+    prof_begin(b, GFFX_K_SORT, &pe);
+    {
+        uint64_t grid = (nq + (uint64_t)kBucketThreads * 8 - 1) / ((uint64_t)kBucketThreads * 8);
+        grid = std::max<uint64_t>(1, std::min<uint64_t>(grid, 1024));
+        uint64_t chunk = (nq + grid - 1) / grid;
+        chunk = (chunk + kBucketThreads - 1) / kBucketThreads * kBucketThreads;
+        uint32_t *err = reinterpret_cast<uint32_t *>(b->d_status);
+        if (aos)
+            hipLaunchKernelGGL((k_bucket_hist<true>), dim3((uint32_t)grid), dim3(kBucketThreads), lds_b, b->stream, bp,
+                               b->q, (unsigned long long)nq, (unsigned long long)chunk, b->d_hist, err);
+        else
+            hipLaunchKernelGGL((k_bucket_hist<false>), dim3((uint32_t)grid), dim3(kBucketThreads), lds_b, b->stream, bp,
+                               b->q, (unsigned long long)nq, (unsigned long long)chunk, b->d_hist, err);
+    }
+    hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, b->stream, ix->n_buckets, b->d_hist, b->d_cursor,
+                       b->d_bucket_start, b->d_work_start, b->d_n_work);
+    {
+        const uint64_t per = (uint64_t)kBucketThreads * kBucketItems;
+        const uint32_t grid = (uint32_t)((nq + per - 1) / per);
+        if (aos)
+            hipLaunchKernelGGL((k_bucket_scatter<true>), dim3(grid), dim3(kBucketThreads), lds_b, b->stream, bp, b->q,
+                               (unsigned long long)nq, b->d_bucket_start, b->d_cursor, b->d_records);
+        else
+            hipLaunchKernelGGL((k_bucket_scatter<false>), dim3(grid), dim3(kBucketThreads), lds_b, b->stream, bp, b->q,
+                               (unsigned long long)nq, b->d_bucket_start, b->d_cursor, b->d_records);
+    }
+    prof_end(b, &pe);
+    GFFX_HIP_TRY(hipGetLastError());
+    {
+        SortedWork w{b->d_records, b->d_bucket_start, b->d_work_start, b->d_n_work, ix->n_buckets};
+        prof_begin(b, GFFX_K_JOIN_COUNT, &pe);
+        dispatch_tile<false>(b, sorted_grid(b), w, make_tile_out(b, false));
+        prof_end(b, &pe);
+        GFFX_HIP_TRY(hipGetLastError());
+    }
+    if (wants_pairs(b->flags) && (rc = enqueue_tile_emit(b))) return rc;
+    return GFFX_OK;
+}
+
 extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags,
                                   int strategy) {
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: batch is NULL");
     if (!b->have_regions) return fail(GFFX_E_STATE, "gffx_hip_batch_run: no regions set");
     if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad mode %d", mode);
-    if (strategy != GFFX_STRATEGY_AUTO && strategy != GFFX_STRATEGY_DIRECT)
-        return fail(GFFX_E_INVALID, "gffx_hip_batch_run: strategy %d not available", strategy);
+    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_SORTED)
+        return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad strategy %d", strategy);
+    if (strategy == GFFX_STRATEGY_SORTED && !b->ix->sorted_ok)
+        return fail(GFFX_E_INVALID, "gffx_hip_batch_run: the sorted strategy needs <= %u genome-window buckets "
+                                    "(this index has %u: too many seqids)", kMaxBuckets, b->ix->n_buckets);
     GFFX_HIP_TRY(hipSetDevice(b->ix->device));
     b->mode = mode;
     b->invert = invert ? 1 : 0;
     b->flags = out_flags | GFFX_OUT_COUNTS;
-    b->strategy = GFFX_STRATEGY_DIRECT;
+    b->strategy = strategy == GFFX_STRATEGY_SORTED ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_DIRECT;
     b->ran = true;
     b->waited = false;
     b->total = 0;
@@ -539,9 +767,20 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         b->n_blocks = 0;
         return GFFX_OK;
     }
+    if (b->strategy == GFFX_STRATEGY_SORTED) {
+        const uint64_t want = std::max<uint64_t>(b->reserve ? b->reserve : 2 * nq, 1024);
+        if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want && (rc = grow(&b->d_fids, &b->cap_fids, want, 1))) return rc;
+        if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want && (rc = grow(&b->d_triples, &b->cap_triples, want, 3)))
+            return rc;
+        return run_sorted(b);
+    }
     // contiguous chunk of queries per block, a multiple of the block size; <= 2048 blocks
     const uint64_t tiles = (nq + kJoinThreads - 1) / kJoinThreads;
-    const uint64_t max_blocks = gffx_hip_batch::kMaxBlocks;
+    uint64_t max_blocks = 2048;  // 8 resident 256-thread blocks per CU
+    if (const char *e = getenv("GFFX_HIP_MAX_BLOCKS")) {  // experiments only
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= (long)gffx_hip_batch::kMaxBlocks) max_blocks = (uint64_t)v;
+    }
     const uint64_t tiles_per_block = (tiles + max_blocks - 1) / max_blocks;
     b->chunk = tiles_per_block * kJoinThreads;
     b->n_blocks = (uint32_t)((nq + b->chunk - 1) / b->chunk);
@@ -585,6 +824,11 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         return GFFX_OK;
     }
     GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (b->strategy == GFFX_STRATEGY_SORTED) {
+        uint32_t n_work = 0;
+        GFFX_HIP_TRY(hipMemcpy(&n_work, b->d_n_work, 4, hipMemcpyDeviceToHost));
+        b->n_blocks = n_work;
+    }
     GFFX_HIP_TRY(hipMemcpy(b->h_status + 1, b->d_block_sums, b->n_blocks * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost));
     if (b->h_status[0] & 1ull) {
@@ -605,8 +849,12 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         if ((rc = grow(&b->d_triples, &b->cap_triples, b->total + b->total / 8, 3))) return rc;
         replay = true;
     }
+    if (b->strategy == GFFX_STRATEGY_SORTED && (b->flags & GFFX_OUT_OFFSETS)) {
+        const unsigned long long tot = b->total;  // offsets[nq] = number of pairs, as in the direct path
+        GFFX_HIP_TRY(hipMemcpy(b->d_offsets + b->nq, &tot, sizeof tot, hipMemcpyHostToDevice));
+    }
     if (replay) {
-        if ((rc = enqueue_emit(b))) return rc;
+        if ((rc = b->strategy == GFFX_STRATEGY_SORTED ? enqueue_tile_emit(b) : enqueue_emit(b))) return rc;
         if ((rc = gffx_hip_batch_sync(b))) return rc;
     }
     b->waited = true;

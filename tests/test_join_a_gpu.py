@@ -13,7 +13,7 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 FLAGS = engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS
-STRATEGIES = [engine.STRATEGY_DIRECT]
+STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED]
 
 
 def _sorted_rows(t):
@@ -40,10 +40,18 @@ def _check(roots, regions, mode, invert, soa=False, strategy=engine.STRATEGY_AUT
     assert np.array_equal(_sorted_rows(got_t), _sorted_rows(want_t))
     assert np.array_equal(b.fids(), got_t[:, 0])
     off = b.offsets()
-    assert np.array_equal(off, np.concatenate([[0], np.cumsum(want_c.astype(np.uint64))]).astype(np.uint64))
+    assert int(off[-1]) == len(want_t)
+    if strategy != engine.STRATEGY_SORTED:  # direct: CSR in input order
+        assert np.array_equal(off, np.concatenate([[0], np.cumsum(want_c.astype(np.uint64))]).astype(np.uint64))
+    else:  # sorted: pairs grouped by genome-window bucket, every query's segment given explicitly
+        nz = want_c > 0
+        seg_lo, seg_hi = off[:-1][nz], off[:-1][nz] + want_c[nz]
+        order = np.argsort(seg_lo)
+        assert len(seg_lo) == 0 or (seg_lo[order][0] == 0 and seg_hi[order][-1] == len(want_t)
+                                    and np.array_equal(seg_hi[order][:-1], seg_lo[order][1:]))
     # pairs of query i are exactly the oracle's pairs of query i (their order inside a query is free)
     for qi in np.random.default_rng(0).choice(len(regions), size=min(200, len(regions)), replace=False):
-        seg = got_t[int(off[qi]):int(off[qi + 1])]
+        seg = got_t[int(off[qi]):int(off[qi]) + int(got_c[qi])]
         one_t, _ = oix.query_features(regions[qi:qi + 1], int(mode), invert)
         assert np.array_equal(_sorted_rows(seg), _sorted_rows(one_t))
     assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
@@ -133,6 +141,33 @@ def test_many_seqids_metadata_outside_lds():
     regions = synth.synth_bed(30000, seed=9, chroms=chroms, width=(10, 5000), edge_frac=0.05, roots=roots)
     for mode in OverlapMode:
         _check(roots, regions, mode, False)
+    # ... and there are more genome-window buckets than the sorted strategy supports: loud error
+    ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    b = engine.QueryBatch(ix, 10)
+    b.set_regions(regions[:10])
+    with pytest.raises(engine._ffi.GffxHipError):
+        b.run(OverlapMode.Overlap, False, engine.OUT_FIDS, engine.STRATEGY_SORTED)
+
+
+def test_sorted_strategy_long_queries_and_dense_windows():
+    """Queries far longer than a genome window (the sweep leaves the LDS tile and continues in
+    global memory) and a window with more intervals than fit the LDS tile (gather fallback)."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    start = np.sort(rng.integers(0, 200_000_000, n)).astype(np.uint32)
+    start[1000:4000] = 50_000_000 + np.arange(3000, dtype=np.uint32) * 7  # 3000 intervals inside one window
+    start.sort()
+    end = start + rng.integers(1, 3_000_000, n).astype(np.uint32)
+    roots = {"chr_offsets": np.array([0, n], np.uint32), "start": start, "end": end,
+             "fid": np.arange(n, dtype=np.uint32)}
+    nq = 4000
+    qs = rng.integers(0, 200_000_000, nq).astype(np.int64)
+    w = np.where(rng.random(nq) < 0.3, rng.integers(5_000_000, 150_000_000, nq), rng.integers(1, 20000, nq))
+    regions = np.stack([np.zeros(nq, np.int64), qs, qs + w], axis=1).astype(np.uint32)
+    regions[:50, 1] = 0  # start at 0, end anywhere
+    for mode in OverlapMode:
+        for strategy in STRATEGIES:
+            _check(roots, regions, mode, False, strategy=strategy)
 
 
 def test_dense_bins_saturate_the_bin_counter():
@@ -146,7 +181,8 @@ def test_dense_bins_saturate_the_bin_counter():
     regions = np.array([[0, 900, 1001], [0, 1000, 1001], [0, 999, 1000], [0, 1001, 1200], [0, 0, 4_100_000],
                         [0, 1400, 1500]] * 50, np.uint32)
     for mode in OverlapMode:
-        _check(roots, regions, mode, False)
+        for strategy in STRATEGIES:
+            _check(roots, regions, mode, False, strategy=strategy)
 
 
 def test_capacity_replay_and_reuse():
@@ -155,7 +191,8 @@ def test_capacity_replay_and_reuse():
     roots = {"chr_offsets": np.array([0, k], np.uint32), "start": np.arange(k, dtype=np.uint32),
              "end": (10_000 - np.arange(k)).astype(np.uint32), "fid": np.arange(k, dtype=np.uint32) * 3}
     regions = np.tile(np.array([[0, 1000, 2000]], np.uint32), (3000, 1))
-    _check(roots, regions, OverlapMode.Overlap, False)
+    for strategy in STRATEGIES:
+        _check(roots, regions, OverlapMode.Overlap, False, strategy=strategy)
     ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
     b = engine.QueryBatch(ix, 3000)
     for n in (3000, 10, 0, 2999):  # the same batch object, different sizes
@@ -166,8 +203,9 @@ def test_capacity_replay_and_reuse():
         assert np.array_equal(b.counts(), np.full(n, k, np.uint32))
 
 
+@pytest.mark.parametrize("strategy", STRATEGIES)
 @pytest.mark.parametrize("nq", [1_000_000])
-def test_full_size_c2_properties(nq):
+def test_full_size_c2_properties(nq, strategy):
     """BASELINE config 2 size (1 M regions x 63 k roots): sampled oracle parity + size-independent
     properties (sum of counts == pairs; invert complements the mode predicate inside the hit set)."""
     roots = synth.gencode_like_roots(63000, seed=42)
@@ -179,7 +217,7 @@ def test_full_size_c2_properties(nq):
     res = {}
     for mode in OverlapMode:
         for inv in (False, True):
-            b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS)
+            b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS, strategy)
             b.wait()
             c = b.counts()
             assert int(c.sum(dtype=np.uint64)) == b.total_hits == int(b.offsets()[-1])
