@@ -40,6 +40,8 @@ def parse_args():
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
     ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
+    ap.add_argument("--no-offsets", action="store_true",
+                    help="partitioned strategy: do not write every region's segment offset (counts + unattributed pairs)")
     ap.add_argument("--presort", default="none", choices=["none", "chr_end", "bucket"],
                     help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
     ap.add_argument("--exchange", default="final", choices=["final", "per-step"],
@@ -110,8 +112,8 @@ def main():
     mode = {"contained": 0, "contains_region": 1, "overlap": 2}[args.mode]
     strategy = {"auto": 0, "direct": 1, "sorted": 2}[args.strategy]
     out_flags = {"counts": engine.OUT_COUNTS, "fids": engine.OUT_FIDS, "triples": engine.OUT_TRIPLES}[args.out]
-    if args.strategy == "sorted" and args.out != "counts":
-        out_flags |= engine.OUT_OFFSETS  # pairs are grouped by bucket: every region's segment is explicit
+    if args.strategy != "direct" and args.out != "counts" and not args.no_offsets:
+        out_flags |= engine.OUT_OFFSETS  # pairs are grouped by genome tile: every region's segment is explicit
 
     # ---- synthetic inputs (identical on every rank; each rank keeps its shard)
     roots = synth.gencode_like_roots(63000, seed=42)

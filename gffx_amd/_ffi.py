@@ -39,6 +39,7 @@ SIGNATURES = {
     "gffx_hip_batch_total_hits": (C.c_uint64, [vp]),
     "gffx_hip_batch_copy_counts": (C.c_int, [vp, u32p]),
     "gffx_hip_batch_copy_offsets": (C.c_int, [vp, u64p]),
+    "gffx_hip_batch_copy_query_records": (C.c_int, [vp, u32p, u32p, u64p]),
     "gffx_hip_batch_copy_fids": (C.c_int, [vp, u32p]),
     "gffx_hip_batch_copy_triples": (C.c_int, [vp, u32p]),
     "gffx_hip_batch_copy_root_bitmap": (C.c_int, [vp, u64p, C.c_uint64]),

@@ -1,12 +1,12 @@
 // engine.hip -- C-ABI (include/gffx_hip.h) of the gfx950 engine: index upload, query batches.
 //
-// HBM layout of an index (uploaded once, immutable):
-//   ent[R]        uint4 {start, end, pmax_end, root_fid}   16 B/root   (gather kernels)
-//   start/end/pmax/fid[R]  u32 SoA copies                  16 B/root   (sorted-strategy kernels)
-//   chr_lists[n_chr] uint2 {first list, n_lists};  list_meta[n_lists] uint4 {first, last+1, bin base, shift|n_bins}
-//   bins[sum(n_bins+1)] uint2 per-list bin directory over `start` (<= ~4 bins per entry: L2-sized)
-// At GENCODE scale (63 k roots, 25 seqids) that is ~2 MB + ~0.8 MB of directory: resident in
-// every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and the results out.
+// HBM layout of an index (uploaded once, immutable; gffx_device.hpp has the field meanings):
+//   start[R] u32, aux[R] uint4 {end, pmax, skip, root_fid}     20 B/root, seqid after seqid, by start
+//   chr_meta[n_chr] uint4, bins[...] uint2                      per-seqid bin directory (direct strategy)
+//   cell_base / cell_tile / tile_meta / tile_aux / tile_bins    genome-window tile plan (partitioned strategy)
+// At GENCODE scale (63 k roots, 25 seqids) that is ~1.3 MB + ~2 MB of directory + ~0.2 MB of tile
+// plan: resident in every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and
+// the results out.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -15,7 +15,8 @@
 
 #include "gffx_device.hpp"
 #include "join_a_kernels.hpp"
-#include "join_a_tile_kernels.hpp"
+#include "partition_kernels.hpp"
+#include "tile_join_kernels.hpp"
 
 namespace gffx {
 
@@ -40,20 +41,27 @@ static int device_count_quiet() {
     return n;
 }
 
-// T of the list decomposition (gffx_device.hpp); GFFX_HIP_DECOMPOSE_T overrides for experiments
-static uint32_t gffx_decompose_T() {
-    const char *e = getenv("GFFX_HIP_DECOMPOSE_T");
+static long env_long(const char *name, long dflt, long lo, long hi) {
+    const char *e = getenv(name);
     if (e && *e) {
-        long v = strtol(e, nullptr, 10);
-        if (v >= 1 && v <= (1 << 20)) return (uint32_t)v;
+        const long v = strtol(e, nullptr, 10);
+        if (v >= lo && v <= hi) return v;
     }
-    return 4;
+    return dflt;
 }
 
 template <typename T>
 static int dev_alloc(T **p, size_t n) {
     *p = nullptr;
     GFFX_HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return GFFX_OK;
+}
+
+template <typename T>
+static int dev_upload(T **p, const std::vector<T> &v) {
+    int rc = dev_alloc(p, v.size());
+    if (rc) return rc;
+    if (!v.empty()) GFFX_HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return GFFX_OK;
 }
 
@@ -65,39 +73,34 @@ struct gffx_hip_index {
     int device = 0;
     uint32_t n_chr = 0;
     uint32_t n_roots = 0;
-    uint4 *d_ent = nullptr;
-    uint32_t *d_start = nullptr, *d_end = nullptr, *d_pmax = nullptr, *d_fid = nullptr;
-    uint2 *d_chr_lists = nullptr;
-    uint4 *d_list_meta = nullptr;
+    uint32_t *d_start = nullptr;
+    uint4 *d_aux = nullptr;
+    uint4 *d_chr_meta = nullptr;
     uint2 *d_bins = nullptr;
-    uint32_t n_lists = 0;
-    // sorted strategy: genome-window buckets and their LDS tiles (join_a_tile_kernels.hpp)
-    uint32_t *d_chr_bucket_base = nullptr;
-    uint32_t *d_tile_first = nullptr;
-    uint4 *d_tiles = nullptr;
-    uint8_t *d_bucket_in_lds = nullptr;
-    uint32_t n_buckets = 0, bucket_shift = 0;
-    bool sorted_ok = false;  // n_buckets <= kMaxBuckets
+    // partitioned strategy: genome-window tiles (gffx_device.hpp)
+    uint32_t *d_cell_base = nullptr;
+    uint16_t *d_cell_tile = nullptr;
+    uint4 *d_tile_meta = nullptr;
+    uint2 *d_tile_aux = nullptr;
+    uint16_t *d_tile_bins = nullptr;
+    uint4 *d_tile_blocks = nullptr;  // static grid of k_tile_join: two uint4 per block
+    uint32_t n_cells = 0, n_tiles = 0, cshift = 0, n_join_blocks = 0;
+    bool partition_ok = false;  // the tile plan exists (n_chr <= kMaxCells)
     std::vector<uint32_t> h_sorted_fids;
-    std::vector<uint32_t> h_chr_offsets;
 
     IndexView view() const {
         IndexView v;
-        v.ent = d_ent;
         v.start = d_start;
-        v.end = d_end;
-        v.pmax = d_pmax;
-        v.fid = d_fid;
-        v.chr_lists = d_chr_lists;
-        v.list_meta = d_list_meta;
+        v.aux = d_aux;
+        v.chr_meta = d_chr_meta;
         v.bins = d_bins;
         v.n_chr = n_chr;
-        v.n_lists = n_lists;
         v.n_roots = n_roots;
         return v;
     }
-    BucketPlanView bucket_view() const { return BucketPlanView{d_chr_bucket_base, n_chr, n_buckets, bucket_shift}; }
-    TileView tile_view() const { return TileView{d_tile_first, d_tiles, d_bucket_in_lds}; }
+    TilePlanView plan_view() const {
+        return TilePlanView{d_cell_base, d_cell_tile, d_tile_meta, d_tile_aux, d_tile_bins, n_chr, n_cells, n_tiles, cshift};
+    }
 };
 
 struct ProfEvent {
@@ -117,20 +120,21 @@ struct gffx_hip_batch {
     // outputs / workspace
     uint32_t *d_counts = nullptr;
     unsigned long long *d_block_sums = nullptr;
-    unsigned long long *d_status = nullptr;     // [0] error bits
-    unsigned long long *h_status = nullptr;     // pinned: [0] error bits, [1..] block sums
+    unsigned long long *d_status = nullptr;     // [0] error bits; partitioned strategy: [1] kept pairs
+    unsigned long long *h_status = nullptr;     // pinned: [0] error bits, [1] pair cursor / [1..] block sums
     static constexpr uint32_t kMaxBlocks = 8192;
     uint32_t *d_fids = nullptr, *d_triples = nullptr, *d_bitmap = nullptr;
     unsigned long long *d_offsets = nullptr;
     uint64_t cap_fids = 0, cap_triples = 0;
     uint64_t reserve = 0;
-    // sorted strategy workspace (allocated on first use)
-    uint32_t *d_hist = nullptr, *d_cursor = nullptr, *d_bucket_start = nullptr, *d_work_start = nullptr;
-    uint32_t *d_n_work = nullptr, *d_counts_b = nullptr;
-    uint4 *d_records = nullptr;
-    unsigned long long *d_work_base = nullptr;
-    uint32_t max_work = 0;
-    uint64_t cap_sums = 0;  // entries in d_block_sums / h_status
+    // partitioned strategy workspace (allocated on first use)
+    uint32_t *d_rec = nullptr;      // 3 arrays of n_tiles * sub_cap records
+    uint32_t *d_cursor = nullptr;   // 2 sets of n_tiles cursors (alternating; the join zeroes the other set)
+    uint32_t *d_q_rows = nullptr, *d_q_counts = nullptr;  // per-query results in emission order (max_q each)
+    unsigned long long *d_q_offsets = nullptr;
+    bool unpermuted = false;        // d_counts / d_offsets hold the input-order view of the last pass
+    uint32_t sub_cap = 0;           // queries per sub-batch == records per tile region
+    int cursor_phase = 0;
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
     uint32_t flags = 0;
@@ -176,164 +180,174 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
     GFFX_HIP_TRY(hipSetDevice(device));
 
-    // Per seqid: stable sort by start (the tree does the same: utils/tree.rs:40), then split into
-    // lists: an interval reaching past the start of its T-th successor moves to the next list
-    // (see gffx_device.hpp).  Every list gets the running max of `end` and a bin directory.
-    const uint32_t T = gffx_decompose_T();
-    const uint32_t kMaxLists = 8;
-    std::vector<uint4> ent;
-    ent.reserve(R);
-    std::vector<uint2> chr_lists(n_chr);
-    std::vector<uint4> list_meta;
+    // Per seqid: stable sort by start (the tree does the same: utils/tree.rs:40), running max of
+    // `end`, skip links (nearest earlier entry with a strictly greater end: monotonic stack), and
+    // the bin directory of the direct strategy (<= ~4 bins per entry, >= 64).
+    std::vector<uint32_t> h_start(R);
+    std::vector<uint4> h_aux(R);
+    std::vector<uint4> chr_meta(n_chr);
     std::vector<uint2> bins;
-    std::vector<uint32_t> order, cur, next;
+    std::vector<uint32_t> order, stack;
+    std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
+    ix->h_sorted_fids.resize(R);
     for (uint32_t c = 0; c < n_chr; c++) {
         const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
         order.resize(hi - lo);
         std::iota(order.begin(), order.end(), lo);
         std::stable_sort(order.begin(), order.end(),
                          [&](uint32_t a, uint32_t b) { return start[a] < start[b]; });
-        chr_lists[c] = make_uint2((uint32_t)list_meta.size(), 0);
-        cur = order;
-        uint32_t n_l = 0;
-        while (!cur.empty()) {
-            next.clear();
-            std::vector<uint32_t> keep;
-            keep.reserve(cur.size());
-            const bool last = (n_l + 1 == kMaxLists) || cur.size() <= T;
-            for (size_t i = 0; i < cur.size(); i++) {
-                const bool reaches = !last && i + T < cur.size() && end[cur[i]] > start[cur[i + T]];
-                (reaches ? next : keep).push_back(cur[i]);
-            }
-            // emit the list
-            const uint32_t first = (uint32_t)ent.size();
-            uint32_t pm = 0;
-            for (uint32_t j : keep) {
-                pm = std::max(pm, end[j]);
-                ent.push_back(make_uint4(start[j], end[j], pm, root_fid[j]));
-            }
-            const uint32_t endp = (uint32_t)ent.size();
-            if (endp > first) {
-                const uint32_t max_start = ent[endp - 1].x;
-                const uint64_t budget = std::max<uint64_t>(4ull * (endp - first), 64);
-                uint32_t shift = 0;
-                while ((((uint64_t)max_start >> shift) + 1) > budget) shift++;
-                const uint32_t nb = (max_start >> shift) + 1;  // < 2^27 since budget <= 4*2^32/..: checked below
-                if (nb >= (1u << 27)) return fail(GFFX_E_INVALID, "index too large for the bin directory");
-                list_meta.push_back(make_uint4(first, endp, (uint32_t)bins.size(), (shift << kPosBits) | nb));
-                uint32_t p = first;
-                for (uint32_t b = 0; b < nb; b++) {
-                    const uint64_t edge = (uint64_t)b << shift, next_edge = (uint64_t)(b + 1) << shift;
-                    while (p < endp && ent[p].x < edge) p++;
-                    uint32_t q = p;
-                    while (q < endp && ent[q].x < next_edge) q++;
-                    bins.push_back(make_uint2(p | (std::min(q - p, kCntSat) << kPosBits),
-                                              p > first ? ent[p - 1].z : 0u));
-                }
-                // sentinel: nothing starts at or after nb << shift
-                bins.push_back(make_uint2(endp, ent[endp - 1].z));
-                n_l++;
-            }
-            cur.swap(next);
+        stack.clear();
+        uint32_t pm = 0;
+        for (uint32_t k = 0; k < hi - lo; k++) {
+            const uint32_t j = order[k], i = lo + k;
+            pm = std::max(pm, end[j]);
+            while (!stack.empty() && h_aux[stack.back()].x <= end[j]) stack.pop_back();
+            const uint32_t skip = stack.empty() ? lo : stack.back() + 1;
+            stack.push_back(i);
+            h_start[i] = start[j];
+            h_aux[i] = make_uint4(end[j], pm, skip, root_fid[j]);
+            ix->h_sorted_fids[i] = root_fid[j];
         }
-        chr_lists[c].y = n_l;
+        if (hi == lo) {
+            chr_meta[c] = make_uint4(lo, lo, (uint32_t)bins.size(), 0u);
+            continue;
+        }
+        const uint32_t max_start = h_start[hi - 1];
+        const uint64_t budget = std::max<uint64_t>(4ull * (hi - lo), 64);
+        uint32_t shift = 0;
+        while ((((uint64_t)max_start >> shift) + 1) > budget) shift++;
+        const uint32_t nb = (max_start >> shift) + 1;
+        if (nb >= (1u << kPosBits)) return fail(GFFX_E_INVALID, "index too large for the bin directory");
+        chr_meta[c] = make_uint4(lo, hi, (uint32_t)bins.size(), (shift << kPosBits) | nb);
+        uint32_t p = lo;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint64_t edge = (uint64_t)b << shift, next_edge = (uint64_t)(b + 1) << shift;
+            while (p < hi && h_start[p] < edge) p++;
+            uint32_t q = p;
+            while (q < hi && h_start[q] < next_edge) q++;
+            bins.push_back(make_uint2(p | (std::min(q - p, kCntSat) << kPosBits), p > lo ? h_aux[p - 1].y : 0u));
+        }
+        bins.push_back(make_uint2(hi, h_aux[hi - 1].y));  // sentinel: nothing starts at or after nb << shift
     }
 
-    // Sorted strategy: genome-window buckets (<= 2048 in total) and, per bucket and list, the
-    // entries a query ending inside the window can reach (see join_a_tile_kernels.hpp).
-    std::vector<uint32_t> chr_bucket_base(n_chr + 1, 0), tile_first;
-    std::vector<uint4> tiles;
-    std::vector<uint8_t> bucket_in_lds;
-    uint32_t bshift = 0;
-    {
-        std::vector<uint32_t> chr_max_start(n_chr, 0);
-        for (uint32_t c = 0; c < n_chr; c++)
-            for (uint32_t l = chr_lists[c].x; l < chr_lists[c].x + chr_lists[c].y; l++)
-                chr_max_start[c] = std::max(chr_max_start[c], ent[list_meta[l].y - 1].x);
-        for (;; bshift++) {
+    // Partitioned strategy: cells of 2^cshift bp (<= kMaxCells in total, >= 1 per seqid) merged into
+    // tiles of <= kTileEntries entries; per tile a 1024-bin u16 directory over start (gffx_device.hpp).
+    std::vector<uint32_t> cell_base(n_chr + 1, 0);
+    std::vector<uint16_t> cell_tile;
+    std::vector<uint4> tile_meta;
+    std::vector<uint2> tile_aux;
+    std::vector<uint16_t> tile_bins;
+    uint32_t cshift = 0;
+    const bool plan = n_chr >= 1 && n_chr <= kMaxCells;
+    if (plan) {
+        auto cells_of = [&](uint32_t c, uint32_t sh) -> uint64_t {
+            const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+            return hi > lo ? ((uint64_t)h_start[hi - 1] >> sh) + 1 : 1;
+        };
+        for (;; cshift++) {
             uint64_t tot = 0;
-            for (uint32_t c = 0; c < n_chr; c++)
-                tot += chr_lists[c].y ? ((uint64_t)chr_max_start[c] >> bshift) + 2 : 1;
-            if (tot <= 2048 || bshift == 31) break;
+            for (uint32_t c = 0; c < n_chr; c++) tot += cells_of(c, cshift);
+            if (tot <= kMaxCells || cshift == 31) break;
         }
-        const uint64_t W = 1ull << bshift;
+        for (uint32_t c = 0; c < n_chr; c++) cell_base[c + 1] = cell_base[c] + (uint32_t)cells_of(c, cshift);
+    }
+    const bool plan_ok = plan && cell_base[n_chr] <= kMaxCells;
+    if (plan_ok) {
+        cell_tile.resize(cell_base[n_chr]);
         for (uint32_t c = 0; c < n_chr; c++) {
-            const uint32_t nb = chr_lists[c].y ? (chr_max_start[c] >> bshift) + 2 : 1;
-            chr_bucket_base[c + 1] = chr_bucket_base[c] + nb;
-            for (uint32_t b = 0; b < nb; b++) {
-                tile_first.push_back((uint32_t)tiles.size());
-                const uint64_t win_lo = (uint64_t)b << bshift, win_hi = (uint64_t)(b + 1) << bshift;
-                const uint64_t thr = win_lo > W ? win_lo - W : 0;
-                uint64_t total = 0;
-                for (uint32_t l = chr_lists[c].x; l < chr_lists[c].x + chr_lists[c].y; l++) {
-                    const uint32_t first = list_meta[l].x, endp = list_meta[l].y;
-                    uint32_t hi = endp;
-                    if (b + 1 < nb)  // the last bucket of a seqid also takes every query beyond it
-                        hi = (uint32_t)(std::lower_bound(ent.begin() + first, ent.begin() + endp, win_hi,
-                                                         [](const uint4 &e, uint64_t v) { return e.x < v; }) -
-                                        ent.begin());
-                    uint32_t lo = (uint32_t)(std::upper_bound(ent.begin() + first, ent.begin() + endp, thr,
-                                                              [](uint64_t v, const uint4 &e) { return v < e.z; }) -
-                                             ent.begin());  // first entry whose running max exceeds thr
-                    if (lo > hi) lo = hi;
-                    tiles.push_back(make_uint4(lo, hi, lo > first ? ent[lo - 1].z : 0u, first));
-                    total += hi - lo;
+            const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+            const uint32_t nc = cell_base[c + 1] - cell_base[c];
+            uint32_t p = lo;          // first entry of the current cell
+            uint32_t t_first = lo;    // first entry of the open tile
+            uint32_t t_cell = 0;      // first cell of the open tile
+            auto close_tile = [&](uint32_t cell_end, uint32_t ent_end, bool last) {
+                const uint32_t tid = (uint32_t)tile_meta.size();
+                for (uint32_t x = t_cell; x < cell_end; x++) cell_tile[cell_base[c] + x] = (uint16_t)tid;
+                const uint64_t w0 = (uint64_t)t_cell << cshift;
+                const uint64_t w1 = last ? (hi > lo ? (uint64_t)h_start[hi - 1] + 1 : w0 + 1) : (uint64_t)cell_end << cshift;
+                const uint64_t span = std::max<uint64_t>(w1 > w0 ? w1 - w0 : 1, 1);
+                uint32_t bs = 0;
+                while (((span - 1) >> bs) >= kTileBins) bs++;
+                const uint32_t n_ent = ent_end - t_first;
+                tile_meta.push_back(make_uint4(t_first, ent_end, (uint32_t)w0, lo));
+                tile_aux.push_back(make_uint2(bs, n_ent <= kTileEntries ? 1u : 0u));
+                const size_t base = tile_bins.size();
+                tile_bins.resize(base + kTileBinStride, 0);
+                if (n_ent <= kTileEntries) {
+                    uint32_t k = 0;
+                    for (uint32_t b = 0; b <= kTileBins; b++) {
+                        const uint64_t edge = w0 + ((uint64_t)b << bs);
+                        while (k < n_ent && (uint64_t)h_start[t_first + k] < edge) k++;
+                        tile_bins[base + b] = (uint16_t)k;
+                    }
                 }
-                bucket_in_lds.push_back(total <= kTileEntries ? 1 : 0);
+                t_first = ent_end;
+                t_cell = cell_end;
+            };
+            for (uint32_t x = 0; x < nc; x++) {
+                uint32_t q = p;
+                if (x + 1 == nc) {
+                    q = hi;
+                } else {
+                    const uint64_t edge = (uint64_t)(x + 1) << cshift;
+                    while (q < hi && (uint64_t)h_start[q] < edge) q++;
+                }
+                // adding cell x would overflow the open tile: close it before x
+                if (x > t_cell && (q - t_first) > kTileEntries) close_tile(x, p, false);
+                p = q;
             }
+            close_tile(nc, hi, true);
         }
-        tile_first.push_back((uint32_t)tiles.size());
     }
 
-    std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
+    // Static grid of k_tile_join: tile t gets S_t ~ (its share of the genome) x target blocks, >= 1.
+    // Under a uniform query load every block then serves about the same number of queries; under a
+    // skewed load the blocks of a crowded tile simply loop longer (correct, just less balanced).
+    std::vector<uint4> tile_blocks;
+    if (plan_ok) {
+        const uint32_t target = (uint32_t)env_long("GFFX_HIP_JOIN_BLOCKS", 1024, 1, 16384);
+        std::vector<double> wgt(tile_meta.size());
+        double wsum = 0;
+        for (size_t t = 0; t < tile_meta.size(); t++) {
+            const uint4 m = tile_meta[t];
+            const uint64_t w0 = m.z;
+            // window end: the next tile's start inside the same seqid, else the seqid's last start + 1
+            uint64_t w1;
+            if (t + 1 < tile_meta.size() && tile_meta[t + 1].w == m.w && tile_meta[t + 1].z > m.z)
+                w1 = tile_meta[t + 1].z;
+            else
+                w1 = m.y > m.w ? (uint64_t)h_start[m.y > m.x ? m.y - 1 : m.w] + 1 : w0 + 1;
+            wgt[t] = (double)(w1 > w0 ? w1 - w0 : 1) + 1.0;
+            wsum += wgt[t];
+        }
+        for (size_t t = 0; t < tile_meta.size(); t++) {
+            const uint4 m = tile_meta[t];
+            uint32_t S = (uint32_t)std::max(1.0, std::floor(target * wgt[t] / wsum + 0.5));
+            for (uint32_t sidx = 0; sidx < S; sidx++) {
+                tile_blocks.push_back(make_uint4((uint32_t)t, sidx, S, m.x));
+                tile_blocks.push_back(make_uint4((m.y - m.x) | (tile_aux[t].y ? 0x80000000u : 0u), m.z, m.w, tile_aux[t].x));
+            }
+        }
+        if (cell_tile.size() & 1) cell_tile.push_back(0);  // k_partition copies the table as 4-byte words
+    }
+
     ix->device = device;
     ix->n_chr = n_chr;
     ix->n_roots = R;
-    ix->n_lists = (uint32_t)list_meta.size();
-    ix->n_buckets = chr_bucket_base[n_chr];
-    ix->bucket_shift = bshift;
-    ix->sorted_ok = ix->n_buckets <= kMaxBuckets;
-    ix->h_chr_offsets.assign(chr_offsets, chr_offsets + n_chr + 1);
-    ix->h_sorted_fids.resize(R);
-    std::vector<uint32_t> s(R), e(R), pm(R);
-    for (uint32_t i = 0; i < R; i++) {
-        s[i] = ent[i].x;
-        e[i] = ent[i].y;
-        pm[i] = ent[i].z;
-        ix->h_sorted_fids[i] = ent[i].w;
-    }
+    ix->n_join_blocks = (uint32_t)(tile_blocks.size() / 2);
+    ix->n_cells = plan_ok ? cell_base[n_chr] : 0;
+    ix->n_tiles = (uint32_t)tile_meta.size();
+    ix->cshift = cshift;
+    ix->partition_ok = plan_ok && ix->n_tiles >= 1 && ix->n_tiles <= kMaxTiles;
     int rc;
-    if ((rc = dev_alloc(&ix->d_ent, R)) || (rc = dev_alloc(&ix->d_start, R)) ||
-        (rc = dev_alloc(&ix->d_end, R)) || (rc = dev_alloc(&ix->d_pmax, R)) ||
-        (rc = dev_alloc(&ix->d_fid, R)) || (rc = dev_alloc(&ix->d_chr_lists, n_chr)) ||
-        (rc = dev_alloc(&ix->d_list_meta, list_meta.size())) ||
-        (rc = dev_alloc(&ix->d_bins, bins.size())) ||
-        (rc = dev_alloc(&ix->d_chr_bucket_base, chr_bucket_base.size())) ||
-        (rc = dev_alloc(&ix->d_tile_first, tile_first.size())) || (rc = dev_alloc(&ix->d_tiles, tiles.size())) ||
-        (rc = dev_alloc(&ix->d_bucket_in_lds, bucket_in_lds.size()))) {
+    if ((rc = dev_upload(&ix->d_start, h_start)) || (rc = dev_upload(&ix->d_aux, h_aux)) ||
+        (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
+        (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
+        (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
+        (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_blocks, tile_blocks))) {
         gffx_hip_index_destroy(ix.release());
         return rc;
     }
-    if (R) {
-        GFFX_HIP_TRY(hipMemcpy(ix->d_ent, ent.data(), R * sizeof(uint4), hipMemcpyHostToDevice));
-        GFFX_HIP_TRY(hipMemcpy(ix->d_start, s.data(), R * 4, hipMemcpyHostToDevice));
-        GFFX_HIP_TRY(hipMemcpy(ix->d_end, e.data(), R * 4, hipMemcpyHostToDevice));
-        GFFX_HIP_TRY(hipMemcpy(ix->d_pmax, pm.data(), R * 4, hipMemcpyHostToDevice));
-        GFFX_HIP_TRY(hipMemcpy(ix->d_fid, ix->h_sorted_fids.data(), R * 4, hipMemcpyHostToDevice));
-    }
-    if (n_chr)
-        GFFX_HIP_TRY(hipMemcpy(ix->d_chr_lists, chr_lists.data(), n_chr * sizeof(uint2), hipMemcpyHostToDevice));
-    if (!list_meta.empty())
-        GFFX_HIP_TRY(hipMemcpy(ix->d_list_meta, list_meta.data(), list_meta.size() * sizeof(uint4),
-                               hipMemcpyHostToDevice));
-    if (!bins.empty())
-        GFFX_HIP_TRY(hipMemcpy(ix->d_bins, bins.data(), bins.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    GFFX_HIP_TRY(hipMemcpy(ix->d_chr_bucket_base, chr_bucket_base.data(), chr_bucket_base.size() * 4, hipMemcpyHostToDevice));
-    GFFX_HIP_TRY(hipMemcpy(ix->d_tile_first, tile_first.data(), tile_first.size() * 4, hipMemcpyHostToDevice));
-    if (!tiles.empty())
-        GFFX_HIP_TRY(hipMemcpy(ix->d_tiles, tiles.data(), tiles.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    if (!bucket_in_lds.empty())
-        GFFX_HIP_TRY(hipMemcpy(ix->d_bucket_in_lds, bucket_in_lds.data(), bucket_in_lds.size(), hipMemcpyHostToDevice));
     *out = ix.release();
     return GFFX_OK;
 }
@@ -341,18 +355,16 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
 extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    (void)hipFree(ix->d_ent);
     (void)hipFree(ix->d_start);
-    (void)hipFree(ix->d_end);
-    (void)hipFree(ix->d_pmax);
-    (void)hipFree(ix->d_fid);
-    (void)hipFree(ix->d_chr_lists);
-    (void)hipFree(ix->d_list_meta);
+    (void)hipFree(ix->d_aux);
+    (void)hipFree(ix->d_chr_meta);
     (void)hipFree(ix->d_bins);
-    (void)hipFree(ix->d_chr_bucket_base);
-    (void)hipFree(ix->d_tile_first);
-    (void)hipFree(ix->d_tiles);
-    (void)hipFree(ix->d_bucket_in_lds);
+    (void)hipFree(ix->d_cell_base);
+    (void)hipFree(ix->d_cell_tile);
+    (void)hipFree(ix->d_tile_meta);
+    (void)hipFree(ix->d_tile_aux);
+    (void)hipFree(ix->d_tile_bins);
+    (void)hipFree(ix->d_tile_blocks);
     delete ix;
 }
 
@@ -378,18 +390,17 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(GFFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     if ((rc = dev_alloc(&b->d_counts, max_queries)) || (rc = dev_alloc(&b->d_block_sums, gffx_hip_batch::kMaxBlocks)) ||
-        (rc = dev_alloc(&b->d_status, 2))) {
+        (rc = dev_alloc(&b->d_status, 4))) {
         gffx_hip_batch_destroy(b.release());
         return rc;
     }
-    GFFX_HIP_TRY(hipMemset(b->d_status, 0, 2 * sizeof(unsigned long long)));
+    GFFX_HIP_TRY(hipMemset(b->d_status, 0, 4 * sizeof(unsigned long long)));
     e = hipHostMalloc((void **)&b->h_status, (1 + gffx_hip_batch::kMaxBlocks) * sizeof(unsigned long long),
                       hipHostMallocDefault);
     if (e != hipSuccess) {
         gffx_hip_batch_destroy(b.release());
         return fail(GFFX_E_OOM, "hipHostMalloc failed: %s", hipGetErrorString(e));
     }
-    b->cap_sums = gffx_hip_batch::kMaxBlocks;
     *out = b.release();
     return GFFX_OK;
 }
@@ -411,14 +422,11 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     (void)hipFree(b->d_triples);
     (void)hipFree(b->d_bitmap);
     (void)hipFree(b->d_offsets);
-    (void)hipFree(b->d_hist);
+    (void)hipFree(b->d_rec);
     (void)hipFree(b->d_cursor);
-    (void)hipFree(b->d_bucket_start);
-    (void)hipFree(b->d_work_start);
-    (void)hipFree(b->d_n_work);
-    (void)hipFree(b->d_counts_b);
-    (void)hipFree(b->d_records);
-    (void)hipFree(b->d_work_base);
+    (void)hipFree(b->d_q_rows);
+    (void)hipFree(b->d_q_counts);
+    (void)hipFree(b->d_q_offsets);
     if (b->h_status) (void)hipHostFree(b->h_status);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -542,9 +550,7 @@ static JoinOut make_out(gffx_hip_batch *b) {
     return o;
 }
 
-static uint32_t meta_bytes(const gffx_hip_index *ix) {
-    return ((ix->n_chr * 8u + 15u) & ~15u) + ix->n_lists * 16u;
-}
+static uint32_t meta_bytes(const gffx_hip_index *ix) { return ix->n_chr * 16u; }
 
 template <int MODE, bool INV, bool AOS, bool ML>
 static void launch_count(gffx_hip_batch *b, const JoinOut &o) {
@@ -597,141 +603,126 @@ static int enqueue_emit(gffx_hip_batch *b) {
     return GFFX_OK;
 }
 
-// ------------------------------------------------------------------------------------ sorted strategy
+// ------------------------------------------------------------------------------------ partitioned strategy
 
-static int sorted_prepare(gffx_hip_batch *b) {
+// Workspace: three record arrays of n_tiles regions x sub_cap records.  A region can hold a whole
+// sub-batch, so k_partition needs no histogram pre-pass; sub_cap is the batch capacity unless that
+// would exceed the budget (GFFX_HIP_PARTITION_BUDGET_MB, default 12 GiB), in which case a pass runs
+// as several partition+join pairs.
+static int partition_prepare(gffx_hip_batch *b) {
+    if (b->d_rec) return GFFX_OK;
     const gffx_hip_index *ix = b->ix;
-    if (b->d_records) return GFFX_OK;
+    const uint64_t budget = (uint64_t)env_long("GFFX_HIP_PARTITION_BUDGET_MB", 12 * 1024, 1, 256 * 1024) << 20;
+    uint64_t cap = std::max<uint64_t>(b->max_q, 1);
+    const uint64_t fit = budget / (12ull * ix->n_tiles);
+    if (cap > fit) cap = std::max<uint64_t>(fit / kPartChunk * kPartChunk, kPartChunk);
+    if (cap * ix->n_tiles >= (1ull << 32))  // record positions are u32
+        cap = std::max<uint64_t>(((1ull << 32) - 1) / ix->n_tiles / kPartChunk * kPartChunk, kPartChunk);
+    b->sub_cap = (uint32_t)cap;
     int rc;
-    const size_t nb = ix->n_buckets;
-    b->max_work = (uint32_t)(nb + b->max_q / kQueriesPerWork + 2);
-    if ((rc = dev_alloc(&b->d_hist, nb + 1)) || (rc = dev_alloc(&b->d_cursor, nb + 1)) ||
-        (rc = dev_alloc(&b->d_bucket_start, nb + 2)) || (rc = dev_alloc(&b->d_work_start, nb + 2)) ||
-        (rc = dev_alloc(&b->d_n_work, 1)) || (rc = dev_alloc(&b->d_counts_b, b->max_q)) ||
-        (rc = dev_alloc(&b->d_records, b->max_q)) || (rc = dev_alloc(&b->d_work_base, b->max_work)))
+    if ((rc = dev_alloc(&b->d_rec, 3ull * ix->n_tiles * cap)) || (rc = dev_alloc(&b->d_cursor, 2ull * ix->n_tiles)) ||
+        (rc = dev_alloc(&b->d_q_rows, b->max_q)) || (rc = dev_alloc(&b->d_q_counts, b->max_q)))
         return rc;
-    GFFX_HIP_TRY(hipMemset(b->d_hist, 0, (nb + 1) * 4));
-    GFFX_HIP_TRY(hipMemset(b->d_cursor, 0, (nb + 1) * 4));
-    if (b->max_work > b->cap_sums) {  // one partial sum per work item
-        GFFX_HIP_TRY(hipFree(b->d_block_sums));
-        b->d_block_sums = nullptr;
-        if ((rc = dev_alloc(&b->d_block_sums, b->max_work))) return rc;
-        GFFX_HIP_TRY(hipHostFree(b->h_status));
-        b->h_status = nullptr;
-        GFFX_HIP_TRY(hipHostMalloc((void **)&b->h_status, (1 + (size_t)b->max_work) * sizeof(unsigned long long),
-                                   hipHostMallocDefault));
-        b->cap_sums = b->max_work;
-    }
+    GFFX_HIP_TRY(hipMemset(b->d_cursor, 0, 2ull * ix->n_tiles * 4));
+    b->cursor_phase = 0;
     return GFFX_OK;
 }
 
-static TileOut make_tile_out(gffx_hip_batch *b, bool prefix_ready) {
+template <int MODE, bool INV>
+static void launch_tile_join(gffx_hip_batch *b, uint32_t grid, const TileWork &w, const TileOut &o) {
+    hipLaunchKernelGGL((k_tile_join<MODE, INV>), dim3(grid), dim3(kTJThreads), 0, b->stream, b->ix->view(),
+                       b->ix->plan_view(), w, o);
+}
+
+static int enqueue_unpermute(gffx_hip_batch *b) {
+    if (b->unpermuted || b->nq == 0) return GFFX_OK;
+    ProfEvent pe;
+    prof_begin(b, GFFX_K_UNPERMUTE, &pe);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((b->nq + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(256), 0, b->stream, (unsigned long long)b->nq, b->d_q_rows,
+                       b->d_q_counts, (b->flags & GFFX_OUT_OFFSETS) ? b->d_q_offsets : nullptr, b->d_counts,
+                       (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr);
+    prof_end(b, &pe);
+    GFFX_HIP_TRY(hipGetLastError());
+    b->unpermuted = true;
+    return GFFX_OK;
+}
+
+static int run_partitioned(gffx_hip_batch *b) {
+    int rc = partition_prepare(b);
+    if (rc) return rc;
+    const gffx_hip_index *ix = b->ix;
+    const TilePlanView tp = ix->plan_view();
+    const bool aos = b->q.aos != nullptr;
+    if (b->flags & GFFX_OUT_ROOT_BITMAP)
+        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)ix->n_roots + 31) / 32 * 4 + 4, b->stream));
+    const size_t region = (size_t)ix->n_tiles * b->sub_cap;
+    if ((b->flags & GFFX_OUT_OFFSETS) && !b->d_q_offsets && (rc = dev_alloc(&b->d_q_offsets, b->max_q))) return rc;
     TileOut o;
-    o.work_base = prefix_ready ? b->d_work_base : nullptr;
-    o.counts_b = b->d_counts_b;
-    o.counts_in = getenv("GFFX_EXP_NOSCATTER") ? nullptr : b->d_counts;
-    o.block_sums = b->d_block_sums;
+    o.q_rows = b->d_q_rows;
+    o.q_counts = b->d_q_counts;
+    o.q_offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_q_offsets : nullptr;
     o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
     o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
     o.bitmap = (b->flags & GFFX_OUT_ROOT_BITMAP) ? b->d_bitmap : nullptr;
-    o.offsets_in = ((b->flags & GFFX_OUT_OFFSETS) && !getenv("GFFX_EXP_NOSCATTER")) ? b->d_offsets : nullptr;
+    o.cursors = b->d_status + 1;
     uint64_t cap = UINT64_MAX;
     if (o.fids) cap = std::min(cap, b->cap_fids);
     if (o.triples) cap = std::min(cap, b->cap_triples);
     o.capacity = cap;
-    return o;
-}
-
-template <bool EMIT, int MODE, bool INV, bool ML>
-static void launch_tile(gffx_hip_batch *b, uint32_t grid, const SortedWork &w, const TileOut &o) {
-    const uint32_t lds = kTileEntries * 16 + 224 + (ML ? meta_bytes(b->ix) : 0);
-    if (EMIT)
-        hipLaunchKernelGGL((k_tile_emit<MODE, INV, ML>), dim3(grid), dim3(kJoinThreads), lds, b->stream,
-                           b->ix->view(), b->ix->tile_view(), w, o);
-    else
-        hipLaunchKernelGGL((k_tile_count<MODE, INV, ML>), dim3(grid), dim3(kJoinThreads), lds, b->stream,
-                           b->ix->view(), b->ix->tile_view(), w, o);
-}
-
-template <bool EMIT>
-static void dispatch_tile(gffx_hip_batch *b, uint32_t grid, const SortedWork &w, const TileOut &o) {
-    const bool ml = meta_bytes(b->ix) <= kMetaLdsBytes;
-#define GFFX_CASE(M, I, L)                                    \
-    if (b->mode == M && (b->invert != 0) == I && ml == L) {   \
-        launch_tile<EMIT, M, I, L>(b, grid, w, o);            \
-        return;                                               \
-    }
-    GFFX_CASE(0, false, true) GFFX_CASE(0, false, false) GFFX_CASE(0, true, true) GFFX_CASE(0, true, false)
-    GFFX_CASE(1, false, true) GFFX_CASE(1, false, false) GFFX_CASE(1, true, true) GFFX_CASE(1, true, false)
-    GFFX_CASE(2, false, true) GFFX_CASE(2, false, false) GFFX_CASE(2, true, true) GFFX_CASE(2, true, false)
-#undef GFFX_CASE
-}
-
-static uint32_t sorted_grid(const gffx_hip_batch *b) {
-    return (uint32_t)(b->ix->n_buckets + b->nq / kQueriesPerWork + 1);
-}
-
-static int enqueue_tile_emit(gffx_hip_batch *b) {
-    if (b->flags & GFFX_OUT_ROOT_BITMAP)
-        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
-    const uint32_t grid = sorted_grid(b);
-    const bool big = grid > 4096;  // too many work items for every block to add up its predecessors
-    SortedWork w{b->d_records, b->d_bucket_start, b->d_work_start, b->d_n_work, b->ix->n_buckets};
-    ProfEvent pe;
-    prof_begin(b, GFFX_K_JOIN_EMIT, &pe);
-    if (big) hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, b->stream, b->d_n_work, b->d_block_sums, b->d_work_base);
-    dispatch_tile<true>(b, grid, w, make_tile_out(b, big));
-    prof_end(b, &pe);
-    GFFX_HIP_TRY(hipGetLastError());
-    return GFFX_OK;
-}
-
-static int run_sorted(gffx_hip_batch *b) {
-    int rc = sorted_prepare(b);
-    if (rc) return rc;
-    const gffx_hip_index *ix = b->ix;
-    const uint64_t nq = b->nq;
-    const bool aos = b->q.aos != nullptr;
-    const BucketPlanView bp = ix->bucket_view();
-    const uint32_t lds_b = (ix->n_buckets + ix->n_chr + 1) * 4;
-    ProfEvent pe;
-    prof_begin(b, GFFX_K_SORT, &pe);
-    {
-        uint64_t grid = (nq + (uint64_t)kBucketThreads * 8 - 1) / ((uint64_t)kBucketThreads * 8);
-        grid = std::max<uint64_t>(1, std::min<uint64_t>(grid, 1024));
-        uint64_t chunk = (nq + grid - 1) / grid;
-        chunk = (chunk + kBucketThreads - 1) / kBucketThreads * kBucketThreads;
-        uint32_t *err = reinterpret_cast<uint32_t *>(b->d_status);
-        if (aos)
-            hipLaunchKernelGGL((k_bucket_hist<true>), dim3((uint32_t)grid), dim3(kBucketThreads), lds_b, b->stream, bp,
-                               b->q, (unsigned long long)nq, (unsigned long long)chunk, b->d_hist, err);
-        else
-            hipLaunchKernelGGL((k_bucket_hist<false>), dim3((uint32_t)grid), dim3(kBucketThreads), lds_b, b->stream, bp,
-                               b->q, (unsigned long long)nq, (unsigned long long)chunk, b->d_hist, err);
-    }
-    hipLaunchKernelGGL(k_bucket_plan, dim3(1), dim3(1024), 0, b->stream, ix->n_buckets, b->d_hist, b->d_cursor,
-                       b->d_bucket_start, b->d_work_start, b->d_n_work);
-    {
-        const uint64_t per = (uint64_t)kBucketThreads * kBucketItems;
-        const uint32_t grid = (uint32_t)((nq + per - 1) / per);
-        if (aos)
-            hipLaunchKernelGGL((k_bucket_scatter<true>), dim3(grid), dim3(kBucketThreads), lds_b, b->stream, bp, b->q,
-                               (unsigned long long)nq, b->d_bucket_start, b->d_cursor, b->d_records);
-        else
-            hipLaunchKernelGGL((k_bucket_scatter<false>), dim3(grid), dim3(kBucketThreads), lds_b, b->stream, bp, b->q,
-                               (unsigned long long)nq, b->d_bucket_start, b->d_cursor, b->d_records);
-    }
-    prof_end(b, &pe);
-    GFFX_HIP_TRY(hipGetLastError());
-    {
-        SortedWork w{b->d_records, b->d_bucket_start, b->d_work_start, b->d_n_work, ix->n_buckets};
-        prof_begin(b, GFFX_K_JOIN_COUNT, &pe);
-        dispatch_tile<false>(b, sorted_grid(b), w, make_tile_out(b, false));
+    for (uint64_t q0 = 0; q0 < b->nq; q0 += b->sub_cap) {
+        o.q0 = q0;
+        const uint32_t n = (uint32_t)std::min<uint64_t>(b->sub_cap, b->nq - q0);
+        uint32_t *cur = b->d_cursor + (size_t)b->cursor_phase * ix->n_tiles;
+        uint32_t *nxt = b->d_cursor + (size_t)(b->cursor_phase ^ 1) * ix->n_tiles;
+        PartOut po{b->d_rec, b->d_rec + region, b->d_rec + 2 * region, cur,
+                   reinterpret_cast<uint32_t *>(b->d_status), b->d_status + 1, b->sub_cap};
+        ProfEvent pe;
+        prof_begin(b, GFFX_K_SORT, &pe);
+        {
+            const uint32_t grid = (n + kPartChunk - 1) / kPartChunk;
+            const uint32_t lds = part_lds_bytes(ix->n_chr, ix->n_cells, ix->n_tiles);
+            if (lds > 64 * 1024) {  // many seqids / tiles: opt in to more than the default dynamic LDS limit
+                GFFX_HIP_TRY(hipFuncSetAttribute(aos ? (const void *)k_partition<true> : (const void *)k_partition<false>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            if (aos)
+                hipLaunchKernelGGL((k_partition<true>), dim3(grid), dim3(kPartThreads), lds, b->stream, tp, b->q,
+                                   (unsigned long long)q0, n, po, q0 == 0 ? 1 : 0);
+            else
+                hipLaunchKernelGGL((k_partition<false>), dim3(grid), dim3(kPartThreads), lds, b->stream, tp, b->q,
+                                   (unsigned long long)q0, n, po, q0 == 0 ? 1 : 0);
+        }
         prof_end(b, &pe);
         GFFX_HIP_TRY(hipGetLastError());
+        prof_begin(b, GFFX_K_FUSED, &pe);
+        {
+            const TileWork w{po.rec_qs, po.rec_qe, po.rec_row, cur, nxt, ix->d_tile_blocks, b->sub_cap};
+            const uint32_t grid = ix->n_join_blocks;
+#define GFFX_CASE(M, I)                                  \
+    if (b->mode == M && (b->invert != 0) == I) launch_tile_join<M, I>(b, grid, w, o);
+            GFFX_CASE(0, false) GFFX_CASE(0, true) GFFX_CASE(1, false) GFFX_CASE(1, true) GFFX_CASE(2, false)
+            GFFX_CASE(2, true)
+#undef GFFX_CASE
+        }
+        prof_end(b, &pe);
+        GFFX_HIP_TRY(hipGetLastError());
+        b->cursor_phase ^= 1;
     }
-    if (wants_pairs(b->flags) && (rc = enqueue_tile_emit(b))) return rc;
+    b->unpermuted = false;
+    if (!(b->flags & GFFX_OUT_EMIT_ORDER)) {
+        // the caller wants input-order counts / offsets: scatter them from the emission-order arrays
+        if ((rc = enqueue_unpermute(b))) return rc;
+    }
     return GFFX_OK;
+}
+
+// AUTO: the partitioned strategy pays for its extra pass from a few tens of thousands of queries on
+static bool pick_partitioned(const gffx_hip_batch *b, int strategy) {
+    if (!b->ix->partition_ok || b->max_q >= (1ull << 32)) return false;
+    if (strategy == GFFX_STRATEGY_SORTED) return true;
+    if (strategy == GFFX_STRATEGY_DIRECT) return false;
+    return b->nq >= (uint64_t)env_long("GFFX_HIP_PARTITION_MIN_QUERIES", 32768, 0, 1L << 40);
 }
 
 extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags,
@@ -741,14 +732,14 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad mode %d", mode);
     if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_SORTED)
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad strategy %d", strategy);
-    if (strategy == GFFX_STRATEGY_SORTED && !b->ix->sorted_ok)
-        return fail(GFFX_E_INVALID, "gffx_hip_batch_run: the sorted strategy needs <= %u genome-window buckets "
-                                    "(this index has %u: too many seqids)", kMaxBuckets, b->ix->n_buckets);
+    if (strategy == GFFX_STRATEGY_SORTED && (!b->ix->partition_ok || b->max_q >= (1ull << 32)))
+        return fail(GFFX_E_INVALID, "gffx_hip_batch_run: the partitioned strategy needs <= %u seqids / genome cells "
+                                    "and < 2^32 queries per batch (this index has %u seqids)", kMaxCells, b->ix->n_chr);
     GFFX_HIP_TRY(hipSetDevice(b->ix->device));
     b->mode = mode;
     b->invert = invert ? 1 : 0;
     b->flags = out_flags | GFFX_OUT_COUNTS;
-    b->strategy = strategy == GFFX_STRATEGY_SORTED ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_DIRECT;
+    b->strategy = pick_partitioned(b, strategy) ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_DIRECT;
     b->ran = true;
     b->waited = false;
     b->total = 0;
@@ -772,7 +763,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want && (rc = grow(&b->d_fids, &b->cap_fids, want, 1))) return rc;
         if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want && (rc = grow(&b->d_triples, &b->cap_triples, want, 3)))
             return rc;
-        return run_sorted(b);
+        return run_partitioned(b);
     }
     // contiguous chunk of queries per block, a multiple of the block size; <= 2048 blocks
     const uint64_t tiles = (nq + kJoinThreads - 1) / kJoinThreads;
@@ -823,14 +814,12 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         b->waited = true;
         return GFFX_OK;
     }
-    GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (b->strategy == GFFX_STRATEGY_SORTED) {
-        uint32_t n_work = 0;
-        GFFX_HIP_TRY(hipMemcpy(&n_work, b->d_n_work, 4, hipMemcpyDeviceToHost));
-        b->n_blocks = n_work;
-    }
-    GFFX_HIP_TRY(hipMemcpy(b->h_status + 1, b->d_block_sums, b->n_blocks * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost));
+    const bool part = b->strategy == GFFX_STRATEGY_SORTED;
+    // error word (+ the pair cursor of the partitioned strategy) in one copy; block sums of the direct one
+    GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, (part ? 2 : 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (!part)
+        GFFX_HIP_TRY(hipMemcpy(b->h_status + 1, b->d_block_sums, b->n_blocks * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost));
     if (b->h_status[0] & 1ull) {
         // the flag is sticky on the device (kernels only ever set it): clear it for the next pass
         GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
@@ -839,7 +828,10 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
                     b->ix->n_chr);
     }
     b->total = 0;
-    for (uint32_t i = 0; i < b->n_blocks; i++) b->total += b->h_status[1 + i];
+    if (part)
+        b->total = b->h_status[1];
+    else
+        for (uint32_t i = 0; i < b->n_blocks; i++) b->total += b->h_status[1 + i];
     bool replay = false;
     if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < b->total) {
         if ((rc = grow(&b->d_fids, &b->cap_fids, b->total + b->total / 8, 1))) return rc;
@@ -849,12 +841,13 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         if ((rc = grow(&b->d_triples, &b->cap_triples, b->total + b->total / 8, 3))) return rc;
         replay = true;
     }
-    if (b->strategy == GFFX_STRATEGY_SORTED && (b->flags & GFFX_OUT_OFFSETS)) {
+    if (part && (b->flags & GFFX_OUT_OFFSETS)) {
         const unsigned long long tot = b->total;  // offsets[nq] = number of pairs, as in the direct path
         GFFX_HIP_TRY(hipMemcpy(b->d_offsets + b->nq, &tot, sizeof tot, hipMemcpyHostToDevice));
     }
     if (replay) {
-        if ((rc = b->strategy == GFFX_STRATEGY_SORTED ? enqueue_tile_emit(b) : enqueue_emit(b))) return rc;
+        // the partitioned strategy counts and emits in one kernel: the whole pass runs again
+        if ((rc = part ? run_partitioned(b) : enqueue_emit(b))) return rc;
         if ((rc = gffx_hip_batch_sync(b))) return rc;
     }
     b->waited = true;
@@ -873,16 +866,43 @@ static int need_waited(gffx_hip_batch *b, const char *who, uint32_t flag) {
     return GFFX_OK;
 }
 
+// input-order views of the partitioned strategy are materialised on demand (k_unpermute)
+static int need_input_order(gffx_hip_batch *b) {
+    if (b->strategy != GFFX_STRATEGY_SORTED || b->unpermuted || b->nq == 0) return GFFX_OK;
+    GFFX_HIP_TRY(hipSetDevice(b->ix->device));
+    int rc = enqueue_unpermute(b);
+    if (rc) return rc;
+    return gffx_hip_batch_sync(b);
+}
+
 extern "C" int gffx_hip_batch_copy_counts(gffx_hip_batch *b, uint32_t *host) {
     int rc = need_waited(b, "gffx_hip_batch_copy_counts", GFFX_OUT_COUNTS);
-    if (rc) return rc;
+    if (rc || (rc = need_input_order(b))) return rc;
     if (b->nq) GFFX_HIP_TRY(hipMemcpy(host, b->d_counts, b->nq * 4, hipMemcpyDeviceToHost));
     return GFFX_OK;
 }
 extern "C" int gffx_hip_batch_copy_offsets(gffx_hip_batch *b, uint64_t *host) {
     int rc = need_waited(b, "gffx_hip_batch_copy_offsets", GFFX_OUT_OFFSETS);
-    if (rc) return rc;
+    if (rc || (rc = need_input_order(b))) return rc;
     GFFX_HIP_TRY(hipMemcpy(host, b->d_offsets, (b->nq + 1) * 8, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_copy_query_records(gffx_hip_batch *b, uint32_t *rows, uint32_t *counts,
+                                                 uint64_t *offsets) {
+    int rc = need_waited(b, "gffx_hip_batch_copy_query_records", offsets ? GFFX_OUT_OFFSETS : 0);
+    if (rc) return rc;
+    const uint64_t n = b->nq;
+    if (!n) return GFFX_OK;
+    if (b->strategy == GFFX_STRATEGY_SORTED) {
+        if (rows) GFFX_HIP_TRY(hipMemcpy(rows, b->d_q_rows, n * 4, hipMemcpyDeviceToHost));
+        if (counts) GFFX_HIP_TRY(hipMemcpy(counts, b->d_q_counts, n * 4, hipMemcpyDeviceToHost));
+        if (offsets) GFFX_HIP_TRY(hipMemcpy(offsets, b->d_q_offsets, n * 8, hipMemcpyDeviceToHost));
+    } else {  // direct strategy: emission order == input order
+        if (rows)
+            for (uint64_t i = 0; i < n; i++) rows[i] = (uint32_t)i;
+        if (counts) GFFX_HIP_TRY(hipMemcpy(counts, b->d_counts, n * 4, hipMemcpyDeviceToHost));
+        if (offsets) GFFX_HIP_TRY(hipMemcpy(offsets, b->d_offsets, n * 8, hipMemcpyDeviceToHost));
+    }
     return GFFX_OK;
 }
 extern "C" int gffx_hip_batch_copy_fids(gffx_hip_batch *b, uint32_t *host) {
@@ -908,7 +928,11 @@ extern "C" int gffx_hip_batch_copy_root_bitmap(gffx_hip_batch *b, uint64_t *host
     for (uint64_t i = 0; i < need; i++) host[i] = (uint64_t)tmp[2 * i] | ((uint64_t)tmp[2 * i + 1] << 32);
     return GFFX_OK;
 }
-extern "C" const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *b) { return b ? b->d_counts : nullptr; }
+extern "C" const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *b) {
+    // input order; NULL while a partitioned pass has not been un-permuted (GFFX_OUT_EMIT_ORDER)
+    if (!b || (b->strategy == GFFX_STRATEGY_SORTED && !b->unpermuted)) return nullptr;
+    return b->d_counts;
+}
 extern "C" const uint32_t *gffx_hip_batch_device_fids(const gffx_hip_batch *b) {
     return (b && (b->flags & GFFX_OUT_FIDS)) ? b->d_fids : nullptr;
 }

@@ -10,6 +10,13 @@
 
 #include "../../../include/gffx_hip.h"
 
+// development hook (tools/kbench.hip): in-kernel phase stamps; compiled out of the product
+#ifndef GFFX_STAMP
+#define GFFX_STAMP(kernel, slot) \
+    do {                         \
+    } while (0)
+#endif
+
 namespace gffx {
 
 // ---- error plumbing -------------------------------------------------------------------------
@@ -26,44 +33,43 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 // ---- device-side view of the index -------------------------------------------------------------
-// One entry per root interval.  The intervals of a seqid are split into a few LISTS (an
-// AIList-style decomposition done once at index creation): going through the seqid's intervals
-// in start order, an interval that reaches past the start of its T-th successor is moved to the
-// next list, and the rule is applied again to the moved ones.  Inside a list every interval ends
-// before its T-th successor starts, so a backward sweep guided by the running maximum of `end`
-// visits at most (hits + T) entries -- without this, one 2 Mb gene makes every query behind it
-// walk ~40 entries, and wave64 divergence turns the rare long walk into the common case.
-// Entries are stored list after list, each list sorted by start (ties in builder order):
-//   x = start (0-based)          utils/tree.rs:7
-//   y = end   (exclusive)        utils/tree.rs:8
-//   z = running max of `end` over the entries of the same LIST up to and including this one
-//   w = root_fid                 utils/tree.rs:9
-// The AoS form serves the gather kernels: one 16-byte load per sweep step.  The SoA copies serve
-// kernels whose neighbouring lanes read neighbouring entries.
+// One entry per root interval (utils/tree.rs:5-10), seqid after seqid, each seqid sorted stably by
+// start (what IntervalTree::build does first, utils/tree.rs:40).  Two arrays, same positions:
+//   start[i]                     0-based start                                  utils/tree.rs:7
+//   aux[i].x = end               exclusive end                                  utils/tree.rs:8
+//   aux[i].y = pmax              running max of `end` over the seqid's entries up to and incl. i
+//   aux[i].z = skip              1 + position of the nearest EARLIER entry of the seqid whose end is
+//                                strictly greater than end[i]; the seqid's first position if none
+//   aux[i].w = root_fid                                                         utils/tree.rs:9
+// The hit set of a query (qs, qe) is {i : start[i] < qe && end[i] > qs} (utils/tree.rs:110).  With
+// p = #{start < qe} (a position) it is enumerated backwards from p-1:
+//       pmax[i] <= qs  -> nothing at or before i ends after qs: stop
+//       end[i]  >  qs  -> hit; continue at i-1
+//       otherwise      -> every entry in [skip[i], i) ends at or before end[i] <= qs: continue at skip[i]-1
+// so a sweep costs (hits + the few "staircase" entries between them) steps no matter how many short
+// genes sit behind a 2 Mb one -- on GENCODE-like data ~hits + 1.5 -- where a plain pmax-guided
+// sweep walks ~40 entries in the slowest lane of a wave.
 struct IndexView {
-    const uint4 *ent;
-    const uint32_t *start, *end, *pmax, *fid;
-    // per seqid: x = first list, y = number of lists
-    const uint2 *chr_lists;
-    // per list: x = first entry, y = one past last entry, z = base into bins,
-    //           w = (shift << 27) | n_bins   (n_bins < 2^27)
-    const uint4 *list_meta;
-    // Bin directory of a list, one 8-byte record per bin b (plus a sentinel at b == n_bins):
-    //   x = pos | (min(cnt, 31) << 27)   pos = first entry (global position) whose start >= b << shift,
+    const uint32_t *start;
+    const uint4 *aux;
+    // per seqid: x = first position, y = one past the last, z = base into bins,
+    //            w = (shift << 27) | n_bins   (n_bins < 2^27; 0 bins for an empty seqid)
+    const uint4 *chr_meta;
+    // Bin directory of a seqid, one 8-byte record per bin b (plus a sentinel at b == n_bins):
+    //   x = pos | (min(cnt, 31) << 27)   pos = first position whose start >= b << shift,
     //                                    cnt = number of entries whose start falls into bin b
-    //   y = running max of `end` over the list's entries BEFORE pos (0 if none)
-    // One gather answers "where does the backward sweep start" and, when the bin holds nothing
-    // below the query's end, "can anything before it still reach the query" -- most (query, list)
-    // pairs finish after this single access.  kPosMask limits an index to 2^27 roots.
+    //   y = pmax of the entry before pos (0 if none)
+    // One gather answers "where does the sweep start" and, when the bin holds nothing below the
+    // query's end, "can anything before it still reach the query" -- queries in gene deserts end
+    // after this single access.  kPosMask limits an index to 2^27 roots.
     const uint2 *bins;
     uint32_t n_chr;
-    uint32_t n_lists;
     uint32_t n_roots;
 };
 constexpr uint32_t kPosBits = 27;
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1;
 constexpr uint32_t kCntSat = 31;
-// seqid/list metadata is staged in LDS when it fits this many bytes (8 B/seqid + 16 B/list)
+// seqid metadata is staged in LDS when it fits this many bytes (16 B/seqid)
 constexpr uint32_t kMetaLdsBytes = 24 * 1024;
 
 // queries: either AoS triples (the reference's &[(u32,u32,u32)]) or three SoA arrays
@@ -81,6 +87,29 @@ struct JoinOut {
     unsigned long long *offsets;    // nq+1, or nullptr
     uint32_t *bitmap;               // ceil(n_roots/32) words, or nullptr
     unsigned long long capacity;    // pairs
+};
+
+// ---- genome-window tiles (partitioned strategy) ---------------------------------------------------
+// The genome is cut into CELLS of 2^cshift bp (<= kMaxCells over all seqids); consecutive cells of a
+// seqid are merged into TILES holding <= kTileEntries entries (by start).  A query belongs to the tile
+// of its END: p = #{start < qe} then lies inside or at the end of the tile's entry range, and the
+// backward sweep starts in the tile.  The last tile of a seqid also takes every query ending beyond it.
+constexpr uint32_t kMaxCells = 4096;
+constexpr uint32_t kMaxTiles = 4096;
+constexpr uint32_t kTileEntries = 1024;  // 20 KB of LDS (start 4 B + aux 16 B)
+constexpr uint32_t kTileBins = 1024;     // per-tile directory over `start`, u16 positions
+constexpr uint32_t kTileBinStride = kTileBins + 2;  // u16 per tile (kTileBins + 1 used; even -> 4-byte rows)
+
+struct TilePlanView {
+    const uint32_t *cell_base;   // n_chr + 1: first cell of every seqid
+    const uint16_t *cell_tile;   // n_cells: tile of every cell
+    // per tile: x = first position, y = one past the last, z = genome coordinate of the window start,
+    //           w = first position of the seqid
+    const uint4 *tile_meta;
+    // per tile: x = bin shift, y = 1 if the entries fit kTileEntries (LDS path), else 0 (gather path)
+    const uint2 *tile_aux;
+    const uint16_t *tile_bins;   // n_tiles * kTileBinStride: bins[b] = #{tile entries with start < w0 + (b << shift)}
+    uint32_t n_chr, n_cells, n_tiles, cshift;
 };
 
 }  // namespace gffx

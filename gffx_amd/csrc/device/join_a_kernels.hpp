@@ -1,24 +1,22 @@
-// join_a_kernels.hpp -- Join A (queries x root intervals) for gfx950.
+// join_a_kernels.hpp -- Join A (queries x root intervals) for gfx950, queries in INPUT order
+// ("direct" strategy: small batches, indexes with too many seqids for the partitioned strategy).
 //
 // What it computes (reference: utils/tree.rs:98-121 + commands/intersect.rs:139-165):
 //   for every query (chr, qs, qe), every root interval iv of seqid `chr` with
 //       iv.start < qe && iv.end > qs                  (tree.rs:110, strict, u32)
 //   is a hit; the pair is kept iff  invert ^ predicate(mode)   (intersect.rs:145-161).
-// The reference reaches the hit set by walking a pointer-based centered interval tree.  Here
-// the seqid's intervals sit in HBM as a few lists (gffx_device.hpp), each sorted by start and
-// carrying the running maximum of `end` (pmax), and the same set is enumerated per list as
-//       hi = #{ iv : iv.start < qe }                   -- one 8-byte bin record (+ short refine)
-//       for i = hi-1 down to the list's first entry:   -- backward sweep
-//           stop as soon as pmax[i] <= qs              -- nothing at or before i can end after qs
-//           hit iff end[i] > qs
+// The reference reaches the hit set by walking a pointer-based centered interval tree.  Here the
+// seqid's intervals sit in HBM sorted by start with pmax/skip links (gffx_device.hpp), and the same
+// set is enumerated as
+//       p = #{ iv : iv.start < qe }          -- one 8-byte bin record (+ short refine over start[])
+//       backward sweep from p-1 following the skip links, stop when pmax <= qs
 // which needs no per-query state and no recursion.  Degenerate rows (qs >= qe) need no special
 // case: the predicate is evaluated literally.
 //
-// What bounds it (rocprofv3, profiles/): the index (~2 MB) is L2-resident and L2 latency is
-// ~180 cycles, but every lane of a gather touches its own cache line, so the per-CU L1 tag
-// pipeline (one line access per clock) is the limiter -- not HBM, not L2.  Hence: seqid/list
-// metadata in LDS, one record per bin, early-out before touching `ent`, and (sorted strategy)
-// queries grouped by genome position so that the lanes of a wave share lines.
+// What bounds it (rocprofv3, profiles/): the index (~1.3 MB) is L2-resident, but every lane of a
+// gather touches its own cache line, so the per-CU L1 tag pipeline (one line per clock) is the
+// limiter -- not HBM, not L2.  Hence: seqid metadata in LDS, one record per bin, early-out before
+// touching `aux`, and skip links so a sweep touches ~hits + 1.5 lines.
 //
 // Kernel pair (two launches; the second depends on the first through counts/block_sums):
 //   k_join_count  one query per thread, contiguous chunk of queries per block; writes the kept
@@ -49,77 +47,96 @@ __device__ __forceinline__ void load_query(const QueryView &q, unsigned long lon
     }
 }
 
-// seqid -> lists -> (first entry, bin base, shift|n_bins): from LDS when staged, else from global
-struct MetaLds {
-    const uint2 *chr_lists;  // LDS
-    const uint4 *list_meta;  // LDS
-};
-
+// seqid -> (first, last+1, bin base, shift|n_bins): from LDS when staged, else from global
 template <bool META_LDS>
-__device__ __forceinline__ MetaLds stage_meta(const IndexView &ix, unsigned char *smem) {
-    MetaLds m;
+__device__ __forceinline__ const uint4 *stage_meta(const IndexView &ix, unsigned char *smem) {
     if (META_LDS) {
-        uint2 *cl = reinterpret_cast<uint2 *>(smem);
-        uint4 *lm = reinterpret_cast<uint4 *>(smem + ((ix.n_chr * 8u + 15u) & ~15u));
-        for (uint32_t i = threadIdx.x; i < ix.n_chr; i += blockDim.x) cl[i] = ix.chr_lists[i];
-        for (uint32_t i = threadIdx.x; i < ix.n_lists; i += blockDim.x) lm[i] = ix.list_meta[i];
+        uint4 *cm = reinterpret_cast<uint4 *>(smem);
+        for (uint32_t i = threadIdx.x; i < ix.n_chr; i += blockDim.x) cm[i] = ix.chr_meta[i];
         __syncthreads();
-        m.chr_lists = cl;
-        m.list_meta = lm;
-    } else {
-        m.chr_lists = ix.chr_lists;
-        m.list_meta = ix.list_meta;
+        return cm;
     }
-    return m;
+    return ix.chr_meta;
 }
 
+// intersect.rs:145-161 on one overlapping interval [s, e)
 template <int MODE, bool INVERT>
-__device__ __forceinline__ bool keep_pair(const uint4 e, uint32_t qs, uint32_t qe) {
+__device__ __forceinline__ bool keep_pair(uint32_t s, uint32_t e, uint32_t qs, uint32_t qe) {
     bool k;
     if (MODE == GFFX_MODE_CONTAINED)
-        k = e.x >= qs && e.y <= qe;  // intersect.rs:148
+        k = s >= qs && e <= qe;  // intersect.rs:148
     else if (MODE == GFFX_MODE_CONTAINS_REGION)
-        k = e.x <= qs && e.y >= qe;  // intersect.rs:152
+        k = s <= qs && e >= qe;  // intersect.rs:152
     else
         k = true;  // intersect.rs:156
     return INVERT ^ k;  // intersect.rs:161
 }
 
-// Calls f(position, entry) for every kept pair of the query; f returns false to stop early.
-template <int MODE, bool INVERT, typename F>
-__device__ __forceinline__ void for_each_kept(const IndexView &ix, const MetaLds &m, uint32_t chr,
-                                              uint32_t qs, uint32_t qe, F &&f) {
-    const uint2 cl = m.chr_lists[chr];
-    for (uint32_t l = cl.x; l < cl.x + cl.y; ++l) {
-        const uint4 meta = m.list_meta[l];
-        const uint32_t nb = meta.w & kPosMask;
-        uint32_t b = qe >> (meta.w >> kPosBits);
-        if (b > nb) b = nb;  // sentinel record: every start < qe
-        const uint2 rec = ix.bins[meta.z + b];
-        uint32_t lo = rec.x & kPosMask;
-        uint32_t p = lo;
-        if (b < nb) {
-            uint32_t cnt = rec.x >> kPosBits;
-            if (cnt == kCntSat) cnt = (ix.bins[meta.z + b + 1].x & kPosMask) - lo;
-            uint32_t hi = lo + cnt;  // entries of bin b: find the first with start >= qe
-            while (p < hi) {
-                const uint32_t mid = (p + hi) >> 1;
-                if (ix.ent[mid].x < qe)
-                    p = mid + 1;
-                else
-                    hi = mid;
-            }
-        }
-        // p = number of entries with start < qe (as a position).  Nothing of this bin below qe
-        // and nothing before the bin reaching past qs -> no hit in this list, `ent` untouched.
-        if (p == lo && rec.y <= qs) continue;
-        while (p > meta.x) {
-            const uint4 e = ix.ent[--p];
-            if (e.z <= qs) break;
-            if (e.y > qs && keep_pair<MODE, INVERT>(e, qs, qe))
-                if (!f(p, e)) return;
+// Backward sweep from position p (= #{start < qe} as a position) down to `lower`.
+// aux_at(i) / start_at(i) fetch the entry (LDS tile or global); f(i, start, aux) is called for every
+// kept pair and returns false to stop.  `start` is fetched only when the mode predicate needs it
+// (it is 0 in Overlap mode: the caller fetches it itself for triples).  Returns true when the sweep
+// is complete, false when it ran into `lower` (p then says where to continue: a skip link may have
+// jumped below `lower`).
+template <int MODE, bool INVERT, typename AUX, typename START, typename F>
+__device__ __forceinline__ bool sweep_kept(uint32_t &p, uint32_t lower, uint32_t qs, uint32_t qe,
+                                           AUX &&aux_at, START &&start_at, F &&f) {
+    if (MODE == GFFX_MODE_OVERLAP && INVERT) return true;  // invert ^ true: nothing is ever kept
+    while (p > lower) {
+        const uint32_t i = p - 1;
+        const uint4 a = aux_at(i);
+        if (a.y <= qs) return true;  // nothing at or before i ends after qs
+        if (a.x > qs) {              // hit (start < qe holds for every position below p)
+            uint32_t s = 0;
+            if (MODE != GFFX_MODE_OVERLAP) s = start_at(i);
+            if (keep_pair<MODE, INVERT>(s, a.x, qs, qe))
+                if (!f(i, s, a)) return true;
+            // Contained needs start >= qs, and starts only decrease from here
+            if (MODE == GFFX_MODE_CONTAINED && !INVERT && s < qs) return true;
+            p = i;
+        } else {
+            p = a.z;  // entries in [skip, i) end at or before end[i] <= qs
         }
     }
+    return false;
+}
+
+// p = #{entries of the seqid with start < qe}, as a position; *dead = provably no hit (the bin holds
+// nothing below qe and nothing before it reaches past qs) without touching start[] / aux[]
+__device__ __forceinline__ uint32_t locate(const IndexView &ix, const uint4 meta, uint32_t qs, uint32_t qe,
+                                           bool *dead) {
+    const uint32_t nb = meta.w & kPosMask;
+    uint32_t b = qe >> (meta.w >> kPosBits);
+    if (b > nb) b = nb;  // sentinel record: every start < qe
+    const uint2 rec = ix.bins[meta.z + b];
+    const uint32_t lo = rec.x & kPosMask;
+    uint32_t p = lo;
+    if (b < nb) {
+        uint32_t cnt = rec.x >> kPosBits;
+        if (cnt == kCntSat) cnt = (ix.bins[meta.z + b + 1].x & kPosMask) - lo;
+        uint32_t hi = lo + cnt;  // entries of bin b: find the first with start >= qe
+        while (p < hi) {
+            const uint32_t mid = (p + hi) >> 1;
+            if (ix.start[mid] < qe)
+                p = mid + 1;
+            else
+                hi = mid;
+        }
+    }
+    *dead = (p == lo && rec.y <= qs);
+    return p;
+}
+
+// Calls f(position, start, aux) for every kept pair of the query; f returns false to stop early.
+template <int MODE, bool INVERT, typename F>
+__device__ __forceinline__ void for_each_kept(const IndexView &ix, const uint4 meta, uint32_t qs, uint32_t qe,
+                                              F &&f) {
+    if (meta.x == meta.y) return;  // seqid without roots
+    bool dead;
+    uint32_t p = locate(ix, meta, qs, qe, &dead);
+    if (dead) return;
+    sweep_kept<MODE, INVERT>(
+        p, meta.x, qs, qe, [&](uint32_t i) { return ix.aux[i]; }, [&](uint32_t i) { return ix.start[i]; }, f);
 }
 
 __device__ __forceinline__ unsigned long long wave_reduce_add(unsigned long long v) {
@@ -145,7 +162,7 @@ __global__ __launch_bounds__(kJoinThreads) void k_join_count(IndexView ix, Query
                                                              unsigned long long chunk, JoinOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *sh = reinterpret_cast<unsigned long long *>(smem);  // 32 B
-    const MetaLds m = stage_meta<META_LDS>(ix, smem + 32);
+    const uint4 *cm = stage_meta<META_LDS>(ix, smem + 32);
     const unsigned long long beg = (unsigned long long)blockIdx.x * chunk;
     unsigned long long end = beg + chunk;
     if (end > nq) end = nq;
@@ -158,7 +175,7 @@ __global__ __launch_bounds__(kJoinThreads) void k_join_count(IndexView ix, Query
         if (chr >= ix.n_chr)
             bad = true;
         else
-            for_each_kept<MODE, INVERT>(ix, m, chr, qs, qe, [&](uint32_t, const uint4 &) {
+            for_each_kept<MODE, INVERT>(ix, cm[chr], qs, qe, [&](uint32_t, uint32_t, const uint4 &) {
                 ++cnt;
                 return true;
             });
@@ -199,7 +216,7 @@ __global__ __launch_bounds__(kJoinThreads) void k_join_emit(IndexView ix, QueryV
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *sh64 = reinterpret_cast<unsigned long long *>(smem);  // 32 B
     uint32_t *sh32 = reinterpret_cast<uint32_t *>(smem + 32);                 // 16 B
-    const MetaLds m = stage_meta<META_LDS>(ix, smem + 48);
+    const uint4 *cm = stage_meta<META_LDS>(ix, smem + 48);
     const unsigned long long beg = (unsigned long long)blockIdx.x * chunk;
     unsigned long long end = beg + chunk;
     if (end > nq) end = nq;
@@ -217,17 +234,17 @@ __global__ __launch_bounds__(kJoinThreads) void k_join_emit(IndexView ix, QueryV
         if (cnt) {
             uint32_t chr, qs, qe;
             load_query<AOS>(q, i, chr, qs, qe);
-            uint32_t done = 0;  // pairs written; order = list by list, descending start inside a list
-            for_each_kept<MODE, INVERT>(ix, m, chr, qs, qe, [&](uint32_t p, const uint4 &e) {
+            uint32_t done = 0;  // pairs written; order = descending position
+            for_each_kept<MODE, INVERT>(ix, cm[chr], qs, qe, [&](uint32_t p, uint32_t s, const uint4 &a) {
                 const unsigned long long o = pos + done;
                 ++done;
                 if (o < out.capacity) {
-                    if (out.fids) out.fids[o] = e.w;
+                    if (out.fids) out.fids[o] = a.w;
                     if (out.triples) {
                         uint32_t *t = out.triples + 3ull * o;
-                        t[0] = e.w;
-                        t[1] = e.x;
-                        t[2] = e.y;
+                        t[0] = a.w;
+                        t[1] = MODE == GFFX_MODE_OVERLAP ? ix.start[p] : s;
+                        t[2] = a.x;
                     }
                     if (out.bitmap) atomicOr(&out.bitmap[p >> 5], 1u << (p & 31));
                 }

@@ -29,11 +29,11 @@ class OverlapMode(enum.IntEnum):
     Overlap = 2
 
 
-OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS = 1, 2, 4, 8, 16
+OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS, OUT_EMIT_ORDER = 1, 2, 4, 8, 16, 32
 STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED = 0, 1, 2
-K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED = 0, 1, 2, 3, 4
-KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_sort",
-                K_LINES: "k_lines_exists", K_FUSED: "k_join_fused"}
+K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_partition",
+                K_LINES: "k_lines_exists", K_FUSED: "k_tile_join", K_UNPERMUTE: "k_unpermute"}
 
 
 def device_count() -> int:
@@ -167,6 +167,16 @@ class QueryBatch:
         out = np.empty(self.n_queries + 1, dtype=np.uint64)
         check(lib().gffx_hip_batch_copy_offsets(self._h, out.ctypes.data_as(u64p)))
         return out
+
+    def query_records(self, with_offsets: bool = True):
+        """(rows, counts, offsets) in emission order: rows[i] = input row of the i-th served query."""
+        n = self.n_queries
+        rows = np.empty(max(n, 1), dtype=np.uint32)
+        cnt = np.empty(max(n, 1), dtype=np.uint32)
+        off = np.empty(max(n, 1), dtype=np.uint64) if with_offsets else None
+        check(lib().gffx_hip_batch_copy_query_records(self._h, _p(rows), _p(cnt),
+                                                      off.ctypes.data_as(u64p) if with_offsets else None))
+        return rows[:n], cnt[:n], (off[:n] if with_offsets else None)
 
     def fids(self) -> np.ndarray:
         n = self.total_hits

@@ -20,10 +20,11 @@
  *   a root interval iv of the query's seqid is a HIT iff  iv.start < q.end && iv.end > q.start
  *   (strict, half-open; u32 compares; q.start >= q.end rows are legal and evaluated as-is);
  *   keep = mode predicate(iv, q);  a (query, root) pair is emitted iff  invert ^ keep.
- * Output order: pairs are grouped per query in INPUT order (CSR: offset[i] = sum of counts
- * of queries < i); inside a query the order is deterministic but unspecified (index list by
- * list, descending iv.start inside a list).  The reference's own order is that of an FxHashMap
- * walk plus a tree DFS and is unspecified as well; the multiset of pairs is the contract.
+ * Output order: the pairs of one query are contiguous (its segment); inside a segment the order is
+ * descending iv.start.  Direct strategy: segments in INPUT order (CSR).  Partitioned strategy:
+ * segments in the order genome tiles were served, each query's offset given explicitly.  The
+ * reference's own order is that of an FxHashMap walk plus a tree DFS and is unspecified as well;
+ * the multiset of pairs is the contract.
  *
  * Threading: an index is immutable after creation and may be shared by threads; a batch owns
  * one HIP stream plus its buffers and must not be used from two threads at once.
@@ -64,13 +65,21 @@ enum gffx_out {
     GFFX_OUT_TRIPLES = 4,     /* (root_fid, iv.start, iv.end) per kept pair == the reference's
                                  Vec<(u32,u32,u32)> (intersect.rs:162) */
     GFFX_OUT_ROOT_BITMAP = 8, /* one bit per root of the index: set iff the root is in >=1 kept pair */
-    GFFX_OUT_OFFSETS = 16     /* u64 exclusive prefix of the counts (nq+1 entries) */
+    GFFX_OUT_OFFSETS = 16,    /* u64 start of every query's pair segment (nq+1 entries; [nq] = number of pairs).
+                                 Direct strategy: the exclusive prefix of the counts (CSR in input order).
+                                 Partitioned strategy: segments follow the order in which genome tiles were
+                                 served, so the offsets are explicit -- they still tile [0, pairs) exactly. */
+    GFFX_OUT_EMIT_ORDER = 32  /* partitioned strategy: leave the per-query results in emission order
+                                 ({input row, count, offset} records: gffx_hip_batch_copy_query_records) and
+                                 skip the scatter into input-order arrays; _copy_counts / _copy_offsets then
+                                 run that scatter on demand */
 };
 
 enum gffx_strategy {
     GFFX_STRATEGY_AUTO = 0,
     GFFX_STRATEGY_DIRECT = 1, /* queries in input order; bin directory + gathers from the L2-resident index */
-    GFFX_STRATEGY_SORTED = 2  /* device radix sort by (chr,start); LDS-staged index tiles; coalesced SoA sweep */
+    GFFX_STRATEGY_SORTED = 2  /* "partitioned": one-pass device radix partition of the batch by genome window,
+                                 then a fused count+emit join served from LDS-staged index tiles */
 };
 
 enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
@@ -79,6 +88,7 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
     GFFX_K_SORT = 2,
     GFFX_K_LINES = 3,
     GFFX_K_FUSED = 4,
+    GFFX_K_UNPERMUTE = 5,
     GFFX_K__COUNT = 8
 };
 
@@ -135,6 +145,9 @@ uint64_t gffx_hip_batch_n_queries(const gffx_hip_batch *);
 uint64_t gffx_hip_batch_total_hits(const gffx_hip_batch *);
 int gffx_hip_batch_copy_counts(gffx_hip_batch *, uint32_t *host /* nq */);
 int gffx_hip_batch_copy_offsets(gffx_hip_batch *, uint64_t *host /* nq+1 */);
+/* per-query records in emission order: rows[i] = input row, counts[i] = kept pairs, offsets[i] = start of
+ * its segment in fids / triples (needs GFFX_OUT_OFFSETS); any pointer may be NULL; nq entries each */
+int gffx_hip_batch_copy_query_records(gffx_hip_batch *, uint32_t *rows, uint32_t *counts, uint64_t *offsets);
 int gffx_hip_batch_copy_fids(gffx_hip_batch *, uint32_t *host /* total_hits */);
 int gffx_hip_batch_copy_triples(gffx_hip_batch *, uint32_t *host /* 3*total_hits */);
 /* n_words = ceil(n_roots/64); bit i <-> gffx_hip_index_sorted_fids()[i] */

@@ -41,9 +41,9 @@ def _check(roots, regions, mode, invert, soa=False, strategy=engine.STRATEGY_AUT
     assert np.array_equal(b.fids(), got_t[:, 0])
     off = b.offsets()
     assert int(off[-1]) == len(want_t)
-    if strategy != engine.STRATEGY_SORTED:  # direct: CSR in input order
+    if strategy == engine.STRATEGY_DIRECT:  # direct: CSR in input order
         assert np.array_equal(off, np.concatenate([[0], np.cumsum(want_c.astype(np.uint64))]).astype(np.uint64))
-    else:  # sorted: pairs grouped by genome-window bucket, every query's segment given explicitly
+    else:  # partitioned (or AUTO): every query's segment is given explicitly; the segments tile [0, pairs)
         nz = want_c > 0
         seg_lo, seg_hi = off[:-1][nz], off[:-1][nz] + want_c[nz]
         order = np.argsort(seg_lo)
@@ -55,6 +55,10 @@ def _check(roots, regions, mode, invert, soa=False, strategy=engine.STRATEGY_AUT
         one_t, _ = oix.query_features(regions[qi:qi + 1], int(mode), invert)
         assert np.array_equal(_sorted_rows(seg), _sorted_rows(one_t))
     assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    # the same results as {input row, count, offset} records in emission order
+    rows, rc, ro = b.query_records()
+    assert np.array_equal(np.sort(rows), np.arange(len(regions), dtype=np.uint32))
+    assert np.array_equal(rc, want_c[rows]) and np.array_equal(ro, off[:-1][rows])
     b.close()
     ix.close()
     return len(want_t)
@@ -135,13 +139,20 @@ def test_edge_inputs(strategy):
 
 
 def test_many_seqids_metadata_outside_lds():
-    """4000 scaffolds: the seqid/list tables no longer fit the LDS staging budget (global path)."""
+    """4000 scaffolds: the seqid table no longer fits the LDS staging budget (global path); the
+    partitioned strategy still works with one genome cell per scaffold."""
     chroms = [("scaf%d" % i, 50_000 + 13 * i) for i in range(4000)]
     roots = synth.gencode_like_roots(12000, seed=8, chroms=chroms)
     regions = synth.synth_bed(30000, seed=9, chroms=chroms, width=(10, 5000), edge_frac=0.05, roots=roots)
     for mode in OverlapMode:
-        _check(roots, regions, mode, False)
-    # ... and there are more genome-window buckets than the sorted strategy supports: loud error
+        for strategy in STRATEGIES:
+            _check(roots, regions, mode, False, strategy=strategy)
+    # ... but 5000 seqids are more genome cells than the partitioned strategy supports: loud error,
+    # while AUTO quietly takes the direct strategy
+    chroms = [("scaf%d" % i, 50_000 + 13 * i) for i in range(5000)]
+    roots = synth.gencode_like_roots(12000, seed=8, chroms=chroms)
+    regions = synth.synth_bed(40000, seed=9, chroms=chroms, width=(10, 5000), edge_frac=0.05, roots=roots)
+    _check(roots, regions, OverlapMode.Overlap, False)
     ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
     b = engine.QueryBatch(ix, 10)
     b.set_regions(regions[:10])
@@ -183,6 +194,38 @@ def test_dense_bins_saturate_the_bin_counter():
     for mode in OverlapMode:
         for strategy in STRATEGIES:
             _check(roots, regions, mode, False, strategy=strategy)
+
+
+@pytest.mark.parametrize("mode", list(OverlapMode))
+def test_emit_order_records_without_the_input_order_scatter(mode):
+    """GFFX_OUT_EMIT_ORDER: the pass leaves {row, count, offset} records; the input-order arrays
+    are still available on demand and agree."""
+    roots = synth.gencode_like_roots(63000, seed=42)
+    regions = synth.synth_bed(200_000, seed=77, edge_frac=0.002, roots=roots)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    want_t, want_c = oix.query_features(regions, int(mode), False)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)
+    for _ in range(2):  # twice: the cursor sets alternate between passes
+        b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_EMIT_ORDER, engine.STRATEGY_SORTED)
+        b.wait()
+        assert b.total_hits == len(want_t)
+        rows, cnt, off = b.query_records()
+        assert np.array_equal(np.sort(rows), np.arange(len(regions), dtype=np.uint32))
+        assert np.array_equal(cnt, want_c[rows])
+        fids = b.fids()
+        assert np.array_equal(np.sort(fids), np.sort(want_t[:, 0]))
+        # every region's segment holds exactly its oracle root_fids
+        order = np.argsort(rows)
+        seg_of_row = off[order]
+        for qi in np.random.default_rng(1).choice(len(regions), size=300, replace=False):
+            one_t, _ = oix.query_features(regions[qi:qi + 1], int(mode), False)
+            seg = fids[int(seg_of_row[qi]):int(seg_of_row[qi]) + int(want_c[qi])]
+            assert np.array_equal(np.sort(seg), np.sort(one_t[:, 0]))
+        assert np.array_equal(b.counts(), want_c)  # scatter on demand
+        assert np.array_equal(b.offsets()[:-1][rows], off)
 
 
 def test_capacity_replay_and_reuse():
