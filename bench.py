@@ -2,8 +2,8 @@
 """bench.py -- BED overlap queries/sec against a GRCh38-scale GFF index on N MI355X.
 
 One "step" = one pass of the intersect hot path (Join A: regions x root intervals -> per-region
-kept counts + CSR list of root_fids) over one batch of synthetic BED regions that is already
-resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: 1 M synthetic BED regions
+kept counts + segment offsets in input order, and the root_fids of every kept pair) over one batch
+of synthetic BED regions that is already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: 1 M synthetic BED regions
 (seed 1001, chr ~ length, width U[100,10000], unsorted) x a GENCODE/GRCh38-shaped index
 (25 seqids, ~63 k root genes of a ~3.4 M-line annotation, seed 42), --overlap mode.
 For N>1 the global batch is N x 1 M regions, sharded by chromosome bucket over the ranks
@@ -38,10 +38,13 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--queries-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
-    ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted"])
+    ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
     ap.add_argument("--no-offsets", action="store_true",
-                    help="partitioned strategy: do not write every region's segment offset (counts + unattributed pairs)")
+                    help="fused / partitioned strategy: do not write every region's segment offset")
+    ap.add_argument("--input-order", action="store_true",
+                    help="partitioned strategy: also scatter the per-region records into input-order arrays "
+                         "inside the pass (k_unpermute); default leaves them as {row, count, offset} records")
     ap.add_argument("--presort", default="none", choices=["none", "chr_end", "bucket"],
                     help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
     ap.add_argument("--exchange", default="final", choices=["final", "per-step"],
@@ -110,10 +113,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     mode = {"contained": 0, "contains_region": 1, "overlap": 2}[args.mode]
-    strategy = {"auto": 0, "direct": 1, "sorted": 2}[args.strategy]
+    strategy = {"auto": 0, "direct": 1, "sorted": 2, "fused": 3}[args.strategy]
     out_flags = {"counts": engine.OUT_COUNTS, "fids": engine.OUT_FIDS, "triples": engine.OUT_TRIPLES}[args.out]
     if args.strategy != "direct" and args.out != "counts" and not args.no_offsets:
-        out_flags |= engine.OUT_OFFSETS  # pairs are grouped by genome tile: every region's segment is explicit
+        out_flags |= engine.OUT_OFFSETS  # segments follow the order rounds / tiles were served: offsets are explicit
+    if args.strategy == "sorted" and not args.input_order:
+        out_flags |= engine.OUT_EMIT_ORDER
 
     # ---- synthetic inputs (identical on every rank; each rank keeps its shard)
     roots = synth.gencode_like_roots(63000, seed=42)
@@ -242,7 +247,12 @@ def main():
                 "regions_total": nq_total,
                 "kept_pairs_total": pairs_total,
                 "pairs_per_region": h_bar,
-                "outputs": "per-region counts + %s (CSR, input order)" % args.out,
+                "outputs": {"direct": "per-region counts (input order) + %s in CSR order" % args.out,
+                            "sorted": "per-region {row, count, offset} records in tile order%s + %s"
+                                      % (" and input-order counts/offsets" if args.input_order else "", args.out),
+                            }.get(args.strategy,
+                                  "per-region counts%s (input order) + %s, segments in round order"
+                                  % ("" if args.no_offsets or args.out == "counts" else " and segment offsets", args.out)),
                 "strategy": args.strategy,
                 "presort": args.presort,
                 "sharding": ("chromosome buckets, LPT with splitting; index replicated; all-gather of hit counts "

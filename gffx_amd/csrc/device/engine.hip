@@ -2,7 +2,7 @@
 //
 // HBM layout of an index (uploaded once, immutable; gffx_device.hpp has the field meanings):
 //   start[R] u32, aux[R] uint4 {end, pmax, skip, root_fid}     20 B/root, seqid after seqid, by start
-//   chr_meta[n_chr] uint4, bins[...] uint2                      per-seqid bin directory (direct strategy)
+//   chr_meta[n_chr] uint4, bins[...] uint4                      per-seqid bin directory (direct / fused strategies)
 //   cell_base / cell_tile / tile_meta / tile_aux / tile_bins    genome-window tile plan (partitioned strategy)
 // At GENCODE scale (63 k roots, 25 seqids) that is ~1.3 MB + ~2 MB of directory + ~0.2 MB of tile
 // plan: resident in every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and
@@ -15,6 +15,7 @@
 
 #include "gffx_device.hpp"
 #include "join_a_kernels.hpp"
+#include "join_fused_kernels.hpp"
 #include "partition_kernels.hpp"
 #include "tile_join_kernels.hpp"
 
@@ -76,15 +77,15 @@ struct gffx_hip_index {
     uint32_t *d_start = nullptr;
     uint4 *d_aux = nullptr;
     uint4 *d_chr_meta = nullptr;
-    uint2 *d_bins = nullptr;
+    uint4 *d_bins = nullptr;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
     uint32_t *d_cell_base = nullptr;
     uint16_t *d_cell_tile = nullptr;
     uint4 *d_tile_meta = nullptr;
     uint2 *d_tile_aux = nullptr;
     uint16_t *d_tile_bins = nullptr;
-    uint4 *d_tile_blocks = nullptr;  // static grid of k_tile_join: two uint4 per block
-    uint32_t n_cells = 0, n_tiles = 0, cshift = 0, n_join_blocks = 0;
+    uint4 *d_tile_desc = nullptr;  // per tile two uint4 (tile_join_kernels.hpp)
+    uint32_t n_cells = 0, n_tiles = 0, cshift = 0;
     bool partition_ok = false;  // the tile plan exists (n_chr <= kMaxCells)
     std::vector<uint32_t> h_sorted_fids;
 
@@ -128,13 +129,14 @@ struct gffx_hip_batch {
     uint64_t cap_fids = 0, cap_triples = 0;
     uint64_t reserve = 0;
     // partitioned strategy workspace (allocated on first use)
-    uint32_t *d_rec = nullptr;      // 3 arrays of n_tiles * sub_cap records
+    uint4 *d_rec = nullptr;         // n_tiles regions of sub_cap 16-byte records
     uint32_t *d_cursor = nullptr;   // 2 sets of n_tiles cursors (alternating; the join zeroes the other set)
-    uint32_t *d_q_rows = nullptr, *d_q_counts = nullptr;  // per-query results in emission order (max_q each)
-    unsigned long long *d_q_offsets = nullptr;
+    uint4 *d_q_rec = nullptr;       // per-query results in emission order: {row, count, offset lo, offset hi}
     bool unpermuted = false;        // d_counts / d_offsets hold the input-order view of the last pass
     uint32_t sub_cap = 0;           // queries per sub-batch == records per tile region
     int cursor_phase = 0;
+    int fused_phase = 0;            // which of d_status[2..3] the next fused pass uses as its pair cursor
+    int fused_word = 2;             // ... and the one the last fused pass used
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
     uint32_t flags = 0;
@@ -182,11 +184,11 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
 
     // Per seqid: stable sort by start (the tree does the same: utils/tree.rs:40), running max of
     // `end`, skip links (nearest earlier entry with a strictly greater end: monotonic stack), and
-    // the bin directory of the direct strategy (<= ~4 bins per entry, >= 64).
+    // the bin directory of the direct / fused strategies (~2 bins per entry, >= 64).
     std::vector<uint32_t> h_start(R);
     std::vector<uint4> h_aux(R);
     std::vector<uint4> chr_meta(n_chr);
-    std::vector<uint2> bins;
+    std::vector<uint4> bins;
     std::vector<uint32_t> order, stack;
     std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
     ix->h_sorted_fids.resize(R);
@@ -213,7 +215,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
             continue;
         }
         const uint32_t max_start = h_start[hi - 1];
-        const uint64_t budget = std::max<uint64_t>(4ull * (hi - lo), 64);
+        const uint64_t budget = std::max<uint64_t>((uint64_t)env_long("GFFX_HIP_BINS_PER_ENTRY", 2, 1, 64) * (hi - lo), 64);
         uint32_t shift = 0;
         while ((((uint64_t)max_start >> shift) + 1) > budget) shift++;
         const uint32_t nb = (max_start >> shift) + 1;
@@ -225,9 +227,11 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
             while (p < hi && h_start[p] < edge) p++;
             uint32_t q = p;
             while (q < hi && h_start[q] < next_edge) q++;
-            bins.push_back(make_uint2(p | (std::min(q - p, kCntSat) << kPosBits), p > lo ? h_aux[p - 1].y : 0u));
+            bins.push_back(make_uint4(p | (std::min(q - p, kCntSat) << kPosBits), p > lo ? h_aux[p - 1].y : 0u,
+                                      q > p ? h_start[p] : 0xFFFFFFFFu, q > p + 1 ? h_start[p + 1] : 0xFFFFFFFFu));
         }
-        bins.push_back(make_uint2(hi, h_aux[hi - 1].y));  // sentinel: nothing starts at or after nb << shift
+        // sentinel: nothing starts at or after nb << shift
+        bins.push_back(make_uint4(hi, h_aux[hi - 1].y, 0xFFFFFFFFu, 0xFFFFFFFFu));
     }
 
     // Partitioned strategy: cells of 2^cshift bp (<= kMaxCells in total, >= 1 per seqid) merged into
@@ -300,33 +304,13 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         }
     }
 
-    // Static grid of k_tile_join: tile t gets S_t ~ (its share of the genome) x target blocks, >= 1.
-    // Under a uniform query load every block then serves about the same number of queries; under a
-    // skewed load the blocks of a crowded tile simply loop longer (correct, just less balanced).
-    std::vector<uint4> tile_blocks;
+    // what k_tile_join needs per tile, in one 32-byte record
+    std::vector<uint4> tile_desc;
     if (plan_ok) {
-        const uint32_t target = (uint32_t)env_long("GFFX_HIP_JOIN_BLOCKS", 1024, 1, 16384);
-        std::vector<double> wgt(tile_meta.size());
-        double wsum = 0;
         for (size_t t = 0; t < tile_meta.size(); t++) {
             const uint4 m = tile_meta[t];
-            const uint64_t w0 = m.z;
-            // window end: the next tile's start inside the same seqid, else the seqid's last start + 1
-            uint64_t w1;
-            if (t + 1 < tile_meta.size() && tile_meta[t + 1].w == m.w && tile_meta[t + 1].z > m.z)
-                w1 = tile_meta[t + 1].z;
-            else
-                w1 = m.y > m.w ? (uint64_t)h_start[m.y > m.x ? m.y - 1 : m.w] + 1 : w0 + 1;
-            wgt[t] = (double)(w1 > w0 ? w1 - w0 : 1) + 1.0;
-            wsum += wgt[t];
-        }
-        for (size_t t = 0; t < tile_meta.size(); t++) {
-            const uint4 m = tile_meta[t];
-            uint32_t S = (uint32_t)std::max(1.0, std::floor(target * wgt[t] / wsum + 0.5));
-            for (uint32_t sidx = 0; sidx < S; sidx++) {
-                tile_blocks.push_back(make_uint4((uint32_t)t, sidx, S, m.x));
-                tile_blocks.push_back(make_uint4((m.y - m.x) | (tile_aux[t].y ? 0x80000000u : 0u), m.z, m.w, tile_aux[t].x));
-            }
+            tile_desc.push_back(make_uint4(m.x, (m.y - m.x) | (tile_aux[t].y ? 0x80000000u : 0u), m.z, m.w));
+            tile_desc.push_back(make_uint4(tile_aux[t].x, 0u, 0u, 0u));
         }
         if (cell_tile.size() & 1) cell_tile.push_back(0);  // k_partition copies the table as 4-byte words
     }
@@ -334,7 +318,6 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     ix->device = device;
     ix->n_chr = n_chr;
     ix->n_roots = R;
-    ix->n_join_blocks = (uint32_t)(tile_blocks.size() / 2);
     ix->n_cells = plan_ok ? cell_base[n_chr] : 0;
     ix->n_tiles = (uint32_t)tile_meta.size();
     ix->cshift = cshift;
@@ -344,10 +327,12 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
-        (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_blocks, tile_blocks))) {
+        (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
         gffx_hip_index_destroy(ix.release());
         return rc;
     }
+    // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
+    GFFX_HIP_TRY(hipDeviceSynchronize());
     *out = ix.release();
     return GFFX_OK;
 }
@@ -364,7 +349,7 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_tile_meta);
     (void)hipFree(ix->d_tile_aux);
     (void)hipFree(ix->d_tile_bins);
-    (void)hipFree(ix->d_tile_blocks);
+    (void)hipFree(ix->d_tile_desc);
     delete ix;
 }
 
@@ -395,6 +380,7 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
         return rc;
     }
     GFFX_HIP_TRY(hipMemset(b->d_status, 0, 4 * sizeof(unsigned long long)));
+    GFFX_HIP_TRY(hipDeviceSynchronize());  // NULL-stream memset vs the batch's non-blocking stream
     e = hipHostMalloc((void **)&b->h_status, (1 + gffx_hip_batch::kMaxBlocks) * sizeof(unsigned long long),
                       hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -424,9 +410,7 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     (void)hipFree(b->d_offsets);
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_cursor);
-    (void)hipFree(b->d_q_rows);
-    (void)hipFree(b->d_q_counts);
-    (void)hipFree(b->d_q_offsets);
+    (void)hipFree(b->d_q_rec);
     if (b->h_status) (void)hipHostFree(b->h_status);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -614,24 +598,22 @@ static int partition_prepare(gffx_hip_batch *b) {
     const gffx_hip_index *ix = b->ix;
     const uint64_t budget = (uint64_t)env_long("GFFX_HIP_PARTITION_BUDGET_MB", 12 * 1024, 1, 256 * 1024) << 20;
     uint64_t cap = std::max<uint64_t>(b->max_q, 1);
-    const uint64_t fit = budget / (12ull * ix->n_tiles);
+    const uint64_t fit = budget / (16ull * ix->n_tiles);
     if (cap > fit) cap = std::max<uint64_t>(fit / kPartChunk * kPartChunk, kPartChunk);
     if (cap * ix->n_tiles >= (1ull << 32))  // record positions are u32
         cap = std::max<uint64_t>(((1ull << 32) - 1) / ix->n_tiles / kPartChunk * kPartChunk, kPartChunk);
     b->sub_cap = (uint32_t)cap;
     int rc;
-    if ((rc = dev_alloc(&b->d_rec, 3ull * ix->n_tiles * cap)) || (rc = dev_alloc(&b->d_cursor, 2ull * ix->n_tiles)) ||
-        (rc = dev_alloc(&b->d_q_rows, b->max_q)) || (rc = dev_alloc(&b->d_q_counts, b->max_q)))
-        return rc;
+    if ((rc = dev_alloc(&b->d_rec, (size_t)ix->n_tiles * cap)) || (rc = dev_alloc(&b->d_cursor, 2ull * ix->n_tiles))) return rc;
     GFFX_HIP_TRY(hipMemset(b->d_cursor, 0, 2ull * ix->n_tiles * 4));
+    GFFX_HIP_TRY(hipDeviceSynchronize());  // NULL-stream memset vs the batch's non-blocking stream
     b->cursor_phase = 0;
     return GFFX_OK;
 }
 
 template <int MODE, bool INV>
-static void launch_tile_join(gffx_hip_batch *b, uint32_t grid, const TileWork &w, const TileOut &o) {
-    hipLaunchKernelGGL((k_tile_join<MODE, INV>), dim3(grid), dim3(kTJThreads), 0, b->stream, b->ix->view(),
-                       b->ix->plan_view(), w, o);
+static void launch_tile_join(gffx_hip_batch *b, uint32_t grid, const TileJoinArgs &a) {
+    hipLaunchKernelGGL((k_tile_join<MODE, INV>), dim3(grid), dim3(kTJThreads), 0, b->stream, a);
 }
 
 static int enqueue_unpermute(gffx_hip_batch *b) {
@@ -639,9 +621,8 @@ static int enqueue_unpermute(gffx_hip_batch *b) {
     ProfEvent pe;
     prof_begin(b, GFFX_K_UNPERMUTE, &pe);
     const uint32_t grid = (uint32_t)std::min<uint64_t>((b->nq + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(256), 0, b->stream, (unsigned long long)b->nq, b->d_q_rows,
-                       b->d_q_counts, (b->flags & GFFX_OUT_OFFSETS) ? b->d_q_offsets : nullptr, b->d_counts,
-                       (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr);
+    hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(256), 0, b->stream, (unsigned long long)b->nq, b->d_q_rec,
+                       b->d_counts, (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr);
     prof_end(b, &pe);
     GFFX_HIP_TRY(hipGetLastError());
     b->unpermuted = true;
@@ -656,27 +637,33 @@ static int run_partitioned(gffx_hip_batch *b) {
     const bool aos = b->q.aos != nullptr;
     if (b->flags & GFFX_OUT_ROOT_BITMAP)
         GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)ix->n_roots + 31) / 32 * 4 + 4, b->stream));
-    const size_t region = (size_t)ix->n_tiles * b->sub_cap;
-    if ((b->flags & GFFX_OUT_OFFSETS) && !b->d_q_offsets && (rc = dev_alloc(&b->d_q_offsets, b->max_q))) return rc;
-    TileOut o;
-    o.q_rows = b->d_q_rows;
-    o.q_counts = b->d_q_counts;
-    o.q_offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_q_offsets : nullptr;
-    o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
-    o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
-    o.bitmap = (b->flags & GFFX_OUT_ROOT_BITMAP) ? b->d_bitmap : nullptr;
-    o.cursors = b->d_status + 1;
+    if (!b->d_q_rec && (rc = dev_alloc(&b->d_q_rec, b->max_q))) return rc;
+    TileJoinArgs ja;
+    ja.start = ix->d_start;
+    ja.aux = ix->d_aux;
+    ja.tile_desc = ix->d_tile_desc;
+    ja.tile_bins = ix->d_tile_bins;
+    ja.rec = b->d_rec;
+    ja.q_rec = b->d_q_rec;
+    ja.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
+    ja.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
+    ja.bitmap = (b->flags & GFFX_OUT_ROOT_BITMAP) ? b->d_bitmap : nullptr;
+    ja.pair_cursor = b->d_status + 1;
     uint64_t cap = UINT64_MAX;
-    if (o.fids) cap = std::min(cap, b->cap_fids);
-    if (o.triples) cap = std::min(cap, b->cap_triples);
-    o.capacity = cap;
+    if (ja.fids) cap = std::min(cap, b->cap_fids);
+    if (ja.triples) cap = std::min(cap, b->cap_triples);
+    ja.capacity = cap;
+    ja.n_tiles = ix->n_tiles;
+    ja.cap = b->sub_cap;
+    // every block takes an equal share of the batch; 2 blocks of 512 threads per CU keep the whole
+    // grid resident and the pair cursor at <= 512 same-line atomics per round
+    const uint32_t join_blocks = (uint32_t)env_long("GFFX_HIP_JOIN_BLOCKS", 512, 1, 65535);
     for (uint64_t q0 = 0; q0 < b->nq; q0 += b->sub_cap) {
-        o.q0 = q0;
+        ja.q0 = q0;
         const uint32_t n = (uint32_t)std::min<uint64_t>(b->sub_cap, b->nq - q0);
         uint32_t *cur = b->d_cursor + (size_t)b->cursor_phase * ix->n_tiles;
         uint32_t *nxt = b->d_cursor + (size_t)(b->cursor_phase ^ 1) * ix->n_tiles;
-        PartOut po{b->d_rec, b->d_rec + region, b->d_rec + 2 * region, cur,
-                   reinterpret_cast<uint32_t *>(b->d_status), b->d_status + 1, b->sub_cap};
+        PartOut po{b->d_rec, cur, reinterpret_cast<uint32_t *>(b->d_status), b->d_status + 1, b->sub_cap};
         ProfEvent pe;
         prof_begin(b, GFFX_K_SORT, &pe);
         {
@@ -697,10 +684,11 @@ static int run_partitioned(gffx_hip_batch *b) {
         GFFX_HIP_TRY(hipGetLastError());
         prof_begin(b, GFFX_K_FUSED, &pe);
         {
-            const TileWork w{po.rec_qs, po.rec_qe, po.rec_row, cur, nxt, ix->d_tile_blocks, b->sub_cap};
-            const uint32_t grid = ix->n_join_blocks;
+            ja.cursor = cur;
+            ja.cursor_next = nxt;
+            const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(join_blocks, (n + 63) / 64));
 #define GFFX_CASE(M, I)                                  \
-    if (b->mode == M && (b->invert != 0) == I) launch_tile_join<M, I>(b, grid, w, o);
+    if (b->mode == M && (b->invert != 0) == I) launch_tile_join<M, I>(b, grid, ja);
             GFFX_CASE(0, false) GFFX_CASE(0, true) GFFX_CASE(1, false) GFFX_CASE(1, true) GFFX_CASE(2, false)
             GFFX_CASE(2, true)
 #undef GFFX_CASE
@@ -717,12 +705,62 @@ static int run_partitioned(gffx_hip_batch *b) {
     return GFFX_OK;
 }
 
+// ------------------------------------------------------------------------------------ fused strategy
+
+template <int MODE, bool INV, bool AOS, bool ML>
+static void launch_fused(gffx_hip_batch *b, uint32_t grid, const FusedOut &o) {
+    const uint32_t lds = 80 + kFusedQueue * 8 + kFusedChunk * 4 + (ML ? meta_bytes(b->ix) : 0);
+    hipLaunchKernelGGL((k_join_fused<MODE, INV, AOS, ML>), dim3(grid), dim3(kFusedThreads), lds, b->stream,
+                       b->ix->view(), b->q, (unsigned long long)b->nq, o);
+}
+
+static int run_fused(gffx_hip_batch *b) {
+    if (b->flags & GFFX_OUT_ROOT_BITMAP)
+        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
+    FusedOut o;
+    o.counts = b->d_counts;
+    o.offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr;
+    o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
+    o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
+    o.bitmap = (b->flags & GFFX_OUT_ROOT_BITMAP) ? b->d_bitmap : nullptr;
+    o.err = reinterpret_cast<uint32_t *>(b->d_status);
+    b->fused_word = 2 + b->fused_phase;
+    o.pair_cursor = b->d_status + b->fused_word;
+    o.pair_cursor_next = b->d_status + 2 + (b->fused_phase ^ 1);
+    b->fused_phase ^= 1;
+    uint64_t cap = UINT64_MAX;
+    if (o.fids) cap = std::min(cap, b->cap_fids);
+    if (o.triples) cap = std::min(cap, b->cap_triples);
+    o.capacity = cap;
+    const uint64_t rounds = (b->nq + kFusedChunk - 1) / kFusedChunk;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", 1024, 1, 65535));
+    const bool aos = b->q.aos != nullptr;
+    const bool ml = meta_bytes(b->ix) <= kMetaLdsBytes;
+    ProfEvent pe;
+    prof_begin(b, GFFX_K_FUSED_DIRECT, &pe);
+#define GFFX_CASE2(M, I, A, L) \
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) launch_fused<M, I, A, L>(b, grid, o);
+#define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
+    GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
+    GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
+    GFFX_CASE(2, false, false) GFFX_CASE(2, false, true) GFFX_CASE(2, true, false) GFFX_CASE(2, true, true)
+#undef GFFX_CASE
+#undef GFFX_CASE2
+    prof_end(b, &pe);
+    GFFX_HIP_TRY(hipGetLastError());
+    return GFFX_OK;
+}
+
 // AUTO: the partitioned strategy pays for its extra pass from a few tens of thousands of queries on
-static bool pick_partitioned(const gffx_hip_batch *b, int strategy) {
-    if (!b->ix->partition_ok || b->max_q >= (1ull << 32)) return false;
-    if (strategy == GFFX_STRATEGY_SORTED) return true;
-    if (strategy == GFFX_STRATEGY_DIRECT) return false;
-    return b->nq >= (uint64_t)env_long("GFFX_HIP_PARTITION_MIN_QUERIES", 32768, 0, 1L << 40);
+static int pick_strategy(const gffx_hip_batch *b, int strategy) {
+    const bool part_ok = b->ix->partition_ok && b->max_q < (1ull << 32);
+    if (strategy == GFFX_STRATEGY_SORTED) return part_ok ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_DIRECT;
+    if (strategy == GFFX_STRATEGY_DIRECT || strategy == GFFX_STRATEGY_FUSED) return strategy;
+    // AUTO (GFFX_HIP_AUTO_STRATEGY overrides for experiments): one kernel beats two at every size measured
+    const long forced = env_long("GFFX_HIP_AUTO_STRATEGY", 0, 1, 3);
+    if (forced == GFFX_STRATEGY_SORTED) return part_ok ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_FUSED;
+    if (forced) return (int)forced;
+    return GFFX_STRATEGY_FUSED;
 }
 
 extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags,
@@ -730,7 +768,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: batch is NULL");
     if (!b->have_regions) return fail(GFFX_E_STATE, "gffx_hip_batch_run: no regions set");
     if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad mode %d", mode);
-    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_SORTED)
+    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_FUSED)
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad strategy %d", strategy);
     if (strategy == GFFX_STRATEGY_SORTED && (!b->ix->partition_ok || b->max_q >= (1ull << 32)))
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: the partitioned strategy needs <= %u seqids / genome cells "
@@ -739,7 +777,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     b->mode = mode;
     b->invert = invert ? 1 : 0;
     b->flags = out_flags | GFFX_OUT_COUNTS;
-    b->strategy = pick_partitioned(b, strategy) ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_DIRECT;
+    b->strategy = pick_strategy(b, strategy);
     b->ran = true;
     b->waited = false;
     b->total = 0;
@@ -758,12 +796,12 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         b->n_blocks = 0;
         return GFFX_OK;
     }
-    if (b->strategy == GFFX_STRATEGY_SORTED) {
+    if (b->strategy != GFFX_STRATEGY_DIRECT) {
         const uint64_t want = std::max<uint64_t>(b->reserve ? b->reserve : 2 * nq, 1024);
         if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want && (rc = grow(&b->d_fids, &b->cap_fids, want, 1))) return rc;
         if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want && (rc = grow(&b->d_triples, &b->cap_triples, want, 3)))
             return rc;
-        return run_partitioned(b);
+        return b->strategy == GFFX_STRATEGY_SORTED ? run_partitioned(b) : run_fused(b);
     }
     // contiguous chunk of queries per block, a multiple of the block size; <= 2048 blocks
     const uint64_t tiles = (nq + kJoinThreads - 1) / kJoinThreads;
@@ -814,15 +852,16 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         b->waited = true;
         return GFFX_OK;
     }
-    const bool part = b->strategy == GFFX_STRATEGY_SORTED;
-    // error word (+ the pair cursor of the partitioned strategy) in one copy; block sums of the direct one
-    GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, (part ? 2 : 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (!part)
+    const bool part = b->strategy == GFFX_STRATEGY_SORTED, fused = b->strategy == GFFX_STRATEGY_FUSED;
+    // error word + the pair cursors in one copy; block sums of the direct strategy
+    GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (!part && !fused)
         GFFX_HIP_TRY(hipMemcpy(b->h_status + 1, b->d_block_sums, b->n_blocks * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost));
     if (b->h_status[0] & 1ull) {
         // the flag is sticky on the device (kernels only ever set it): clear it for the next pass
         GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
+        GFFX_HIP_TRY(hipDeviceSynchronize());
         return fail(GFFX_E_CHR_RANGE, "a query's chr is >= the index's seqid count %u "
                                       "(the reference panics here: commands/intersect.rs:117)",
                     b->ix->n_chr);
@@ -830,6 +869,8 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     b->total = 0;
     if (part)
         b->total = b->h_status[1];
+    else if (fused)
+        b->total = b->h_status[b->fused_word];
     else
         for (uint32_t i = 0; i < b->n_blocks; i++) b->total += b->h_status[1 + i];
     bool replay = false;
@@ -841,13 +882,13 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         if ((rc = grow(&b->d_triples, &b->cap_triples, b->total + b->total / 8, 3))) return rc;
         replay = true;
     }
-    if (part && (b->flags & GFFX_OUT_OFFSETS)) {
+    if ((part || fused) && (b->flags & GFFX_OUT_OFFSETS)) {
         const unsigned long long tot = b->total;  // offsets[nq] = number of pairs, as in the direct path
         GFFX_HIP_TRY(hipMemcpy(b->d_offsets + b->nq, &tot, sizeof tot, hipMemcpyHostToDevice));
     }
     if (replay) {
         // the partitioned strategy counts and emits in one kernel: the whole pass runs again
-        if ((rc = part ? run_partitioned(b) : enqueue_emit(b))) return rc;
+        if ((rc = part ? run_partitioned(b) : fused ? run_fused(b) : enqueue_emit(b))) return rc;
         if ((rc = gffx_hip_batch_sync(b))) return rc;
     }
     b->waited = true;
@@ -889,14 +930,19 @@ extern "C" int gffx_hip_batch_copy_offsets(gffx_hip_batch *b, uint64_t *host) {
 }
 extern "C" int gffx_hip_batch_copy_query_records(gffx_hip_batch *b, uint32_t *rows, uint32_t *counts,
                                                  uint64_t *offsets) {
-    int rc = need_waited(b, "gffx_hip_batch_copy_query_records", offsets ? GFFX_OUT_OFFSETS : 0);
+    int rc = need_waited(b, "gffx_hip_batch_copy_query_records",
+                         (offsets && b && b->strategy != GFFX_STRATEGY_SORTED) ? GFFX_OUT_OFFSETS : 0);
     if (rc) return rc;
     const uint64_t n = b->nq;
     if (!n) return GFFX_OK;
     if (b->strategy == GFFX_STRATEGY_SORTED) {
-        if (rows) GFFX_HIP_TRY(hipMemcpy(rows, b->d_q_rows, n * 4, hipMemcpyDeviceToHost));
-        if (counts) GFFX_HIP_TRY(hipMemcpy(counts, b->d_q_counts, n * 4, hipMemcpyDeviceToHost));
-        if (offsets) GFFX_HIP_TRY(hipMemcpy(offsets, b->d_q_offsets, n * 8, hipMemcpyDeviceToHost));
+        std::vector<uint4> tmp(n);
+        GFFX_HIP_TRY(hipMemcpy(tmp.data(), b->d_q_rec, n * sizeof(uint4), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; i++) {
+            if (rows) rows[i] = tmp[i].x;
+            if (counts) counts[i] = tmp[i].y;
+            if (offsets) offsets[i] = (uint64_t)tmp[i].z | ((uint64_t)tmp[i].w << 32);
+        }
     } else {  // direct strategy: emission order == input order
         if (rows)
             for (uint64_t i = 0; i < n; i++) rows[i] = (uint32_t)i;

@@ -55,14 +55,16 @@ struct IndexView {
     // per seqid: x = first position, y = one past the last, z = base into bins,
     //            w = (shift << 27) | n_bins   (n_bins < 2^27; 0 bins for an empty seqid)
     const uint4 *chr_meta;
-    // Bin directory of a seqid, one 8-byte record per bin b (plus a sentinel at b == n_bins):
+    // Bin directory of a seqid, one 16-byte record per bin b (plus a sentinel at b == n_bins):
     //   x = pos | (min(cnt, 31) << 27)   pos = first position whose start >= b << shift,
     //                                    cnt = number of entries whose start falls into bin b
     //   y = pmax of the entry before pos (0 if none)
-    // One gather answers "where does the sweep start" and, when the bin holds nothing below the
-    // query's end, "can anything before it still reach the query" -- queries in gene deserts end
-    // after this single access.  kPosMask limits an index to 2^27 roots.
-    const uint2 *bins;
+    //   z, w = start of the bin's first / second entry (0xFFFFFFFF if absent)
+    // ONE gather answers "where does the sweep start" for bins with <= 2 entries (the usual case at
+    // ~2 bins per entry) and, when the bin holds nothing below the query's end, "can anything before
+    // it still reach the query" -- queries in gene deserts end after this single access.
+    // kPosMask limits an index to 2^27 roots.
+    const uint4 *bins;
     uint32_t n_chr;
     uint32_t n_roots;
 };

@@ -8,7 +8,7 @@
 // The reference reaches the hit set by walking a pointer-based centered interval tree.  Here the
 // seqid's intervals sit in HBM sorted by start with pmax/skip links (gffx_device.hpp), and the same
 // set is enumerated as
-//       p = #{ iv : iv.start < qe }          -- one 8-byte bin record (+ short refine over start[])
+//       p = #{ iv : iv.start < qe }          -- one 16-byte bin record (rarely + a refine over start[])
 //       backward sweep from p-1 following the skip links, stop when pmax <= qs
 // which needs no per-query state and no recursion.  Degenerate rows (qs >= qe) need no special
 // case: the predicate is evaluated literally.
@@ -108,19 +108,23 @@ __device__ __forceinline__ uint32_t locate(const IndexView &ix, const uint4 meta
     const uint32_t nb = meta.w & kPosMask;
     uint32_t b = qe >> (meta.w >> kPosBits);
     if (b > nb) b = nb;  // sentinel record: every start < qe
-    const uint2 rec = ix.bins[meta.z + b];
+    const uint4 rec = ix.bins[meta.z + b];
     const uint32_t lo = rec.x & kPosMask;
     uint32_t p = lo;
     if (b < nb) {
         uint32_t cnt = rec.x >> kPosBits;
-        if (cnt == kCntSat) cnt = (ix.bins[meta.z + b + 1].x & kPosMask) - lo;
-        uint32_t hi = lo + cnt;  // entries of bin b: find the first with start >= qe
-        while (p < hi) {
-            const uint32_t mid = (p + hi) >> 1;
-            if (ix.start[mid] < qe)
-                p = mid + 1;
-            else
-                hi = mid;
+        if (cnt <= 2) {  // the record carries the starts (absent = 0xFFFFFFFF, never < qe)
+            p += (rec.z < qe) + (rec.w < qe);
+        } else {
+            if (cnt == kCntSat) cnt = (ix.bins[meta.z + b + 1].x & kPosMask) - lo;
+            uint32_t hi = lo + cnt;  // entries of bin b: find the first with start >= qe
+            while (p < hi) {
+                const uint32_t mid = (p + hi) >> 1;
+                if (ix.start[mid] < qe)
+                    p = mid + 1;
+                else
+                    hi = mid;
+            }
         }
     }
     *dead = (p == lo && rec.y <= qs);

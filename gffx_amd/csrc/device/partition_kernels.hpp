@@ -12,10 +12,10 @@
 //      rank inside (block, tile) with one LDS atomic,
 //   2. reserves its run in every non-empty tile with ONE returning global atomicAdd,
 //   3. stages the records tile-sorted in LDS and copies them out, so neighbouring lanes write
-//      neighbouring records of a run (coalesced 4-byte stores into three SoA arrays).
-// Record = {qs, qe, input row}; the seqid is implied by the tile.  The order inside a tile depends
+//      neighbouring records of a run (one coalesced 16-byte store per query).
+// Record = {qs, qe, input row, -}; the seqid is implied by the tile.  The order inside a tile depends
 // on which block reserved first (not reproducible run to run); every record carries its row.
-// Roofline bound: HBM.  Traffic per query: 12 B in + 12 B out.
+// Roofline bound: HBM.  Traffic per query: 12 B in + 16 B out.
 #pragma once
 #include "join_a_kernels.hpp"
 
@@ -33,7 +33,7 @@ constexpr int kPartItems = GFFX_PART_ITEMS;
 constexpr uint32_t kPartChunk = kPartThreads * kPartItems;  // queries per block
 
 struct PartOut {
-    uint32_t *rec_qs, *rec_qe, *rec_row;  // n_tiles * cap each
+    uint4 *rec;                           // {qs, qe, input row, -}: n_tiles regions of `cap` records
     uint32_t *cursor;                     // n_tiles, zero on entry; queries per tile on exit
     uint32_t *err;                        // bit0 = chr out of range
     unsigned long long *cursors;          // [0] kept pairs of the pass: zeroed here at its start
@@ -82,8 +82,8 @@ __host__ __device__ inline uint32_t part_lds_bytes(uint32_t n_chr, uint32_t n_ce
     b += (n_chr + 1) * 4;                 // cell_base
     b += ((n_cells + 1) & ~1u) * 2;       // cell_tile
     b += n_tiles * 4 * 3;                 // hist, loc_off, delta
-    b += kPartChunk * (4 * 3 + 2);        // staged records + their tile
-    b += 64;                              // scan scratch
+    b += kPartChunk * (16 + 2);           // staged records + their tile
+    b += 64 + 16;                         // scan scratch, alignment slack
     return (b + 15) & ~15u;
 }
 
@@ -96,10 +96,9 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(TilePlanView tp, Que
     uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_cell_tile + ((tp.n_cells + 1) & ~1u));
     uint32_t *s_loc = s_hist + tp.n_tiles;
     uint32_t *s_delta = s_loc + tp.n_tiles;
-    uint32_t *s_qs = s_delta + tp.n_tiles;
-    uint32_t *s_qe = s_qs + kPartChunk;
-    uint32_t *s_row = s_qe + kPartChunk;
-    uint16_t *s_tile = reinterpret_cast<uint16_t *>(s_row + kPartChunk);
+    // 16-byte aligned: the fixed part before it is rounded up
+    uint4 *s_rec = reinterpret_cast<uint4 *>((reinterpret_cast<uintptr_t>(s_delta + tp.n_tiles) + 15) & ~(uintptr_t)15);
+    uint16_t *s_tile = reinterpret_cast<uint16_t *>(s_rec + kPartChunk);
     uint32_t *s_scratch = reinterpret_cast<uint32_t *>(s_tile + kPartChunk);
 
     GFFX_STAMP(0, 0);
@@ -159,9 +158,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(TilePlanView tp, Que
     for (int k = 0; k < kPartItems; ++k) {
         if (tl[k] != 0xFFFFFFFFu) {
             const uint32_t slot = s_loc[tl[k]] + rk[k];
-            s_qs[slot] = qs[k];
-            s_qe[slot] = qe[k];
-            s_row[slot] = (uint32_t)q0 + beg + k * kPartThreads + threadIdx.x;
+            s_rec[slot] = make_uint4(qs[k], qe[k], (uint32_t)q0 + beg + k * kPartThreads + threadIdx.x, 0u);
             s_tile[slot] = (uint16_t)tl[k];
         }
     }
@@ -173,9 +170,7 @@ __global__ __launch_bounds__(kPartThreads) void k_partition(TilePlanView tp, Que
         const uint32_t slot = k * kPartThreads + threadIdx.x;
         if (slot < n_valid) {
             const uint32_t dst = slot + s_delta[s_tile[slot]];
-            out.rec_qs[dst] = s_qs[slot];
-            out.rec_qe[dst] = s_qe[slot];
-            out.rec_row[dst] = s_row[slot];
+            out.rec[dst] = s_rec[slot];
         }
     }
     GFFX_STAMP(0, 6);

@@ -30,10 +30,11 @@ class OverlapMode(enum.IntEnum):
 
 
 OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS, OUT_EMIT_ORDER = 1, 2, 4, 8, 16, 32
-STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED = 0, 1, 2
-K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE = 0, 1, 2, 3, 4, 5
+STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED, STRATEGY_FUSED = 0, 1, 2, 3
+K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE, K_FUSED_DIRECT = 0, 1, 2, 3, 4, 5, 6
 KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_partition",
-                K_LINES: "k_lines_exists", K_FUSED: "k_tile_join", K_UNPERMUTE: "k_unpermute"}
+                K_LINES: "k_lines_exists", K_FUSED: "k_tile_join", K_UNPERMUTE: "k_unpermute",
+                K_FUSED_DIRECT: "k_join_fused"}
 
 
 def device_count() -> int:

@@ -76,10 +76,13 @@ enum gffx_out {
 };
 
 enum gffx_strategy {
-    GFFX_STRATEGY_AUTO = 0,
+    GFFX_STRATEGY_AUTO = 0,   /* the engine picks (currently: fused; direct for tiny batches) */
     GFFX_STRATEGY_DIRECT = 1, /* queries in input order; bin directory + gathers from the L2-resident index */
-    GFFX_STRATEGY_SORTED = 2  /* "partitioned": one-pass device radix partition of the batch by genome window,
+    GFFX_STRATEGY_SORTED = 2, /* "partitioned": one-pass device radix partition of the batch by genome window,
                                  then a fused count+emit join served from LDS-staged index tiles */
+    GFFX_STRATEGY_FUSED = 3   /* queries in input order, ONE kernel: interleaved gathers from the L2-resident
+                                 index, count + emit per block round; counts / offsets in input order, pair
+                                 segments in the order rounds reserve them (offsets explicit) */
 };
 
 enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
@@ -89,6 +92,7 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
     GFFX_K_LINES = 3,
     GFFX_K_FUSED = 4,
     GFFX_K_UNPERMUTE = 5,
+    GFFX_K_FUSED_DIRECT = 6,
     GFFX_K__COUNT = 8
 };
 

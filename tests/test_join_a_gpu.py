@@ -13,7 +13,7 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 FLAGS = engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS
-STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED]
+STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED]
 
 
 def _sorted_rows(t):

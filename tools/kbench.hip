@@ -34,6 +34,7 @@ int main(int argc, char **argv) {
     const int strategy = argc > 2 ? atoi(argv[2]) : 2;
     const uint32_t flags = argc > 3 ? (uint32_t)atoi(argv[3]) : (GFFX_OUT_FIDS | GFFX_OUT_OFFSETS);
     const int iters = argc > 4 ? atoi(argv[4]) : 50;
+    const int presort = argc > 5 ? atoi(argv[5]) : 0;  // 1: queries sorted by (chr, end) on the host (experiment)
     const int n_chr = sizeof(kChroms) / sizeof(kChroms[0]);
     std::mt19937_64 rng(42);
     double total_len = 0;
@@ -72,6 +73,22 @@ int main(int argc, char **argv) {
         qs[i] = st;
         qe[i] = st + w;
     }
+    if (presort) {
+        std::vector<uint32_t> o(nq);
+        for (uint64_t i = 0; i < nq; i++) o[i] = (uint32_t)i;
+        std::sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) {
+            return qc[a] != qc[b] ? qc[a] < qc[b] : qe[a] < qe[b];
+        });
+        std::vector<uint32_t> c2(nq), s2(nq), e2(nq);
+        for (uint64_t i = 0; i < nq; i++) {
+            c2[i] = qc[o[i]];
+            s2[i] = qs[o[i]];
+            e2[i] = qe[o[i]];
+        }
+        qc.swap(c2);
+        qs.swap(s2);
+        qe.swap(e2);
+    }
     gffx_hip_index *ix = nullptr;
     if (gffx_hip_index_create(n_chr, co.data(), s.data(), e.data(), f.data(), 0, &ix)) {
         fprintf(stderr, "index: %s\n", gffx_hip_last_error());
@@ -106,8 +123,8 @@ int main(int argc, char **argv) {
         gffx_hip_batch_sync(b);
     }
     gffx_hip_batch_set_profiling(b, 0);
-    const char *names[] = {"join_count", "join_emit", "partition", "lines", "tile_join"};
-    for (int k = 0; k < 5; k++) {
+    const char *names[] = {"join_count", "join_emit", "partition", "lines", "tile_join", "unpermute", "join_fused"};
+    for (int k = 0; k < 7; k++) {
         double t;
         uint64_t n;
         gffx_hip_batch_kernel_ms(b, k, &t, &n);
@@ -115,7 +132,7 @@ int main(int argc, char **argv) {
     }
 #if GFFX_STAMPS
     // one more pass, then dump the phase stamps of the LAST kernel that stamped
-    for (int which = 0; which < 2; which++) {
+    for (int which = 0; which < 3; which++) {
         std::vector<unsigned long long> z(8192 * 16, 0);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z.data(), z.size() * 8);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sel), &which, sizeof(int));
