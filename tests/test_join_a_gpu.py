@@ -84,6 +84,29 @@ def test_gencode_scale_100k_queries(mode, strategy):
     assert n > 0 or mode != OverlapMode.Overlap
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_dense_small_coordinates_all_strategies(seed):
+    """Random intervals on a tiny coordinate range: deep nesting, hundreds of hits per region (the
+    fused kernel's per-wave hit queues overflow and replay; pair buffers are regrown), ties on
+    start and end, degenerate regions -- every strategy, mode and invert against the oracle."""
+    rng = np.random.default_rng(100 + seed)
+    n_chr = int(rng.integers(1, 4))
+    span = int(rng.choice([40, 300, 5000]))
+    per = rng.integers(0, 1500, n_chr)
+    co = np.concatenate([[0], np.cumsum(per)]).astype(np.uint32)
+    n = int(co[-1])
+    start = rng.integers(0, span, n).astype(np.uint32)
+    end = (start + rng.integers(1, max(2, span // int(rng.choice([1, 3, 20]))), n)).astype(np.uint32)
+    roots = {"chr_offsets": co, "start": start, "end": end, "fid": rng.permutation(n).astype(np.uint32) * 7}
+    nq = int(rng.integers(1, 6000))
+    qs = rng.integers(0, span + 5, nq)
+    qe = qs + rng.integers(-3, max(2, span // 2), nq)  # includes qs >= qe rows
+    regions = np.stack([rng.integers(0, n_chr, nq), qs, np.maximum(qe, 0)], axis=1).astype(np.uint32)
+    for strategy in STRATEGIES:
+        for mode in OverlapMode:
+            _check(roots, regions, mode, bool(rng.integers(0, 2)), soa=bool(rng.integers(0, 2)), strategy=strategy)
+
+
 def test_appendix_e_table_on_device():
     # SURVEY.md App. E roots: seq0 {[100,200)->0, [150,400)->4}, seq1 {[0,50)->6}
     ix = engine.TreeIndexData.from_roots([0, 2, 3], [100, 150, 0], [200, 400, 50], [0, 4, 6], ["chr1", "chr2"])
