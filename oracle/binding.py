@@ -71,6 +71,10 @@ def lib():
         L.oracle_intersect_run.restype = C.c_int
         L.oracle_intersect_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
                                            C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.oracle_depth_parse_bed.restype = C.c_int
+        L.oracle_depth_parse_bed.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(u32p), u64p, C.c_char_p, C.c_size_t]
+        L.oracle_depth_run.restype = C.c_int
+        L.oracle_depth_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.oracle_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -175,6 +179,18 @@ class OracleIndex:
         lib().oracle_free(rp)
         return out
 
+    def depth_parse_bed(self, path: str) -> np.ndarray:
+        """commands/depth.rs:429-495: the rows `gffx depth` keeps from a BED file, (n,3) u32."""
+        rp = u32p()
+        nq = C.c_uint64()
+        err = C.create_string_buffer(1024)
+        if lib().oracle_depth_parse_bed(os.fsencode(path), self._h, C.byref(rp), C.byref(nq), err, len(err)) != 0:
+            raise OracleError(err.value.decode(errors="replace"))
+        n = nq.value
+        out = np.ctypeslib.as_array(rp, shape=(max(n, 1), 3))[:n].copy()
+        lib().oracle_free(rp)
+        return out
+
     def parse_region(self, region: str) -> Tuple[int, int, int]:
         out = (C.c_uint32 * 3)()
         err = C.create_string_buffer(1024)
@@ -222,4 +238,11 @@ def intersect_run(gff_path: str, out_path: str, region: Optional[str] = None,
                                     os.fsencode(bed) if bed else None, mode, int(bool(invert)),
                                     int(bool(entire_group)), types.encode() if types is not None else None,
                                     os.fsencode(out_path), err, len(err))
+    return rc, err.value.decode(errors="replace")
+
+
+def depth_run(gff_path: str, bed: str, out_path: str) -> Tuple[int, str]:
+    """commands/depth.rs:548-635 with a .bed source; rows sorted by id.  Returns (exit code, message)."""
+    err = C.create_string_buffer(4096)
+    rc = lib().oracle_depth_run(os.fsencode(gff_path), os.fsencode(bed), os.fsencode(out_path), err, len(err))
     return rc, err.value.decode(errors="replace")

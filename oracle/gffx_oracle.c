@@ -1729,3 +1729,348 @@ int oracle_intersect_run(const char *gff_path, const char *region, const char *b
     oracle_index_free(ix);
     return rc;
 }
+
+/* ------------------------------------------- depth (commands/depth.rs, BED source) */
+
+/* depth.rs:86-97 parse_u32_fast: non-empty, ASCII digits only, checked arithmetic
+ * (identical to intersect.rs's parse_u32_ascii) */
+#define parse_u32_fast parse_u32_ascii
+
+/* depth.rs:105-120 fast_id: the FIRST occurrence of the bytes "ID=" anywhere in the attribute
+ * column (so "geneID=" matches too), value up to the next ';', ' ' or '\t' (a trailing '\r' of a
+ * CRLF file stays part of the value).  Returns 0 if there is none. */
+static int fast_id(const uint8_t *a, size_t n, const uint8_t **id, size_t *idlen) {
+    size_t i = 0;
+    while (i + 2 < n) {
+        if (a[i] == 'I' && a[i + 1] == 'D' && a[i + 2] == '=') {
+            size_t j = i + 3;
+            while (j < n && a[j] != ';' && a[j] != ' ' && a[j] != '\t') j++;
+            *id = a + i + 3;
+            *idlen = j - (i + 3);
+            return 1;
+        }
+        i++;
+    }
+    return 0;
+}
+
+typedef struct {
+    uint32_t start, end, id; /* depth.rs:102-103 FeatureInst (0-based half-open), id = GLOBAL id index */
+    const uint8_t *seq;      /* the line's seqid column (for id_chrom, :151) */
+    size_t seqlen;
+} dfeat_t;
+
+typedef struct {
+    smap_t ids;          /* id string -> index */
+    char **id_str;       /* index -> id (owned by ids) */
+    char **chrom;        /* index -> seqid of the first root block (file order) that gave the ID a depth */
+    uint32_t *min_s, *max_e, *stamp;
+    uint64_t *depth;
+    size_t n, cap;
+    uint32_t serial;     /* root block being processed */
+} dres_t;
+
+static uint32_t dres_id(dres_t *r, const uint8_t *id, size_t idlen) {
+    uint32_t v;
+    if (smap_get(&r->ids, id, idlen, &v)) return v;
+    if (r->n == r->cap) {
+        r->cap = r->cap ? r->cap * 2 : 1024;
+        r->id_str = (char **)realloc(r->id_str, r->cap * sizeof(char *));
+        r->chrom = (char **)realloc(r->chrom, r->cap * sizeof(char *));
+        r->min_s = (uint32_t *)realloc(r->min_s, r->cap * 4);
+        r->max_e = (uint32_t *)realloc(r->max_e, r->cap * 4);
+        r->stamp = (uint32_t *)realloc(r->stamp, r->cap * 4);
+        r->depth = (uint64_t *)realloc(r->depth, r->cap * 8);
+    }
+    v = (uint32_t)r->n++;
+    smap_put(&r->ids, id, idlen, v);
+    r->id_str[v] = dupn(id, idlen);
+    r->chrom[v] = NULL;
+    r->stamp[v] = 0;
+    r->min_s[v] = UINT32_MAX;
+    r->max_e[v] = 0;
+    r->depth[v] = 0;
+    return v;
+}
+
+/* depth.rs:121-217 compute_root_depth on one root's byte block and the regions that hit the root,
+ * merged straight into the global result (the merges of :264-291 and :501-508 are min / max / sum,
+ * hence order-independent; `chrom` comes from the first root block that contributes the ID -- its
+ * id_chrom (:151) is the seqid of the block's first line with that ID.  "First" is hash order in the
+ * reference and file order here; it only matters if one ID sits on two seqids).
+ * The reference gathers candidates through 2^bin_shift bins first (:163-197); a feature and a region
+ * that overlap share the bin of any common position, and bins only ever ADD candidates that the
+ * exact test (:196) then rejects, so the binning cannot change the result and is not restated. */
+static void depth_one_root(const uint8_t *slice, size_t n, const uint32_t *regs /* (s,e) pairs */, size_t nregs,
+                           dres_t *res) {
+    if (!utf8_valid(slice, n) || nregs == 0) return; /* :132 `if let Ok(text)`, :153 */
+    dfeat_t *f = NULL;
+    size_t nf = 0, cf = 0;
+    size_t pos = 0;
+    while (pos < n) { /* :133 split_terminator('\n') */
+        const uint8_t *lb = slice + pos;
+        const uint8_t *nl = (const uint8_t *)memchr(lb, '\n', n - pos);
+        size_t ll = nl ? (size_t)(nl - lb) : n - pos;
+        pos += ll + 1;
+        if (ll == 0 || lb[0] == '#') continue; /* :134 */
+        /* :135-141 splitn(9, '\t'): 8 tabs needed; column 9 is the remainder */
+        const uint8_t *col[9];
+        size_t len[9];
+        const uint8_t *p = lb, *e = lb + ll;
+        int k = 0;
+        for (; k < 8; k++) {
+            const uint8_t *t = find_tab(p, e);
+            if (!t) break;
+            col[k] = p;
+            len[k] = (size_t)(t - p);
+            p = t + 1;
+        }
+        if (k < 8) continue;
+        col[8] = p;
+        len[8] = (size_t)(e - p);
+        uint32_t s1, e1;
+        if (!parse_u32_fast(col[3], len[3], &s1) || !parse_u32_fast(col[4], len[4], &e1)) continue; /* :143 */
+        if (e1 == 0) continue;                                                                      /* :144 */
+        if (s1 > e1) { uint32_t t = s1; s1 = e1; e1 = t; }                                          /* :145 */
+        const uint8_t *id;
+        size_t idlen;
+        if (!fast_id(col[8], len[8], &id, &idlen)) continue; /* :149 */
+        if (nf == cf) {
+            cf = cf ? cf * 2 : 64;
+            f = (dfeat_t *)realloc(f, cf * sizeof(dfeat_t));
+        }
+        f[nf].start = s1 ? s1 - 1 : 0; /* :146 saturating_sub(1) */
+        f[nf].end = e1;               /* :147 */
+        f[nf].id = dres_id(res, id, idlen);
+        f[nf].seq = col[0];
+        f[nf].seqlen = len[0];
+        nf++;
+    }
+    /* :181-208 per region: the set of IDs with an overlapping instance; min/max over those instances */
+    uint32_t *hit = (uint32_t *)malloc((nf ? nf : 1) * 4);
+    for (size_t r = 0; r < nregs; r++) {
+        const uint32_t rs = regs[2 * r], re = regs[2 * r + 1];
+        size_t nh = 0;
+        for (size_t i = 0; i < nf; i++) {
+            const uint32_t l = f[i].start > rs ? f[i].start : rs, rr = f[i].end < re ? f[i].end : re;
+            if (l < rr) { /* :78-82 overlaps */
+                hit[nh++] = f[i].id;
+                if (f[i].start < res->min_s[f[i].id]) res->min_s[f[i].id] = f[i].start;
+                if (f[i].end > res->max_e[f[i].id]) res->max_e[f[i].id] = f[i].end;
+            }
+        }
+        qsort(hit, nh, 4, cmp_u32); /* :202-203 sort + dedup */
+        for (size_t i = 0; i < nh; i++)
+            if (i == 0 || hit[i] != hit[i - 1]) { /* :204-206 */
+                res->depth[hit[i]]++;
+                res->stamp[hit[i]] = res->serial;
+            }
+    }
+    for (size_t i = 0; i < nf; i++) /* :210-216 + the or_insert of the merges: chrom of a new ID */
+        if (res->stamp[f[i].id] == res->serial && !res->chrom[f[i].id]) res->chrom[f[i].id] = dupn(f[i].seq, f[i].seqlen);
+    free(hit);
+    free(f);
+}
+
+/* depth.rs:429-495: BED rows of `depth`.  Lines are cut at '\n' and KEEP it; fields split on tab or
+ * space, empty fields dropped; < 3 fields, '#' lines, a non-UTF-8 or unparsable field, s >= e or an
+ * unknown seqid drop the row silently.  Column 3 is trim_end()ed before parsing (:485). */
+int oracle_depth_parse_bed(const char *bed_path, const oracle_index *ix, uint32_t **regions_out, uint64_t *nq,
+                           char *err, size_t errlen) {
+    map_t m;
+    if (map_file(bed_path, &m) != 0) {
+        set_err(err, errlen, "No such file or directory (os error 2)");
+        return -1;
+    }
+    buf_t out = {0};
+    uint64_t n = 0;
+    size_t pos = 0;
+    while (pos < m.n) {
+        const uint8_t *lb = m.p + pos;
+        const uint8_t *nl = (const uint8_t *)memchr(lb, '\n', m.n - pos);
+        size_t ll = nl ? (size_t)(nl - lb) + 1 : m.n - pos; /* the window includes the '\n' */
+        pos += ll;
+        if (ll == 0 || lb[0] == '#') continue;
+        const uint8_t *fld[3];
+        size_t fl[3];
+        int nfld = 0;
+        size_t i = 0;
+        while (i < ll) {
+            while (i < ll && (lb[i] == '\t' || lb[i] == ' ')) i++;
+            size_t j = i;
+            while (j < ll && lb[j] != '\t' && lb[j] != ' ') j++;
+            if (j > i) {
+                if (nfld < 3) {
+                    fld[nfld] = lb + i;
+                    fl[nfld] = j - i;
+                }
+                nfld++;
+            }
+            i = j;
+        }
+        if (nfld < 3) continue;
+        if (!utf8_valid(fld[0], fl[0]) || !utf8_valid(fld[1], fl[1]) || !utf8_valid(fld[2], fl[2])) continue;
+        uint32_t s, e, chr;
+        if (!parse_u32_rust(fld[1], fl[1], &s)) continue;
+        const uint8_t *f2 = fld[2];
+        size_t l2 = fl[2];
+        for (;;) { /* str::trim_end(): trailing Unicode whitespace */
+            size_t k = 0, w = 0;
+            /* find a whitespace char that ends exactly at l2 (ASCII fast path, then multi-byte) */
+            if (l2 && (f2[l2 - 1] == ' ' || (f2[l2 - 1] >= 0x09 && f2[l2 - 1] <= 0x0D))) {
+                l2--;
+                continue;
+            }
+            for (k = 2; k <= 3 && k <= l2; k++)
+                if ((w = ws_at(f2 + l2 - k, k)) == k) break;
+            if (k <= 3 && k <= l2 && w == k) {
+                l2 -= k;
+                continue;
+            }
+            break;
+        }
+        if (!parse_u32_rust(f2, l2, &e)) continue;
+        if (s >= e) continue;
+        if (!seq_lookup(ix, fld[0], fl[0], &chr)) continue;
+        uint32_t t[3] = {chr, s, e};
+        buf_push(&out, t, 12);
+        n++;
+    }
+    unmap_file(&m);
+    *regions_out = (uint32_t *)out.p;
+    if (!out.p) *regions_out = (uint32_t *)malloc(4);
+    *nq = n;
+    return 0;
+}
+
+static int cmp_cstr_idx(const void *a, const void *b, void *ctx) {
+    char **s = (char **)ctx;
+    return strcmp(s[*(const uint32_t *)a], s[*(const uint32_t *)b]);
+}
+
+/* depth.rs:548-635 run with a .bed source: "id\tchr\tstart\tend\tdepth" rows for every ID with depth > 0.
+ * The reference writes them in FxHashMap order (unspecified); here they are sorted by id bytes so that two
+ * outputs can be compared.  Batching by 100 000 BED lines (:462) only bounds memory: every merge is min /
+ * max / sum, so one pass over all regions gives the same rows.  Returns 0, or 1 with the message in err. */
+int oracle_depth_run(const char *gff_path, const char *bed_path, const char *out_path, char *err, size_t errlen) {
+    gofe_t *g = NULL;
+    size_t ng = 0;
+    if (load_gof(gff_path, &g, &ng, err, errlen) != 0) return 1; /* :563 */
+    map_t m;
+    if (map_file(gff_path, &m) != 0) { /* :564-565 */
+        set_err(err, errlen, "Cannot open GFF file: \"%s\"", gff_path);
+        free(g);
+        return 1;
+    }
+    oracle_index *ix = NULL;
+    if (oracle_load_tree_index(gff_path, &ix, err, errlen) != 0) { /* :573 */
+        unmap_file(&m);
+        free(g);
+        return 1;
+    }
+    uint32_t *regions = NULL;
+    uint64_t nq = 0;
+    if (oracle_depth_parse_bed(bed_path, ix, &regions, &nq, err, errlen) != 0) {
+        oracle_index_free(ix);
+        unmap_file(&m);
+        free(g);
+        return 1;
+    }
+    /* gof.index_cached(): fid -> (start, end), later duplicates win (gof.rs:32-37) */
+    uint32_t max_fid = 0;
+    for (size_t k = 0; k < ng; k++)
+        if (g[k].fid > max_fid) max_fid = g[k].fid;
+    uint32_t *rec_of = (uint32_t *)malloc(((size_t)max_fid + 2) * 4);
+    memset(rec_of, 0xFF, ((size_t)max_fid + 2) * 4);
+    for (size_t k = 0; k < ng; k++) rec_of[g[k].fid] = (uint32_t)k;
+    /* depth.rs:222-249 compute_hit_depth, first half: regions per root (deduped per region by root_fid) */
+    buf_t *by_root = (buf_t *)calloc(ng ? ng : 1, sizeof(buf_t));
+    hits_t hits = {0};
+    uint32_t seen[64];
+    for (uint64_t i = 0; i < nq; i++) {
+        const uint32_t chr = regions[3 * i], rs = regions[3 * i + 1], re = regions[3 * i + 2];
+        if (chr >= ix->n_chr) continue; /* chr_entries.get(&chr) */
+        hits.n = 0;
+        tree_query(ix->trees[chr], rs, re, &hits);
+        size_t ns = 0;
+        uint32_t *big = NULL;
+        for (size_t h = 0; h < hits.n; h++) {
+            const uint32_t fid = hits.p[h]->root_fid;
+            int dup = 0;
+            const uint32_t *sv = big ? big : seen;
+            for (size_t x = 0; x < ns; x++)
+                if (sv[x] == fid) dup = 1;
+            if (dup) continue; /* :241 seen_in_region */
+            if (!big && ns == 64) {
+                big = (uint32_t *)malloc((hits.n + 1) * 4);
+                memcpy(big, seen, 64 * 4);
+            }
+            (big ? big : seen)[ns++] = fid;
+            if (fid > max_fid || rec_of[fid] == UINT32_MAX) continue; /* :242 idx.get */
+            const gofe_t *ge = &g[rec_of[fid]];
+            if (ge->s == MISSING || ge->e == MISSING || ge->e <= ge->s) continue; /* :243 */
+            uint32_t se[2] = {rs, re};
+            buf_push(&by_root[rec_of[fid]], se, 8); /* :244 */
+        }
+        free(big);
+    }
+    free(hits.p);
+    dres_t res;
+    memset(&res, 0, sizeof res);
+    smap_init(&res.ids, 1024);
+    for (size_t k = 0; k < ng; k++) { /* :251-292, roots in file order instead of hash order */
+        if (!by_root[k].n) continue;
+        res.serial++;
+        if (g[k].e <= m.n) depth_one_root(m.p + g[k].s, (size_t)(g[k].e - g[k].s), (const uint32_t *)by_root[k].p, by_root[k].n / 8, &res);
+        free(by_root[k].p);
+    }
+    free(by_root);
+    /* :515-546 write_depth_results */
+    uint32_t *order = (uint32_t *)malloc((res.n ? res.n : 1) * 4);
+    size_t no = 0;
+    for (size_t i = 0; i < res.n; i++)
+        if (res.depth[i] > 0) order[no++] = (uint32_t)i;
+    qsort_r(order, no, 4, cmp_cstr_idx, res.id_str);
+    buf_t out = {0};
+    const char *hdr = "id\tchr\tstart\tend\tdepth\n";
+    buf_push(&out, hdr, strlen(hdr));
+    for (size_t x = 0; x < no; x++) {
+        const uint32_t i = order[x];
+        char num[96];
+        buf_push(&out, res.id_str[i], strlen(res.id_str[i]));
+        buf_push(&out, "\t", 1);
+        buf_push(&out, res.chrom[i], strlen(res.chrom[i]));
+        int nn = snprintf(num, sizeof num, "\t%u\t%u\t%llu\n", res.min_s[i] == UINT32_MAX ? 0u : res.min_s[i], res.max_e[i],
+                          (unsigned long long)res.depth[i]);
+        buf_push(&out, num, (size_t)nn);
+    }
+    int rc = 0;
+    if (out_path) {
+        if (write_file(out_path, out.p, out.n) != 0) {
+            set_err(err, errlen, "cannot write %s", out_path);
+            rc = 1;
+        }
+    } else {
+        fwrite(out.p, 1, out.n, stdout);
+        fflush(stdout);
+    }
+    free(out.p);
+    free(order);
+    for (size_t i = 0; i < res.n; i++) {
+        free(res.id_str[i]);
+        free(res.chrom[i]);
+    }
+    free(res.id_str);
+    free(res.chrom);
+    free(res.min_s);
+    free(res.max_e);
+    free(res.stamp);
+    free(res.depth);
+    smap_free(&res.ids);
+    free(rec_of);
+    free(regions);
+    oracle_index_free(ix);
+    unmap_file(&m);
+    free(g);
+    return rc;
+}

@@ -97,6 +97,16 @@ int oracle_intersect_run(const char *gff_path, const char *region, const char *b
                          int invert, int entire_group, const char *types, const char *out_path,
                          char *err, size_t errlen);
 
+/* commands/depth.rs:429-495: the BED rows `gffx depth` keeps (its rules differ from intersect's:
+ * malformed rows, s >= e and unknown seqids are dropped silently). */
+int oracle_depth_parse_bed(const char *bed_path, const oracle_index *, uint32_t **regions_out,
+                           uint64_t *nq, char *err, size_t errlen);
+/* commands/depth.rs:548-635 run with a .bed source: per feature ID the number of regions overlapping
+ * a line of that ID (deduped per region inside a root's block), with min start / max end of the
+ * overlapped lines.  Rows sorted by id (the reference's order is a hash-map walk). */
+int oracle_depth_run(const char *gff_path, const char *bed_path, const char *out_path, char *err,
+                     size_t errlen);
+
 void oracle_free(void *);
 
 #ifdef __cplusplus
