@@ -1,0 +1,301 @@
+// depth.cpp -- `gffx depth` with a BED source over the C-ABI (reference: commands/depth.rs).
+//   process_bed            depth.rs:429-512   BED rows -> regions (rules differ from intersect's parser)
+//   compute_hit_depth      depth.rs:222-293   Join A (tree query per region, root deduped per region)  -> device
+//   compute_root_depth     depth.rs:121-217   lines of the root's block x the root's regions          -> device
+//   write_depth_results    depth.rs:515-546   "id\tchr\tstart\tend\tdepth" rows
+// The reference re-parses a root's byte block for every batch that touches it; here every block is
+// parsed ONCE into the device line table (include/gffx_hip.h "gffx depth"), the regions stream through
+// Join A in batches, and k_depth_regions accumulates per (block, ID) group.  BAM/SAM/CRAM sources need
+// htslib, which this build does not carry: they are refused with a clear message.
+#include <algorithm>
+#include <cstdio>
+
+#include "gffx.hpp"
+
+namespace gffx {
+namespace commands {
+namespace depth {
+
+namespace {
+
+[[noreturn]] void hip_fail(const char *what) { throw Error(std::string(what) + ": " + gffx_hip_last_error()); }
+
+// depth.rs:105-120 fast_id: first "ID=" anywhere in the attributes, value up to ';', ' ' or '\t'
+bool fast_id(std::string_view attrs, std::string_view &id) {
+    for (size_t i = 0; i + 2 < attrs.size(); ++i) {
+        if (attrs[i] == 'I' && attrs[i + 1] == 'D' && attrs[i + 2] == '=') {
+            size_t j = i + 3;
+            while (j < attrs.size() && attrs[j] != ';' && attrs[j] != ' ' && attrs[j] != '\t') ++j;
+            id = attrs.substr(i + 3, j - (i + 3));
+            return true;
+        }
+    }
+    return false;
+}
+
+std::string_view trim_end_unicode_ws(std::string_view s) {  // str::trim_end()
+    for (;;) {
+        if (s.empty()) return s;
+        const unsigned char c = static_cast<unsigned char>(s.back());
+        if (c == ' ' || (c >= 0x09 && c <= 0x0D)) {
+            s.remove_suffix(1);
+            continue;
+        }
+        bool cut = false;
+        for (size_t k = 2; k <= 3 && k <= s.size(); ++k)
+            if (unicode_ws_len(s.data() + s.size() - k, k) == k) {
+                s.remove_suffix(k);
+                cut = true;
+                break;
+            }
+        if (!cut) return s;
+    }
+}
+
+}  // namespace
+
+// depth.rs:450-495: lines are cut at '\n' and keep it; fields split on tab or space, empty ones dropped;
+// fewer than 3 fields, '#', a non-UTF-8 / unparsable field, s >= e or an unknown seqid drop the row.
+std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
+                                              const std::unordered_map<std::string, uint32_t> &seqid_to_num) {
+    MappedFile f;
+    try {
+        f = MappedFile(bed_path);
+    } catch (const Error &) {
+        throw Error("No such file or directory (os error 2)");  // File::open(bed_path)? (depth.rs:441)
+    }
+    const std::string_view d = f.view();
+    std::vector<intersect::Region> out;
+    size_t pos = 0;
+    while (pos < d.size()) {
+        size_t nl = d.find('\n', pos);
+        const size_t end = nl == std::string_view::npos ? d.size() : nl + 1;
+        const std::string_view line = d.substr(pos, end - pos);
+        pos = end;
+        if (line.empty() || line[0] == '#') continue;
+        std::string_view fld[3];
+        int n = 0;
+        size_t i = 0;
+        while (i < line.size()) {
+            while (i < line.size() && (line[i] == '\t' || line[i] == ' ')) ++i;
+            size_t j = i;
+            while (j < line.size() && line[j] != '\t' && line[j] != ' ') ++j;
+            if (j > i) {
+                if (n < 3) fld[n] = line.substr(i, j - i);
+                ++n;
+            }
+            i = j;
+        }
+        if (n < 3) continue;
+        if (!utf8_valid(fld[0]) || !utf8_valid(fld[1]) || !utf8_valid(fld[2])) continue;
+        const auto s = parse_u32_rust(fld[1]);
+        const auto e = parse_u32_rust(trim_end_unicode_ws(fld[2]));
+        if (!s || !e || *s >= *e) continue;
+        const auto it = seqid_to_num.find(std::string(fld[0]));
+        if (it == seqid_to_num.end()) continue;
+        out.emplace_back(it->second, *s, *e);
+    }
+    return out;
+}
+
+struct BlockTable {  // the device line table + what the writer needs to name the groups
+    std::vector<uint64_t> block_line_off{0};
+    std::vector<uint32_t> line_start, line_end, line_group, block_of_fid;
+    std::vector<uint32_t> group_id;        // group -> index into ids
+    std::vector<std::string> group_chrom;  // group -> seqid column of the block's first line with that ID (depth.rs:151)
+    std::vector<std::string> ids;
+};
+
+// depth.rs:131-152 on every root block: the lines that carry an ID, 0-based half-open
+BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view gff) {
+    BlockTable t;
+    uint32_t max_fid = 0;
+    for (const auto &g : gof.entries) max_fid = std::max(max_fid, g.feature_id);
+    t.block_of_fid.assign(gof.entries.empty() ? 0 : (size_t)max_fid + 1, 0xFFFFFFFFu);
+    // fid -> its LAST record (index_cached(), gof.rs:32-37); blocks in file order of those records
+    std::vector<uint32_t> last(t.block_of_fid.size(), 0xFFFFFFFFu);
+    for (size_t k = 0; k < gof.entries.size(); ++k) last[gof.entries[k].feature_id] = static_cast<uint32_t>(k);
+    std::unordered_map<std::string, uint32_t> id_index;
+    struct L {
+        uint32_t start, end, id;
+        std::string_view seq;
+    };
+    std::vector<L> lines;
+    for (size_t k = 0; k < gof.entries.size(); ++k) {
+        const auto &g = gof.entries[k];
+        if (last[g.feature_id] != k) continue;
+        if (g.start_offset == MISSING || g.end_offset == MISSING || g.end_offset <= g.start_offset) continue;  // depth.rs:243
+        if (g.end_offset > gff.size()) throw Error("GOF record " + std::to_string(k) + " out of range");
+        const std::string_view slice = gff.substr(g.start_offset, g.end_offset - g.start_offset);
+        lines.clear();
+        if (utf8_valid(slice)) {  // depth.rs:132: a block that is not UTF-8 contributes nothing
+            size_t a = 0;
+            while (a < slice.size()) {  // split_terminator('\n')
+                size_t nl = slice.find('\n', a);
+                if (nl == std::string_view::npos) nl = slice.size();
+                const std::string_view line = slice.substr(a, nl - a);
+                a = nl + 1;
+                if (line.empty() || line[0] == '#') continue;
+                std::string_view col[9];  // splitn(9, '\t')
+                size_t p = 0;
+                int c = 0;
+                for (; c < 8; ++c) {
+                    const size_t tpos = line.find('\t', p);
+                    if (tpos == std::string_view::npos) break;
+                    col[c] = line.substr(p, tpos - p);
+                    p = tpos + 1;
+                }
+                if (c < 8) continue;
+                col[8] = line.substr(p);
+                const auto s1 = parse_u32_ascii(col[3]), e1 = parse_u32_ascii(col[4]);  // parse_u32_fast (:86-97)
+                if (!s1 || !e1 || *e1 == 0) continue;
+                uint32_t s = *s1, e = *e1;
+                if (s > e) std::swap(s, e);
+                std::string_view id;
+                if (!fast_id(col[8], id)) continue;
+                auto it = id_index.find(std::string(id));
+                if (it == id_index.end()) {
+                    it = id_index.emplace(std::string(id), static_cast<uint32_t>(t.ids.size())).first;
+                    t.ids.emplace_back(id);
+                }
+                lines.push_back(L{s ? s - 1 : 0, e, it->second, col[0]});
+            }
+        }
+        const uint32_t blk = static_cast<uint32_t>(t.block_line_off.size() - 1);
+        t.block_of_fid[g.feature_id] = blk;
+        // group the block's lines by ID (stable: the first line of an ID names the group's chrom)
+        std::stable_sort(lines.begin(), lines.end(), [](const L &x, const L &y) { return x.id < y.id; });
+        for (size_t i = 0; i < lines.size(); ++i) {
+            if (i == 0 || lines[i].id != lines[i - 1].id) {
+                t.group_id.push_back(lines[i].id);
+                t.group_chrom.emplace_back(lines[i].seq);
+            }
+            t.line_start.push_back(lines[i].start);
+            t.line_end.push_back(lines[i].end);
+            t.line_group.push_back(static_cast<uint32_t>(t.group_id.size() - 1));
+        }
+        t.block_line_off.push_back(t.line_start.size());
+    }
+    return t;
+}
+
+void run(const DepthArgs &args) {
+    const bool verbose = args.verbose;
+    // depth.rs:590-601: dispatch on the source's extension
+    std::string ext;
+    {
+        const size_t slash = args.source.find_last_of('/');
+        const std::string base = slash == std::string::npos ? args.source : args.source.substr(slash + 1);
+        const size_t dot = base.find_last_of('.');
+        if (dot != std::string::npos && dot > 0) ext = base.substr(dot + 1);
+        for (char &c : ext) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+    }
+    const index_loader::GofMap gof = index_loader::load_gof(args.input);  // :563
+    MappedFile gff;
+    try {
+        gff = MappedFile(args.input);  // :564-565
+    } catch (const Error &) {
+        throw Error("Cannot open GFF file: \"" + args.input + "\"");
+    }
+    TreeIndexData index_data = TreeIndexData::load_tree_index(args.input);  // :573
+    if (ext == "bam" || ext == "sam" || ext == "cram")
+        throw Error("BAM/SAM/CRAM sources need htslib, which this build does not carry; use a .bed source");
+    if (ext != "bed")
+        throw Error("Unsupported file type: \"" + args.source + "\". Expected .bam/.sam/.cram or .bed");  // :597-600
+    const std::vector<intersect::Region> regions = parse_bed_rows(args.source, index_data.seqid_to_num);
+    if (verbose) std::fprintf(stderr, "[INFO] %zu BED rows kept\n", regions.size());
+
+    const BlockTable t = build_block_table(gof, gff.view());
+    const uint32_t n_groups = static_cast<uint32_t>(t.group_id.size());
+    std::vector<uint64_t> depth(std::max<size_t>(n_groups, 1), 0);
+    std::vector<uint32_t> mn(std::max<size_t>(n_groups, 1), 0xFFFFFFFFu), mx(std::max<size_t>(n_groups, 1), 0);
+    if (!regions.empty()) {
+        index_data.ensure_device(args.device);
+        gffx_hip_depth *dt = nullptr;
+        if (gffx_hip_depth_create(args.device, n_groups, static_cast<uint32_t>(t.block_line_off.size() - 1),
+                                  t.block_line_off.data(), t.line_start.data(), t.line_end.data(), t.line_group.data(),
+                                  static_cast<uint32_t>(t.block_of_fid.size()), t.block_of_fid.data(), &dt) != GFFX_OK)
+            hip_fail("gffx_hip_depth_create");
+        struct Guard {
+            gffx_hip_depth *d;
+            gffx_hip_batch *b = nullptr;
+            ~Guard() {
+                if (b) gffx_hip_batch_destroy(b);
+                gffx_hip_depth_destroy(d);
+            }
+        } guard{dt};
+        // regions stream through Join A in batches (the reference's BATCH_SIZE, depth.rs:24, only bounds memory:
+        // every merge is min / max / sum)
+        const size_t kBatch = 4u << 20;
+        const size_t cap = std::min(regions.size(), kBatch);
+        if (gffx_hip_batch_create(index_data.device_index, cap, &guard.b) != GFFX_OK) hip_fail("gffx_hip_batch_create");
+        std::vector<uint32_t> flat;
+        for (size_t a = 0; a < regions.size(); a += kBatch) {
+            const size_t n = std::min(kBatch, regions.size() - a);
+            flat.resize(3 * n);
+            for (size_t i = 0; i < n; ++i) {
+                flat[3 * i] = std::get<0>(regions[a + i]);
+                flat[3 * i + 1] = std::get<1>(regions[a + i]);
+                flat[3 * i + 2] = std::get<2>(regions[a + i]);
+            }
+            if (gffx_hip_batch_set_regions_host(guard.b, flat.data(), n) != GFFX_OK) hip_fail("set_regions");
+            if (gffx_hip_batch_run(guard.b, GFFX_MODE_OVERLAP, 0, GFFX_OUT_FIDS | GFFX_OUT_OFFSETS, GFFX_STRATEGY_AUTO) != GFFX_OK)
+                hip_fail("gffx_hip_batch_run");
+            if (gffx_hip_batch_wait(guard.b) != GFFX_OK) hip_fail("query_features");
+            if (gffx_hip_depth_accumulate(dt, guard.b) != GFFX_OK) hip_fail("gffx_hip_depth_accumulate");
+        }
+        if (gffx_hip_depth_copy(dt, depth.data(), mn.data(), mx.data()) != GFFX_OK) hip_fail("gffx_hip_depth_copy");
+    }
+    // merge the groups of an ID (depth.rs:264-291): min start, max end, summed depth; chrom from the first
+    // contributing block (file order here, hash order in the reference)
+    struct Row {
+        bool set = false;
+        std::string chrom;
+        uint32_t s = 0, e = 0;
+        uint64_t d = 0;
+    };
+    std::vector<Row> rows(t.ids.size());
+    std::vector<uint32_t> order;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        if (depth[g] == 0) continue;
+        Row &r = rows[t.group_id[g]];
+        if (!r.set) {
+            r.set = true;
+            r.chrom = t.group_chrom[g];
+            r.s = mn[g];
+            r.e = mx[g];
+            r.d = depth[g];
+            order.push_back(t.group_id[g]);
+        } else {
+            r.s = std::min(r.s, mn[g]);
+            r.e = std::max(r.e, mx[g]);
+            r.d += depth[g];
+        }
+    }
+    // depth.rs:515-546 write_depth_results (rows in first-contribution order; the reference's is a hash walk)
+    std::string out = "id\tchr\tstart\tend\tdepth\n";
+    for (uint32_t i : order) {
+        const Row &r = rows[i];
+        out += t.ids[i];
+        out.push_back('\t');
+        out += r.chrom;
+        out.push_back('\t');
+        out += std::to_string(r.s == 0xFFFFFFFFu ? 0u : r.s);
+        out.push_back('\t');
+        out += std::to_string(r.e);
+        out.push_back('\t');
+        out += std::to_string(r.d);
+        out.push_back('\n');
+    }
+    if (args.output) {
+        write_whole_file(*args.output, out);
+    } else {
+        std::fwrite(out.data(), 1, out.size(), stdout);
+        std::fflush(stdout);
+    }
+    if (verbose) std::fprintf(stderr, "[INFO] Wrote %zu ID depth records\n", order.size());
+}
+
+}  // namespace depth
+}  // namespace commands
+}  // namespace gffx

@@ -6,6 +6,7 @@
 //   gffx::TreeIndexData                                                          utils/tree_index.rs
 //   gffx::commands::intersect::{OverlapMode, IntersectArgs, parse_region, parse_bed_file,
 //        query_features, gff_type_allowed, write_gff_match_only_by_coords, run}  commands/intersect.rs
+//   gffx::commands::depth::{DepthArgs, parse_bed_rows, run}                      commands/depth.rs (BED source)
 // Compute (Join A, Join B) goes through include/gffx_hip.h only; there is no CPU join here.
 #pragma once
 #include <cstdint>
@@ -143,9 +144,29 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
 void run(const IntersectArgs &args);  // intersect.rs:541-655
 
 }  // namespace intersect
+
+// ---- commands/depth.rs (BED source) ----------------------------------------------------------------
+namespace depth {
+
+struct DepthArgs {  // depth.rs:34-72
+    std::string input;                  // -i/--input
+    std::string source;                 // -s/--source (BED; BAM/SAM/CRAM need htslib: refused)
+    std::optional<std::string> output;  // -o/--output
+    uint32_t bin_shift = 12;            // --bin-shift (only bounds the reference's candidate lists; accepted, unused)
+    size_t threads = 12;                // -t/--threads
+    bool verbose = false;               // -v/--verbose
+    int device = 0;                     // --device (addition)
+};
+
+// depth.rs:450-495: the rows `depth` keeps from a BED file (its rules differ from intersect's parser)
+std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
+                                              const std::unordered_map<std::string, uint32_t> &seqid_to_num);
+void run(const DepthArgs &args);  // depth.rs:548-635
+
+}  // namespace depth
 }  // namespace commands
 
-// main.rs: `gffx <index|intersect> ...`; returns the process exit code
+// main.rs: `gffx <index|intersect|depth> ...`; returns the process exit code
 int cli_main(int argc, char **argv);
 
 }  // namespace gffx

@@ -1,5 +1,5 @@
-// main.cpp -- `gffx` command line for the intersect path: `gffx index` (prerequisite) and
-// `gffx intersect` (reference: main.rs:11-39, commands/index.rs:11-23, commands/intersect.rs:32-70,
+// main.cpp -- `gffx` command line for the intersect path: `gffx index` (prerequisite),
+// `gffx intersect` and `gffx depth` (BED source) (reference: main.rs:11-39, commands/depth.rs:34-72, commands/index.rs:11-23, commands/intersect.rs:32-70,
 // utils/common.rs:17-52).  Flag names, short flags, defaults and groups follow the reference's
 // clap derive; usage errors exit 2 like clap, run-time errors print `Error: <msg>` and exit 1.
 #include <cstdio>
@@ -87,6 +87,7 @@ const char *kTopUsage =
     "Usage: gffx <COMMAND>\n\nCommands:\n"
     "  index      Build index for GFF file\n"
     "  intersect  Extract models by a region or regions from a BED file (MI355X engine)\n"
+    "  depth      Compute coverage depth across genomic features from a BED file (MI355X engine)\n"
     "  help       Print this message\n";
 
 const char *kIntersectUsage =
@@ -104,6 +105,16 @@ const char *kIntersectUsage =
     "  -O, --overlap            Return any overlapping features (default)\n"
     "  -I, --invert             Invert the selection (exclude matching features)\n"
     "      --device <N>         HIP device to run on [default: 0]\n";
+
+const char *kDepthUsage =
+    "Usage: gffx depth [OPTIONS] --input <FILE> --source <SOURCE>\n\nOptions:\n"
+    "  -i, --input <FILE>           Input GFF file path\n"
+    "  -s, --source <SOURCE>        Input source (BED; BAM/SAM/CRAM are not supported by this build)\n"
+    "  -o, --output <FILE>          Output file (stdout if not provided)\n"
+    "      --bin-shift <BIN_SHIFT>  Bin width parameter (2^k bp) [default: 12]\n"
+    "  -t, --threads <THREADS>      Number of threads for parallel processing [default: 12]\n"
+    "  -v, --verbose                Enable verbose output\n"
+    "      --device <N>             HIP device to run on [default: 0]\n";
 
 const char *kIndexUsage =
     "Usage: gffx index [OPTIONS] --input <INPUT>\n\nOptions:\n"
@@ -155,6 +166,30 @@ int run_intersect_cli(int argc, char **argv) {
     return 0;
 }
 
+int run_depth_cli(int argc, char **argv) {
+    static const std::vector<OptSpec> specs = {{'i', "input", true},   {'s', "source", true},   {'o', "output", true},
+                                               {0, "bin-shift", true}, {'t', "threads", true},  {'v', "verbose", false},
+                                               {0, "device", true},    {'h', "help", false}};
+    const auto o = parse_opts(argc, argv, 2, specs);
+    if (o.count("help")) {
+        std::fputs(kDepthUsage, stdout);
+        return 0;
+    }
+    commands::depth::DepthArgs a;
+    if (!o.count("input") || !o.count("source"))
+        throw UsageError(std::string("the following required arguments were not provided:") +
+                         (o.count("input") ? "" : "\n  --input <FILE>") + (o.count("source") ? "" : "\n  --source <SOURCE>"));
+    a.input = o.at("input")[0];
+    a.source = o.at("source")[0];
+    if (o.count("output")) a.output = o.at("output")[0];
+    if (o.count("bin-shift")) a.bin_shift = static_cast<uint32_t>(parse_size(o.at("bin-shift")[0], "--bin-shift <BIN_SHIFT>"));
+    if (o.count("threads")) a.threads = parse_size(o.at("threads")[0], "--threads <THREADS>");
+    a.verbose = o.count("verbose") > 0;
+    if (o.count("device")) a.device = static_cast<int>(parse_size(o.at("device")[0], "--device <N>"));
+    commands::depth::run(a);
+    return 0;
+}
+
 int run_index_cli(int argc, char **argv) {
     static const std::vector<OptSpec> specs = {{'i', "input", true},
                                                {'a', "attribute", true},
@@ -198,7 +233,11 @@ int cli_main(int argc, char **argv) {
             usage = kIndexUsage;
             return run_index_cli(argc, argv);
         }
-        throw UsageError("unrecognized subcommand '" + cmd + "' (this build carries the intersect path only)");
+        if (cmd == "depth") {
+            usage = kDepthUsage;
+            return run_depth_cli(argc, argv);
+        }
+        throw UsageError("unrecognized subcommand '" + cmd + "' (this build carries the intersect and depth paths only)");
     } catch (const UsageError &e) {
         std::fprintf(stderr, "error: %s\n\n%s\nFor more information, try '--help'.\n", e.what(), usage);
         return 2;

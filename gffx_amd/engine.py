@@ -31,10 +31,10 @@ class OverlapMode(enum.IntEnum):
 
 OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS, OUT_EMIT_ORDER = 1, 2, 4, 8, 16, 32
 STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED, STRATEGY_FUSED = 0, 1, 2, 3
-K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE, K_FUSED_DIRECT = 0, 1, 2, 3, 4, 5, 6
+K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE, K_FUSED_DIRECT, K_DEPTH = 0, 1, 2, 3, 4, 5, 6, 7
 KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_partition",
                 K_LINES: "k_lines_exists", K_FUSED: "k_tile_join", K_UNPERMUTE: "k_unpermute",
-                K_FUSED_DIRECT: "k_join_fused"}
+                K_FUSED_DIRECT: "k_join_fused", K_DEPTH: "k_depth_regions"}
 
 
 def device_count() -> int:
@@ -249,6 +249,44 @@ class LineTable:
         check(lib().gffx_hip_lines_test(self._h, _p(r), r.shape[0], int(n_seq), int(mode),
                                         keep.ctypes.data_as(_ffi.u8p)))
         return keep[: self.n].astype(bool)
+
+
+class DepthTable:
+    """Feature lines of the root blocks, resident in HBM, plus the per-group accumulators of `gffx depth`
+    (commands/depth.rs:121-293).  ``accumulate(batch)`` adds the regions of a finished Overlap pass."""
+
+    def __init__(self, n_groups: int, block_line_off, line_start, line_end, line_group, block_of_fid, device: int = 0):
+        bo = np.ascontiguousarray(block_line_off, dtype=np.uint64)
+        ls, le, lg, bf = _u32(line_start), _u32(line_end), _u32(line_group), _u32(block_of_fid)
+        self.n_groups = int(n_groups)
+        self._h = C.c_void_p()
+        check(lib().gffx_hip_depth_create(device, self.n_groups, len(bo) - 1, bo.ctypes.data_as(u64p), _p(ls), _p(le),
+                                          _p(lg), len(bf), _p(bf), C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().gffx_hip_depth_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def accumulate(self, batch: "QueryBatch") -> None:
+        check(lib().gffx_hip_depth_accumulate(self._h, batch._h))
+
+    def reset(self) -> None:
+        check(lib().gffx_hip_depth_reset(self._h))
+
+    def results(self):
+        n = max(self.n_groups, 1)
+        d = np.zeros(n, dtype=np.uint64)
+        s = np.zeros(n, dtype=np.uint32)
+        e = np.zeros(n, dtype=np.uint32)
+        check(lib().gffx_hip_depth_copy(self._h, d.ctypes.data_as(u64p), _p(s), _p(e)))
+        return d[: self.n_groups], s[: self.n_groups], e[: self.n_groups]
 
 
 def query_features(index_data: TreeIndexData, regions, mode: int = OverlapMode.Overlap,

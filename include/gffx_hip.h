@@ -15,6 +15,8 @@
  *   unique-root collection (commands/intersect.rs:598-615)  GFFX_OUT_ROOT_BITMAP
  *   gff_line_overlaps_queries, numeric part             gffx_hip_lines_* (Join B)
  *     (commands/intersect.rs:500-521)
+ *   compute_hit_depth / compute_root_depth              gffx_hip_depth_* (`gffx depth`, BED source)
+ *     (commands/depth.rs:121-293)
  *
  * Semantics (bit-exact with the reference):
  *   a root interval iv of the query's seqid is a HIT iff  iv.start < q.end && iv.end > q.start
@@ -93,12 +95,14 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
     GFFX_K_FUSED = 4,
     GFFX_K_UNPERMUTE = 5,
     GFFX_K_FUSED_DIRECT = 6,
+    GFFX_K_DEPTH = 7,
     GFFX_K__COUNT = 8
 };
 
 typedef struct gffx_hip_index gffx_hip_index;
 typedef struct gffx_hip_batch gffx_hip_batch;
 typedef struct gffx_hip_lines gffx_hip_lines;
+typedef struct gffx_hip_depth gffx_hip_depth;
 
 int gffx_hip_abi_version(void);
 /* number of visible HIP devices (0 when none / no driver); never fails */
@@ -189,6 +193,23 @@ void gffx_hip_lines_destroy(gffx_hip_lines *);
  * n_seq = number of seqids; keep_host receives n_lines bytes (0/1). */
 int gffx_hip_lines_test(gffx_hip_lines *, const uint32_t *regions, uint64_t nq, uint32_t n_seq,
                         int mode, uint8_t *keep_host);
+
+/* ---- `gffx depth` with a BED source: compute_hit_depth / compute_root_depth (commands/depth.rs:121-293) --
+ * The host parses every root BLOCK once (the byte range of a .gof record; for a root_fid with several
+ * records the LAST one, index_loader/gof.rs:32-37) into the lines that carry an ID, with the 0-based
+ * half-open coordinates of depth.rs:145-147.  Inside a block the lines are ordered by ID; a GROUP is one
+ * (block, ID) -- the unit depth.rs:202-206 dedups on -- numbered globally.  block_of_fid[root_fid] is
+ * the block (UINT32_MAX: no usable record, depth.rs:242-243).
+ * _accumulate adds the regions of a finished Join A pass (Overlap, no invert, GFFX_OUT_FIDS |
+ * GFFX_OUT_OFFSETS): per group the number of regions with an overlapping line (a region counts a root
+ * once, depth.rs:241) and the min start / max end of the overlapped lines (UINT32_MAX / 0 when none). */
+int gffx_hip_depth_create(int device, uint32_t n_groups, uint32_t n_blocks, const uint64_t *block_line_off /* n_blocks+1 */,
+                          const uint32_t *line_start, const uint32_t *line_end, const uint32_t *line_group,
+                          uint32_t n_fid, const uint32_t *block_of_fid, gffx_hip_depth **out);
+void gffx_hip_depth_destroy(gffx_hip_depth *);
+int gffx_hip_depth_accumulate(gffx_hip_depth *, gffx_hip_batch *);
+int gffx_hip_depth_reset(gffx_hip_depth *);
+int gffx_hip_depth_copy(gffx_hip_depth *, uint64_t *depth, uint32_t *min_start, uint32_t *max_end /* n_groups each */);
 
 #ifdef __cplusplus
 }
