@@ -128,5 +128,56 @@ extern "C" int gffx_host_split_line(const char *line, size_t len, size_t *seq_le
     return 1;
 }
 
+extern "C" int gffx_host_depth_parse_bed(const char *gff, const char *bed, uint32_t **regions, uint64_t *n_regions,
+                                         char *err, size_t errlen) {
+    return guard(err, errlen, [&] {
+        const auto sqs = index_loader::load_sqs(gff);
+        const auto r = commands::depth::parse_bed_rows(bed, sqs.second);
+        std::vector<uint32_t> flat;
+        flat.reserve(r.size() * 3);
+        for (const auto &[c, s, e] : r) {
+            flat.push_back(c);
+            flat.push_back(s);
+            flat.push_back(e);
+        }
+        *regions = dup_vec(flat);
+        *n_regions = r.size();
+    });
+}
+
+extern "C" int gffx_host_depth_block_table(const char *gff, uint32_t *n_blocks, uint64_t **block_line_off,
+                                           uint64_t *n_lines, uint32_t **line_start, uint32_t **line_end,
+                                           uint32_t **line_group, uint32_t *n_fid, uint32_t **block_of_fid,
+                                           uint32_t *n_groups, uint32_t **group_id, char **group_chrom, char **ids,
+                                           char *err, size_t errlen) {
+    return guard(err, errlen, [&] {
+        const index_loader::GofMap gof = index_loader::load_gof(gff);
+        const MappedFile text(gff);
+        const commands::depth::BlockTable t = commands::depth::build_block_table(gof, text.view());
+        *n_blocks = static_cast<uint32_t>(t.block_line_off.size() - 1);
+        *block_line_off = dup_vec(t.block_line_off);
+        *n_lines = t.line_start.size();
+        *line_start = dup_vec(t.line_start);
+        *line_end = dup_vec(t.line_end);
+        *line_group = dup_vec(t.line_group);
+        *n_fid = static_cast<uint32_t>(t.block_of_fid.size());
+        *block_of_fid = dup_vec(t.block_of_fid);
+        *n_groups = static_cast<uint32_t>(t.group_id.size());
+        *group_id = dup_vec(t.group_id);
+        auto join = [](const std::vector<std::string> &v) {
+            std::string j;
+            for (size_t i = 0; i < v.size(); ++i) {
+                if (i) j.push_back('\n');
+                j += v[i];
+            }
+            char *p = static_cast<char *>(std::malloc(j.size() + 1));
+            std::memcpy(p, j.c_str(), j.size() + 1);
+            return p;
+        };
+        *group_chrom = join(t.group_chrom);
+        *ids = join(t.ids);
+    });
+}
+
 extern "C" int gffx_host_cli(int argc, char **argv) { return cli_main(argc, argv); }
 extern "C" void gffx_host_free(void *p) { std::free(p); }

@@ -98,14 +98,6 @@ std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
     return out;
 }
 
-struct BlockTable {  // the device line table + what the writer needs to name the groups
-    std::vector<uint64_t> block_line_off{0};
-    std::vector<uint32_t> line_start, line_end, line_group, block_of_fid;
-    std::vector<uint32_t> group_id;        // group -> index into ids
-    std::vector<std::string> group_chrom;  // group -> seqid column of the block's first line with that ID (depth.rs:151)
-    std::vector<std::string> ids;
-};
-
 // depth.rs:131-152 on every root block: the lines that carry an ID, 0-based half-open
 BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view gff) {
     BlockTable t;

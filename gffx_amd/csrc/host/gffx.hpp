@@ -161,6 +161,15 @@ struct DepthArgs {  // depth.rs:34-72
 // depth.rs:450-495: the rows `depth` keeps from a BED file (its rules differ from intersect's parser)
 std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
                                               const std::unordered_map<std::string, uint32_t> &seqid_to_num);
+struct BlockTable {  // the device line table (include/gffx_hip.h "gffx depth") + what names the groups
+    std::vector<uint64_t> block_line_off{0};
+    std::vector<uint32_t> line_start, line_end, line_group, block_of_fid;
+    std::vector<uint32_t> group_id;        // group -> index into ids
+    std::vector<std::string> group_chrom;  // group -> seqid column of the block's first line with that ID (depth.rs:151)
+    std::vector<std::string> ids;
+};
+// depth.rs:131-152 on every root block (the LAST .gof record of a root_fid): the lines that carry an ID
+BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view gff);
 void run(const DepthArgs &args);  // depth.rs:548-635
 
 }  // namespace depth

@@ -34,6 +34,15 @@ int gffx_host_write_gff_output(const char *gff, const uint64_t *blocks, uint64_t
 int gffx_host_gff_type_allowed(const char *line, size_t len, const char *types);
 /* commands/intersect.rs:446-494: returns 1 and fills seq offsets/len + raw start/end, else 0 */
 int gffx_host_split_line(const char *line, size_t len, size_t *seq_len, uint32_t *start, uint32_t *end);
+/* commands/depth.rs:450-495: the BED rows `gffx depth` keeps (seqid map from <gff>.sqs) */
+int gffx_host_depth_parse_bed(const char *gff, const char *bed, uint32_t **regions, uint64_t *n_regions,
+                              char *err, size_t errlen);
+/* commands/depth.rs:131-152 over every root block: the device line table of include/gffx_hip.h
+ * ("gffx depth") plus, per group, the id (index into ids, '\n'-joined) and the chrom text ('\n'-joined) */
+int gffx_host_depth_block_table(const char *gff, uint32_t *n_blocks, uint64_t **block_line_off, uint64_t *n_lines,
+                                uint32_t **line_start, uint32_t **line_end, uint32_t **line_group, uint32_t *n_fid,
+                                uint32_t **block_of_fid, uint32_t *n_groups, uint32_t **group_id, char **group_chrom,
+                                char **ids, char *err, size_t errlen);
 /* the `gffx` command line in-process (main.rs); returns the exit code */
 int gffx_host_cli(int argc, char **argv);
 void gffx_host_free(void *);

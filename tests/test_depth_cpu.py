@@ -130,3 +130,96 @@ def test_depth_oracle_equals_the_definition_on_synthetic_gffs(tmp_path, seed, qu
     got = rows_of(out)
     assert len(got) > 20
     assert got == brute_depth(gff, kept, names)
+
+
+# ---- the product's host side (C++ above the C-ABI), no GPU: BED rows and the block line table -------------
+import ctypes as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def host():
+    L = C.CDLL(os.path.join(ROOT, "gffx_amd", "lib", "libgffx_host.so"))
+    L.gffx_host_build_index.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    L.gffx_host_depth_parse_bed.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(u32p), u64p, C.c_char_p, C.c_size_t]
+    L.gffx_host_depth_block_table.argtypes = [C.c_char_p, u32p, C.POINTER(u64p), u64p, C.POINTER(u32p), C.POINTER(u32p),
+                                              C.POINTER(u32p), u32p, C.POINTER(u32p), u32p, C.POINTER(u32p),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    L.gffx_host_free.argtypes = [C.c_void_p]
+    return L
+
+
+def _host_table(host, gff):
+    err = C.create_string_buffer(2048)
+    nb, nl, nf, ng = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+    bo, ls, le, lg, bf, gi = u64p(), u32p(), u32p(), u32p(), u32p(), u32p()
+    gc, ids = C.c_void_p(), C.c_void_p()
+    rc = host.gffx_host_depth_block_table(gff.encode(), C.byref(nb), C.byref(bo), C.byref(nl), C.byref(ls), C.byref(le),
+                                          C.byref(lg), C.byref(nf), C.byref(bf), C.byref(ng), C.byref(gi), C.byref(gc),
+                                          C.byref(ids), err, len(err))
+    assert rc == 0, err.value
+    arr = lambda p, n: np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n].copy()  # noqa: E731
+    out = dict(block_off=arr(bo, nb.value + 1), ls=arr(ls, nl.value), le=arr(le, nl.value), lg=arr(lg, nl.value),
+               block_of_fid=arr(bf, nf.value), group_id=arr(gi, ng.value),
+               group_chrom=C.string_at(gc.value).split(b"\n") if ng.value else [],
+               ids=C.string_at(ids.value).split(b"\n"))
+    for p in (bo, ls, le, lg, bf, gi):
+        host.gffx_host_free(p)
+    host.gffx_host_free(gc)
+    host.gffx_host_free(ids)
+    return out
+
+
+@pytest.mark.parametrize("seed,quirks,crlf", [(4, False, False), (5, True, False), (6, True, True)])
+def test_host_bed_rows_and_block_table_reproduce_the_oracle_rows(host, tmp_path, seed, quirks, crlf):
+    roots = synth.gencode_like_roots(150, seed=seed, chroms=synth.SMALL2)
+    gff = str(tmp_path / "s.gff")
+    synth.write_gff3(gff, roots, seed=seed, quirks=quirks, crlf=crlf)
+    err = C.create_string_buffer(2048)
+    assert host.gffx_host_build_index(gff.encode(), b"gene_name", ob.DEFAULT_SKIP.encode(), 0, err, len(err)) == 0
+    oix = ob.OracleIndex.load(gff)
+    regions = synth.synth_bed(600, seed=seed + 10, chroms=synth.SMALL2, width=(1, 60000), edge_frac=0.1, roots=roots)
+    bed = str(tmp_path / "q.bed")
+    synth.write_bed(bed, regions, [n for n, _ in synth.SMALL2],
+                    extra_lines=["# header\n", "chrZ\t1\t2\n", "chr1\t7\n", "\n", "chr1 5 9 name\n", "chr1\t3\tx\n",
+                                 "chr1\t+4\t8\n", "chr1\t4\t8 \n", "chr1\t4\t8\r\n", "chr1\t\t4\t\t9\n"])
+    rp, n = u32p(), C.c_uint64()
+    assert host.gffx_host_depth_parse_bed(gff.encode(), bed.encode(), C.byref(rp), C.byref(n), err, len(err)) == 0
+    kept = np.ctypeslib.as_array(rp, shape=(max(n.value, 1), 3))[: n.value].copy()
+    host.gffx_host_free(rp)
+    assert np.array_equal(kept, oix.depth_parse_bed(bed))
+    # join on the CPU from the host's table (numpy) -> rows == the oracle's rows
+    t = _host_table(host, gff)
+    co, S, E, F = oix.export()
+    S, E = S.astype(np.int64), E.astype(np.int64)
+    ng = len(t["group_id"])
+    depth, mn, mx = np.zeros(ng, np.int64), np.full(ng, 2**32, np.int64), np.zeros(ng, np.int64)
+    for c, qs, qe in kept.astype(np.int64).tolist():
+        lo, hi = int(co[c]), int(co[c + 1])
+        hit = np.nonzero((S[lo:hi] < qe) & (E[lo:hi] > qs))[0] + lo
+        for fid in np.unique(F[hit]).tolist():
+            b = int(t["block_of_fid"][fid]) if fid < len(t["block_of_fid"]) else 0xFFFFFFFF
+            if b == 0xFFFFFFFF:
+                continue
+            a, z = int(t["block_off"][b]), int(t["block_off"][b + 1])
+            ov = np.maximum(t["ls"][a:z].astype(np.int64), qs) < np.minimum(t["le"][a:z].astype(np.int64), qe)
+            g = t["lg"][a:z][ov]
+            depth[np.unique(g)] += 1
+            np.minimum.at(mn, g, t["ls"][a:z][ov])
+            np.maximum.at(mx, g, t["le"][a:z][ov])
+    rows = {}
+    for g in range(ng):
+        if depth[g] == 0:
+            continue
+        k = t["ids"][t["group_id"][g]]
+        if k in rows:
+            o = rows[k]
+            rows[k] = (o[0], min(o[1], int(mn[g])), max(o[2], int(mx[g])), o[3] + int(depth[g]))
+        else:
+            rows[k] = (t["group_chrom"][g], int(mn[g]), int(mx[g]), int(depth[g]))
+    out = str(tmp_path / "want.tsv")
+    rc, msg = ob.depth_run(gff, bed, out)
+    assert rc == 0, msg
+    assert sorted((k,) + v for k, v in rows.items()) == rows_of(out)
