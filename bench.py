@@ -59,6 +59,9 @@ def parse_args():
                     help="batches in flight per GPU: steps are issued round-robin to this many QueryBatch objects "
                          "(own HIP stream and buffers each, same resident regions), so one pass's ramp/drain overlaps "
                          "the next pass; 1 = strictly serial passes")
+    ap.add_argument("--depth", action="store_true",
+                    help="additionally time the `gffx depth` join (k_depth_regions) on the same regions against a "
+                         "GENCODE-shaped line table (~3.4 M lines) and report it as an extra \"depth\" object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -86,6 +89,36 @@ def cpu_baseline(roots, regions, mode, budget_s):
                       "interval tree, serial, as commands/intersect.rs:124-166); C restatement, not the Rust binary"
                       % (reps, n),
             "pairs_per_batch": hits}
+
+
+def depth_leg(engine, synth, roots, batch, mode, nq, pairs):
+    """`gffx depth` (BASELINE configs[4]'s command, reference semantics: per-feature-ID region counts):
+    k_depth_regions over the pairs of an Overlap pass, HIP-event time per 1 M-region batch."""
+    tab = synth.gencode_like_block_table(roots)
+    table = engine.DepthTable(tab["n_groups"], tab["block_line_off"], tab["line_start"], tab["line_end"],
+                              tab["line_group"], tab["block_of_fid"])
+    flags = engine.OUT_FIDS | engine.OUT_OFFSETS
+    batch.run(2, False, flags, 0)
+    batch.wait()
+    table.accumulate(batch)  # warm
+    batch.set_profiling(True)
+    batch.reset_profile()
+    reps = 10
+    for _ in range(reps):
+        table.accumulate(batch)
+    batch.set_profiling(False)
+    ms, n = batch.kernel_ms(engine.K_DEPTH)
+    d, _, _ = table.results()
+    lines = int(tab["block_line_off"][-1])
+    pair_lines = float(np.diff(tab["block_line_off"]).mean()) * pairs  # (pair, block line) tests per batch
+    us = 1e3 * ms / max(n, 1)
+    return {"kernel": "k_depth_regions", "avg_us": us, "regions_per_s": nq / (us * 1e-6),
+            "line_table": {"lines": lines, "groups": tab["n_groups"], "blocks": len(tab["block_line_off"]) - 1},
+            "pair_line_tests_per_batch": pair_lines,
+            "achieved_GBps": 12.0 * pair_lines / (us * 1e-6) / 1e9,
+            "depth_sum_check": int(d.sum() // (reps + 1)),
+            "note": "12 B per (pair, block line) read; reference: commands/depth.rs:121-217 (it re-parses a root's "
+                    "block text for every batch that touches it)"}
 
 
 def main():
@@ -301,6 +334,8 @@ def main():
                         "durations of the pass's kernels on the engine's stream (rank 0)",
             },
         }
+        if args.depth:
+            result["depth"] = depth_leg(engine, synth, roots, batch, mode, nq, pairs)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(roots, regions, mode, args.cpu_seconds)
         elif not args.no_cpu_baseline:

@@ -110,6 +110,37 @@ def synth_bed(n: int, seed: int, chroms: Sequence[Tuple[str, int]] = GRCH38,
     return out
 
 
+def gencode_like_block_table(roots: Dict[str, np.ndarray], seed: int = 7, lines_per_gene: float = 53.0):
+    """The feature-line table of `gffx depth` (include/gffx_hip.h) for ``roots`` without materialising GFF
+    text: per root one block holding the gene line plus ~``lines_per_gene`` child lines (transcripts,
+    exons, CDS) with 0-based half-open coordinates inside the gene; 30 % of the lines share their ID with
+    the previous one (multi-line CDS), so groups are ~0.7 per line.  Returns a dict with ``block_line_off``
+    (u64), ``line_start/line_end/line_group`` (u32), ``block_of_fid`` (u32, indexed by root fid) and
+    ``n_groups``."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = len(roots["fid"])
+    per = 1 + rng.poisson(lines_per_gene, size=n).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(per)]).astype(np.uint64)
+    total = int(off[-1])
+    blk = np.repeat(np.arange(n), per)
+    gs = roots["start"].astype(np.int64)[blk]
+    ge = roots["end"].astype(np.int64)[blk]
+    span = np.maximum(ge - gs, 1)
+    a = gs + (rng.random(total) * span).astype(np.int64)
+    w = 1 + (rng.random(total) * np.minimum(span, 2000)).astype(np.int64)
+    first = np.zeros(total, bool)
+    first[off[:-1].astype(np.int64)] = True
+    a[first], w[first] = gs[first], span[first]  # the gene line itself
+    b = np.minimum(a + w, ge)
+    b = np.maximum(b, a + 1)
+    new_group = first | (rng.random(total) > 0.3)
+    group = np.cumsum(new_group) - 1
+    block_of_fid = np.full(int(roots["fid"].max()) + 1, 0xFFFFFFFF, np.uint32)
+    block_of_fid[roots["fid"]] = np.arange(n, dtype=np.uint32)
+    return {"block_line_off": off, "line_start": a.astype(np.uint32), "line_end": b.astype(np.uint32),
+            "line_group": group.astype(np.uint32), "block_of_fid": block_of_fid, "n_groups": int(group[-1]) + 1}
+
+
 def write_bed(path: str, regions: np.ndarray, names: Sequence[str], extra_lines: Sequence[str] = ()) -> None:
     with open(path, "w") as f:
         for ln in extra_lines:
