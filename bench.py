@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--depth", action="store_true",
                     help="additionally time the `gffx depth` join (k_depth_regions) on the same regions against a "
                          "GENCODE-shaped line table (~3.4 M lines) and report it as an extra \"depth\" object")
+    ap.add_argument("--join-b", action="store_true",
+                    help="additionally time Join B (k_lines_exists: every line of a GENCODE-shaped line table against "
+                         "all regions of its seqid) and report it as an extra \"join_b\" object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -119,6 +122,27 @@ def depth_leg(engine, synth, roots, batch, mode, nq, pairs):
             "depth_sum_check": int(d.sum() // (reps + 1)),
             "note": "12 B per (pair, block line) read; reference: commands/depth.rs:121-217 (it re-parses a root's "
                     "block text for every batch that touches it)"}
+
+
+def join_b_leg(engine, synth, roots, regions, mode):
+    """Join B (commands/intersect.rs:500-521 for every line of the annotation): k_lines_exists, HIP-event time."""
+    tab = synth.gencode_like_block_table(roots)
+    per_block = np.diff(tab["block_line_off"]).astype(np.int64)
+    chr_of_root = np.repeat(np.arange(len(roots["chr_offsets"]) - 1), np.diff(roots["chr_offsets"]))
+    seq = np.repeat(chr_of_root, per_block).astype(np.uint32)
+    lt = engine.LineTable(seq, tab["line_start"] + 1, tab["line_end"])  # raw 1-based closed columns 4/5
+    n_seq = len(roots["chr_offsets"]) - 1
+    kept = lt.test(regions, n_seq, mode)  # warm
+    us = []
+    for _ in range(5):
+        lt.test(regions, n_seq, mode)
+        us.append(1e3 * lt.last_kernel_ms)
+    avg = float(np.mean(us))
+    return {"kernel": "k_lines_exists", "avg_us": avg, "lines": int(lt.n), "regions": int(len(regions)),
+            "lines_per_s": lt.n / (avg * 1e-6), "achieved_GBps": 13.0 * lt.n / (avg * 1e-6) / 1e9,
+            "kept_lines": int(kept.sum()),
+            "note": "13 B per line (seq, start, end in; keep flag out); the regions' sort / prefix-max tables are "
+                    "prepared on the host per call and are not in this time"}
 
 
 def main():
@@ -336,6 +360,8 @@ def main():
         }
         if args.depth:
             result["depth"] = depth_leg(engine, synth, roots, batch, mode, nq, pairs)
+        if args.join_b:
+            result["join_b"] = join_b_leg(engine, synth, roots, regions, mode)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(roots, regions, mode, args.cpu_seconds)
         elif not args.no_cpu_baseline:

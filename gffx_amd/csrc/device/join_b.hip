@@ -114,6 +114,8 @@ struct gffx_hip_lines {
     uint32_t *d_seq = nullptr, *d_start = nullptr, *d_end = nullptr;
     uint8_t *d_keep = nullptr;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;  // bracket k_lines_exists of the last _test
+    double last_kernel_ms = 0.0;
 };
 
 template <typename T>
@@ -130,6 +132,8 @@ extern "C" void gffx_hip_lines_destroy(gffx_hip_lines *L) {
     (void)hipFree(L->d_start);
     (void)hipFree(L->d_end);
     (void)hipFree(L->d_keep);
+    if (L->ev_a) (void)hipEventDestroy(L->ev_a);
+    if (L->ev_b) (void)hipEventDestroy(L->ev_b);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
 }
@@ -156,6 +160,8 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
         (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)))
         return rc;
     GFFX_HIP_TRY(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
+    GFFX_HIP_TRY(hipEventCreate(&L->ev_a));
+    GFFX_HIP_TRY(hipEventCreate(&L->ev_b));
     if (n_lines) {
         GFFX_HIP_TRY(hipMemcpyAsync(L->d_seq, seq, n_lines * 4, hipMemcpyHostToDevice, L->stream));
         GFFX_HIP_TRY(hipMemcpyAsync(L->d_start, start, n_lines * 4, hipMemcpyHostToDevice, L->stream));
@@ -238,6 +244,7 @@ extern "C" int gffx_hip_lines_test(gffx_hip_lines *L, const uint32_t *regions, u
         LinesView lv{L->d_seq, L->d_start, L->d_end, (unsigned long long)L->n};
         RegionsView rv{d_off, d_q, d_q + nq, d_q + 2 * nq, d_q + 3 * nq, n_seq};
         const unsigned blocks = (unsigned)((L->n + 255) / 256);
+        GFFX_TRY_C(hipEventRecord(L->ev_a, L->stream));
         if (mode == GFFX_MODE_CONTAINED)
             hipLaunchKernelGGL((k_lines_exists<GFFX_MODE_CONTAINED>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
         else if (mode == GFFX_MODE_CONTAINS_REGION)
@@ -245,10 +252,17 @@ extern "C" int gffx_hip_lines_test(gffx_hip_lines *L, const uint32_t *regions, u
         else
             hipLaunchKernelGGL((k_lines_exists<GFFX_MODE_OVERLAP>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
         GFFX_TRY_C(hipGetLastError());
+        GFFX_TRY_C(hipEventRecord(L->ev_b, L->stream));
         GFFX_TRY_C(hipMemcpyAsync(keep_host, L->d_keep, L->n, hipMemcpyDeviceToHost, L->stream));
     }
     GFFX_TRY_C(hipStreamSynchronize(L->stream));
+    if (L->n) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, L->ev_a, L->ev_b) == hipSuccess) L->last_kernel_ms = ms;
+    }
 #undef GFFX_TRY_C
     cleanup();
     return GFFX_OK;
 }
+
+extern "C" double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *L) { return L ? L->last_kernel_ms : 0.0; }

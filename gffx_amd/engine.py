@@ -250,6 +250,11 @@ class LineTable:
                                         keep.ctypes.data_as(_ffi.u8p)))
         return keep[: self.n].astype(bool)
 
+    @property
+    def last_kernel_ms(self) -> float:
+        """HIP-event duration of k_lines_exists in the last ``test`` call."""
+        return lib().gffx_hip_lines_last_kernel_ms(self._h)
+
 
 class DepthTable:
     """Feature lines of the root blocks, resident in HBM, plus the per-group accumulators of `gffx depth`

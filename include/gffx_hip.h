@@ -193,6 +193,8 @@ void gffx_hip_lines_destroy(gffx_hip_lines *);
  * n_seq = number of seqids; keep_host receives n_lines bytes (0/1). */
 int gffx_hip_lines_test(gffx_hip_lines *, const uint32_t *regions, uint64_t nq, uint32_t n_seq,
                         int mode, uint8_t *keep_host);
+/* HIP-event duration (ms) of k_lines_exists in the last _test call, on the table's own stream */
+double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *);
 
 /* ---- `gffx depth` with a BED source: compute_hit_depth / compute_root_depth (commands/depth.rs:121-293) --
  * The host parses every root BLOCK once (the byte range of a .gof record; for a root_fid with several
