@@ -1,7 +1,7 @@
 // engine.hip -- C-ABI (include/gffx_hip.h) of the gfx950 engine: index upload, query batches.
 //
 // HBM layout of an index (uploaded once, immutable; gffx_device.hpp has the field meanings):
-//   start[R] u32, aux[R] uint4 {end, pmax, skip, root_fid}     20 B/root, seqid after seqid, by start
+//   start[R] u32, aux[R] uint4 {end, pmax_prev, skip, root_fid} 20 B/root, seqid after seqid, by start
 //   chr_meta[n_chr] uint4, bins[...] uint4                      per-seqid bin directory (direct / fused strategies)
 //   cell_base / cell_tile / tile_meta / tile_aux / tile_bins    genome-window tile plan (partitioned strategy)
 // At GENCODE scale (63 k roots, 25 seqids) that is ~1.3 MB + ~2 MB of directory + ~0.2 MB of tile
@@ -200,17 +200,18 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         std::stable_sort(order.begin(), order.end(),
                          [&](uint32_t a, uint32_t b) { return start[a] < start[b]; });
         stack.clear();
-        uint32_t pm = 0;
+        uint32_t pm = 0;  // running max of `end` over the entries before i
         for (uint32_t k = 0; k < hi - lo; k++) {
             const uint32_t j = order[k], i = lo + k;
-            pm = std::max(pm, end[j]);
             while (!stack.empty() && h_aux[stack.back()].x <= end[j]) stack.pop_back();
             const uint32_t skip = stack.empty() ? lo : stack.back() + 1;
             stack.push_back(i);
             h_start[i] = start[j];
             h_aux[i] = make_uint4(end[j], pm, skip, root_fid[j]);
             ix->h_sorted_fids[i] = root_fid[j];
+            pm = std::max(pm, end[j]);
         }
+        auto pmax_incl = [&](uint32_t i) { return std::max(h_aux[i].x, h_aux[i].y); };
         if (hi == lo) {
             chr_meta[c] = make_uint4(lo, lo, (uint32_t)bins.size(), 0u);
             continue;
@@ -228,11 +229,11 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
             while (p < hi && h_start[p] < edge) p++;
             uint32_t q = p;
             while (q < hi && h_start[q] < next_edge) q++;
-            bins.push_back(make_uint4(p | (std::min(q - p, kCntSat) << kPosBits), p > lo ? h_aux[p - 1].y : 0u,
+            bins.push_back(make_uint4(p | (std::min(q - p, kCntSat) << kPosBits), p > lo ? pmax_incl(p - 1) : 0u,
                                       q > p ? h_start[p] : 0xFFFFFFFFu, q > p + 1 ? h_start[p + 1] : 0xFFFFFFFFu));
         }
         // sentinel: nothing starts at or after nb << shift
-        bins.push_back(make_uint4(hi, h_aux[hi - 1].y, 0xFFFFFFFFu, 0xFFFFFFFFu));
+        bins.push_back(make_uint4(hi, pmax_incl(hi - 1), 0xFFFFFFFFu, 0xFFFFFFFFu));
     }
 
     // Partitioned strategy: cells of 2^cshift bp (<= kMaxCells in total, >= 1 per seqid) merged into

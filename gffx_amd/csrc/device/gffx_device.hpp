@@ -37,14 +37,15 @@ int fail(int code, const char *fmt, ...);
 // start (what IntervalTree::build does first, utils/tree.rs:40).  Two arrays, same positions:
 //   start[i]                     0-based start                                  utils/tree.rs:7
 //   aux[i].x = end               exclusive end                                  utils/tree.rs:8
-//   aux[i].y = pmax              running max of `end` over the seqid's entries up to and incl. i
+//   aux[i].y = pmax_prev         running max of `end` over the seqid's entries BEFORE i (0 for the first)
 //   aux[i].z = skip              1 + position of the nearest EARLIER entry of the seqid whose end is
 //                                strictly greater than end[i]; the seqid's first position if none
 //   aux[i].w = root_fid                                                         utils/tree.rs:9
 // The hit set of a query (qs, qe) is {i : start[i] < qe && end[i] > qs} (utils/tree.rs:110).  With
 // p = #{start < qe} (a position) it is enumerated backwards from p-1:
-//       pmax[i] <= qs  -> nothing at or before i ends after qs: stop
-//       end[i]  >  qs  -> hit; continue at i-1
+//       max(pmax_prev[i], end[i]) <= qs  -> nothing at or before i ends after qs: stop
+//       end[i]  >  qs  -> hit; stop if pmax_prev[i] <= qs (nothing before i reaches qs: the read of
+//                         i-1 that would only discover this is saved), else continue at i-1
 //       otherwise      -> every entry in [skip[i], i) ends at or before end[i] <= qs: continue at skip[i]-1
 // so a sweep costs (hits + the few "staircase" entries between them) steps no matter how many short
 // genes sit behind a 2 Mb one -- on GENCODE-like data ~hits + 1.5 -- where a plain pmax-guided

@@ -85,14 +85,15 @@ __device__ __forceinline__ bool sweep_kept(uint32_t &p, uint32_t lower, uint32_t
     while (p > lower) {
         const uint32_t i = p - 1;
         const uint4 a = aux_at(i);
-        if (a.y <= qs) return true;  // nothing at or before i ends after qs
-        if (a.x > qs) {              // hit (start < qe holds for every position below p)
+        if (max(a.y, a.x) <= qs) return true;  // nothing at or before i ends after qs
+        if (a.x > qs) {                        // hit (start < qe holds for every position below p)
             uint32_t s = 0;
             if (MODE != GFFX_MODE_OVERLAP) s = start_at(i);
             if (keep_pair<MODE, INVERT>(s, a.x, qs, qe))
                 if (!f(i, s, a)) return true;
             // Contained needs start >= qs, and starts only decrease from here
             if (MODE == GFFX_MODE_CONTAINED && !INVERT && s < qs) return true;
+            if (a.y <= qs) return true;  // nothing BEFORE i ends after qs: no need to look at i-1 at all
             p = i;
         } else {
             p = a.z;  // entries in [skip, i) end at or before end[i] <= qs

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kFusedThreads, GFFX_FUSED_MIN_WAVES) void k_join_fu
 #pragma unroll
             for (int k = 0; k < kFusedItems; ++k) {
                 if (st[k] != 0) continue;
-                if (a[k].y <= qs[k]) {
+                if (max(a[k].y, a[k].x) <= qs[k]) {  // nothing at or before this entry ends after qs
                     st[k] = 1;
                     continue;
                 }
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(kFusedThreads, GFFX_FUSED_MIN_WAVES) void k_join_fu
                         ++cnt[k];
                     }
                     if (MODE == GFFX_MODE_CONTAINED && !INVERT && s < qs[k]) st[k] = 1;
+                    if (a[k].y <= qs[k]) st[k] = 1;  // nothing BEFORE it ends after qs: the next gather is not needed
                     p[k] -= 1;
                 } else {
                     p[k] = a[k].z;
