@@ -138,7 +138,22 @@ def join_b_leg(engine, synth, roots, regions, mode):
         lt.test(regions, n_seq, mode)
         us.append(1e3 * lt.last_kernel_ms)
     avg = float(np.mean(us))
-    return {"kernel": "k_lines_exists", "avg_us": avg, "lines": int(lt.n), "regions": int(len(regions)),
+    # CPU beside it: the reference scans ALL regions of the line's seqid per line (intersect.rs:500-521);
+    # the oracle's literal scan on a bounded sample of lines, 1 thread
+    from oracle import binding as ob
+    order = np.argsort(regions[:, 0], kind="stable")
+    r = regions[order]
+    off = np.concatenate([[0], np.cumsum(np.bincount(r[:, 0], minlength=n_seq))])
+    pick = np.random.default_rng(5).choice(lt.n, size=400, replace=False)
+    raw_s, raw_e = tab["line_start"] + 1, tab["line_end"]
+    t0 = time.perf_counter()
+    for i in pick.tolist():
+        c = int(seq[i])
+        ob.line_predicate(int(raw_s[i]), int(raw_e[i]), r[off[c]:off[c + 1], 1], r[off[c]:off[c + 1], 2], mode)
+    cpu_s = time.perf_counter() - t0
+    return {"kernel": "k_lines_exists", "avg_us": avg,
+            "cpu_baseline": {"value": len(pick) / cpu_s, "unit": "lines/s", "cores": 1, "kind": "port",
+                             "sample": "%d random lines, literal scan of all regions of the line's seqid" % len(pick)}, "lines": int(lt.n), "regions": int(len(regions)),
             "lines_per_s": lt.n / (avg * 1e-6), "achieved_GBps": 13.0 * lt.n / (avg * 1e-6) / 1e9,
             "kept_lines": int(kept.sum()),
             "note": "13 B per line (seq, start, end in; keep flag out); the regions' sort / prefix-max tables are "
