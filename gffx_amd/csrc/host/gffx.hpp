@@ -73,6 +73,12 @@ class GofMap {  // gof.rs:20-93
 
 GofMap load_gof(const std::string &gff);  // gof.rs:95-128
 
+struct RootInterval {  // utils/tree.rs:5-10 Interval<u32>
+    uint32_t start, end, root_fid;
+};
+// utils/tree_index.rs:36-82: the intervals of every seqid's tree image in `.rit` (tree DFS order), by `.rix` offsets
+std::vector<std::vector<RootInterval>> load_region_index(const std::string &rit_path, const std::string &rix_path);
+
 }  // namespace index_loader
 
 // ---- utils/tree_index.rs -------------------------------------------------------------------------
@@ -90,8 +96,9 @@ struct TreeIndexData {
     TreeIndexData(TreeIndexData &&o) noexcept;
     ~TreeIndexData();
 
-    // tree_index.rs:21-34.  The interval lists are rebuilt from .gof + the root lines of the
-    // GFF (1:1 with the builder's tree inputs, core.rs:170-186); .rit is not needed.
+    // tree_index.rs:21-34: .sqs + .rit/.rix (layout unpinned, see index_loader.cpp); when the images are
+    // absent or do not parse, the interval lists are rebuilt from .gof + the root lines of the GFF
+    // (1:1 with the builder's tree inputs, core.rs:170-186).
     static TreeIndexData load_tree_index(const std::string &gff);
     void ensure_device(int device);  // throws Error (incl. "no HIP device")
 };

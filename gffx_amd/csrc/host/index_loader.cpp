@@ -1,6 +1,8 @@
 // index_loader.cpp -- loaders of the side-car files the intersect path reads
 // (reference: index_loader/core.rs:19-34 load_sqs, index_loader/gof.rs:20-128, utils/tree_index.rs).
 #include <cstdio>
+#include <cstdlib>
+#include <functional>
 
 #include "gffx.hpp"
 
@@ -75,6 +77,110 @@ GofMap load_gof(const std::string &gff) {
     return m;
 }
 
+// utils/tree_index.rs:36-82 load_region_index: `.rix` (JSON array of u64 offsets) + `.rit` (one
+// bincode2 image of IntervalTree<u32> per seqid).  The byte layout of the image is the one SURVEY
+// App. A.2 derives from bincode-1.x defaults (little-endian, fixed-width ints, u64 lengths, a 1-byte
+// Option tag; struct order of utils/tree.rs:5-23) -- it could not be checked against a file written
+// by the reference (no Rust toolchain here), so the caller falls back to the .gof route when an
+// image does not parse.  Validations and messages follow tree_index.rs:54-79.
+std::vector<std::vector<RootInterval>> load_region_index(const std::string &rit_path, const std::string &rix_path) {
+    MappedFile rit, rix;
+    try {
+        rit = MappedFile(rit_path);
+    } catch (const Error &) {
+        throw Error("open " + rit_path);
+    }
+    try {
+        rix = MappedFile(rix_path);
+    } catch (const Error &) {
+        throw Error("open " + rix_path);
+    }
+    // serde_json: Vec<u64> -- '[' ws (digits (ws ',' ws digits)*)? ws ']'
+    std::vector<uint64_t> offsets;
+    {
+        const std::string_view j = rix.view();
+        size_t i = 0;
+        auto ws = [&] {
+            while (i < j.size() && (j[i] == ' ' || j[i] == '\t' || j[i] == '\n' || j[i] == '\r')) ++i;
+        };
+        auto bad = [&]() -> Error { return Error("parse json " + rix_path); };
+        ws();
+        if (i >= j.size() || j[i] != '[') throw bad();
+        ++i;
+        ws();
+        if (i < j.size() && j[i] == ']') {
+            ++i;
+        } else {
+            for (;;) {
+                ws();
+                if (i >= j.size() || j[i] < '0' || j[i] > '9') throw bad();
+                uint64_t v = 0;
+                const size_t d0 = i;
+                while (i < j.size() && j[i] >= '0' && j[i] <= '9') {
+                    if (v > (UINT64_MAX - (uint64_t)(j[i] - '0')) / 10) throw bad();
+                    v = v * 10 + (uint64_t)(j[i] - '0');
+                    ++i;
+                }
+                if (i - d0 > 1 && j[d0] == '0') throw bad();  // JSON forbids leading zeros
+                offsets.push_back(v);
+                ws();
+                if (i < j.size() && j[i] == ',') {
+                    ++i;
+                    continue;
+                }
+                if (i < j.size() && j[i] == ']') {
+                    ++i;
+                    break;
+                }
+                throw bad();
+            }
+        }
+        ws();
+        if (i != j.size()) throw bad();
+    }
+    std::vector<std::vector<RootInterval>> trees;
+    if (offsets.empty()) return trees;  // tree_index.rs:50-52
+    for (size_t k = 0; k + 1 < offsets.size(); ++k)
+        if (offsets[k] > offsets[k + 1])
+            throw Error("offsets not sorted ascending: " + std::to_string(offsets[k]) + " > " + std::to_string(offsets[k + 1]));
+    if (offsets.back() > rit.size())
+        throw Error("last offset " + std::to_string(offsets.back()) + " out of file size " + std::to_string(rit.size()));
+    trees.resize(offsets.size());
+    for (size_t t = 0; t < offsets.size(); ++t) {
+        const size_t start = offsets[t], end = t + 1 < offsets.size() ? offsets[t + 1] : rit.size();
+        const uint8_t *p = rit.data() + start, *e = rit.data() + end;
+        bool ok = true;
+        // Tree := OptNode ; OptNode := 0x00 | 0x01 Node ; Node := center:u32 n:u64 Interval[n] left right
+        std::function<void(int)> node = [&](int depth) {
+            if (!ok) return;
+            if (p >= e || depth > 4096) {
+                ok = false;
+                return;
+            }
+            const uint8_t tag = *p++;
+            if (tag == 0) return;
+            if (tag != 1 || e - p < 12) {
+                ok = false;
+                return;
+            }
+            p += 4;  // center
+            const uint64_t n = get_le64(p);
+            p += 8;
+            if (n > (uint64_t)(e - p) / 12) {
+                ok = false;
+                return;
+            }
+            for (uint64_t k = 0; k < n; ++k, p += 12) trees[t].push_back(RootInterval{get_le32(p), get_le32(p + 4), get_le32(p + 8)});
+            node(depth + 1);
+            node(depth + 1);
+        };
+        node(0);
+        if (!ok)  // (bincode tolerates trailing bytes inside the slice; so do we)
+            throw Error("bincode2 deserialize tree #" + std::to_string(t) + " (" + std::to_string(start) + ".." + std::to_string(end) + ")");
+    }
+    return trees;
+}
+
 }  // namespace index_loader
 
 TreeIndexData::TreeIndexData(TreeIndexData &&o) noexcept
@@ -93,6 +199,37 @@ TreeIndexData TreeIndexData::load_tree_index(const std::string &gff) {
     auto sqs = index_loader::load_sqs(gff);
     t.num_to_seqid = std::move(sqs.first);
     t.seqid_to_num = std::move(sqs.second);
+    // tree_index.rs:21-34: the reference's route is .rit/.rix.  Taken when both files are there and every
+    // image parses in the (unpinned) bincode layout; otherwise the .gof route below, which rebuilds the
+    // same multiset of intervals (index_builder/core.rs:170-186).  GFFX_TREE_INDEX=gof|rit forces one.
+    {
+        const char *force = std::getenv("GFFX_TREE_INDEX");
+        const bool want_rit = !force || std::string(force) != "gof";
+        const bool must_rit = force && std::string(force) == "rit";
+        if (want_rit) {
+            try {
+                auto trees = index_loader::load_region_index(append_suffix(gff, ".rit"), append_suffix(gff, ".rix"));
+                t.chr_offsets.assign(1, 0);
+                for (const auto &tr : trees) {  // tree i <-> seqid_num i (tree_index.rs:65-79)
+                    for (const auto &iv : tr) {
+                        t.start.push_back(iv.start);
+                        t.end.push_back(iv.end);
+                        t.root_fid.push_back(iv.root_fid);
+                    }
+                    t.chr_offsets.push_back(static_cast<uint32_t>(t.start.size()));
+                }
+                // seqids without a tree image (none in a builder-written index) get empty lists
+                while (t.chr_offsets.size() < t.num_to_seqid.size() + 1) t.chr_offsets.push_back(t.chr_offsets.back());
+                return t;
+            } catch (const Error &) {
+                if (must_rit) throw;
+                t.chr_offsets.clear();
+                t.start.clear();
+                t.end.clear();
+                t.root_fid.clear();
+            }
+        }
+    }
     const index_loader::GofMap gof = index_loader::load_gof(gff);
     MappedFile text(gff);
     const std::string_view d = text.view();

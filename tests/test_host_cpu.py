@@ -100,7 +100,67 @@ def test_build_index_appendix_e_and_errors(host, tmp_path, golden_dir):
     assert r.returncode == 1 and r.stderr.startswith(b"Error: ")
 
 
-def test_load_tree_index_parse_bed_and_offsets_equal_the_oracle(host, tmp_path):
+def _host_tree_index(host, gff):
+    n = C.c_uint32()
+    pco, ps, pe, pf, names = u32p(), u32p(), u32p(), u32p(), C.c_void_p()
+    e = _err()
+    rc = host.gffx_host_load_tree_index(gff.encode(), C.byref(n), C.byref(pco), C.byref(ps), C.byref(pe),
+                                        C.byref(pf), C.byref(names), e, len(e))
+    if rc != 0:
+        return rc, e.value.decode()
+    co = np.ctypeslib.as_array(pco, shape=(n.value + 1,)).copy()
+    R = int(co[-1])
+    arrs = [np.ctypeslib.as_array(p, shape=(max(R, 1),))[:R].copy() for p in (ps, pe, pf)]
+    for p in (pco, ps, pe, pf, names):
+        host.gffx_host_free(p)
+    return 0, (co, *arrs)
+
+
+def test_load_region_index_reads_rit_rix_and_falls_back_to_gof(host, tmp_path, monkeypatch):
+    """utils/tree_index.rs:36-82: the .rit/.rix route gives the same intervals per seqid as the .gof route;
+    corrupt images fall back (or fail with the reference's messages when the route is forced)."""
+    gff, roots = _make_gff(tmp_path, 7)
+    assert _build(host, gff)[0] == 0
+
+    def per_chr(t):
+        co, s, e, f = t
+        return [sorted(zip(s[co[c]:co[c + 1]].tolist(), e[co[c]:co[c + 1]].tolist(), f[co[c]:co[c + 1]].tolist()))
+                for c in range(len(co) - 1)]
+
+    monkeypatch.setenv("GFFX_TREE_INDEX", "gof")
+    rc, via_gof = _host_tree_index(host, gff)
+    assert rc == 0
+    monkeypatch.setenv("GFFX_TREE_INDEX", "rit")
+    rc, via_rit = _host_tree_index(host, gff)
+    assert rc == 0 and per_chr(via_rit) == per_chr(via_gof)
+    co, s, e, f = ob.OracleIndex.load(gff, via_rit=True).export()
+    assert per_chr(via_rit) == per_chr((co, s, e, f))
+    raw = open(gff + ".rit", "rb").read()
+    rix = json.load(open(gff + ".rix"))
+    for what, expect in (("truncate", "bincode2 deserialize tree #"), ("unsorted", "offsets not sorted ascending"),
+                         ("beyond", "last offset"), ("json", "parse json")):
+        shutil.copy(gff + ".rit", gff + ".rit.bak")
+        shutil.copy(gff + ".rix", gff + ".rix.bak")
+        if what == "truncate":
+            open(gff + ".rit", "wb").write(raw[: len(raw) - 7])
+        elif what == "unsorted":
+            open(gff + ".rix", "w").write(json.dumps(list(reversed(rix))))
+        elif what == "beyond":
+            open(gff + ".rix", "w").write(json.dumps(rix[:-1] + [len(raw) + 5]))
+        else:
+            open(gff + ".rix", "w").write("[0, 12,")
+        monkeypatch.setenv("GFFX_TREE_INDEX", "rit")
+        rc, msg = _host_tree_index(host, gff)
+        assert rc == -1 and expect in msg, (what, msg)
+        monkeypatch.delenv("GFFX_TREE_INDEX")
+        rc, t = _host_tree_index(host, gff)  # default: quiet fallback to the .gof route
+        assert rc == 0 and per_chr(t) == per_chr(via_gof)
+        shutil.move(gff + ".rit.bak", gff + ".rit")
+        shutil.move(gff + ".rix.bak", gff + ".rix")
+
+
+def test_load_tree_index_parse_bed_and_offsets_equal_the_oracle(host, tmp_path, monkeypatch):
+    monkeypatch.setenv("GFFX_TREE_INDEX", "gof")  # builder order, array for array
     gff, roots = _make_gff(tmp_path, 5)
     assert _build(host, gff)[0] == 0
     oix = ob.OracleIndex.load(gff)
