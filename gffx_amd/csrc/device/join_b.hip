@@ -14,7 +14,8 @@
 //                                                       || some qs in [s,e] || some qe in [s,e]
 // Each clause is a conjunction of two comparisons on one region, so the rewrite is exact for every
 // input, including degenerate regions (qs > qe) and lines (s > e); tests check it against the
-// oracle's literal scan.  No invert here: intersect.rs:232-240 has no such parameter.
+// oracle's literal scan.  Every search first narrows to one bin of a per-seqid directory over the
+// sorted array (built with the sort, ~2 bins per region), so it touches ~3 words instead of ~17.  No invert here: intersect.rs:232-240 has no such parameter.
 //
 // HBM layout: line table SoA {seq, start, end} u32 x n_lines, file order (neighbouring lanes =
 // neighbouring lines = nearby coordinates -> the searches of a wave walk the same cache lines);
@@ -37,8 +38,30 @@ struct LinesView {
 struct RegionsView {
     const unsigned long long *q_off;  // n_seq + 1
     const uint32_t *qs, *pm, *sm, *qe;
+    // Directories over the sorted starts and the sorted ends of every seqid: dir[d_off[c] + b] = first position
+    // whose value >= b << shift(c), for b = 0..nb(c) (the last one = the seqid's end).  A search for x only has
+    // to look inside [dir[b], dir[b+1]) with b = x >> shift -- usually zero or one element instead of a 17-step
+    // binary search over all regions of the seqid.  nullptr: no directory (plain binary search).
+    const uint32_t *dir_qs, *dir_qe;
+    const unsigned long long *d_off;  // n_seq + 1
+    const uint2 *d_meta;              // per seqid {shift, nb}
     uint32_t n_seq;
 };
+
+// narrow [lo, hi) to the directory bin of x
+__device__ __forceinline__ void dir_narrow(const uint32_t *dir, const RegionsView &R, uint32_t seq, uint32_t x,
+                                           unsigned long long &lo, unsigned long long &hi) {
+    if (!dir) return;
+    const uint2 m = R.d_meta[seq];
+    const uint32_t b = x >> m.x;
+    if (b >= m.y) {
+        lo = hi;  // beyond the largest value of the seqid
+        return;
+    }
+    const uint32_t *d = dir + R.d_off[seq] + b;
+    lo = d[0];
+    hi = d[1];
+}
 
 // first index in [lo, hi) with a[i] >= x
 __device__ __forceinline__ unsigned long long lower_bound_u32(const uint32_t *a, unsigned long long lo,
@@ -75,24 +98,44 @@ __global__ __launch_bounds__(256) void k_lines_exists(LinesView L, RegionsView R
         const unsigned long long lo = R.q_off[seq], hi = R.q_off[seq + 1];
         if (hi > lo) {  // a seqid without regions has no map entry (intersect.rs:495-498)
             const uint32_t s = L.start[i], e = L.end[i];
+            auto ub_qs = [&](uint32_t x) {
+                unsigned long long a = lo, b = hi;
+                dir_narrow(R.dir_qs, R, seq, x, a, b);
+                return upper_bound_u32(R.qs, a, b, x);
+            };
+            auto lb_qs = [&](uint32_t x) {
+                unsigned long long a = lo, b = hi;
+                dir_narrow(R.dir_qs, R, seq, x, a, b);
+                return lower_bound_u32(R.qs, a, b, x);
+            };
+            auto lb_qe = [&](uint32_t x) {
+                unsigned long long a = lo, b = hi;
+                dir_narrow(R.dir_qe, R, seq, x, a, b);
+                return lower_bound_u32(R.qe, a, b, x);
+            };
+            auto ub_qe = [&](uint32_t x) {
+                unsigned long long a = lo, b = hi;
+                dir_narrow(R.dir_qe, R, seq, x, a, b);
+                return upper_bound_u32(R.qe, a, b, x);
+            };
             if (MODE == GFFX_MODE_CONTAINED) {
-                const unsigned long long u = upper_bound_u32(R.qs, lo, hi, s);  // regions with qs <= s
+                const unsigned long long u = ub_qs(s);  // regions with qs <= s
                 k = (u > lo && R.pm[u - 1] >= e) ? 1 : 0;
             } else if (MODE == GFFX_MODE_CONTAINS_REGION) {
-                const unsigned long long l = lower_bound_u32(R.qs, lo, hi, s);  // regions with qs >= s
+                const unsigned long long l = lb_qs(s);  // regions with qs >= s
                 k = (l < hi && R.sm[l] <= e) ? 1 : 0;
             } else {
-                const unsigned long long us = upper_bound_u32(R.qs, lo, hi, s);
+                const unsigned long long us = ub_qs(s);
                 bool any = us > lo && R.pm[us - 1] >= s;  // qs <= s <= qe
                 if (!any) {
-                    const unsigned long long ue = upper_bound_u32(R.qs, lo, hi, e);
+                    const unsigned long long ue = ub_qs(e);
                     any = ue > lo && R.pm[ue - 1] >= e;  // qs <= e <= qe
                     if (!any && s <= e) {
-                        const unsigned long long ls = lower_bound_u32(R.qs, lo, hi, s);
+                        const unsigned long long ls = lb_qs(s);
                         any = ls < ue;  // some qs in [s, e]
                         if (!any) {
-                            const unsigned long long a = lower_bound_u32(R.qe, lo, hi, s);
-                            const unsigned long long b = upper_bound_u32(R.qe, lo, hi, e);
+                            const unsigned long long a = lb_qe(s);
+                            const unsigned long long b = ub_qe(e);
                             any = a < b;  // some qe in [s, e]
                         }
                     }
@@ -213,18 +256,51 @@ extern "C" int gffx_hip_lines_test(gffx_hip_lines *L, const uint32_t *regions, u
         }
         std::sort(qe.begin() + lo, qe.begin() + hi);
     }
-    unsigned long long *d_off = nullptr;
-    uint32_t *d_q = nullptr;
-    int rc;
-    if ((rc = dalloc(&d_off, n_seq + 1))) return rc;
-    if ((rc = dalloc(&d_q, 4 * nq))) {
-        (void)hipFree(d_off);
-        return rc;
+    // directories over the sorted starts / ends (see RegionsView); positions are u32: skipped for >= 2^32 regions
+    std::vector<unsigned long long> dir_off(n_seq + 1, 0);
+    std::vector<uint2> dir_meta(n_seq, make_uint2(0, 0));
+    std::vector<uint32_t> dir_qs, dir_qe;
+    const bool use_dir = nq > 0 && nq < 0xFFFFFFFFull;
+    if (use_dir) {
+        for (uint32_t c = 0; c < n_seq; c++) {
+            const uint64_t lo = q_off[c], hi = q_off[c + 1];
+            dir_off[c + 1] = dir_off[c];
+            if (hi == lo) continue;
+            const uint32_t vmax = std::max(qs[hi - 1], qe[hi - 1]);
+            const uint64_t budget = std::max<uint64_t>(2 * (hi - lo), 16);
+            uint32_t shift = 0;
+            while ((((uint64_t)vmax >> shift) + 1) > budget) shift++;
+            const uint32_t nb = (vmax >> shift) + 1;
+            dir_meta[c] = make_uint2(shift, nb);
+            uint64_t ps = lo, pe = lo;
+            for (uint32_t b = 0; b < nb; b++) {
+                const uint64_t edge = (uint64_t)b << shift;
+                while (ps < hi && qs[ps] < edge) ps++;
+                while (pe < hi && qe[pe] < edge) pe++;
+                dir_qs.push_back((uint32_t)ps);
+                dir_qe.push_back((uint32_t)pe);
+            }
+            dir_qs.push_back((uint32_t)hi);
+            dir_qe.push_back((uint32_t)hi);
+            dir_off[c + 1] = dir_qs.size();
+        }
     }
+    unsigned long long *d_off = nullptr, *d_doff = nullptr;
+    uint32_t *d_q = nullptr, *d_dir = nullptr;
+    uint2 *d_dmeta = nullptr;
     auto cleanup = [&]() {
         (void)hipFree(d_off);
         (void)hipFree(d_q);
+        (void)hipFree(d_doff);
+        (void)hipFree(d_dir);
+        (void)hipFree(d_dmeta);
     };
+    int rc;
+    if ((rc = dalloc(&d_off, n_seq + 1)) || (rc = dalloc(&d_q, 4 * nq)) || (rc = dalloc(&d_doff, n_seq + 1)) ||
+        (rc = dalloc(&d_dir, 2 * dir_qs.size())) || (rc = dalloc(&d_dmeta, n_seq))) {
+        cleanup();
+        return rc;
+    }
 #define GFFX_TRY_C(expr)                                                                       \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -240,9 +316,16 @@ extern "C" int gffx_hip_lines_test(gffx_hip_lines *L, const uint32_t *regions, u
         GFFX_TRY_C(hipMemcpyAsync(d_q + 2 * nq, sm.data(), nq * 4, hipMemcpyHostToDevice, L->stream));
         GFFX_TRY_C(hipMemcpyAsync(d_q + 3 * nq, qe.data(), nq * 4, hipMemcpyHostToDevice, L->stream));
     }
+    if (use_dir) {
+        GFFX_TRY_C(hipMemcpyAsync(d_doff, dir_off.data(), (n_seq + 1) * 8, hipMemcpyHostToDevice, L->stream));
+        GFFX_TRY_C(hipMemcpyAsync(d_dmeta, dir_meta.data(), n_seq * sizeof(uint2), hipMemcpyHostToDevice, L->stream));
+        GFFX_TRY_C(hipMemcpyAsync(d_dir, dir_qs.data(), dir_qs.size() * 4, hipMemcpyHostToDevice, L->stream));
+        GFFX_TRY_C(hipMemcpyAsync(d_dir + dir_qs.size(), dir_qe.data(), dir_qe.size() * 4, hipMemcpyHostToDevice, L->stream));
+    }
     if (L->n) {
         LinesView lv{L->d_seq, L->d_start, L->d_end, (unsigned long long)L->n};
-        RegionsView rv{d_off, d_q, d_q + nq, d_q + 2 * nq, d_q + 3 * nq, n_seq};
+        RegionsView rv{d_off, d_q, d_q + nq, d_q + 2 * nq, d_q + 3 * nq,
+                       use_dir ? d_dir : nullptr, use_dir ? d_dir + dir_qs.size() : nullptr, d_doff, d_dmeta, n_seq};
         const unsigned blocks = (unsigned)((L->n + 255) / 256);
         GFFX_TRY_C(hipEventRecord(L->ev_a, L->stream));
         if (mode == GFFX_MODE_CONTAINED)
