@@ -325,7 +325,7 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "BED overlap queries/sec vs GRCh38-scale GFF index",
+            "metric": "BED overlap queries/sec vs GRCh38-scale GFF index at 1/2/4/8 MI355X",  # BASELINE.json
             "value": nq_total * args.steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
