@@ -87,7 +87,16 @@ def cpu_baseline(roots, regions, mode, budget_s):
         done += n
         hits = len(t)
         reps += 1
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": done / t_used, "unit": "queries/s", "cores": 1, "kind": "port",
+            "host": {"cpu": model, "nproc": os.cpu_count()},
             "sample": "%d x the full %d-region batch of this workload, Join A only (pointer-based centered "
                       "interval tree, serial, as commands/intersect.rs:124-166); C restatement, not the Rust binary"
                       % (reps, n),
