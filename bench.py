@@ -67,6 +67,9 @@ def parse_args():
                          "all regions of its seqid) and report it as an extra \"join_b\" object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-allcore", action="store_true",
+                    help="also report the oracle's Join A with the batch split over all host cores (tools/cpu_allcore.py, "
+                         "run as a child process) as \"cpu_allcore\" -- a fairer CPU upper bound, not the reference's behaviour")
     return ap.parse_args()
 
 
@@ -390,6 +393,14 @@ def main():
             result["cpu_baseline"] = cpu_baseline(roots, regions, mode, args.cpu_seconds)
         elif not args.no_cpu_baseline:
             result["cpu_baseline"] = None
+        if args.cpu_allcore and world == 1:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_allcore.py"), str(nq), str(mode), "5"],
+                               capture_output=True, text=True)
+            try:
+                result["cpu_allcore"] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception:
+                result["cpu_allcore"] = {"error": (r.stderr or r.stdout)[-300:]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
