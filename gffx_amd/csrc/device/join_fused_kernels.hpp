@@ -278,13 +278,15 @@ __global__ __launch_bounds__(kFusedThreads, GFFX_FUSED_MIN_WAVES) void k_join_fu
                     out.fids[o] = h.y;
                     continue;
                 }
-                const uint4 e = ix.aux[h.y];
-                if (out.fids) out.fids[o] = e.w;
-                if (out.triples) {
-                    uint32_t *tr = out.triples + 3ull * o;
-                    tr[0] = e.w;
-                    tr[1] = ix.start[h.y];
-                    tr[2] = e.x;
+                if (out.fids || out.triples) {  // (a bitmap-only pass -- the CLI -- gathers nothing here)
+                    const uint4 e = ix.aux[h.y];
+                    if (out.fids) out.fids[o] = e.w;
+                    if (out.triples) {
+                        uint32_t *tr = out.triples + 3ull * o;
+                        tr[0] = e.w;
+                        tr[1] = ix.start[h.y];
+                        tr[2] = e.x;
+                    }
                 }
                 if (out.bitmap) atomicOr(&out.bitmap[h.y >> 5], 1u << (h.y & 31));
             }
