@@ -251,6 +251,32 @@ def test_emit_order_records_without_the_input_order_scatter(mode):
         assert np.array_equal(b.offsets()[:-1][rows], off)
 
 
+def test_one_batch_object_alternating_strategies_and_modes():
+    """The cursor words / cursor sets of the fused and partitioned strategies alternate between passes;
+    mixing strategies, modes and batch sizes on ONE batch object must not leak state between passes."""
+    roots = synth.gencode_like_roots(5000, seed=21)
+    regions = synth.synth_bed(150_000, seed=22, edge_frac=0.01, roots=roots)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, len(regions))
+    rng = np.random.default_rng(3)
+    want = {}
+    for step in range(14):
+        strategy = STRATEGIES[int(rng.integers(0, len(STRATEGIES)))]
+        mode = int(rng.integers(0, 3))
+        n = int(rng.choice([len(regions), 70_000, 33, 0]))
+        if (mode, n) not in want:
+            want[(mode, n)] = oix.query_features(regions[:n], mode, False)
+        wt, wc = want[(mode, n)]
+        b.set_regions(regions[:n])
+        b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS, strategy)
+        b.wait()
+        assert b.total_hits == len(wt), (step, strategy, mode, n)
+        assert np.array_equal(b.counts(), wc)
+        assert np.array_equal(np.sort(b.fids()), np.sort(wt[:, 0]))
+
+
 def test_capacity_replay_and_reuse():
     """More pairs than the initial buffer guess -> the emit step is replayed, results unchanged."""
     k = 400  # 400 nested intervals, every query hits all of them
