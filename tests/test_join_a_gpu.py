@@ -277,6 +277,29 @@ def test_one_batch_object_alternating_strategies_and_modes():
         assert np.array_equal(np.sort(b.fids()), np.sort(wt[:, 0]))
 
 
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_more_than_2pow20_pairs_for_one_region(strategy):
+    """1.1 M identical intervals: a region's rank inside the fused kernel's hit queue no longer fits 20 bits
+    (chain replay), the whole seqid is one over-full genome cell (partitioned: gather path)."""
+    k = 1_100_000
+    roots = {"chr_offsets": np.array([0, k, k + 2], np.uint32),
+             "start": np.concatenate([np.full(k, 5, np.uint32), [1, 50]]).astype(np.uint32),
+             "end": np.concatenate([np.full(k, 10, np.uint32), [3, 60]]).astype(np.uint32),
+             "fid": np.arange(k + 2, dtype=np.uint32)}
+    regions = np.array([[0, 9, 20], [1, 0, 100], [0, 10, 11], [0, 0, 6]], np.uint32)
+    ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)
+    b.run(OverlapMode.Overlap, False, engine.OUT_FIDS | engine.OUT_OFFSETS, strategy)
+    b.wait()
+    c, off, fids = b.counts(), b.offsets(), b.fids()
+    assert c.tolist() == [k, 2, 0, k] and b.total_hits == 2 * k + 2
+    for i in (0, 3):
+        seg = fids[int(off[i]):int(off[i]) + k]
+        assert np.array_equal(np.sort(seg), np.arange(k, dtype=np.uint32))
+    assert sorted(fids[int(off[1]):int(off[1]) + 2].tolist()) == [k, k + 1]
+
+
 def test_capacity_replay_and_reuse():
     """More pairs than the initial buffer guess -> the emit step is replayed, results unchanged."""
     k = 400  # 400 nested intervals, every query hits all of them
