@@ -20,7 +20,8 @@ _REG = None
 _MODE = 2
 
 
-_INNER = 20  # passes over the worker's slice per dispatch (amortises the pool's ~10 ms round trip)
+_INNER = 20  # passes over the worker's slice per dispatch (set so that a dispatch is ~0.25 s of work: the pool's
+             # round trip over a few hundred workers is ~10 ms)
 
 
 def _work(sl):
@@ -40,12 +41,18 @@ def main():
     roots = synth.gencode_like_roots(63000, seed=42)
     _REG = synth.synth_bed(nq, seed=1001)
     _OIX = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    global _INNER
     step = -(-nq // cores)
     slices = [(a, min(nq, a + step)) for a in range(0, nq, step)]
+    t0 = time.perf_counter()
+    _OIX.query_features(_REG[slices[0][0]:slices[0][1]], _MODE, False)
+    _OIX.query_features(_REG[slices[0][0]:slices[0][1]], _MODE, False)
+    t_slice = max((time.perf_counter() - t0) / 2, 1e-6)
+    _INNER = max(1, min(5000, int(0.25 / t_slice)))
     with mp.get_context("fork").Pool(cores) as pool:
         pool.map(_work, slices)  # warm
         done, used, reps, pairs = 0, 0.0, 0, 0
-        while used < budget and reps < 4000:
+        while used < budget and reps < 1000000:
             t0 = time.perf_counter()
             pairs = sum(pool.map(_work, slices))
             used += time.perf_counter() - t0
