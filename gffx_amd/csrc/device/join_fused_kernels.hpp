@@ -31,11 +31,14 @@
 // The regions and the results are streams (touched once per pass): nontemporal loads / stores keep them from
 // displacing the index in L1 / L2 (measured: 26.8 -> 25.3 us per 1 M regions).  The macro form lets
 // tools/kbench.hip time the plain variant (-DGFFX_FUSED_PLAIN_STREAMS).
-#ifdef GFFX_FUSED_PLAIN_STREAMS
+#if defined(GFFX_FUSED_PLAIN_STREAMS) || defined(GFFX_FUSED_PLAIN_LOADS)
 #define GFFX_NT_LOAD(p) (*(p))
-#define GFFX_NT_STORE(v, p) (*(p) = (v))
 #else
 #define GFFX_NT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
+#if defined(GFFX_FUSED_PLAIN_STREAMS) || defined(GFFX_FUSED_PLAIN_STORES)
+#define GFFX_NT_STORE(v, p) (*(p) = (v))
+#else
 #define GFFX_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
 #endif
 
