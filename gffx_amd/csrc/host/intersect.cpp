@@ -3,6 +3,7 @@
 // include/gffx_hip.h; everything else here is the reference's host logic: region/BED parsing,
 // root -> byte-block lookup, line splitting, type filter, ordered copy-out.
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cstdio>
 #include <thread>
@@ -327,8 +328,29 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
 }
 
 // intersect.rs:541-655
+namespace {
+// stage timers under --verbose, in the style of the reference's other commands (depth.rs:562-632
+// "[TIMER] [run] Step n: ..."); `intersect` itself has none
+struct StageTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[TIMER] [run] %s took %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+    void total() {
+        if (on)
+            std::fprintf(stderr, "[TIMER] [run] Total pipeline time: %.3f ms\n",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+}  // namespace
+
 void run(const IntersectArgs &args) {
     const bool verbose = args.common.verbose;
+    StageTimer timer{verbose};
     if (verbose) {
         std::fprintf(stderr, "[DEBUG] Starting processing of \"%s\"\n", args.common.input.c_str());
         std::fprintf(stderr, "[DEBUG] Thread pool initialized with %zu threads\n", args.common.effective_threads());
@@ -337,6 +359,7 @@ void run(const IntersectArgs &args) {
                              : args.contains_region ? OverlapMode::ContainsRegion
                                                     : OverlapMode::Overlap;
     TreeIndexData index_data = TreeIndexData::load_tree_index(args.common.input);
+    timer.lap("Loading tree index");
     std::vector<Region> regions;
     if (args.bed)
         regions = parse_bed_file(*args.bed, index_data.seqid_to_num);
@@ -344,6 +367,7 @@ void run(const IntersectArgs &args) {
         regions.push_back(parse_region(*args.region, index_data.seqid_to_num, args.common));
     else
         throw Error("No region specified");
+    timer.lap("Parsing regions");
     if (verbose) {
         std::fprintf(stderr, "[DEBUG] Starting query_features with %zu regions\n", regions.size());
         static const char *kNames[] = {"Contained", "ContainsRegion", "Overlap"};
@@ -351,13 +375,17 @@ void run(const IntersectArgs &args) {
     }
     // Join A; the CLI only consumes the unique root ids (intersect.rs:598-615)
     const std::vector<uint32_t> roots = query_unique_roots(index_data, regions, mode, args.invert, verbose, args.device);
+    timer.lap("Join A on the device (index upload, regions H2D, kernel, root bitmap D2H)");
     const index_loader::GofMap gof = index_loader::load_gof(args.common.input);
     const std::vector<Block> blocks = gof.roots_to_offsets(roots, args.common.effective_threads());
+    timer.lap("Root offsets");
     if (!args.common.entire_group || args.common.types)  // intersect.rs:619
         write_gff_match_only_by_coords(args.common.input, blocks, regions, index_data.num_to_seqid, args.common.types,
                                        args.common.output, mode, verbose, args.common.effective_threads(), args.device);
     else
         write_gff_output(args.common.input, blocks, args.common.output, verbose);
+    timer.lap(!args.common.entire_group || args.common.types ? "Join B + writing matched lines" : "Writing blocks");
+    timer.total();
 }
 
 }  // namespace intersect
