@@ -75,6 +75,8 @@ def lib():
         L.oracle_depth_parse_bed.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(u32p), u64p, C.c_char_p, C.c_size_t]
         L.oracle_depth_run.restype = C.c_int
         L.oracle_depth_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.oracle_coverage_run.restype = C.c_int
+        L.oracle_coverage_run.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.oracle_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -245,4 +247,11 @@ def depth_run(gff_path: str, bed: str, out_path: str) -> Tuple[int, str]:
     """commands/depth.rs:548-635 with a .bed source; rows sorted by id.  Returns (exit code, message)."""
     err = C.create_string_buffer(4096)
     rc = lib().oracle_depth_run(os.fsencode(gff_path), os.fsencode(bed), os.fsencode(out_path), err, len(err))
+    return rc, err.value.decode(errors="replace")
+
+
+def coverage_run(gff_path: str, bed: str, out_path: str) -> Tuple[int, str]:
+    """commands/coverage.rs:487-582 with a .bed source; rows sorted by id.  Returns (exit code, message)."""
+    err = C.create_string_buffer(4096)
+    rc = lib().oracle_coverage_run(os.fsencode(gff_path), os.fsencode(bed), os.fsencode(out_path), err, len(err))
     return rc, err.value.decode(errors="replace")

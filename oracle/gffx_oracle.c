@@ -2074,3 +2074,342 @@ int oracle_depth_run(const char *gff_path, const char *bed_path, const char *out
     free(g);
     return rc;
 }
+
+/* ---------------------------------------- coverage (commands/coverage.rs, BED source) */
+
+typedef struct {
+    uint32_t s, e;
+} cspan_t;
+
+static int cmp_cspan(const void *a, const void *b) {
+    const cspan_t *x = (const cspan_t *)a, *y = (const cspan_t *)b;
+    return x->s < y->s ? -1 : x->s > y->s;
+}
+
+/* coverage.rs:92-109 merge_intervals: sort by start, merge while s <= current end (touching spans merge) */
+static size_t merge_spans(cspan_t *v, size_t n) {
+    if (!n) return 0;
+    qsort(v, n, sizeof *v, cmp_cspan);
+    size_t o = 0;
+    uint32_t cs = v[0].s, ce = v[0].e;
+    for (size_t i = 1; i < n; i++) {
+        if (v[i].s <= ce) {
+            if (v[i].e > ce) ce = v[i].e;
+        } else {
+            v[o].s = cs;
+            v[o].e = ce;
+            o++;
+            cs = v[i].s;
+            ce = v[i].e;
+        }
+    }
+    v[o].s = cs;
+    v[o].e = ce;
+    return o + 1;
+}
+
+/* coverage.rs:112-124 union_len */
+static uint64_t union_len(cspan_t *v, size_t n) {
+    if (!n) return 0;
+    qsort(v, n, sizeof *v, cmp_cspan);
+    uint64_t total = 0;
+    uint32_t cs = v[0].s, ce = v[0].e;
+    for (size_t i = 1; i < n; i++) {
+        if (v[i].s <= ce) {
+            if (v[i].e > ce) ce = v[i].e;
+        } else {
+            total += ce - cs;
+            cs = v[i].s;
+            ce = v[i].e;
+        }
+    }
+    return total + (ce - cs);
+}
+
+typedef struct {
+    smap_t ids;
+    char **id_str, **chrom;
+    uint32_t *min_s, *max_e, *stamp;
+    uint64_t *breadth;
+    uint8_t *present;  /* the ID has a row (coverage.rs:372: length > 0 || breadth > 0) */
+    size_t n, cap;
+    uint32_t serial;
+} cres_t;
+
+static uint32_t cres_id(cres_t *r, const uint8_t *id, size_t idlen) {
+    uint32_t v;
+    if (smap_get(&r->ids, id, idlen, &v)) return v;
+    if (r->n == r->cap) {
+        r->cap = r->cap ? r->cap * 2 : 1024;
+        r->id_str = (char **)realloc(r->id_str, r->cap * sizeof(char *));
+        r->chrom = (char **)realloc(r->chrom, r->cap * sizeof(char *));
+        r->min_s = (uint32_t *)realloc(r->min_s, r->cap * 4);
+        r->max_e = (uint32_t *)realloc(r->max_e, r->cap * 4);
+        r->stamp = (uint32_t *)realloc(r->stamp, r->cap * 4);
+        r->breadth = (uint64_t *)realloc(r->breadth, r->cap * 8);
+        r->present = (uint8_t *)realloc(r->present, r->cap);
+    }
+    v = (uint32_t)r->n++;
+    smap_put(&r->ids, id, idlen, v);
+    r->id_str[v] = dupn(id, idlen);
+    r->chrom[v] = NULL;
+    r->stamp[v] = 0;
+    r->min_s[v] = UINT32_MAX;
+    r->max_e[v] = 0;
+    r->breadth[v] = 0;
+    r->present[v] = 0;
+    return v;
+}
+
+typedef struct {
+    uint32_t start, end, id;
+    const uint8_t *seq;
+    size_t seqlen;
+} cline_t;
+
+static int cmp_cline(const void *a, const void *b) {
+    const cline_t *x = (const cline_t *)a, *y = (const cline_t *)b;
+    return x->start < y->start ? -1 : x->start > y->start;
+}
+
+/* coverage.rs:277-378 compute_breadth_for_root on one root's block and its merged coverage, merged into the
+ * global map with the rule of :417-428 (min start, max end, breadth summed; chrom of the first contribution --
+ * hash order in the reference, file order of the blocks here). */
+static void breadth_one_root(const uint8_t *slice, size_t n, const cspan_t *cov, size_t ncov, cres_t *res) {
+    cline_t *ln = NULL;
+    size_t nl = 0, cl = 0;
+    if (utf8_valid(slice, n)) { /* :296 */
+        size_t pos = 0;
+        while (pos < n) {
+            const uint8_t *lb = slice + pos;
+            const uint8_t *nlp = (const uint8_t *)memchr(lb, '\n', n - pos);
+            size_t ll = nlp ? (size_t)(nlp - lb) : n - pos;
+            pos += ll + 1;
+            if (ll == 0 || lb[0] == '#') continue; /* :298 */
+            const uint8_t *col[9];
+            size_t len[9];
+            const uint8_t *p = lb, *e = lb + ll;
+            int k = 0;
+            for (; k < 8; k++) {
+                const uint8_t *t = find_tab(p, e);
+                if (!t) break;
+                col[k] = p;
+                len[k] = (size_t)(t - p);
+                p = t + 1;
+            }
+            if (k < 8) continue;
+            col[8] = p;
+            len[8] = (size_t)(e - p);
+            uint32_t s1, e1;
+            if (!parse_u32_ascii(col[3], len[3], &s1) || !parse_u32_ascii(col[4], len[4], &e1)) continue; /* :306 */
+            if (e1 == 0) continue;                                                                       /* :307 */
+            if (s1 > e1) { uint32_t t = s1; s1 = e1; e1 = t; }                                           /* :308 */
+            const uint8_t *id;
+            size_t idlen;
+            if (!fast_id(col[8], len[8], &id, &idlen)) continue; /* :313 */
+            if (nl == cl) {
+                cl = cl ? cl * 2 : 64;
+                ln = (cline_t *)realloc(ln, cl * sizeof(cline_t));
+            }
+            ln[nl].start = s1 ? s1 - 1 : 0;
+            ln[nl].end = e1;
+            ln[nl].id = cres_id(res, id, idlen);
+            ln[nl].seq = col[0];
+            ln[nl].seqlen = len[0];
+            nl++;
+        }
+    }
+    if (nl == 0 || ncov == 0) { /* :325-327 */
+        free(ln);
+        return;
+    }
+    /* per-block accumulators, folded into the global map at the end (the per-root map of :369-377) */
+    size_t nid = res->n;
+    uint32_t *bmin = (uint32_t *)malloc(nid * 4), *bmax = (uint32_t *)malloc(nid * 4);
+    size_t *pcs = (size_t *)calloc(nid + 1, sizeof(size_t));
+    for (size_t i = 0; i < nid; i++) {
+        bmin[i] = UINT32_MAX;
+        bmax[i] = 0;
+    }
+    /* chrom of an ID inside this block = seqid of its first line in FILE order (:316-319), taken before the sort */
+    for (size_t i = 0; i < nl; i++)
+        if (res->stamp[ln[i].id] != res->serial) {
+            res->stamp[ln[i].id] = res->serial;
+            if (!res->chrom[ln[i].id]) res->chrom[ln[i].id] = dupn(ln[i].seq, ln[i].seqlen);
+        }
+    qsort(ln, nl, sizeof *ln, cmp_cline); /* :330 sort_unstable_by_key(start0) */
+    cspan_t *pieces = (cspan_t *)malloc((nl * 2 + ncov * 2 + 4) * sizeof(cspan_t));
+    uint32_t *piece_id = (uint32_t *)malloc((nl * 2 + ncov * 2 + 4) * 4);
+    size_t np = 0, cap_p = nl * 2 + ncov * 2 + 4;
+    size_t j = 0;
+    for (size_t i = 0; i < nl; i++) { /* :339-364 two-pointer walk */
+        const cline_t *fl = &ln[i];
+        while (j < ncov && cov[j].e <= fl->start) j++;
+        if (fl->start < bmin[fl->id]) bmin[fl->id] = fl->start;
+        if (fl->end > bmax[fl->id]) bmax[fl->id] = fl->end;
+        size_t k = j;
+        while (k < ncov && cov[k].s < fl->end) {
+            const uint32_t s = fl->start > cov[k].s ? fl->start : cov[k].s;
+            const uint32_t e = fl->end < cov[k].e ? fl->end : cov[k].e;
+            if (e > s) {
+                if (np == cap_p) {
+                    cap_p *= 2;
+                    pieces = (cspan_t *)realloc(pieces, cap_p * sizeof(cspan_t));
+                    piece_id = (uint32_t *)realloc(piece_id, cap_p * 4);
+                }
+                pieces[np].s = s;
+                pieces[np].e = e;
+                piece_id[np] = fl->id;
+                np++;
+            }
+            if (cov[k].e <= fl->end)
+                k++;
+            else
+                break;
+        }
+    }
+    /* :367-377 per ID: union of its pieces; a row exists if length > 0 || breadth > 0 */
+    for (size_t x = 0; x < np; x++) pcs[piece_id[x] + 1]++;
+    for (size_t i = 0; i < nid; i++) pcs[i + 1] += pcs[i];
+    cspan_t *byid = (cspan_t *)malloc((np ? np : 1) * sizeof(cspan_t));
+    size_t *cur = (size_t *)malloc((nid + 1) * sizeof(size_t));
+    memcpy(cur, pcs, (nid + 1) * sizeof(size_t));
+    for (size_t x = 0; x < np; x++) byid[cur[piece_id[x]]++] = pieces[x];
+    for (size_t i = 0; i < nid; i++) {
+        if (bmin[i] == UINT32_MAX && bmax[i] == 0) continue; /* no line of this ID in the block */
+        const uint64_t length = bmax[i] > bmin[i] ? (uint64_t)(bmax[i] - bmin[i]) : 0;
+        const uint64_t br = union_len(byid + pcs[i], pcs[i + 1] - pcs[i]);
+        if (length > 0 || br > 0) {
+            res->present[i] = 1;
+            if (bmin[i] < res->min_s[i]) res->min_s[i] = bmin[i];
+            if (bmax[i] > res->max_e[i]) res->max_e[i] = bmax[i];
+            res->breadth[i] += br;
+        }
+    }
+    free(cur);
+    free(byid);
+    free(piece_id);
+    free(pieces);
+    free(pcs);
+    free(bmin);
+    free(bmax);
+    free(ln);
+}
+
+/* coverage.rs:487-582 run with a .bed source: "id\tchr\tstart\tend\tbreadth\tfraction" rows (fraction with six
+ * decimals, :466-472) for every ID of every root block that at least one region hits; rows sorted by id here
+ * (hash-map order in the reference).  BED rows follow coverage.rs:230-256 (the same rules as depth's). */
+int oracle_coverage_run(const char *gff_path, const char *bed_path, const char *out_path, char *err, size_t errlen) {
+    gofe_t *g = NULL;
+    size_t ng = 0;
+    if (load_gof(gff_path, &g, &ng, err, errlen) != 0) return 1; /* :501 */
+    map_t m;
+    if (map_file(gff_path, &m) != 0) {
+        set_err(err, errlen, "Cannot open GFF file: \"%s\"", gff_path);
+        free(g);
+        return 1;
+    }
+    oracle_index *ix = NULL;
+    if (oracle_load_tree_index(gff_path, &ix, err, errlen) != 0) { /* :511 */
+        unmap_file(&m);
+        free(g);
+        return 1;
+    }
+    uint32_t *regions = NULL;
+    uint64_t nq = 0;
+    if (oracle_depth_parse_bed(bed_path, ix, &regions, &nq, err, errlen) != 0) { /* :208-256: same row rules */
+        oracle_index_free(ix);
+        unmap_file(&m);
+        free(g);
+        return 1;
+    }
+    uint32_t max_fid = 0;
+    for (size_t k = 0; k < ng; k++)
+        if (g[k].fid > max_fid) max_fid = g[k].fid;
+    uint32_t *rec_of = (uint32_t *)malloc(((size_t)max_fid + 2) * 4);
+    memset(rec_of, 0xFF, ((size_t)max_fid + 2) * 4);
+    for (size_t k = 0; k < ng; k++) rec_of[g[k].fid] = (uint32_t)k; /* index_cached(): last record wins */
+    /* :258-268 by_root[root_fid].push((s, e)), a region once per root_fid */
+    buf_t *by_root = (buf_t *)calloc((size_t)max_fid + 2, sizeof(buf_t));
+    hits_t hits = {0};
+    for (uint64_t i = 0; i < nq; i++) {
+        const uint32_t chr = regions[3 * i], rs = regions[3 * i + 1], re = regions[3 * i + 2];
+        if (chr >= ix->n_chr) continue;
+        hits.n = 0;
+        tree_query(ix->trees[chr], rs, re, &hits);
+        for (size_t h = 0; h < hits.n; h++) {
+            const uint32_t fid = hits.p[h]->root_fid;
+            int dup = 0;
+            for (size_t x = 0; x < h; x++)
+                if (hits.p[x]->root_fid == fid) dup = 1;
+            if (dup || fid > max_fid + 1u) continue;
+            cspan_t sp = {rs, re};
+            buf_push(&by_root[fid], &sp, sizeof sp);
+        }
+    }
+    free(hits.p);
+    cres_t res;
+    memset(&res, 0, sizeof res);
+    smap_init(&res.ids, 1024);
+    /* :383-431 finalize_compute_breadth, roots in file order of their blocks */
+    for (size_t k = 0; k < ng; k++) {
+        const uint32_t fid = g[k].fid;
+        if (rec_of[fid] != k || !by_root[fid].n) continue;
+        const size_t ncov = merge_spans((cspan_t *)by_root[fid].p, by_root[fid].n / sizeof(cspan_t)); /* :401 */
+        if (g[k].s == MISSING || g[k].e == MISSING || g[k].e <= g[k].s || g[k].e > m.n) continue;       /* :403 */
+        res.serial++;
+        breadth_one_root(m.p + g[k].s, (size_t)(g[k].e - g[k].s), (const cspan_t *)by_root[fid].p, ncov, &res);
+    }
+    for (size_t f = 0; f <= (size_t)max_fid + 1; f++) free(by_root[f].p);
+    free(by_root);
+    uint32_t *order = (uint32_t *)malloc((res.n ? res.n : 1) * 4);
+    size_t no = 0;
+    for (size_t i = 0; i < res.n; i++)
+        if (res.present[i]) order[no++] = (uint32_t)i;
+    qsort_r(order, no, 4, cmp_cstr_idx, res.id_str);
+    buf_t out = {0};
+    const char *hdr = "id\tchr\tstart\tend\tbreadth\tfraction\n";
+    buf_push(&out, hdr, strlen(hdr));
+    for (size_t x = 0; x < no; x++) {
+        const uint32_t i = order[x];
+        char num[160];
+        const uint64_t length = res.max_e[i] > res.min_s[i] ? (uint64_t)(res.max_e[i] - res.min_s[i]) : 0; /* saturating_sub */
+        const double frac = length > 0 ? (double)res.breadth[i] / (double)length : 0.0;
+        buf_push(&out, res.id_str[i], strlen(res.id_str[i]));
+        buf_push(&out, "\t", 1);
+        buf_push(&out, res.chrom[i] ? res.chrom[i] : "", res.chrom[i] ? strlen(res.chrom[i]) : 0);
+        int nn = snprintf(num, sizeof num, "\t%u\t%u\t%llu\t%.6f\n", res.min_s[i], res.max_e[i],
+                          (unsigned long long)res.breadth[i], frac);
+        buf_push(&out, num, (size_t)nn);
+    }
+    int rc = 0;
+    if (out_path) {
+        if (write_file(out_path, out.p, out.n) != 0) {
+            set_err(err, errlen, "cannot write %s", out_path);
+            rc = 1;
+        }
+    } else {
+        fwrite(out.p, 1, out.n, stdout);
+        fflush(stdout);
+    }
+    free(out.p);
+    free(order);
+    for (size_t i = 0; i < res.n; i++) {
+        free(res.id_str[i]);
+        free(res.chrom[i]);
+    }
+    free(res.id_str);
+    free(res.chrom);
+    free(res.min_s);
+    free(res.max_e);
+    free(res.stamp);
+    free(res.breadth);
+    free(res.present);
+    smap_free(&res.ids);
+    free(rec_of);
+    free(regions);
+    oracle_index_free(ix);
+    unmap_file(&m);
+    free(g);
+    return rc;
+}

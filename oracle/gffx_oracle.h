@@ -107,6 +107,12 @@ int oracle_depth_parse_bed(const char *bed_path, const oracle_index *, uint32_t 
 int oracle_depth_run(const char *gff_path, const char *bed_path, const char *out_path, char *err,
                      size_t errlen);
 
+/* commands/coverage.rs:487-582 run with a .bed source: per feature ID of every root block hit by a region the
+ * covered bases (breadth) = |union of the regions that hit the root  ∩  union of the ID's lines|, the extent
+ * over ALL lines of the ID in those blocks, and breadth / extent with six decimals.  Rows sorted by id. */
+int oracle_coverage_run(const char *gff_path, const char *bed_path, const char *out_path, char *err,
+                        size_t errlen);
+
 void oracle_free(void *);
 
 #ifdef __cplusplus
