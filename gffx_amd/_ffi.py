@@ -56,6 +56,7 @@ SIGNATURES = {
     "gffx_hip_lines_destroy": (None, [vp]),
     "gffx_hip_lines_test": (C.c_int, [vp, u32p, C.c_uint64, C.c_uint32, C.c_int, u8p]),
     "gffx_hip_lines_last_kernel_ms": (C.c_double, [vp]),
+    "gffx_hip_segments_covered": (C.c_int, [C.c_int, C.c_uint64, u32p, u32p, u32p, u32p, C.c_uint64, C.c_uint32, u32p]),
     "gffx_hip_depth_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, u64p, u32p, u32p, u32p, C.c_uint32, u32p,
                                         C.POINTER(vp)]),
     "gffx_hip_depth_destroy": (None, [vp]),

@@ -7,6 +7,7 @@
 //   gffx::commands::intersect::{OverlapMode, IntersectArgs, parse_region, parse_bed_file,
 //        query_features, gff_type_allowed, write_gff_match_only_by_coords, run}  commands/intersect.rs
 //   gffx::commands::depth::{DepthArgs, parse_bed_rows, run}                      commands/depth.rs (BED source)
+//   gffx::commands::coverage::{CoverageArgs, run}                                commands/coverage.rs (BED source)
 // Compute (Join A, Join B) goes through include/gffx_hip.h only; there is no CPU join here.
 #pragma once
 #include <cstdint>
@@ -180,9 +181,25 @@ BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view g
 void run(const DepthArgs &args);  // depth.rs:548-635
 
 }  // namespace depth
+
+// ---- commands/coverage.rs (BED source) -------------------------------------------------------------
+namespace coverage {
+
+struct CoverageArgs {  // coverage.rs:37-57
+    std::string input;                  // -i/--input
+    std::string source;                 // -s/--source (BED; BAM/SAM/CRAM need htslib: refused)
+    std::optional<std::string> output;  // -o/--output
+    size_t threads = 12;                // -t/--threads
+    bool verbose = false;               // -v/--verbose
+    int device = 0;                     // --device (addition)
+};
+
+void run(const CoverageArgs &args);  // coverage.rs:487-582
+
+}  // namespace coverage
 }  // namespace commands
 
-// main.rs: `gffx <index|intersect|depth> ...`; returns the process exit code
+// main.rs: `gffx <index|intersect|depth|coverage> ...`; returns the process exit code
 int cli_main(int argc, char **argv);
 
 }  // namespace gffx

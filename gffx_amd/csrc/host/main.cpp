@@ -88,6 +88,7 @@ const char *kTopUsage =
     "  index      Build index for GFF file\n"
     "  intersect  Extract models by a region or regions from a BED file (MI355X engine)\n"
     "  depth      Compute coverage depth across genomic features from a BED file (MI355X engine)\n"
+    "  coverage   Compute coverage breadth across genomic features from a BED file (MI355X engine)\n"
     "  help       Print this message\n";
 
 const char *kIntersectUsage =
@@ -115,6 +116,15 @@ const char *kDepthUsage =
     "  -t, --threads <THREADS>      Number of threads for parallel processing [default: 12]\n"
     "  -v, --verbose                Enable verbose output\n"
     "      --device <N>             HIP device to run on [default: 0]\n";
+
+const char *kCoverageUsage =
+    "Usage: gffx coverage [OPTIONS] --input <FILE> --source <SOURCE>\n\nOptions:\n"
+    "  -i, --input <FILE>       Input GFF file path\n"
+    "  -s, --source <SOURCE>    Input source (BED; BAM/SAM/CRAM are not supported by this build)\n"
+    "  -o, --output <FILE>      Output file (stdout if not provided)\n"
+    "  -t, --threads <NUM>      Number of threads for parallel processing [default: 12]\n"
+    "  -v, --verbose            Enable verbose output\n"
+    "      --device <N>         HIP device to run on [default: 0]\n";
 
 const char *kIndexUsage =
     "Usage: gffx index [OPTIONS] --input <INPUT>\n\nOptions:\n"
@@ -190,6 +200,29 @@ int run_depth_cli(int argc, char **argv) {
     return 0;
 }
 
+int run_coverage_cli(int argc, char **argv) {
+    static const std::vector<OptSpec> specs = {{'i', "input", true},   {'s', "source", true},   {'o', "output", true},
+                                               {'t', "threads", true}, {'v', "verbose", false}, {0, "device", true},
+                                               {'h', "help", false}};
+    const auto o = parse_opts(argc, argv, 2, specs);
+    if (o.count("help")) {
+        std::fputs(kCoverageUsage, stdout);
+        return 0;
+    }
+    commands::coverage::CoverageArgs a;
+    if (!o.count("input") || !o.count("source"))
+        throw UsageError(std::string("the following required arguments were not provided:") +
+                         (o.count("input") ? "" : "\n  --input <FILE>") + (o.count("source") ? "" : "\n  --source <SOURCE>"));
+    a.input = o.at("input")[0];
+    a.source = o.at("source")[0];
+    if (o.count("output")) a.output = o.at("output")[0];
+    if (o.count("threads")) a.threads = parse_size(o.at("threads")[0], "--threads <NUM>");
+    a.verbose = o.count("verbose") > 0;
+    if (o.count("device")) a.device = static_cast<int>(parse_size(o.at("device")[0], "--device <N>"));
+    commands::coverage::run(a);
+    return 0;
+}
+
 int run_index_cli(int argc, char **argv) {
     static const std::vector<OptSpec> specs = {{'i', "input", true},
                                                {'a', "attribute", true},
@@ -237,7 +270,11 @@ int cli_main(int argc, char **argv) {
             usage = kDepthUsage;
             return run_depth_cli(argc, argv);
         }
-        throw UsageError("unrecognized subcommand '" + cmd + "' (this build carries the intersect and depth paths only)");
+        if (cmd == "coverage") {
+            usage = kCoverageUsage;
+            return run_coverage_cli(argc, argv);
+        }
+        throw UsageError("unrecognized subcommand '" + cmd + "' (this build carries the intersect, depth and coverage paths only)");
     } catch (const UsageError &e) {
         std::fprintf(stderr, "error: %s\n\n%s\nFor more information, try '--help'.\n", e.what(), usage);
         return 2;

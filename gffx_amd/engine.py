@@ -294,6 +294,16 @@ class DepthTable:
         return d[: self.n_groups], s[: self.n_groups], e[: self.n_groups]
 
 
+def segments_covered(seg_seq, seg_start, seg_end, regions, n_seq: int, device: int = 0) -> np.ndarray:
+    """Covered bases of every segment under the union of the regions of its seqid (commands/coverage.rs:92-124,
+    :339-364); regions = (n,3) u32 rows (chr, start, end) with start < end."""
+    q, s, e = _u32(seg_seq), _u32(seg_start), _u32(seg_end)
+    r = _u32(regions).reshape(-1, 3)
+    out = np.zeros(max(len(q), 1), dtype=np.uint32)
+    check(lib().gffx_hip_segments_covered(device, len(q), _p(q), _p(s), _p(e), _p(r), r.shape[0], int(n_seq), _p(out)))
+    return out[: len(q)]
+
+
 def query_features(index_data: TreeIndexData, regions, mode: int = OverlapMode.Overlap,
                    invert: bool = False, verbose: bool = False) -> np.ndarray:
     """commands/intersect.rs:105-169: (root_fid, iv.start, iv.end) per kept (region, root) pair.

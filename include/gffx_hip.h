@@ -17,6 +17,8 @@
  *     (commands/intersect.rs:500-521)
  *   compute_hit_depth / compute_root_depth              gffx_hip_depth_* (`gffx depth`, BED source)
  *     (commands/depth.rs:121-293)
+ *   merge_intervals + the two-pointer walk              gffx_hip_segments_covered (`gffx coverage`, BED source)
+ *     (commands/coverage.rs:92-124, :339-364)
  *
  * Semantics (bit-exact with the reference):
  *   a root interval iv of the query's seqid is a HIT iff  iv.start < q.end && iv.end > q.start
@@ -212,6 +214,15 @@ void gffx_hip_depth_destroy(gffx_hip_depth *);
 int gffx_hip_depth_accumulate(gffx_hip_depth *, gffx_hip_batch *);
 int gffx_hip_depth_reset(gffx_hip_depth *);
 int gffx_hip_depth_copy(gffx_hip_depth *, uint64_t *depth, uint32_t *min_start, uint32_t *max_end /* n_groups each */);
+
+/* ---- `gffx coverage` with a BED source: the covered bases of feature segments (commands/coverage.rs:339-364) --
+ * covered_out[i] = |[seg_start[i], seg_end[i])  ∩  union of the regions of seqid seg_seq[i]|  (regions = AoS
+ * (chr, start, end) rows with start < end; touching regions merge like merge_intervals, coverage.rs:92-109).
+ * For a segment inside its root's interval this equals the reference's per-root figure: a region that overlaps
+ * the segment then hits the root.  Segments sticking out of their root are the caller's to handle. */
+int gffx_hip_segments_covered(int device, uint64_t n_seg, const uint32_t *seg_seq, const uint32_t *seg_start,
+                              const uint32_t *seg_end, const uint32_t *regions, uint64_t nq, uint32_t n_seq,
+                              uint32_t *covered_out);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,119 @@
+"""`gffx coverage` on the GPU: k_segments_covered through the C-ABI == a numpy evaluation of the definition
+(covered bases of a segment under the union of its seqid's regions), and the `gffx coverage` CLI == the oracle's
+restatement of commands/coverage.rs (rows compared as sorted sets: the reference writes them in hash-map order)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from gffx_amd import engine, synth
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GFFX = os.path.join(ROOT, "gffx_amd", "bin", "gffx")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _numpy_covered(seg_seq, seg_start, seg_end, regions, n_seq):
+    out = np.zeros(len(seg_seq), np.uint32)
+    for c in range(n_seq):
+        r = regions[regions[:, 0] == c]
+        if not len(r):
+            continue
+        hi = int(r[:, 2].max())
+        mask = np.zeros(hi + 1, np.int32)  # difference array over the seqid's bases
+        np.add.at(mask, r[:, 1], 1)
+        np.add.at(mask, r[:, 2], -1)
+        covered = np.concatenate([[0], np.cumsum(np.cumsum(mask)[:hi] > 0)])  # covered[x] = covered bases in [0, x)
+        for i in np.nonzero(seg_seq == c)[0]:
+            a, b = min(int(seg_start[i]), hi), min(int(seg_end[i]), hi)
+            out[i] = covered[b] - covered[a] if b > a else 0
+    return out
+
+
+@pytest.mark.parametrize("seed,nq,nseg", [(0, 1, 50), (1, 400, 3000), (2, 20000, 50000), (3, 300000, 200000)])
+def test_segments_covered_equals_the_definition(seed, nq, nseg):
+    rng = np.random.default_rng(seed)
+    n_seq, span = 5, 2_000_000
+    regions = np.empty((nq, 3), np.uint32)
+    regions[:, 0] = rng.integers(0, n_seq - 1, nq)  # the last seqid has no regions at all
+    regions[:, 1] = rng.integers(0, span, nq)
+    regions[:, 2] = regions[:, 1] + rng.choice([1, 30, 500, 40000], nq) + rng.integers(0, 50, nq)
+    seg_seq = rng.integers(0, n_seq, nseg).astype(np.uint32)
+    seg_start = rng.integers(0, span + 50000, nseg).astype(np.uint32)
+    seg_end = (seg_start + rng.choice([1, 100, 5000, 300000], nseg)).astype(np.uint32)
+    if nq > 1:  # touching and nested regions, a segment equal to a region, an empty segment
+        regions[1] = (regions[0, 0], regions[0, 2], regions[0, 2] + 10)
+        seg_seq[0], seg_start[0], seg_end[0] = regions[0]
+        seg_end[1] = seg_start[1]
+    got = engine.segments_covered(seg_seq, seg_start, seg_end, regions, n_seq)
+    assert np.array_equal(got, _numpy_covered(seg_seq, seg_start, seg_end, regions, n_seq))
+
+
+def test_segments_covered_empty_inputs_and_bad_seqid():
+    z = np.zeros(0, np.uint32)
+    assert len(engine.segments_covered(z, z, z, np.zeros((0, 3), np.uint32), 3)) == 0
+    got = engine.segments_covered(np.array([0, 1], np.uint32), np.array([5, 5], np.uint32), np.array([9, 9], np.uint32),
+                                  np.zeros((0, 3), np.uint32), 3)
+    assert got.tolist() == [0, 0]
+    with pytest.raises(engine._ffi.GffxHipError):
+        engine.segments_covered(np.array([7], np.uint32), np.array([1], np.uint32), np.array([2], np.uint32),
+                                np.array([[0, 1, 2]], np.uint32), 3)
+
+
+def _rows(data):
+    lines = data.split(b"\n")
+    assert lines[0] == b"id\tchr\tstart\tend\tbreadth\tfraction" and lines[-1] == b""
+    return sorted(lines[1:-1])
+
+
+def test_coverage_cli_appendix_e_golden(tmp_path):
+    gold = json.load(open(os.path.join(GOLD, "appendix_e_coverage.json")))
+    gff = str(tmp_path / "e.gff")
+    with open(gff, "wb") as f:
+        f.write(open(os.path.join(GOLD, "appendix_e.gff"), "rb").read())
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", os.path.join(GOLD, gold["bed"])], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert _rows(r.stdout) == sorted("\t".join(str(x) for x in row).encode() for row in gold["rows"])
+
+
+@pytest.mark.parametrize("seed,quirks,crlf", [(1, False, False), (2, True, False), (3, True, True)])
+def test_coverage_cli_rows_equal_the_oracle(tmp_path, seed, quirks, crlf):
+    roots = synth.gencode_like_roots(300, seed=seed, chroms=synth.SMALL2)
+    gff = str(tmp_path / "s.gff")
+    synth.write_gff3(gff, roots, seed=seed, quirks=quirks, crlf=crlf)
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    regions = synth.synth_bed(4000, seed=seed + 10, chroms=synth.SMALL2, width=(1, 3000), edge_frac=0.1, roots=roots)
+    bed = str(tmp_path / "q.bed")
+    synth.write_bed(bed, regions, [n for n, _ in synth.SMALL2],
+                    extra_lines=["# header\n", "chrZ\t1\t2\n", "chr1\t7\n", "\n", "chr1 5 9 name\n", "chr1\t3\tx\n"])
+    want = str(tmp_path / "want.tsv")
+    rc, msg = ob.coverage_run(gff, bed, want)
+    assert rc == 0, msg
+    out = str(tmp_path / "got.tsv")
+    r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", bed, "-o", out], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    want_rows = _rows(open(want, "rb").read())
+    assert len(want_rows) > 50 and _rows(open(out, "rb").read()) == want_rows
+    r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", bed], capture_output=True)  # stdout
+    assert r.returncode == 0 and _rows(r.stdout) == want_rows
+    r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", str(tmp_path / "reads.txt")], capture_output=True)
+    assert r.returncode == 1 and b"Unsupported file type" in r.stderr  # coverage.rs:535-540
+    r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", str(tmp_path / "reads.bam")], capture_output=True)
+    assert r.returncode == 1 and b"htslib" in r.stderr
+
+
+def test_coverage_cli_empty_bed_writes_the_header_only(tmp_path):
+    roots = synth.gencode_like_roots(20, seed=4, chroms=synth.SMALL2)
+    gff = str(tmp_path / "s.gff")
+    synth.write_gff3(gff, roots, seed=4)
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    bed = str(tmp_path / "q.bed")
+    open(bed, "w").write("# nothing\n")
+    r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", bed], capture_output=True)
+    assert r.returncode == 0 and r.stdout == b"id\tchr\tstart\tend\tbreadth\tfraction\n"
