@@ -137,6 +137,9 @@ void run(const CoverageArgs &args) {
                 }
             }
         }
+        if (verbose)
+            std::fprintf(stderr, "[INFO] %zu hit blocks, %zu segments (%zu evaluated on the host)\n", hit_blocks.size(),
+                         segs.size(), segs.size() - seg_seq.size());
         // device: covered bases of the segments inside their root, under the union of all regions of the seqid
         std::vector<uint32_t> flat(3 * regions.size());
         for (size_t i = 0; i < regions.size(); ++i) {

@@ -318,11 +318,12 @@ def test_capacity_replay_and_reuse():
         assert np.array_equal(b.counts(), np.full(n, k, np.uint32))
 
 
-@pytest.mark.parametrize("strategy", STRATEGIES)
-@pytest.mark.parametrize("nq", [1_000_000])
+@pytest.mark.parametrize("nq,strategy", [(1_000_000, st) for st in STRATEGIES] +
+                         [(10_000_000, engine.STRATEGY_FUSED), (12_500_000, engine.STRATEGY_SORTED)])
 def test_full_size_c2_properties(nq, strategy):
-    """BASELINE config 2 size (1 M regions x 63 k roots): sampled oracle parity + size-independent
-    properties (sum of counts == pairs; invert complements the mode predicate inside the hit set)."""
+    """BASELINE config sizes (configs[1]: 1 M regions x 63 k roots; configs[2]: 10 M; configs[3]: one GPU's 12.5 M
+    share of 100 M): sampled oracle parity + size-independent properties (sum of counts == pairs; invert
+    complements the mode predicate inside the hit set)."""
     roots = synth.gencode_like_roots(63000, seed=42)
     regions = synth.synth_bed(nq, seed=1001)
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]

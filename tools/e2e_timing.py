@@ -1,4 +1,4 @@
-"""Development timing script (run on the GPU box): transfer-inclusive Join A rates and wall-clock of the gffx CLI\n(index / intersect / intersect -e / depth) on a synthetic annotation + a 1 M-row BED.  python tools/e2e_timing.py [n_genes]"""
+"""Development timing script (run on the GPU box): transfer-inclusive Join A rates and wall-clock of the gffx CLI\n(index / intersect / intersect -e / depth / coverage) on a synthetic annotation + a 1 M-row BED.  python tools/e2e_timing.py [n_genes]"""
 import os, sys, time, subprocess, numpy as np
 sys.path.insert(0, os.getcwd())
 from gffx_amd import engine, synth
@@ -22,7 +22,7 @@ gff = d + "/a.gff"
 t0 = time.perf_counter(); n = synth.write_gff3(gff, small, seed=3); print("wrote %d GFF lines (%.0f MB) in %.1f s" % (n, os.path.getsize(gff) / 1e6, time.perf_counter() - t0))
 bed = d + "/q.bed"; synth.write_bed(bed, regions, small["names"])
 G = "gffx_amd/bin/gffx"
-for cmd in ([G, "index", "-i", gff], [G, "intersect", "-i", gff, "-b", bed, "-o", d + "/o1.gff"], [G, "intersect", "-i", gff, "-b", bed, "-e", "-o", d + "/o2.gff"], [G, "depth", "-i", gff, "-s", bed, "-o", d + "/d.tsv"]):
+for cmd in ([G, "index", "-i", gff], [G, "intersect", "-i", gff, "-b", bed, "-o", d + "/o1.gff"], [G, "intersect", "-i", gff, "-b", bed, "-e", "-o", d + "/o2.gff"], [G, "depth", "-i", gff, "-s", bed, "-o", d + "/d.tsv"], [G, "coverage", "-v", "-i", gff, "-s", bed, "-o", d + "/c.tsv"]):
     t0 = time.perf_counter(); r = subprocess.run(cmd, capture_output=True); dt = time.perf_counter() - t0
-    print(" ".join(cmd[1:4]), ("-e" if "-e" in cmd else ""), "rc", r.returncode, "%.2f s" % dt, r.stderr[-200:].decode())
-print("outputs MB:", [round(os.path.getsize(d + "/" + f) / 1e6, 1) for f in ("o1.gff", "o2.gff", "d.tsv")])
+    print(" ".join(cmd[1:4]), ("-e" if "-e" in cmd else ""), "rc", r.returncode, "%.2f s" % dt, r.stderr[-300:].decode())
+print("outputs MB:", [round(os.path.getsize(d + "/" + f) / 1e6, 1) for f in ("o1.gff", "o2.gff", "d.tsv", "c.tsv")])
