@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--queries-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
@@ -276,6 +276,8 @@ def main():
         if bb is batch or args.warmup > 0:
             bb.wait()
     issued[0] = 0
+    if world > 1:  # the collective's first call sets up its channels: not part of the job's steady state
+        shard.allgather_hit_counts(nq, pairs, device=coll_dev)
 
     def barrier():
         if world > 1:
@@ -293,8 +295,9 @@ def main():
         shard.allgather_hit_counts(nq, batch.total_hits, device=coll_dev)
     else:
         sync_all()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0  # this rank's K steps (+ the exchange); MAX over ranks below
     barrier()
-    elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
