@@ -85,3 +85,40 @@ def allgather_hit_counts(n_queries: int, n_hits: int, device=None):
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
     return torch.stack(out).cpu().numpy()
+
+
+def allgather_root_bitmap(words: np.ndarray, device=None) -> np.ndarray:
+    """The CLI's exchange step: every rank learns the union of the ranks' root-hit bitmaps.
+
+    ``words`` = this rank's packed bitmap (u64 words over the index's roots in sorted order, as
+    QueryBatch.root_bitmap packs it).  RCCL has no bitwise-OR reduction, and max/sum over packed words is not an OR
+    once a chromosome bucket is split across ranks, so the packed bitmaps (<= 8 KB each at 63 k roots) are
+    all-gathered and OR-ed locally.  Returns the OR-ed words."""
+    import torch
+    import torch.distributed as dist
+
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return w.copy()
+    mine = torch.from_numpy(w.view(np.int64).copy())
+    if device is not None:
+        mine = mine.to(device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return np.bitwise_or.reduce(torch.stack(out).cpu().numpy().view(np.uint64), axis=0)
+
+
+def allgather_seqid_hits(per_seqid_hits: np.ndarray, device=None) -> np.ndarray:
+    """Per-seqid kept-pair counts of every rank ((world, n_seq) i64; a few hundred bytes per rank)."""
+    import torch
+    import torch.distributed as dist
+
+    h = np.ascontiguousarray(per_seqid_hits, dtype=np.int64)
+    if not (dist.is_available() and dist.is_initialized()):
+        return h[None, :].copy()
+    mine = torch.from_numpy(h.copy())
+    if device is not None:
+        mine = mine.to(device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return torch.stack(out).cpu().numpy()

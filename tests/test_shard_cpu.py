@@ -70,9 +70,17 @@ def _worker(rank, world, port, q):
     oix = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
     t, c = oix.query_features(regions[rows], 2, False)
     got = shard.allgather_hit_counts(len(rows), len(t))
+    # the CLI's exchange: packed root-hit bitmaps (roots in (seqid, start) order) OR-ed over ranks; per-seqid hits
+    hit = np.zeros(len(roots["fid"]), bool)
+    hit[np.searchsorted(roots["fid"], t[:, 0])] = True  # (synth fids ascend with the sorted order)
+    words = np.packbits(np.concatenate([hit, np.zeros(-len(hit) % 64, bool)]), bitorder="little").view(np.uint64)
+    union = shard.allgather_root_bitmap(words)
+    per_seq = np.zeros(25, np.int64)
+    np.add.at(per_seq, regions[rows][:, 0].astype(np.int64), c.astype(np.int64))
+    seq_tab = shard.allgather_seqid_hits(per_seq)
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, got.tolist(), len(rows), len(t)))
+    q.put((rank, got.tolist(), len(rows), len(t), union.tolist(), seq_tab.sum(axis=0).tolist()))
 
 
 def test_two_rank_gloo_allgather_matches_single_process():
@@ -98,5 +106,13 @@ def test_two_rank_gloo_allgather_matches_single_process():
     roots = synth.gencode_like_roots(3000, seed=4)
     regions = synth.synth_bed(40_000, seed=6, edge_frac=0.01, roots=roots)
     oix = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
-    t, _ = oix.query_features(regions, 2, False)
+    t, c = oix.query_features(regions, 2, False)
     assert table[:, 0].sum() == len(regions) and table[:, 1].sum() == len(t)
+    # bitmap union over the ranks == the single-process hit set; per-seqid hits add up
+    assert res[0][4] == res[1][4] and res[0][5] == res[1][5]
+    bits = np.unpackbits(np.array(res[0][4], np.uint64).view(np.uint8), bitorder="little")[: len(roots["fid"])].astype(bool)
+    assert np.array_equal(roots["fid"][bits], np.unique(t[:, 0]))
+    per_seq = np.zeros(25, np.int64)
+    np.add.at(per_seq, regions[:, 0].astype(np.int64), c.astype(np.int64))
+    assert res[0][5] == per_seq.tolist()
+    assert np.array_equal(shard.allgather_root_bitmap(np.array([5, 9], np.uint64)), np.array([5, 9], np.uint64))
