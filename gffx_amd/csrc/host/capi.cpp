@@ -153,7 +153,7 @@ extern "C" int gffx_host_depth_block_table(const char *gff, uint32_t *n_blocks, 
     return guard(err, errlen, [&] {
         const index_loader::GofMap gof = index_loader::load_gof(gff);
         const MappedFile text(gff);
-        const commands::depth::BlockTable t = commands::depth::build_block_table(gof, text.view());
+        const commands::depth::BlockTable t = commands::depth::build_block_table(gof, text.view(), 4);
         *n_blocks = static_cast<uint32_t>(t.block_line_off.size() - 1);
         *block_line_off = dup_vec(t.block_line_off);
         *n_lines = t.line_start.size();
@@ -164,19 +164,44 @@ extern "C" int gffx_host_depth_block_table(const char *gff, uint32_t *n_blocks, 
         *block_of_fid = dup_vec(t.block_of_fid);
         *n_groups = static_cast<uint32_t>(t.group_id.size());
         *group_id = dup_vec(t.group_id);
-        auto join = [](const std::vector<std::string> &v) {
-            std::string j;
-            for (size_t i = 0; i < v.size(); ++i) {
-                if (i) j.push_back('\n');
-                j += v[i];
-            }
+        auto dup_str = [](const std::string &j) {
             char *p = static_cast<char *>(std::malloc(j.size() + 1));
             std::memcpy(p, j.c_str(), j.size() + 1);
             return p;
         };
-        *group_chrom = join(t.group_chrom);
-        *ids = join(t.ids);
+        std::string chrom_text, id_text;
+        for (size_t g = 0; g < t.group_chrom.size(); ++g) {
+            if (g) chrom_text.push_back('\n');
+            chrom_text += t.chroms[t.group_chrom[g]];
+        }
+        for (uint32_t i = 0; i < t.n_ids(); ++i) {
+            if (i) id_text.push_back('\n');
+            id_text += t.id(i);
+        }
+        *group_chrom = dup_str(chrom_text);
+        *ids = dup_str(id_text);
     });
+}
+
+extern "C" int gffx_host_line_table_check(const char *gff, uint32_t threads, char *err, size_t errlen) {
+    int usable = 0;
+    const int rc = guard(err, errlen, [&] {
+        const index_loader::GofMap gof = index_loader::load_gof(gff);
+        const MappedFile text(gff);
+        commands::depth::BlockTable img;
+        std::string why;
+        if (!commands::depth::load_block_table(append_suffix(gff, ".lsoa"), text.size(), gof.entries.size() * 24ull, img, why)) {
+            if (err && errlen) std::snprintf(err, errlen, "%s", why.c_str());
+            return;
+        }
+        const commands::depth::BlockTable t = commands::depth::build_block_table(gof, text.view(), threads);
+        if (!(t.block_line_off == img.block_line_off && t.line_start == img.line_start && t.line_end == img.line_end &&
+              t.line_group == img.line_group && t.block_of_fid == img.block_of_fid && t.group_id == img.group_id &&
+              t.group_chrom == img.group_chrom && t.chroms == img.chroms && t.id_off == img.id_off && t.id_pool == img.id_pool))
+            throw Error("the line table image differs from a fresh parse");
+        usable = 1;
+    });
+    return rc != 0 ? rc : usable;
 }
 
 extern "C" int gffx_host_cli(int argc, char **argv) { return cli_main(argc, argv); }

@@ -55,6 +55,7 @@ uint64_t covered(const std::vector<Span> &cov, uint32_t a, uint32_t b) {  // cov
 
 void run(const CoverageArgs &args) {
     const bool verbose = args.verbose;
+    StageTimer timer{verbose};
     std::string ext;  // coverage.rs:520-541: dispatch on the source's extension
     {
         const size_t slash = args.source.find_last_of('/');
@@ -77,6 +78,7 @@ void run(const CoverageArgs &args) {
         throw Error("Unsupported file type: \"" + args.source + "\". Expected .bam/.sam/.cram or .bed");  // :535-540
     const std::vector<intersect::Region> regions = depth::parse_bed_rows(args.source, index_data.seqid_to_num);  // :230-256
     if (verbose) std::fprintf(stderr, "[INFO] %zu BED rows kept\n", regions.size());
+    timer.lap("Loading index + parsing BED");
 
     std::string out = "id\tchr\tstart\tend\tbreadth\tfraction\n";  // :463
     size_t written = 0;
@@ -84,7 +86,9 @@ void run(const CoverageArgs &args) {
         // which roots are hit (by_root's key set, coverage.rs:258-268): Join A's unique-root output
         const std::vector<uint32_t> hit_roots =
             intersect::query_unique_roots(index_data, regions, intersect::OverlapMode::Overlap, false, verbose, args.device);
-        const depth::BlockTable t = depth::build_block_table(gof, gff.view());
+        timer.lap("Join A on the device (root bitmap)");
+        const depth::BlockTable t = depth::load_or_build_block_table(args.input, gof, gff.view(), args.threads, verbose);
+        timer.lap("Line table (image or parse)");
         // the tree intervals of every root_fid (several when root lines share an ID)
         const uint32_t n_seq = static_cast<uint32_t>(index_data.chr_offsets.size() - 1);
         std::unordered_map<uint32_t, std::vector<std::tuple<uint32_t, uint32_t, uint32_t>>> ivs;  // fid -> (seq, start, end)
@@ -140,6 +144,7 @@ void run(const CoverageArgs &args) {
         if (verbose)
             std::fprintf(stderr, "[INFO] %zu hit blocks, %zu segments (%zu evaluated on the host)\n", hit_blocks.size(),
                          segs.size(), segs.size() - seg_seq.size());
+        timer.lap("Segments of the hit blocks");
         // device: covered bases of the segments inside their root, under the union of all regions of the seqid
         std::vector<uint32_t> flat(3 * regions.size());
         for (size_t i = 0; i < regions.size(); ++i) {
@@ -151,6 +156,7 @@ void run(const CoverageArgs &args) {
         if (gffx_hip_segments_covered(args.device, seg_seq.size(), seg_seq.data(), seg_start.data(), seg_end.data(), flat.data(),
                                       regions.size(), n_seq, cov_fast.data()) != GFFX_OK)
             hip_fail("gffx_hip_segments_covered");
+        timer.lap("Covered bases on the device (union build, upload, kernel, D2H)");
         // host: the segments that stick out of their root, against the root's own merged list (coverage.rs:401)
         std::vector<uint64_t> breadth(t.group_id.size(), 0);
         std::unordered_map<uint32_t, std::vector<Span>> root_cov;  // block -> merged regions that hit its root
@@ -180,11 +186,11 @@ void run(const CoverageArgs &args) {
         // merge the groups of an ID (coverage.rs:417-428) in block order; a row if length > 0 || breadth > 0 (:372)
         struct Row {
             bool set = false;
-            std::string chrom;
+            const std::string *chrom = nullptr;
             uint32_t s = 0, e = 0;
             uint64_t b = 0;
         };
-        std::vector<Row> rows(t.ids.size());
+        std::vector<Row> rows(t.n_ids());
         std::vector<uint32_t> order;
         for (uint32_t g = 0; g < t.group_id.size(); ++g) {
             if (!g_hit[g]) continue;
@@ -193,7 +199,7 @@ void run(const CoverageArgs &args) {
             Row &r = rows[t.group_id[g]];
             if (!r.set) {
                 r.set = true;
-                r.chrom = t.group_chrom[g];
+                r.chrom = &t.chroms[t.group_chrom[g]];
                 r.s = g_min[g];
                 r.e = g_max[g];
                 r.b = breadth[g];
@@ -209,9 +215,9 @@ void run(const CoverageArgs &args) {
             const Row &r = rows[i];
             const uint64_t length = r.e > r.s ? r.e - r.s : 0;
             const double fraction = length > 0 ? static_cast<double>(r.b) / static_cast<double>(length) : 0.0;
-            out += t.ids[i];
+            out += t.id(i);
             out.push_back('\t');
-            out += r.chrom;
+            out += *r.chrom;
             out.push_back('\t');
             out += std::to_string(r.s);
             out.push_back('\t');
@@ -230,6 +236,8 @@ void run(const CoverageArgs &args) {
         std::fflush(stdout);
     }
     if (verbose) std::fprintf(stderr, "[INFO] Wrote %zu feature coverage rows.\n", written);
+    timer.lap("Merging groups and writing rows");
+    timer.total();
 }
 
 }  // namespace coverage

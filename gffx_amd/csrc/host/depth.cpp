@@ -20,19 +20,6 @@ namespace {
 
 [[noreturn]] void hip_fail(const char *what) { throw Error(std::string(what) + ": " + gffx_hip_last_error()); }
 
-// depth.rs:105-120 fast_id: first "ID=" anywhere in the attributes, value up to ';', ' ' or '\t'
-bool fast_id(std::string_view attrs, std::string_view &id) {
-    for (size_t i = 0; i + 2 < attrs.size(); ++i) {
-        if (attrs[i] == 'I' && attrs[i + 1] == 'D' && attrs[i + 2] == '=') {
-            size_t j = i + 3;
-            while (j < attrs.size() && attrs[j] != ';' && attrs[j] != ' ' && attrs[j] != '\t') ++j;
-            id = attrs.substr(i + 3, j - (i + 3));
-            return true;
-        }
-    }
-    return false;
-}
-
 std::string_view trim_end_unicode_ws(std::string_view s) {  // str::trim_end()
     for (;;) {
         if (s.empty()) return s;
@@ -98,81 +85,9 @@ std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
     return out;
 }
 
-// depth.rs:131-152 on every root block: the lines that carry an ID, 0-based half-open
-BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view gff) {
-    BlockTable t;
-    uint32_t max_fid = 0;
-    for (const auto &g : gof.entries) max_fid = std::max(max_fid, g.feature_id);
-    t.block_of_fid.assign(gof.entries.empty() ? 0 : (size_t)max_fid + 1, 0xFFFFFFFFu);
-    // fid -> its LAST record (index_cached(), gof.rs:32-37); blocks in file order of those records
-    std::vector<uint32_t> last(t.block_of_fid.size(), 0xFFFFFFFFu);
-    for (size_t k = 0; k < gof.entries.size(); ++k) last[gof.entries[k].feature_id] = static_cast<uint32_t>(k);
-    std::unordered_map<std::string, uint32_t> id_index;
-    struct L {
-        uint32_t start, end, id;
-        std::string_view seq;
-    };
-    std::vector<L> lines;
-    for (size_t k = 0; k < gof.entries.size(); ++k) {
-        const auto &g = gof.entries[k];
-        if (last[g.feature_id] != k) continue;
-        if (g.start_offset == MISSING || g.end_offset == MISSING || g.end_offset <= g.start_offset) continue;  // depth.rs:243
-        if (g.end_offset > gff.size()) throw Error("GOF record " + std::to_string(k) + " out of range");
-        const std::string_view slice = gff.substr(g.start_offset, g.end_offset - g.start_offset);
-        lines.clear();
-        if (utf8_valid(slice)) {  // depth.rs:132: a block that is not UTF-8 contributes nothing
-            size_t a = 0;
-            while (a < slice.size()) {  // split_terminator('\n')
-                size_t nl = slice.find('\n', a);
-                if (nl == std::string_view::npos) nl = slice.size();
-                const std::string_view line = slice.substr(a, nl - a);
-                a = nl + 1;
-                if (line.empty() || line[0] == '#') continue;
-                std::string_view col[9];  // splitn(9, '\t')
-                size_t p = 0;
-                int c = 0;
-                for (; c < 8; ++c) {
-                    const size_t tpos = line.find('\t', p);
-                    if (tpos == std::string_view::npos) break;
-                    col[c] = line.substr(p, tpos - p);
-                    p = tpos + 1;
-                }
-                if (c < 8) continue;
-                col[8] = line.substr(p);
-                const auto s1 = parse_u32_ascii(col[3]), e1 = parse_u32_ascii(col[4]);  // parse_u32_fast (:86-97)
-                if (!s1 || !e1 || *e1 == 0) continue;
-                uint32_t s = *s1, e = *e1;
-                if (s > e) std::swap(s, e);
-                std::string_view id;
-                if (!fast_id(col[8], id)) continue;
-                auto it = id_index.find(std::string(id));
-                if (it == id_index.end()) {
-                    it = id_index.emplace(std::string(id), static_cast<uint32_t>(t.ids.size())).first;
-                    t.ids.emplace_back(id);
-                }
-                lines.push_back(L{s ? s - 1 : 0, e, it->second, col[0]});
-            }
-        }
-        const uint32_t blk = static_cast<uint32_t>(t.block_line_off.size() - 1);
-        t.block_of_fid[g.feature_id] = blk;
-        // group the block's lines by ID (stable: the first line of an ID names the group's chrom)
-        std::stable_sort(lines.begin(), lines.end(), [](const L &x, const L &y) { return x.id < y.id; });
-        for (size_t i = 0; i < lines.size(); ++i) {
-            if (i == 0 || lines[i].id != lines[i - 1].id) {
-                t.group_id.push_back(lines[i].id);
-                t.group_chrom.emplace_back(lines[i].seq);
-            }
-            t.line_start.push_back(lines[i].start);
-            t.line_end.push_back(lines[i].end);
-            t.line_group.push_back(static_cast<uint32_t>(t.group_id.size() - 1));
-        }
-        t.block_line_off.push_back(t.line_start.size());
-    }
-    return t;
-}
-
 void run(const DepthArgs &args) {
     const bool verbose = args.verbose;
+    StageTimer timer{verbose};
     // depth.rs:590-601: dispatch on the source's extension
     std::string ext;
     {
@@ -194,10 +109,13 @@ void run(const DepthArgs &args) {
         throw Error("BAM/SAM/CRAM sources need htslib, which this build does not carry; use a .bed source");
     if (ext != "bed")
         throw Error("Unsupported file type: \"" + args.source + "\". Expected .bam/.sam/.cram or .bed");  // :597-600
+    timer.lap("Loading index");
     const std::vector<intersect::Region> regions = parse_bed_rows(args.source, index_data.seqid_to_num);
     if (verbose) std::fprintf(stderr, "[INFO] %zu BED rows kept\n", regions.size());
+    timer.lap("Parsing BED");
 
-    const BlockTable t = build_block_table(gof, gff.view());
+    const BlockTable t = load_or_build_block_table(args.input, gof, gff.view(), args.threads, verbose);
+    timer.lap("Line table (image or parse)");
     const uint32_t n_groups = static_cast<uint32_t>(t.group_id.size());
     std::vector<uint64_t> depth(std::max<size_t>(n_groups, 1), 0);
     std::vector<uint32_t> mn(std::max<size_t>(n_groups, 1), 0xFFFFFFFFu), mx(std::max<size_t>(n_groups, 1), 0);
@@ -238,22 +156,23 @@ void run(const DepthArgs &args) {
         }
         if (gffx_hip_depth_copy(dt, depth.data(), mn.data(), mx.data()) != GFFX_OK) hip_fail("gffx_hip_depth_copy");
     }
+    timer.lap("Join A + depth on the device (uploads, kernels, results D2H)");
     // merge the groups of an ID (depth.rs:264-291): min start, max end, summed depth; chrom from the first
     // contributing block (file order here, hash order in the reference)
     struct Row {
         bool set = false;
-        std::string chrom;
+        const std::string *chrom = nullptr;
         uint32_t s = 0, e = 0;
         uint64_t d = 0;
     };
-    std::vector<Row> rows(t.ids.size());
+    std::vector<Row> rows(t.n_ids());
     std::vector<uint32_t> order;
     for (uint32_t g = 0; g < n_groups; ++g) {
         if (depth[g] == 0) continue;
         Row &r = rows[t.group_id[g]];
         if (!r.set) {
             r.set = true;
-            r.chrom = t.group_chrom[g];
+            r.chrom = &t.chroms[t.group_chrom[g]];
             r.s = mn[g];
             r.e = mx[g];
             r.d = depth[g];
@@ -268,9 +187,9 @@ void run(const DepthArgs &args) {
     std::string out = "id\tchr\tstart\tend\tdepth\n";
     for (uint32_t i : order) {
         const Row &r = rows[i];
-        out += t.ids[i];
+        out += t.id(i);
         out.push_back('\t');
-        out += r.chrom;
+        out += *r.chrom;
         out.push_back('\t');
         out += std::to_string(r.s == 0xFFFFFFFFu ? 0u : r.s);
         out.push_back('\t');
@@ -286,6 +205,8 @@ void run(const DepthArgs &args) {
         std::fflush(stdout);
     }
     if (verbose) std::fprintf(stderr, "[INFO] Wrote %zu ID depth records\n", order.size());
+    timer.lap("Merging groups and writing rows");
+    timer.total();
 }
 
 }  // namespace depth

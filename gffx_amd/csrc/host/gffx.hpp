@@ -10,7 +10,9 @@
 //   gffx::commands::coverage::{CoverageArgs, run}                                commands/coverage.rs (BED source)
 // Compute (Join A, Join B) goes through include/gffx_hip.h only; there is no CPU join here.
 #pragma once
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <optional>
 #include <string>
 #include <string_view>
@@ -24,6 +26,24 @@
 namespace gffx {
 
 constexpr uint64_t MISSING = UINT64_MAX;  // index_loader/gof.rs:7, commands/intersect.rs:18
+
+// stage timers under --verbose, in the reference's style (depth.rs:562-632 "[TIMER] [run] Step n: ...";
+// `intersect` itself has none)
+struct StageTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void lap(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[TIMER] [run] %s took %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    }
+    void total() {
+        if (on)
+            std::fprintf(stderr, "[TIMER] [run] Total pipeline time: %.3f ms\n",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 // ---- utils/common.rs -------------------------------------------------------------------------
 struct CommonArgs {  // common.rs:17-52
@@ -172,12 +192,21 @@ std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
 struct BlockTable {  // the device line table (include/gffx_hip.h "gffx depth") + what names the groups
     std::vector<uint64_t> block_line_off{0};
     std::vector<uint32_t> line_start, line_end, line_group, block_of_fid;
-    std::vector<uint32_t> group_id;        // group -> index into ids
-    std::vector<std::string> group_chrom;  // group -> seqid column of the block's first line with that ID (depth.rs:151)
-    std::vector<std::string> ids;
+    std::vector<uint32_t> group_id;     // group -> ID number
+    std::vector<uint32_t> group_chrom;  // group -> index into chroms: the seqid column of the block's first line with that ID (depth.rs:151)
+    std::vector<std::string> chroms;    // the distinct seqid column texts
+    std::vector<uint64_t> id_off{0};    // ID i = id_pool[id_off[i], id_off[i+1]), numbered by first appearance
+    std::string id_pool;
+    size_t n_ids() const { return id_off.size() - 1; }
+    std::string_view id(uint32_t i) const { return std::string_view(id_pool).substr(id_off[i], id_off[i + 1] - id_off[i]); }
 };
 // depth.rs:131-152 on every root block (the LAST .gof record of a root_fid): the lines that carry an ID
-BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view gff);
+BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view gff, size_t threads = 1);
+// the same table as a flat image `<gff>.lsoa` (written by `gffx index`; block_table.cpp has the layout)
+void write_block_table(const std::string &path, const BlockTable &t, uint64_t gff_bytes, uint64_t gof_bytes);
+bool load_block_table(const std::string &path, uint64_t gff_bytes, uint64_t gof_bytes, BlockTable &t, std::string &why);
+BlockTable load_or_build_block_table(const std::string &gff_path, const index_loader::GofMap &gof, std::string_view gff,
+                                     size_t threads, bool verbose);
 void run(const DepthArgs &args);  // depth.rs:548-635
 
 }  // namespace depth

@@ -328,26 +328,6 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
 }
 
 // intersect.rs:541-655
-namespace {
-// stage timers under --verbose, in the style of the reference's other commands (depth.rs:562-632
-// "[TIMER] [run] Step n: ..."); `intersect` itself has none
-struct StageTimer {
-    bool on;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
-    void lap(const char *what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[TIMER] [run] %s took %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
-        last = now;
-    }
-    void total() {
-        if (on)
-            std::fprintf(stderr, "[TIMER] [run] Total pipeline time: %.3f ms\n",
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    }
-};
-}  // namespace
-
 void run(const IntersectArgs &args) {
     const bool verbose = args.common.verbose;
     StageTimer timer{verbose};

@@ -8,6 +8,8 @@
 #include <functional>
 #include <map>
 
+#include <thread>
+
 #include "gffx.hpp"
 
 namespace gffx {
@@ -243,6 +245,16 @@ int run_index_cli(int argc, char **argv) {
     const bool verbose = o.count("verbose") > 0;
     if (verbose) std::printf("Indexing: %s\n", input.c_str());  // commands/index.rs:26-28
     build_index(input, attr, skip, verbose);
+    // addition: the all-line SoA image `<gff>.lsoa` for depth / coverage (block_table.cpp); GFFX_LINE_TABLE=off skips it
+    const char *lt = std::getenv("GFFX_LINE_TABLE");
+    if (!(lt && std::string(lt) == "off")) {
+        const index_loader::GofMap gof = index_loader::load_gof(input);
+        const MappedFile text(input);
+        unsigned hw = std::thread::hardware_concurrency();
+        const auto t = commands::depth::build_block_table(gof, text.view(), std::min(hw ? hw : 1u, 12u));
+        commands::depth::write_block_table(append_suffix(input, ".lsoa"), t, text.size(), gof.entries.size() * 24ull);
+        if (verbose) std::printf("Line table image: %zu lines in %zu blocks.\n", t.line_start.size(), t.block_line_off.size() - 1);
+    }
     if (verbose) std::printf("Index created successfully.\n");
     return 0;
 }

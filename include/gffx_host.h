@@ -43,6 +43,10 @@ int gffx_host_depth_block_table(const char *gff, uint32_t *n_blocks, uint64_t **
                                 uint32_t **line_start, uint32_t **line_end, uint32_t **line_group, uint32_t *n_fid,
                                 uint32_t **block_of_fid, uint32_t *n_groups, uint32_t **group_id, char **group_chrom,
                                 char **ids, char *err, size_t errlen);
+/* the all-line SoA image `<gff>.lsoa` written by `gffx index` ("cached GPU-SoA side-car"):
+ * 1 = it loads and equals a fresh parse on `threads` host threads, 0 = not usable (absent / stale / does not
+ * validate; the reason in err), < 0 = error or mismatch */
+int gffx_host_line_table_check(const char *gff, uint32_t threads, char *err, size_t errlen);
 /* the `gffx` command line in-process (main.rs); returns the exit code */
 int gffx_host_cli(int argc, char **argv);
 void gffx_host_free(void *);

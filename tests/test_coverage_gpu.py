@@ -100,6 +100,15 @@ def test_coverage_cli_rows_equal_the_oracle(tmp_path, seed, quirks, crlf):
     assert r.returncode == 0, r.stderr
     want_rows = _rows(open(want, "rb").read())
     assert len(want_rows) > 50 and _rows(open(out, "rb").read()) == want_rows
+    # the image written by `gffx index` was the source of the lines; a fresh parse of the GFF (1 and 5 host threads)
+    # gives the same rows
+    r = subprocess.run([GFFX, "coverage", "-v", "-i", gff, "-s", bed, "-o", out], capture_output=True)
+    assert r.returncode == 0 and b"line table from" in r.stderr
+    for threads in ("1", "5"):
+        r = subprocess.run([GFFX, "coverage", "-v", "-t", threads, "-i", gff, "-s", bed, "-o", out], capture_output=True,
+                           env=dict(os.environ, GFFX_LINE_TABLE="parse"))
+        assert r.returncode == 0 and b"parsing the GFF" in r.stderr
+        assert _rows(open(out, "rb").read()) == _rows(open(want, "rb").read())
     r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", bed], capture_output=True)  # stdout
     assert r.returncode == 0 and _rows(r.stdout) == want_rows
     r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", str(tmp_path / "reads.txt")], capture_output=True)

@@ -223,3 +223,39 @@ def test_host_bed_rows_and_block_table_reproduce_the_oracle_rows(host, tmp_path,
     rc, msg = ob.depth_run(gff, bed, out)
     assert rc == 0, msg
     assert sorted((k,) + v for k, v in rows.items()) == rows_of(out)
+
+
+def test_line_table_image_roundtrip_stale_and_corrupt(host, tmp_path):
+    """`gffx index` writes the all-line SoA image `<gff>.lsoa`; it loads equal to a fresh parse at any thread count,
+    is ignored when the GFF changed size or the image is damaged, and GFFX_LINE_TABLE=off skips it."""
+    import subprocess
+
+    host.gffx_host_line_table_check.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_size_t]
+    gffx = os.path.join(ROOT, "gffx_amd", "bin", "gffx")
+    roots = synth.gencode_like_roots(2500, seed=9, chroms=synth.SMALL2)
+    gff = str(tmp_path / "s.gff")
+    synth.write_gff3(gff, roots, seed=9, quirks=True)
+    assert subprocess.run([gffx, "index", "-i", gff]).returncode == 0
+    assert os.path.getsize(gff + ".lsoa") > 96
+    err = C.create_string_buffer(2048)
+    for threads in (1, 3, 12, 64):
+        assert host.gffx_host_line_table_check(gff.encode(), threads, err, len(err)) == 1, err.value
+    # a damaged image is refused, not trusted
+    img = bytearray(open(gff + ".lsoa", "rb").read())
+    for name, edit in (("truncated", lambda b: b[:-8]), ("magic", lambda b: b"X" + b[1:]),
+                       ("line_group", lambda b: b[:96 + 8 * 3] + b"\xff" * 8 + b[96 + 8 * 4:])):
+        open(gff + ".lsoa", "wb").write(bytes(edit(bytes(img))))
+        rc = host.gffx_host_line_table_check(gff.encode(), 2, err, len(err))
+        assert rc == 0 and err.value, (name, rc, err.value)
+    open(gff + ".lsoa", "wb").write(bytes(img))
+    assert host.gffx_host_line_table_check(gff.encode(), 2, err, len(err)) == 1
+    # the GFF grew: stale
+    with open(gff, "ab") as f:
+        f.write(b"# trailing comment\n")
+    assert host.gffx_host_line_table_check(gff.encode(), 2, err, len(err)) == 0 and b"stale" in err.value
+    # opt-out at index time
+    gff2 = str(tmp_path / "t.gff")
+    synth.write_gff3(gff2, roots, seed=9)
+    assert subprocess.run([gffx, "index", "-i", gff2], env=dict(os.environ, GFFX_LINE_TABLE="off")).returncode == 0
+    assert not os.path.exists(gff2 + ".lsoa")
+    assert host.gffx_host_line_table_check(gff2.encode(), 2, err, len(err)) == 0 and err.value == b"absent"

@@ -124,6 +124,15 @@ def test_depth_cli_rows_equal_the_oracle(tmp_path, seed, quirks, crlf):
     r = subprocess.run([GFFX, "depth", "-i", gff, "-s", bed, "-o", out], capture_output=True)
     assert r.returncode == 0, r.stderr
     assert _rows(open(out, "rb").read()) == _rows(open(want, "rb").read())
+    # the image written by `gffx index` was the source of the lines; a fresh parse of the GFF (1 and 5 host threads)
+    # gives the same rows
+    r = subprocess.run([GFFX, "depth", "-v", "-i", gff, "-s", bed, "-o", out], capture_output=True)
+    assert r.returncode == 0 and b"line table from" in r.stderr
+    for threads in ("1", "5"):
+        r = subprocess.run([GFFX, "depth", "-v", "-t", threads, "-i", gff, "-s", bed, "-o", out], capture_output=True,
+                           env=dict(os.environ, GFFX_LINE_TABLE="parse"))
+        assert r.returncode == 0 and b"parsing the GFF" in r.stderr
+        assert _rows(open(out, "rb").read()) == _rows(open(want, "rb").read())
     r = subprocess.run([GFFX, "depth", "-i", gff, "-s", bed], capture_output=True)  # stdout
     assert r.returncode == 0 and _rows(r.stdout) == _rows(open(want, "rb").read())
     # unsupported sources fail like the reference (depth.rs:596-600)
