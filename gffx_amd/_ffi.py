@@ -20,6 +20,7 @@ vp = C.c_void_p
 SIGNATURES = {
     "gffx_hip_abi_version": (C.c_int, []),
     "gffx_hip_device_count": (C.c_int, []),
+    "gffx_hip_warmup": (C.c_int, [C.c_int]),
     "gffx_hip_last_error": (C.c_char_p, []),
     "gffx_hip_index_create": (C.c_int, [C.c_uint32, u32p, u32p, u32p, u32p, C.c_int, C.POINTER(vp)]),
     "gffx_hip_index_destroy": (None, [vp]),

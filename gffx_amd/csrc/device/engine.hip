@@ -157,6 +157,23 @@ struct gffx_hip_batch {
 extern "C" int gffx_hip_abi_version(void) { return GFFX_HIP_ABI_VERSION; }
 extern "C" int gffx_hip_device_count(void) { return device_count_quiet(); }
 extern "C" const char *gffx_hip_last_error(void) { return g_last_error.c_str(); }
+
+__global__ void k_warm(uint32_t *p) {
+    if (p) *p = 1;
+}
+// Pay the process's one-off HIP costs (runtime + context creation, code-object load) now, e.g. on a host thread
+// while the BED file is still being parsed.  Errors are reported but nothing depends on the call.
+extern "C" int gffx_hip_warmup(int device) {
+    const int ndev = device_count_quiet();
+    if (ndev <= 0) return fail(GFFX_E_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
+    GFFX_HIP_TRY(hipSetDevice(device));
+    GFFX_HIP_TRY(hipFree(nullptr));
+    hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, 0, (uint32_t *)nullptr);
+    GFFX_HIP_TRY(hipGetLastError());
+    GFFX_HIP_TRY(hipDeviceSynchronize());
+    return GFFX_OK;
+}
 extern "C" void gffx_hip_free_host(void *p) { free(p); }
 
 // ------------------------------------------------------------------------------------ index

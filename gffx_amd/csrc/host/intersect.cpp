@@ -132,15 +132,19 @@ std::vector<Region> query_features(TreeIndexData &index_data, const std::vector<
 
 std::vector<uint32_t> query_unique_roots(TreeIndexData &index_data, const std::vector<Region> &regions,
                                          OverlapMode mode, bool invert, bool verbose, int device) {
+    StageTimer sub{verbose};
     index_data.ensure_device(device);
+    sub.lap("  index upload");
     if (verbose) std::fprintf(stderr, "[DEBUG] Querying %zu regions on HIP device %d\n", regions.size(), device);
     const std::vector<uint32_t> flat = flatten(regions);
     Batch b;
     if (gffx_hip_batch_create(index_data.device_index, regions.size(), &b.h) != GFFX_OK) hip_fail("batch_create");
+    sub.lap("  batch buffers");
     if (gffx_hip_batch_set_regions_host(b.h, flat.data(), regions.size()) != GFFX_OK) hip_fail("set_regions");
     if (gffx_hip_batch_run(b.h, static_cast<int>(mode), invert ? 1 : 0, GFFX_OUT_ROOT_BITMAP, GFFX_STRATEGY_AUTO) != GFFX_OK)
         hip_fail("batch_run");
     if (gffx_hip_batch_wait(b.h) != GFFX_OK) hip_fail("query_features");
+    sub.lap("  regions H2D + Join A kernel");
     const uint64_t n_roots = gffx_hip_index_n_roots(index_data.device_index);
     std::vector<uint64_t> words((n_roots + 63) / 64 + 1, 0);
     if (gffx_hip_batch_copy_root_bitmap(b.h, words.data(), words.size()) != GFFX_OK) hip_fail("copy_root_bitmap");

@@ -109,6 +109,9 @@ typedef struct gffx_hip_depth gffx_hip_depth;
 int gffx_hip_abi_version(void);
 /* number of visible HIP devices (0 when none / no driver); never fails */
 int gffx_hip_device_count(void);
+/* optional: pay the process's one-off HIP costs (runtime and context creation, code-object load) now -- a host
+ * can call it on a side thread while it still parses its inputs.  Nothing depends on it. */
+int gffx_hip_warmup(int device);
 /* thread-local, valid until the next failing call on this thread */
 const char *gffx_hip_last_error(void);
 
