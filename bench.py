@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--queries-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
-    ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused"])
+    ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused", "slots"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
     ap.add_argument("--no-offsets", action="store_true",
                     help="fused / partitioned strategy: do not write every region's segment offset")
@@ -206,7 +206,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     mode = {"contained": 0, "contains_region": 1, "overlap": 2}[args.mode]
-    strategy = {"auto": 0, "direct": 1, "sorted": 2, "fused": 3}[args.strategy]
+    strategy = {"auto": 0, "direct": 1, "sorted": 2, "fused": 3, "slots": 4}[args.strategy]
     out_flags = {"counts": engine.OUT_COUNTS, "fids": engine.OUT_FIDS, "triples": engine.OUT_TRIPLES}[args.out]
     if args.strategy != "direct" and args.out != "counts" and not args.no_offsets:
         out_flags |= engine.OUT_OFFSETS  # segments follow the order rounds / tiles were served: offsets are explicit

@@ -3,6 +3,7 @@
 // HBM layout of an index (uploaded once, immutable; gffx_device.hpp has the field meanings):
 //   start[R] u32, aux[R] uint4 {end, pmax_prev, skip, root_fid} 20 B/root, seqid after seqid, by start
 //   chr_meta[n_chr] uint4, bins[...] uint4                      per-seqid bin directory (direct / fused strategies)
+//   slot_meta[n_chr] uint4, slots[...] 32 B, spill[...] 16 B    per-seqid candidate lists (slots strategy, the default)
 //   cell_base / cell_tile / tile_meta / tile_aux / tile_bins    genome-window tile plan (partitioned strategy)
 // At GENCODE scale (63 k roots, 25 seqids) that is ~1.3 MB + ~2 MB of directory + ~0.2 MB of tile
 // plan: resident in every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and
@@ -17,6 +18,7 @@
 #include "gffx_device.hpp"
 #include "join_a_kernels.hpp"
 #include "join_fused_kernels.hpp"
+#include "join_slot_kernels.hpp"
 #include "partition_kernels.hpp"
 #include "tile_join_kernels.hpp"
 
@@ -79,6 +81,9 @@ struct gffx_hip_index {
     uint4 *d_aux = nullptr;
     uint4 *d_chr_meta = nullptr;
     uint4 *d_bins = nullptr;
+    uint4 *d_slot_meta = nullptr, *d_slots = nullptr, *d_spill = nullptr;  // slot index (join_slot_kernels.hpp)
+    uint32_t *d_slot_pos = nullptr;
+    uint64_t n_slots = 0, n_spill = 0;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
     uint32_t *d_cell_base = nullptr;
     uint16_t *d_cell_tile = nullptr;
@@ -96,6 +101,10 @@ struct gffx_hip_index {
         v.aux = d_aux;
         v.chr_meta = d_chr_meta;
         v.bins = d_bins;
+        v.slot_meta = d_slot_meta;
+        v.slots = d_slots;
+        v.spill = d_spill;
+        v.slot_pos = d_slot_pos;
         v.n_chr = n_chr;
         v.n_roots = n_roots;
         return v;
@@ -138,6 +147,9 @@ struct gffx_hip_batch {
     int cursor_phase = 0;
     int fused_phase = 0;            // which of d_status[2..3] the next fused pass uses as its pair cursor
     int fused_word = 2;             // ... and the one the last fused pass used
+    uint64_t slow_seen = 0;         // slots strategy: the device's slow-lane counter at the last wait
+    uint64_t slots_passes = 0;      // ... and the slot passes enqueued since
+    bool mostly_slow = false;       // ... > 1/4 of the regions took the slow lane: AUTO uses the sweep kernel
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
     uint32_t flags = 0;
@@ -253,6 +265,82 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         bins.push_back(make_uint4(hi, pmax_incl(hi - 1), 0xFFFFFFFFu, 0xFFFFFFFFu));
     }
 
+    // Slot index (gffx_device.hpp): ~GFFX_HIP_SLOTS_PER_ENTRY windows per entry, widened until the lists total
+    // <= 8 per entry (a seqid of chromosome-long intervals ends with one window).
+    std::vector<uint4> slot_meta(n_chr, make_uint4(0, 0, 0, 0)), slots, spill;
+    std::vector<uint32_t> slot_pos;
+    {
+        const uint64_t per_entry = (uint64_t)env_long("GFFX_HIP_SLOTS_PER_ENTRY", 1, 1, 16);
+        const uint64_t wmax_min = (uint64_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
+        std::vector<uint32_t> len, fill;
+        // widest region the lists answer: 16 Ki, but between a quarter of the window and four windows (a dense
+        // seqid has narrow windows; every extra window of wmax lengthens every list by the entries it holds)
+        auto slot_wmax = [&](uint32_t shift) {
+            const uint64_t w = 1ull << shift;
+            return std::max<uint64_t>(w >> 2, std::min<uint64_t>(wmax_min, w << 2));
+        };
+        for (uint32_t c = 0; c < n_chr; c++) {
+            const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+            if (hi == lo) continue;
+            const uint64_t max_end = std::max(h_aux[hi - 1].x, h_aux[hi - 1].y);
+            const uint64_t budget = std::max<uint64_t>(per_entry * (hi - lo), 16);
+            uint32_t shift = 0;
+            uint64_t wmax = 0, ns = 0;
+            for (;; shift++) {
+                wmax = slot_wmax(shift);
+                ns = ((max_end + wmax) >> shift) + 1;
+                if (ns > budget && shift < 40) continue;
+                uint64_t total = 0;  // list entries over all windows at this width
+                for (uint32_t i = lo; i < hi && total <= 8ull * (hi - lo) + 1024; i++)
+                    total += std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift) - ((uint64_t)h_start[i] >> shift) + 1;
+                if (total <= 8ull * (hi - lo) + 1024 || shift >= 40) break;
+            }
+            if (shift > 31) shift = 31, wmax = slot_wmax(31), ns = ((max_end + wmax) >> 31) + 1;
+            wmax = std::min<uint64_t>(wmax, 0xFFFFFFFFull);
+            if (slots.size() / 2 + ns >= 0xFFFFFFFFull) return fail(GFFX_E_INVALID, "index too large for the slot directory");
+            const uint32_t base = (uint32_t)(slots.size() / 2);
+            slot_meta[c] = make_uint4(base, (uint32_t)ns, shift, (uint32_t)wmax);
+            auto first_w = [&](uint32_t i) { return ((uint64_t)h_start[i] >> shift); };
+            auto last_w = [&](uint32_t i) { return std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift); };
+            len.assign(ns, 0);
+            for (uint32_t i = lo; i < hi; i++)
+                for (uint64_t b = first_w(i); b <= last_w(i); b++) len[b]++;
+            slots.resize(2 * ((size_t)base + ns), make_uint4(0, 0, 0xFFFFFFFFu, 0));
+            slot_pos.resize(2 * ((size_t)base + ns), 0);
+            fill.assign(ns, 0);
+            for (uint64_t b = 0; b < ns; b++) {
+                uint32_t n = len[b];
+                uint64_t off = 0;
+                if (n > kSlotMaxList || (n > 2 && spill.size() + (n - 2) >= (1ull << 24))) {
+                    n = 255;  // dense window (or the 24-bit spill offsets are used up): exact sweep
+                } else if (n > 2) {
+                    off = spill.size();
+                    spill.resize(spill.size() + (n - 2));
+                }
+                slots[2 * ((size_t)base + b)] = make_uint4(n | (uint32_t)(off << 8), 0, 0xFFFFFFFFu, 0);
+                slots[2 * ((size_t)base + b) + 1] = make_uint4(0, 0xFFFFFFFFu, 0, 0);
+            }
+            for (uint32_t i = lo; i < hi; i++) {  // ascending start: the lists come out sorted
+                for (uint64_t b = first_w(i); b <= last_w(i); b++) {
+                    uint4 &a = slots[2 * ((size_t)base + b)], &d = slots[2 * ((size_t)base + b) + 1];
+                    if ((a.x & 255u) == 255u) continue;
+                    const uint32_t j = fill[b]++;
+                    if (j == 0) {
+                        a.z = h_start[i], a.w = h_aux[i].x, d.x = h_aux[i].w;
+                        slot_pos[2 * ((size_t)base + b)] = i;
+                    } else if (j == 1) {
+                        d.y = h_start[i], d.z = h_aux[i].x, d.w = h_aux[i].w;
+                        slot_pos[2 * ((size_t)base + b) + 1] = i;
+                    } else {
+                        spill[(a.x >> 8) + j - 2] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
+                    }
+                }
+            }
+        }
+    }
+    ix->n_slots = slots.size() / 2;
+    ix->n_spill = spill.size();
+
     // Partitioned strategy: cells of 2^cshift bp (<= kMaxCells in total, >= 1 per seqid) merged into
     // tiles of <= kTileEntries entries; per tile a 1024-bin u16 directory over start (gffx_device.hpp).
     std::vector<uint32_t> cell_base(n_chr + 1, 0);
@@ -344,6 +432,8 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     int rc;
     if ((rc = dev_upload(&ix->d_start, h_start)) || (rc = dev_upload(&ix->d_aux, h_aux)) ||
         (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
+        (rc = dev_upload(&ix->d_slot_meta, slot_meta)) || (rc = dev_upload(&ix->d_slots, slots)) ||
+        (rc = dev_upload(&ix->d_spill, spill)) || (rc = dev_upload(&ix->d_slot_pos, slot_pos)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -363,6 +453,10 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_aux);
     (void)hipFree(ix->d_chr_meta);
     (void)hipFree(ix->d_bins);
+    (void)hipFree(ix->d_slot_meta);
+    (void)hipFree(ix->d_slots);
+    (void)hipFree(ix->d_spill);
+    (void)hipFree(ix->d_slot_pos);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);
     (void)hipFree(ix->d_tile_meta);
@@ -455,6 +549,7 @@ extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t
     b->q = QueryView{b->d_regions, nullptr, nullptr, nullptr};
     b->nq = nq;
     b->have_regions = true;
+    b->mostly_slow = false;
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -476,6 +571,7 @@ extern "C" int gffx_hip_batch_set_regions_soa_host(gffx_hip_batch *b, const uint
     b->q = QueryView{nullptr, dc, ds, de};
     b->nq = nq;
     b->have_regions = true;
+    b->mostly_slow = false;
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -490,6 +586,7 @@ extern "C" int gffx_hip_batch_set_regions_device(gffx_hip_batch *b, const uint32
     b->q = QueryView{nullptr, d_chr, d_start, d_end};
     b->nq = nq;
     b->have_regions = true;
+    b->mostly_slow = false;
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -770,16 +867,69 @@ static int run_fused(gffx_hip_batch *b) {
     return GFFX_OK;
 }
 
-// AUTO: the partitioned strategy pays for its extra pass from a few tens of thousands of queries on
+// ------------------------------------------------------------------------------------ slots strategy
+
+template <int MODE, bool INV, bool AOS, bool ML>
+static void launch_slots(gffx_hip_batch *b, uint32_t grid, const FusedOut &o, int vec_ok) {
+    const uint32_t lds = 80 + 4 * kSlotStage + 4 * kSlotExtras * kSlotThreads + (ML ? meta_bytes(b->ix) : 0);
+    hipLaunchKernelGGL((k_join_slots<MODE, INV, AOS, ML>), dim3(grid), dim3(kSlotThreads), lds, b->stream, b->ix->view(),
+                       b->q, (unsigned long long)b->nq, o, vec_ok);
+}
+
+static int run_slots(gffx_hip_batch *b) {
+    if (b->flags & GFFX_OUT_ROOT_BITMAP)
+        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
+    FusedOut o;
+    o.counts = b->d_counts;
+    o.offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr;
+    o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
+    o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
+    o.bitmap = (b->flags & GFFX_OUT_ROOT_BITMAP) ? b->d_bitmap : nullptr;
+    o.err = reinterpret_cast<uint32_t *>(b->d_status);  // err[1] (the word's upper half) counts slow-lane queries
+    b->fused_word = 2 + b->fused_phase;
+    o.pair_cursor = b->d_status + b->fused_word;
+    o.pair_cursor_next = b->d_status + 2 + (b->fused_phase ^ 1);
+    b->fused_phase ^= 1;
+    uint64_t cap = UINT64_MAX;
+    if (o.fids) cap = std::min(cap, b->cap_fids);
+    if (o.triples) cap = std::min(cap, b->cap_triples);
+    o.capacity = cap;
+    b->slots_passes++;
+    const uint64_t rounds = (b->nq + kSlotChunk - 1) / kSlotChunk;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", 1024, 1, 65535));
+    const bool aos = b->q.aos != nullptr;
+    const bool ml = meta_bytes(b->ix) <= kMetaLdsBytes;
+    // 16-byte query loads need 16-byte aligned columns (a caller's device pointers may not be)
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int vec_ok = aos ? al(b->q.aos) : (al(b->q.chr) && al(b->q.start) && al(b->q.end));
+    ProfEvent pe;
+    prof_begin(b, GFFX_K_SLOTS, &pe);
+#define GFFX_CASE2(M, I, A, L) \
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) launch_slots<M, I, A, L>(b, grid, o, vec_ok);
+#define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
+    GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
+    GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
+    GFFX_CASE(2, false, false) GFFX_CASE(2, false, true) GFFX_CASE(2, true, false) GFFX_CASE(2, true, true)
+#undef GFFX_CASE
+#undef GFFX_CASE2
+    prof_end(b, &pe);
+    GFFX_HIP_TRY(hipGetLastError());
+    return GFFX_OK;
+}
+
+static bool one_kernel(int strategy) { return strategy == GFFX_STRATEGY_FUSED || strategy == GFFX_STRATEGY_SLOTS; }
+
+// AUTO: the slot kernel, unless the last waited pass over these regions sent most of them down its slow lane
+// (wide queries / dense windows): then the sweep kernel, which interleaves those chains, serves the batch.
 static int pick_strategy(const gffx_hip_batch *b, int strategy) {
     const bool part_ok = b->ix->partition_ok && b->max_q < (1ull << 32);
     if (strategy == GFFX_STRATEGY_SORTED) return part_ok ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_DIRECT;
-    if (strategy == GFFX_STRATEGY_DIRECT || strategy == GFFX_STRATEGY_FUSED) return strategy;
-    // AUTO (GFFX_HIP_AUTO_STRATEGY overrides for experiments): one kernel beats two at every size measured
-    const long forced = env_long("GFFX_HIP_AUTO_STRATEGY", 0, 1, 3);
+    if (strategy != GFFX_STRATEGY_AUTO) return strategy;
+    // GFFX_HIP_AUTO_STRATEGY overrides for experiments
+    const long forced = env_long("GFFX_HIP_AUTO_STRATEGY", 0, 1, 4);
     if (forced == GFFX_STRATEGY_SORTED) return part_ok ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_FUSED;
     if (forced) return (int)forced;
-    return GFFX_STRATEGY_FUSED;
+    return b->mostly_slow ? GFFX_STRATEGY_FUSED : GFFX_STRATEGY_SLOTS;
 }
 
 extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags,
@@ -787,7 +937,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: batch is NULL");
     if (!b->have_regions) return fail(GFFX_E_STATE, "gffx_hip_batch_run: no regions set");
     if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad mode %d", mode);
-    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_FUSED)
+    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_SLOTS)
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad strategy %d", strategy);
     if (strategy == GFFX_STRATEGY_SORTED && (!b->ix->partition_ok || b->max_q >= (1ull << 32)))
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: the partitioned strategy needs <= %u seqids / genome cells "
@@ -820,7 +970,9 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want && (rc = grow(&b->d_fids, &b->cap_fids, want, 1))) return rc;
         if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want && (rc = grow(&b->d_triples, &b->cap_triples, want, 3)))
             return rc;
-        return b->strategy == GFFX_STRATEGY_SORTED ? run_partitioned(b) : run_fused(b);
+        return b->strategy == GFFX_STRATEGY_SORTED ? run_partitioned(b)
+               : b->strategy == GFFX_STRATEGY_SLOTS ? run_slots(b)
+                                                    : run_fused(b);
     }
     // contiguous chunk of queries per block, a multiple of the block size; <= 2048 blocks
     const uint64_t tiles = (nq + kJoinThreads - 1) / kJoinThreads;
@@ -871,7 +1023,7 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         b->waited = true;
         return GFFX_OK;
     }
-    const bool part = b->strategy == GFFX_STRATEGY_SORTED, fused = b->strategy == GFFX_STRATEGY_FUSED;
+    const bool part = b->strategy == GFFX_STRATEGY_SORTED, fused = one_kernel(b->strategy);
     // error word + the pair cursors in one copy; block sums of the direct strategy
     GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (!part && !fused)
@@ -881,9 +1033,17 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         // the flag is sticky on the device (kernels only ever set it): clear it for the next pass
         GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
         GFFX_HIP_TRY(hipDeviceSynchronize());
+        b->slow_seen = 0;
         return fail(GFFX_E_CHR_RANGE, "a query's chr is >= the index's seqid count %u "
                                       "(the reference panics here: commands/intersect.rs:117)",
                     b->ix->n_chr);
+    }
+    if (b->strategy == GFFX_STRATEGY_SLOTS) {  // slow-lane queries of the passes since the last wait
+        const uint64_t slow_now = b->h_status[0] >> 32;
+        const uint64_t passes = std::max<uint64_t>(b->slots_passes, 1);
+        b->mostly_slow = ((slow_now - b->slow_seen) & 0xFFFFFFFFull) / passes > b->nq / 4;
+        b->slow_seen = slow_now;
+        b->slots_passes = 0;
     }
     b->total = 0;
     if (part)
@@ -907,8 +1067,14 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     }
     if (replay) {
         // the partitioned strategy counts and emits in one kernel: the whole pass runs again
-        if ((rc = part ? run_partitioned(b) : fused ? run_fused(b) : enqueue_emit(b))) return rc;
+        if ((rc = part ? run_partitioned(b) : b->strategy == GFFX_STRATEGY_SLOTS ? run_slots(b) : fused ? run_fused(b) : enqueue_emit(b)))
+            return rc;
         if ((rc = gffx_hip_batch_sync(b))) return rc;
+        if (b->strategy == GFFX_STRATEGY_SLOTS) {  // the replay counted its slow-lane queries again: not news
+            GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            b->slow_seen = b->h_status[0] >> 32;
+            b->slots_passes = 0;
+        }
     }
     b->waited = true;
     return GFFX_OK;

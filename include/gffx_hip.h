@@ -80,13 +80,16 @@ enum gffx_out {
 };
 
 enum gffx_strategy {
-    GFFX_STRATEGY_AUTO = 0,   /* the engine picks (currently: fused; direct for tiny batches) */
+    GFFX_STRATEGY_AUTO = 0,   /* the engine picks: slots; fused for a batch of mostly wide regions */
     GFFX_STRATEGY_DIRECT = 1, /* queries in input order; bin directory + gathers from the L2-resident index */
     GFFX_STRATEGY_SORTED = 2, /* "partitioned": one-pass device radix partition of the batch by genome window,
                                  then a fused count+emit join served from LDS-staged index tiles */
-    GFFX_STRATEGY_FUSED = 3   /* queries in input order, ONE kernel: interleaved gathers from the L2-resident
+    GFFX_STRATEGY_FUSED = 3,  /* queries in input order, ONE kernel: interleaved gathers from the L2-resident
                                  index, count + emit per block round; counts / offsets in input order, pair
                                  segments in the order rounds reserve them (offsets explicit) */
+    GFFX_STRATEGY_SLOTS = 4   /* as FUSED, but over the slot index: one 32-byte gather per region answers the
+                                 usual case (precomputed candidate list of the window the region ends in);
+                                 wide regions and dense windows take the exact sweep in their lane */
 };
 
 enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
@@ -98,7 +101,8 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
     GFFX_K_UNPERMUTE = 5,
     GFFX_K_FUSED_DIRECT = 6,
     GFFX_K_DEPTH = 7,
-    GFFX_K__COUNT = 8
+    GFFX_K_SLOTS = 8,
+    GFFX_K__COUNT = 9
 };
 
 typedef struct gffx_hip_index gffx_hip_index;

@@ -13,7 +13,7 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 FLAGS = engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS
-STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED]
+STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_SLOTS]
 
 
 def _sorted_rows(t):
@@ -55,6 +55,23 @@ def _check(roots, regions, mode, invert, soa=False, strategy=engine.STRATEGY_AUT
         one_t, _ = oix.query_features(regions[qi:qi + 1], int(mode), invert)
         assert np.array_equal(_sorted_rows(seg), _sorted_rows(one_t))
     assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    # a root_fid-only pass (what bench.py and `depth` run: its own emit path in the one-kernel strategies):
+    # the (query, root_fid) pairs of EVERY query
+    b.run(mode, invert, engine.OUT_FIDS | engine.OUT_OFFSETS, strategy)
+    b.wait()
+    c2, off2, f2 = b.counts(), b.offsets(), b.fids()
+    assert np.array_equal(c2, want_c) and len(f2) == len(want_t)
+    wc = want_c.astype(np.int64)
+    qid = np.repeat(np.arange(len(regions), dtype=np.int64), wc)
+    within = np.arange(len(qid), dtype=np.int64) - np.repeat(np.cumsum(wc) - wc, wc)
+    got_pairs = np.stack([qid, f2[off2[:-1].astype(np.int64)[qid] + within].astype(np.int64)], axis=1)
+    by_chr = np.argsort(regions[:, 0], kind="stable")  # the oracle walks seqid after seqid, regions in input order
+    want_pairs = np.stack([np.repeat(by_chr, wc[by_chr]), want_t[:, 0].astype(np.int64)], axis=1)
+    order = lambda a: a[np.lexsort((a[:, 1], a[:, 0]))]  # noqa: E731
+    assert np.array_equal(order(got_pairs), order(want_pairs))
+    b.run(mode, invert, FLAGS, strategy)  # (back to the full pass for the records below; segment order is per pass)
+    b.wait()
+    off = b.offsets()
     # the same results as {input row, count, offset} records in emission order
     rows, rc, ro = b.query_records()
     assert np.array_equal(np.sort(rows), np.arange(len(regions), dtype=np.uint32))
@@ -319,7 +336,7 @@ def test_capacity_replay_and_reuse():
 
 
 @pytest.mark.parametrize("nq,strategy", [(1_000_000, st) for st in STRATEGIES] +
-                         [(10_000_000, engine.STRATEGY_FUSED), (12_500_000, engine.STRATEGY_SORTED)])
+                         [(10_000_000, engine.STRATEGY_FUSED), (10_000_000, engine.STRATEGY_SLOTS), (12_500_000, engine.STRATEGY_SORTED)])
 def test_full_size_c2_properties(nq, strategy):
     """BASELINE config sizes (configs[1]: 1 M regions x 63 k roots; configs[2]: 10 M; configs[3]: one GPU's 12.5 M
     share of 100 M): sampled oracle parity + size-independent properties (sum of counts == pairs; invert
@@ -347,3 +364,62 @@ def test_full_size_c2_properties(nq, strategy):
     for mode in OverlapMode:
         _, want_c = oix.query_features(regions[sel], int(mode), False)
         assert np.array_equal(res[(int(mode), False)][sel], want_c)
+
+
+@pytest.mark.parametrize("mode", list(OverlapMode))
+@pytest.mark.parametrize("invert", [False, True])
+def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert):
+    """The slot index answers regions of width <= wmax from a window's candidate list; everything else -- wide
+    regions, start >= end, windows with more than kSlotMaxList candidates -- walks the sweep in its lane.  A mix
+    of all of them in one batch, odd batch sizes (partial last thread / round), against the oracle."""
+    rng = np.random.default_rng(11)
+    roots = synth.gencode_like_roots(3000, seed=21, chroms=synth.SMALL2, fid_stride=5)
+    # a dense cluster: 60 short roots inside 20 kb of the first seqid, and 30 nested long ones over it
+    co, s, e, f = (roots[k].copy() for k in ("chr_offsets", "start", "end", "fid"))
+    n0 = int(co[1])
+    cs = np.sort(rng.integers(500_000, 520_000, 60)).astype(np.uint32)
+    ce = (cs + rng.integers(50, 3000, 60)).astype(np.uint32)
+    ls = np.sort(rng.integers(100_000, 500_000, 30)).astype(np.uint32)
+    le = (ls + rng.integers(400_000, 3_000_000, 30)).astype(np.uint32)
+    add_s, add_e = np.concatenate([cs, ls]), np.concatenate([ce, le])
+    s = np.concatenate([s[:n0], add_s, s[n0:]])
+    e = np.concatenate([e[:n0], add_e, e[n0:]])
+    f = np.concatenate([f[:n0], f.max() + 5 * np.arange(1, 91, dtype=np.uint32), f[n0:]])
+    co = co.copy()
+    co[1:] += 90
+    roots2 = dict(roots, chr_offsets=co, start=s, end=e, fid=f)
+    for nq in (1, 3, 2047, 2049, 7001):
+        regions = synth.synth_bed(nq, seed=nq, chroms=synth.SMALL2, width=(1, 9000), edge_frac=0.05, roots=roots2)
+        k = rng.random(nq)
+        wide = k < 0.15  # wider than any wmax
+        regions[wide, 2] = regions[wide, 1] + rng.integers(20_000, 5_000_000, int(wide.sum()))
+        flip = (k >= 0.15) & (k < 0.2)  # start >= end
+        regions[flip, 2] = regions[flip, 1] - np.minimum(regions[flip, 1], rng.integers(0, 3, int(flip.sum())))
+        dense = (k >= 0.2) & (k < 0.4)  # inside the cluster
+        regions[dense, 0] = 0
+        regions[dense, 1] = rng.integers(495_000, 525_000, int(dense.sum()))
+        regions[dense, 2] = regions[dense, 1] + rng.integers(1, 4000, int(dense.sum()))
+        _check(roots2, regions, mode, invert, soa=bool(nq & 1), strategy=engine.STRATEGY_SLOTS)
+
+
+def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
+    roots = synth.gencode_like_roots(150, seed=5, chroms=synth.SMALL2)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    wide = synth.synth_bed(5000, seed=1, chroms=synth.SMALL2, width=(200_000, 900_000))
+    narrow = synth.synth_bed(5000, seed=2, chroms=synth.SMALL2, width=(100, 5000))
+    b = engine.QueryBatch(ix, 5000)
+    for regions, want_second in ((wide, "k_join_fused"), (narrow, "k_join_slots")):
+        b.set_regions(regions)
+        _, want_c = oix.query_features(regions, 2, False)
+        used = []
+        for _ in range(2):
+            b.set_profiling(True)
+            b.reset_profile()
+            b.run(OverlapMode.Overlap, False, engine.OUT_FIDS | engine.OUT_OFFSETS)  # AUTO
+            b.wait()
+            b.set_profiling(False)
+            used.append([name for kid, name in engine.KERNEL_NAMES.items() if b.kernel_ms(kid)[1]])
+            assert np.array_equal(b.counts(), want_c)
+        assert used[0] == ["k_join_slots"] and used[1] == [want_second]
