@@ -869,11 +869,21 @@ static int run_fused(gffx_hip_batch *b) {
 
 // ------------------------------------------------------------------------------------ slots strategy
 
+template <int MODE, bool INV, bool AOS, bool ML, int OUT>
+static void launch_slots3(gffx_hip_batch *b, uint32_t grid, const FusedOut &o, int vec_ok, uint32_t lds) {
+    hipLaunchKernelGGL((k_join_slots<MODE, INV, AOS, ML, OUT>), dim3(grid), dim3(kSlotThreads), lds, b->stream, b->ix->view(),
+                       b->q, (unsigned long long)b->nq, o, vec_ok);
+}
+
 template <int MODE, bool INV, bool AOS, bool ML>
 static void launch_slots(gffx_hip_batch *b, uint32_t grid, const FusedOut &o, int vec_ok) {
     const uint32_t lds = 80 + 4 * kSlotStage + 4 * kSlotExtras * kSlotThreads + (ML ? meta_bytes(b->ix) : 0);
-    hipLaunchKernelGGL((k_join_slots<MODE, INV, AOS, ML>), dim3(grid), dim3(kSlotThreads), lds, b->stream, b->ix->view(),
-                       b->q, (unsigned long long)b->nq, o, vec_ok);
+    if (!o.fids && !o.triples && !o.bitmap)
+        launch_slots3<MODE, INV, AOS, ML, 0>(b, grid, o, vec_ok, lds);
+    else if (o.fids && !o.triples && !o.bitmap)
+        launch_slots3<MODE, INV, AOS, ML, 1>(b, grid, o, vec_ok, lds);
+    else
+        launch_slots3<MODE, INV, AOS, ML, 2>(b, grid, o, vec_ok, lds);
 }
 
 static int run_slots(gffx_hip_batch *b) {

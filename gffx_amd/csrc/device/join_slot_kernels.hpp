@@ -76,7 +76,8 @@ __device__ __forceinline__ void slot_slow(const IndexView &ix, uint32_t chr, uin
     for_each_kept<MODE, INVERT>(ix, ix.chr_meta[chr], qs, qe, f);
 }
 
-template <int MODE, bool INVERT, bool AOS, bool META_LDS>
+// OUT: 0 = counts (+ offsets) only, 1 = root_fids as the only pair output (bench / depth), 2 = anything (triples, bitmap)
+template <int MODE, bool INVERT, bool AOS, bool META_LDS, int OUT>
 __global__ __launch_bounds__(kSlotThreads, GFFX_SLOT_MIN_WAVES) void k_join_slots(IndexView ix, QueryView q, unsigned long long nq,
                                                                                    FusedOut out, int vec_ok) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(kSlotThreads, GFFX_SLOT_MIN_WAVES) void k_join_slot
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *out.pair_cursor_next = 0ull;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool want_pairs = out.fids || out.triples || out.bitmap;
-    const bool fids_only = out.fids && !out.triples && !out.bitmap;
+    constexpr bool want_pairs = OUT != 0;
+    constexpr bool fids_only = OUT == 1;
     bool bad = false;
     uint32_t n_slow = 0;
 
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(kSlotThreads, GFFX_SLOT_MIN_WAVES) void k_join_slot
     for (unsigned long long r = blockIdx.x; r < n_rounds; r += gridDim.x) {
         const unsigned long long i0 = r * kSlotChunk + 4ull * threadIdx.x;  // this thread's 4 consecutive queries
         if (r != blockIdx.x) load_round(r);
+        const uint32_t nv = i0 + 4 <= nq ? 4u : (i0 < nq ? (uint32_t)(nq - i0) : 0u);  // this thread's queries in the batch
         // ---- slot record (one 32-byte gather per query, all four in flight together)
         uint32_t kind[4];  // 0 nothing to do, 1 slot list, 2 slow (exact sweep in this lane)
         uint32_t sidx[4];
@@ -142,8 +144,9 @@ __global__ __launch_bounds__(kSlotThreads, GFFX_SLOT_MIN_WAVES) void k_join_slot
         for (int k = 0; k < 4; ++k) {
             kind[k] = 0;
             sidx[k] = 0;
-            h0[k] = h1[k] = make_uint4(0, 0, 0, 0);
-            if (i0 + k >= nq) continue;
+            h0[k] = h1[k] = make_uint4(0, 0, 0xFFFFFFFFu, 0);
+            h1[k].y = 0xFFFFFFFFu;
+            if ((uint32_t)k >= nv) continue;
             if (qc[k] >= ix.n_chr) {
                 bad = true;
                 continue;
@@ -190,10 +193,11 @@ __global__ __launch_bounds__(kSlotThreads, GFFX_SLOT_MIN_WAVES) void k_join_slot
             f0[k] = h1[k].x, f1[k] = h1[k].w, f2[k] = sp0[k].z, f3[k] = sp1[k].z;
             if (kind[k] == 1) {
                 uint32_t mk = 0;
-                if (n[k] > 0 && slot_test<MODE, INVERT>(h0[k].z, h0[k].w, qs[k], qe[k])) mk |= 1u;
-                if (n[k] > 1 && slot_test<MODE, INVERT>(h1[k].y, h1[k].z, qs[k], qe[k])) mk |= 2u;
-                if (n[k] > 2 && slot_test<MODE, INVERT>(sp0[k].x, sp0[k].y, qs[k], qe[k])) mk |= 4u;
-                if (n[k] > 3 && slot_test<MODE, INVERT>(sp1[k].x, sp1[k].y, qs[k], qe[k])) mk |= 8u;
+                // (an absent entry reads start = 0xFFFFFFFF: never < qe)
+                if (slot_test<MODE, INVERT>(h0[k].z, h0[k].w, qs[k], qe[k])) mk |= 1u;
+                if (slot_test<MODE, INVERT>(h1[k].y, h1[k].z, qs[k], qe[k])) mk |= 2u;
+                if (slot_test<MODE, INVERT>(sp0[k].x, sp0[k].y, qs[k], qe[k])) mk |= 4u;
+                if (slot_test<MODE, INVERT>(sp1[k].x, sp1[k].y, qs[k], qe[k])) mk |= 8u;
                 mask[k] = mk;
                 cnt[k] = __popc(mk);
             } else if (kind[k] == 2) {
@@ -289,7 +293,39 @@ __global__ __launch_bounds__(kSlotThreads, GFFX_SLOT_MIN_WAVES) void k_join_slot
         const unsigned long long seg = s_base[0];
         const bool staged = fids_only && btotal <= kSlotStage;  // block-uniform
         uint32_t xr = 0;  // read cursor into this thread's extras
-        if (want_pairs) {
+        if (OUT == 1 && staged) {  // the timed path: LDS positions are 32-bit, nothing but LDS traffic per kept pair
+            uint32_t lp = (uint32_t)(pos - seg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (cnt[k] == 0) continue;
+                if (kind[k] == 1) {
+                    const uint32_t m = mask[k];
+                    if (m & 1u) s_fids[lp] = f0[k];
+                    if (m & 2u) s_fids[lp + (m & 1u)] = f1[k];
+                    if (m & 4u) s_fids[lp + __popc(m & 3u)] = f2[k];
+                    if (m & 8u) s_fids[lp + __popc(m & 7u)] = f3[k];
+                    uint32_t e = lp + __popc(m);
+                    const uint32_t xk = (xc >> (4 * k)) & 15u;
+                    if (xf >> k & 1u) {  // did not fit the thread's LDS share: read entries 4.. again
+                        xr += xk;
+                        const uint32_t off = ix.slots[2ull * sidx[k]].x >> 8;
+                        for (uint32_t j = 4; j < n[k]; ++j) {
+                            const uint4 x = ix.spill[off + j - 2];
+                            if (slot_test<MODE, INVERT>(x.x, x.y, qs[k], qe[k])) s_fids[e++] = x.z;
+                        }
+                    } else {
+                        for (uint32_t x = 0; x < xk; ++x) s_fids[e++] = s_extra[xr++];
+                    }
+                } else {  // slow lane: walk the chain again
+                    uint32_t e = lp;
+                    slot_slow<MODE, INVERT>(ix, qc[k], qs[k], qe[k], [&](uint32_t, uint32_t, const uint4 &a) {
+                        s_fids[e++] = a.w;
+                        return true;
+                    });
+                }
+                lp += cnt[k];
+            }
+        } else if (want_pairs) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 unsigned long long o = pos;
