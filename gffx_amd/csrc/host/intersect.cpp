@@ -325,9 +325,17 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
     }
 
     OutFile out(output_path);
-    for (size_t i = 0; i < n_lines; ++i)
-        if (keep[i] && std::fwrite(gff.data() + ls[i], 1, le[i] - ls[i], out.f) != le[i] - ls[i])
-            throw Error("write failed");
+    for (size_t i = 0; i < n_lines;) {  // kept lines that touch in the file leave as one write
+        if (!keep[i]) {
+            ++i;
+            continue;
+        }
+        size_t j = i + 1;
+        while (j < n_lines && keep[j] && ls[j] == le[j - 1]) ++j;
+        const uint64_t a = ls[i], z = le[j - 1];
+        if (std::fwrite(gff.data() + a, 1, z - a, out.f) != z - a) throw Error("write failed");
+        i = j;
+    }
     if (verbose) std::fprintf(stderr, "[INFO] match-only by coords completed; minput blocks %zu\n", blocks.size());
 }
 
