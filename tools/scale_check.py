@@ -1,5 +1,5 @@
 """Scale check on the GPU box (development tool): a batch far larger than the bench's (default 50 M regions) through the
-fused and the partitioned strategy (the latter in several sub-batches: its tile regions exceed the workspace budget),
+slots, the fused and the partitioned strategy (the latter in several sub-batches: its tile regions exceed the workspace budget),
 with size-independent properties and sampled oracle parity.  python tools/scale_check.py [n_regions]"""
 import os, sys, time
 import numpy as np
@@ -19,7 +19,8 @@ sel = np.random.default_rng(1).choice(n, size=20000, replace=False)
 want_t, want_c = oix.query_features(regions[sel], 2, False)
 b = engine.QueryBatch(ix, n)
 b.set_regions(regions)
-for name, strat, flags in (("fused", engine.STRATEGY_FUSED, engine.OUT_FIDS | engine.OUT_OFFSETS),
+for name, strat, flags in (("slots", engine.STRATEGY_SLOTS, engine.OUT_FIDS | engine.OUT_OFFSETS),
+                           ("fused", engine.STRATEGY_FUSED, engine.OUT_FIDS | engine.OUT_OFFSETS),
                            ("partitioned", engine.STRATEGY_SORTED, engine.OUT_FIDS | engine.OUT_OFFSETS)):
     t0 = time.perf_counter(); b.run(2, False, flags, strat); b.wait(); dt = time.perf_counter() - t0
     t1 = time.perf_counter(); b.run(2, False, flags, strat); b.wait(); dt2 = time.perf_counter() - t1
