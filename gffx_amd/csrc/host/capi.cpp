@@ -59,7 +59,7 @@ extern "C" int gffx_host_parse_bed_file(const char *gff, const char *bed, uint32
                                         uint64_t *n_regions, char *err, size_t errlen) {
     return guard(err, errlen, [&] {
         const auto sqs = index_loader::load_sqs(gff);
-        const auto r = commands::intersect::parse_bed_file(bed, sqs.second);
+        const auto r = commands::intersect::parse_bed_file(bed, sqs.second, 5);  // (5 host threads once the file is > 1 MiB)
         std::vector<uint32_t> flat;
         flat.reserve(r.size() * 3);
         for (const auto &[c, s, e] : r) {
@@ -132,7 +132,7 @@ extern "C" int gffx_host_depth_parse_bed(const char *gff, const char *bed, uint3
                                          char *err, size_t errlen) {
     return guard(err, errlen, [&] {
         const auto sqs = index_loader::load_sqs(gff);
-        const auto r = commands::depth::parse_bed_rows(bed, sqs.second);
+        const auto r = commands::depth::parse_bed_rows(bed, sqs.second, 5);
         std::vector<uint32_t> flat;
         flat.reserve(r.size() * 3);
         for (const auto &[c, s, e] : r) {

@@ -76,7 +76,7 @@ void run(const CoverageArgs &args) {
         throw Error("BAM/SAM/CRAM sources need htslib, which this build does not carry; use a .bed source");
     if (ext != "bed")
         throw Error("Unsupported file type: \"" + args.source + "\". Expected .bam/.sam/.cram or .bed");  // :535-540
-    const std::vector<intersect::Region> regions = depth::parse_bed_rows(args.source, index_data.seqid_to_num);  // :230-256
+    const std::vector<intersect::Region> regions = depth::parse_bed_rows(args.source, index_data.seqid_to_num, args.threads);  // :230-256
     if (verbose) std::fprintf(stderr, "[INFO] %zu BED rows kept\n", regions.size());
     timer.lap("Loading index + parsing BED");
 

@@ -9,6 +9,7 @@
 // htslib, which this build does not carry: they are refused with a clear message.
 #include <algorithm>
 #include <cstdio>
+#include <thread>
 
 #include "gffx.hpp"
 
@@ -43,20 +44,14 @@ std::string_view trim_end_unicode_ws(std::string_view s) {  // str::trim_end()
 
 // depth.rs:450-495: lines are cut at '\n' and keep it; fields split on tab or space, empty ones dropped;
 // fewer than 3 fields, '#', a non-UTF-8 / unparsable field, s >= e or an unknown seqid drop the row.
-std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
-                                              const std::unordered_map<std::string, uint32_t> &seqid_to_num) {
-    MappedFile f;
-    try {
-        f = MappedFile(bed_path);
-    } catch (const Error &) {
-        throw Error("No such file or directory (os error 2)");  // File::open(bed_path)? (depth.rs:441)
-    }
-    const std::string_view d = f.view();
-    std::vector<intersect::Region> out;
-    size_t pos = 0;
-    while (pos < d.size()) {
+namespace {
+void parse_rows_chunk(std::string_view d, size_t pos, size_t z, const std::unordered_map<std::string, uint32_t> &seqid_to_num,
+                      std::vector<intersect::Region> &out) {
+    std::string key;
+    const std::pair<const std::string, uint32_t> *hit = nullptr;  // the seqid of the previous row, usually this row's too
+    while (pos < z) {
         size_t nl = d.find('\n', pos);
-        const size_t end = nl == std::string_view::npos ? d.size() : nl + 1;
+        const size_t end = (nl == std::string_view::npos || nl >= z) ? z : nl + 1;
         const std::string_view line = d.substr(pos, end - pos);
         pos = end;
         if (line.empty() || line[0] == '#') continue;
@@ -78,10 +73,41 @@ std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
         const auto s = parse_u32_rust(fld[1]);
         const auto e = parse_u32_rust(trim_end_unicode_ws(fld[2]));
         if (!s || !e || *s >= *e) continue;
-        const auto it = seqid_to_num.find(std::string(fld[0]));
-        if (it == seqid_to_num.end()) continue;
-        out.emplace_back(it->second, *s, *e);
+        if (!hit || hit->first != fld[0]) {
+            key.assign(fld[0]);
+            const auto it = seqid_to_num.find(key);
+            if (it == seqid_to_num.end()) continue;
+            hit = &*it;
+        }
+        out.emplace_back(hit->second, *s, *e);
     }
+}
+}  // namespace
+
+// (cut at line starts and parsed on `threads` host threads; the rows keep the file's order)
+std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
+                                              const std::unordered_map<std::string, uint32_t> &seqid_to_num, size_t threads) {
+    MappedFile f;
+    try {
+        f = MappedFile(bed_path);
+    } catch (const Error &) {
+        throw Error("No such file or directory (os error 2)");  // File::open(bed_path)? (depth.rs:441)
+    }
+    const std::string_view d = f.view();
+    const size_t parts = d.size() < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(threads, 64));
+    const std::vector<size_t> cut = intersect::line_chunks(d, parts);
+    const size_t n = cut.size() - 1;
+    std::vector<std::vector<intersect::Region>> part(n);
+    std::vector<std::thread> pool;
+    for (size_t c = 1; c < n; ++c) pool.emplace_back([&, c] { parse_rows_chunk(d, cut[c], cut[c + 1], seqid_to_num, part[c]); });
+    parse_rows_chunk(d, cut[0], cut[1], seqid_to_num, part[0]);
+    for (auto &t : pool) t.join();
+    if (n == 1) return std::move(part[0]);
+    std::vector<intersect::Region> out;
+    size_t total = 0;
+    for (const auto &v : part) total += v.size();
+    out.reserve(total);
+    for (const auto &v : part) out.insert(out.end(), v.begin(), v.end());
     return out;
 }
 
@@ -110,7 +136,7 @@ void run(const DepthArgs &args) {
     if (ext != "bed")
         throw Error("Unsupported file type: \"" + args.source + "\". Expected .bam/.sam/.cram or .bed");  // :597-600
     timer.lap("Loading index");
-    const std::vector<intersect::Region> regions = parse_bed_rows(args.source, index_data.seqid_to_num);
+    const std::vector<intersect::Region> regions = parse_bed_rows(args.source, index_data.seqid_to_num, args.threads);
     if (verbose) std::fprintf(stderr, "[INFO] %zu BED rows kept\n", regions.size());
     timer.lap("Parsing BED");
 

@@ -145,8 +145,9 @@ using Region = std::tuple<uint32_t, uint32_t, uint32_t>;  // (chr, start, end)
 
 Region parse_region(const std::string &region, const std::unordered_map<std::string, uint32_t> &seqid_map,
                     const CommonArgs &common);  // intersect.rs:172-198
-std::vector<Region> parse_bed_file(const std::string &bed_path,
-                                   const std::unordered_map<std::string, uint32_t> &seqid_map);  // :201-230
+std::vector<Region> parse_bed_file(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                                   size_t threads = 1);  // :201-230
+std::vector<size_t> line_chunks(std::string_view d, size_t parts);  // cut points at line starts (parallel parsers)
 
 // intersect.rs:105-169 on the device: one (root_fid, iv.start, iv.end) per kept pair.
 std::vector<Region> query_features(TreeIndexData &index_data, const std::vector<Region> &regions,
@@ -188,7 +189,7 @@ struct DepthArgs {  // depth.rs:34-72
 
 // depth.rs:450-495: the rows `depth` keeps from a BED file (its rules differ from intersect's parser)
 std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
-                                              const std::unordered_map<std::string, uint32_t> &seqid_to_num);
+                                              const std::unordered_map<std::string, uint32_t> &seqid_to_num, size_t threads = 1);
 struct BlockTable {  // the device line table (include/gffx_hip.h "gffx depth") + what names the groups
     std::vector<uint64_t> block_line_off{0};
     std::vector<uint32_t> line_start, line_end, line_group, block_of_fid;

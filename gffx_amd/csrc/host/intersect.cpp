@@ -3,6 +3,7 @@
 // include/gffx_hip.h; everything else here is the reference's host logic: region/BED parsing,
 // root -> byte-block lookup, line splitting, type filter, ordered copy-out.
 #include <algorithm>
+#include <exception>
 #include <chrono>
 #include <atomic>
 #include <cstdio>
@@ -79,15 +80,29 @@ Region parse_region(const std::string &region, const std::unordered_map<std::str
 
 // intersect.rs:201-230.  Rows with an unknown seqid or fewer than three fields are skipped;
 // a row whose coordinates do not parse aborts the run; start >= end rows are kept as they are.
-std::vector<Region> parse_bed_file(const std::string &bed_path,
-                                   const std::unordered_map<std::string, uint32_t> &seqid_map) {
-    MappedFile f(bed_path);
-    const std::string_view d = f.view();
-    std::vector<Region> regions;
-    size_t a = 0;
-    while (a <= d.size()) {
-        size_t nl = a < d.size() ? d.find('\n', a) : std::string_view::npos;
-        if (nl == std::string_view::npos) nl = d.size();
+// Cut [0, size) at line starts into about `parts` pieces (the file's lines, each piece whole lines).
+std::vector<size_t> line_chunks(std::string_view d, size_t parts) {
+    std::vector<size_t> cut{0};
+    for (size_t p = 1; p < parts; ++p) {
+        size_t at = d.size() * p / parts;
+        if (at <= cut.back()) continue;
+        const size_t nl = d.find('\n', at);
+        if (nl == std::string_view::npos) break;
+        if (nl + 1 > cut.back() && nl + 1 < d.size()) cut.push_back(nl + 1);
+    }
+    cut.push_back(d.size());
+    return cut;
+}
+
+namespace {
+// intersect.rs:201-230 on the lines of d[a, z); z is a line start or the end of the file
+void parse_bed_chunk(std::string_view d, size_t a, size_t z, bool last, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                     std::vector<Region> &regions) {
+    std::string key;
+    const std::pair<const std::string, uint32_t> *hit = nullptr;  // the seqid of the previous row, usually this row's too
+    while (last ? a <= z : a < z) {
+        size_t nl = a < z ? d.find('\n', a) : std::string_view::npos;
+        if (nl == std::string_view::npos || nl >= z) nl = z;
         const std::string_view line = d.substr(a, nl - a);
         a = nl + 1;
         if (line.empty() || line[0] == '#') continue;
@@ -104,13 +119,50 @@ std::vector<Region> parse_bed_file(const std::string &bed_path,
             i = j;
         }
         if (nf < 3) continue;
-        const auto it = seqid_map.find(std::string(field[0]));
-        if (it == seqid_map.end()) continue;
+        if (!hit || hit->first != field[0]) {
+            key.assign(field[0]);
+            const auto it = seqid_map.find(key);
+            if (it == seqid_map.end()) continue;
+            hit = &*it;
+        }
         const auto s = parse_u32_rust(field[1]);  // lexical_core::parse::<u32>
         const auto e = parse_u32_rust(field[2]);
         if (!s || !e) throw Error("lexical parse error: invalid BED coordinate in \"" + std::string(line) + "\"");
-        regions.emplace_back(it->second, *s, *e);
+        regions.emplace_back(hit->second, *s, *e);
     }
+}
+}  // namespace
+
+// The file is cut at line starts and parsed on `threads` host threads; rows keep the file's order and the error
+// reported is the first one in file order, as in the serial loop of the reference.
+std::vector<Region> parse_bed_file(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                                   size_t threads) {
+    MappedFile f(bed_path);
+    const std::string_view d = f.view();
+    const size_t parts = d.size() < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(threads, 64));
+    const std::vector<size_t> cut = line_chunks(d, parts);
+    const size_t n = cut.size() - 1;
+    std::vector<std::vector<Region>> out(n);
+    std::vector<std::exception_ptr> err(n);
+    auto work = [&](size_t c) {
+        try {
+            parse_bed_chunk(d, cut[c], cut[c + 1], c + 1 == n, seqid_map, out[c]);
+        } catch (...) {
+            err[c] = std::current_exception();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t c = 1; c < n; ++c) pool.emplace_back(work, c);
+    work(0);
+    for (auto &t : pool) t.join();
+    for (size_t c = 0; c < n; ++c)
+        if (err[c]) std::rethrow_exception(err[c]);
+    if (n == 1) return std::move(out[0]);
+    size_t total = 0;
+    for (const auto &v : out) total += v.size();
+    std::vector<Region> regions;
+    regions.reserve(total);
+    for (const auto &v : out) regions.insert(regions.end(), v.begin(), v.end());
     return regions;
 }
 
@@ -354,7 +406,7 @@ void run(const IntersectArgs &args) {
     timer.lap("Loading tree index");
     std::vector<Region> regions;
     if (args.bed)
-        regions = parse_bed_file(*args.bed, index_data.seqid_to_num);
+        regions = parse_bed_file(*args.bed, index_data.seqid_to_num, args.common.effective_threads());
     else if (args.region)
         regions.push_back(parse_region(*args.region, index_data.seqid_to_num, args.common));
     else

@@ -277,3 +277,41 @@ def test_cli_fails_loudly_without_a_gpu(tmp_path):
     assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
     r = subprocess.run([GFFX, "intersect", "-i", gff, "-r", "chr1:1-2000000"], capture_output=True)
     assert r.returncode == 1 and b"no HIP device" in r.stderr and r.stdout == b""
+
+
+def test_bed_parsers_on_a_large_file_take_the_chunked_path(host, tmp_path, monkeypatch):
+    """> 1 MiB of BED text: both parsers cut the file at line starts and parse on several host threads.  Rows keep the
+    file's order, junk rows are skipped as in the serial loops, and intersect's parser reports the FIRST bad row."""
+    monkeypatch.setenv("GFFX_TREE_INDEX", "gof")
+    gff, roots = _make_gff(tmp_path, 6)
+    assert _build(host, gff)[0] == 0
+    oix = ob.OracleIndex.load(gff)
+    rng = np.random.default_rng(8)
+    rows = synth.synth_bed(90_000, seed=4, chroms=synth.SMALL2, width=(1, 50000), edge_frac=0.05, roots=roots)
+    junk = ["#c\n", "\n", "chrUn\t5\t9\n", "chr1 7\n", "chr2   10 \t 20  extra\n", "chr1\t+5\t9\r\n", "chr1\t9\t9\n"]
+    bed = str(tmp_path / "big.bed")
+    with open(bed, "w") as f:
+        for i, (c, s, e) in enumerate(rows.tolist()):
+            if rng.random() < 0.01:
+                f.write(junk[int(rng.integers(len(junk)))])
+            f.write("%s\t%d\t%d\tname%d\n" % (("chr1", "chr2")[c], s, e, i))
+        f.write("chr2\t7\t3")  # no trailing newline
+    assert os.path.getsize(bed) > (1 << 20)
+    e = _err()
+    pr, nr = u32p(), C.c_uint64()
+    assert host.gffx_host_parse_bed_file(gff.encode(), bed.encode(), C.byref(pr), C.byref(nr), e, len(e)) == 0, e.value
+    got = np.ctypeslib.as_array(pr, shape=(max(nr.value, 1), 3))[: nr.value].copy()
+    host.gffx_host_free(pr)
+    assert len(got) > 90_000 and np.array_equal(got, oix.parse_bed_file(bed))
+    host.gffx_host_depth_parse_bed.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(u32p), u64p, C.c_char_p, C.c_size_t]
+    assert host.gffx_host_depth_parse_bed(gff.encode(), bed.encode(), C.byref(pr), C.byref(nr), e, len(e)) == 0, e.value
+    got = np.ctypeslib.as_array(pr, shape=(max(nr.value, 1), 3))[: nr.value].copy()
+    host.gffx_host_free(pr)
+    assert np.array_equal(got, oix.depth_parse_bed(bed))
+    # two bad rows in different chunks: the message names the first one
+    text = open(bed).read().split("\n")
+    text[len(text) // 5] = "chr1\tfirstbad\t5"
+    text[4 * len(text) // 5] = "chr1\tsecondbad\t5"
+    open(bed, "w").write("\n".join(text))
+    assert host.gffx_host_parse_bed_file(gff.encode(), bed.encode(), C.byref(pr), C.byref(nr), e, len(e)) == -1
+    assert b"firstbad" in e.value and b"secondbad" not in e.value
