@@ -210,23 +210,24 @@ void run(const CoverageArgs &args) {
                 r.b += breadth[g];
             }
         }
-        char num[64];
-        for (uint32_t i : order) {  // coverage.rs:465-473
+        append_rows_parallel(out, order.size(), args.threads, [&](size_t k, std::string &o) {  // coverage.rs:465-473
+            const uint32_t i = order[k];
             const Row &r = rows[i];
             const uint64_t length = r.e > r.s ? r.e - r.s : 0;
             const double fraction = length > 0 ? static_cast<double>(r.b) / static_cast<double>(length) : 0.0;
-            out += t.id(i);
-            out.push_back('\t');
-            out += *r.chrom;
-            out.push_back('\t');
-            out += std::to_string(r.s);
-            out.push_back('\t');
-            out += std::to_string(r.e);
-            out.push_back('\t');
-            out += std::to_string(r.b);
+            char num[64];
+            o += t.id(i);
+            o.push_back('\t');
+            o += *r.chrom;
+            o.push_back('\t');
+            o += std::to_string(r.s);
+            o.push_back('\t');
+            o += std::to_string(r.e);
+            o.push_back('\t');
+            o += std::to_string(r.b);
             std::snprintf(num, sizeof num, "\t%.6f\n", fraction);
-            out += num;
-        }
+            o += num;
+        });
         written = order.size();
     }
     if (args.output) {

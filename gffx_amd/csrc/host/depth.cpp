@@ -211,19 +211,20 @@ void run(const DepthArgs &args) {
     }
     // depth.rs:515-546 write_depth_results (rows in first-contribution order; the reference's is a hash walk)
     std::string out = "id\tchr\tstart\tend\tdepth\n";
-    for (uint32_t i : order) {
+    append_rows_parallel(out, order.size(), args.threads, [&](size_t k, std::string &o) {
+        const uint32_t i = order[k];
         const Row &r = rows[i];
-        out += t.id(i);
-        out.push_back('\t');
-        out += *r.chrom;
-        out.push_back('\t');
-        out += std::to_string(r.s == 0xFFFFFFFFu ? 0u : r.s);
-        out.push_back('\t');
-        out += std::to_string(r.e);
-        out.push_back('\t');
-        out += std::to_string(r.d);
-        out.push_back('\n');
-    }
+        o += t.id(i);
+        o.push_back('\t');
+        o += *r.chrom;
+        o.push_back('\t');
+        o += std::to_string(r.s == 0xFFFFFFFFu ? 0u : r.s);
+        o.push_back('\t');
+        o += std::to_string(r.e);
+        o.push_back('\t');
+        o += std::to_string(r.d);
+        o.push_back('\n');
+    });
     if (args.output) {
         write_whole_file(*args.output, out);
     } else {

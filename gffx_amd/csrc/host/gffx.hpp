@@ -10,12 +10,14 @@
 //   gffx::commands::coverage::{CoverageArgs, run}                                commands/coverage.rs (BED source)
 // Compute (Join A, Join B) goes through include/gffx_hip.h only; there is no CPU join here.
 #pragma once
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <optional>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -44,6 +46,25 @@ struct StageTimer {
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
 };
+
+// Text rows 0..n-1 formatted on `threads` host threads (contiguous shares, concatenated in order) and appended to out
+template <typename F>
+void append_rows_parallel(std::string &out, size_t n, size_t threads, F &&format_row) {
+    const size_t parts = n < 20000 ? 1 : std::max<size_t>(1, std::min<size_t>(threads, 64));
+    std::vector<std::string> piece(parts);
+    auto work = [&](size_t p) {
+        std::string &s = piece[p];
+        for (size_t i = n * p / parts; i < n * (p + 1) / parts; ++i) format_row(i, s);
+    };
+    std::vector<std::thread> pool;
+    for (size_t p = 1; p < parts; ++p) pool.emplace_back(work, p);
+    work(0);
+    for (auto &t : pool) t.join();
+    size_t total = out.size();
+    for (const auto &s : piece) total += s.size();
+    out.reserve(total);
+    for (const auto &s : piece) out += s;
+}
 
 // ---- utils/common.rs -------------------------------------------------------------------------
 struct CommonArgs {  // common.rs:17-52

@@ -126,3 +126,25 @@ def test_coverage_cli_empty_bed_writes_the_header_only(tmp_path):
     open(bed, "w").write("# nothing\n")
     r = subprocess.run([GFFX, "coverage", "-i", gff, "-s", bed], capture_output=True)
     assert r.returncode == 0 and r.stdout == b"id\tchr\tstart\tend\tbreadth\tfraction\n"
+
+
+def test_depth_and_coverage_cli_large_outputs_equal_the_oracle(tmp_path):
+    """> 20 000 output rows and > 1 MiB of BED: the chunked BED parsers and the threaded row writers are on the path."""
+    roots = synth.gencode_like_roots(2500, seed=12, chroms=synth.SMALL2)
+    gff = str(tmp_path / "s.gff")
+    synth.write_gff3(gff, roots, seed=12, quirks=True)
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    regions = synth.synth_bed(60000, seed=13, chroms=synth.SMALL2, width=(1, 3000), edge_frac=0.05, roots=roots)
+    bed = str(tmp_path / "q.bed")
+    synth.write_bed(bed, regions, [n for n, _ in synth.SMALL2], extra_lines=["# header\n", "chrZ\t1\t2\n", "chr1\t7\n"])
+    assert os.path.getsize(bed) > (1 << 20)
+    for cmd, run, header in (("coverage", ob.coverage_run, b"id\tchr\tstart\tend\tbreadth\tfraction"),
+                             ("depth", ob.depth_run, b"id\tchr\tstart\tend\tdepth")):
+        want, out = str(tmp_path / (cmd + ".want")), str(tmp_path / (cmd + ".got"))
+        rc, msg = run(gff, bed, want)
+        assert rc == 0, msg
+        r = subprocess.run([GFFX, cmd, "-i", gff, "-s", bed, "-o", out], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        got_l, want_l = open(out, "rb").read().split(b"\n"), open(want, "rb").read().split(b"\n")
+        assert got_l[0] == want_l[0] == header and len(want_l) > 20002
+        assert sorted(got_l[1:]) == sorted(want_l[1:])
