@@ -95,8 +95,10 @@ class TreeIndexData:
 
     def sorted_fids(self) -> np.ndarray:
         n = self.n_roots
+        if n == 0:  # (an index without roots has no array behind the pointer)
+            return np.zeros(0, dtype=np.uint32)
         ptr = lib().gffx_hip_index_sorted_fids(self._h)
-        return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].copy()
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
 
 
 class QueryBatch:

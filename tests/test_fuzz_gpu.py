@@ -1,0 +1,17 @@
+"""A short run of tools/fuzz_parity.py (randomized differential test of Join A: every strategy x mode x invert x output
+set against the oracle on random index shapes and region mixes); the long campaigns are run by hand on the GPU box."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_parity_short(seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "25", str(seed)], cwd=ROOT,
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -1,0 +1,94 @@
+"""Development tool (GPU box): randomized differential test of Join A -- every strategy x mode x invert against the
+oracle on random index shapes (sparse / dense / nested / duplicate intervals, tiny and u32-wide coordinates, empty
+seqids, many seqids) and random region mixes (narrow, wide, empty-width, reversed, out-of-range positions).
+python tools/fuzz_parity.py [iterations] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from gffx_amd import engine
+from oracle import binding as ob
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+STRATS = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_SLOTS]
+t0 = time.time()
+n_checks = 0
+for it in range(iters):
+    n_chr = int(rng.choice([1, 2, 3, 7, 40, 300]))
+    span = int(rng.choice([200, 5_000, 1_000_000, 250_000_000, 0xFFFFFF00]))
+    per = rng.choice([0, 1, 2, 10, 200, 3000], size=n_chr, p=[.1, .1, .1, .3, .3, .1])
+    if n_chr > 50:
+        per = np.minimum(per, 50)
+    co = np.concatenate([[0], np.cumsum(per)]).astype(np.uint32)
+    R = int(co[-1])
+    shape = rng.choice(["short", "mixed", "nested", "dupes"])
+    s = rng.integers(0, span, R, dtype=np.int64)
+    if shape == "short":
+        ln = rng.integers(1, max(2, span // 2000 + 2), R)
+    elif shape == "mixed":
+        ln = np.where(rng.random(R) < 0.1, rng.integers(1, span // 2 + 2, R), rng.integers(1, max(2, span // 500 + 2), R))
+    elif shape == "nested":
+        s = np.sort(s)
+        ln = rng.integers(1, span, R) // (1 + np.arange(R) % 7)
+        ln = np.maximum(ln, 1)
+    else:
+        s = rng.choice(s[: max(1, R // 5)] if R else s, R) if R else s
+        ln = rng.choice([1, 10, 1000], R)
+    e = np.minimum(s + ln, 0xFFFFFFFF)
+    s = np.minimum(s, e - 1).clip(0)
+    f = rng.permutation(R).astype(np.uint32) * 3 + 1
+    if R and rng.random() < 0.3:
+        f[rng.integers(0, R, max(1, R // 10))] = f[0]  # duplicate fids
+    s, e = s.astype(np.uint32), e.astype(np.uint32)
+    nq = int(rng.choice([1, 5, 63, 64, 65, 2047, 2048, 2049, 6000]))
+    qc = rng.integers(0, n_chr, nq).astype(np.uint32)
+    qs = rng.integers(0, min(span + span // 10 + 2, 0xFFFFFFFF), nq, dtype=np.int64)
+    kind = rng.random(nq)
+    w = np.where(kind < 0.6, rng.integers(1, max(2, span // 3000 + 2), nq),
+                 np.where(kind < 0.8, rng.integers(1, span + 2, nq), np.where(kind < 0.9, 0, -rng.integers(1, 50, nq))))
+    qe = np.clip(qs + w, 0, 0xFFFFFFFF)
+    if R and rng.random() < 0.5:  # regions touching interval boundaries exactly
+        pick = rng.integers(0, R, nq // 4 + 1)
+        qs[: len(pick)] = s[pick][: nq]
+        qe[: len(pick)] = e[pick][: nq]
+        c_of = np.searchsorted(co, pick, side="right") - 1
+        qc[: len(pick)] = c_of[: nq]
+    regions = np.stack([qc, qs.astype(np.uint32), qe.astype(np.uint32)], axis=1)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, nq)
+    b.set_regions(regions) if it & 1 else b.set_regions_soa(regions[:, 0], regions[:, 1], regions[:, 2])
+    by_chr = np.argsort(regions[:, 0], kind="stable")
+    for mode in (0, 1, 2):
+        for inv in (False, True):
+            want_t, want_c = oix.query_features(regions, mode, inv)
+            wc = want_c.astype(np.int64)
+            want_pairs = np.stack([np.repeat(by_chr, wc[by_chr]), want_t[:, 0].astype(np.int64)], axis=1)
+            want_pairs = want_pairs[np.lexsort((want_pairs[:, 1], want_pairs[:, 0]))]
+            qid = np.repeat(np.arange(nq, dtype=np.int64), wc)
+            within = np.arange(len(qid), dtype=np.int64) - np.repeat(np.cumsum(wc) - wc, wc)
+            for strat in STRATS:
+                if strat == engine.STRATEGY_SORTED and n_chr > 4000:
+                    continue
+                for flags in (engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS):
+                    b.run(mode, inv, flags, strat)
+                    b.wait()
+                    c, off = b.counts(), b.offsets()
+                    ok = np.array_equal(c, want_c) and b.total_hits == len(want_t)
+                    if ok and flags & engine.OUT_FIDS:
+                        got = np.stack([qid, b.fids()[off[:-1].astype(np.int64)[qid] + within].astype(np.int64)], axis=1)
+                        ok = np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want_pairs)
+                    if ok and flags & engine.OUT_TRIPLES:
+                        t = b.triples()
+                        srt = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]  # noqa: E731
+                        ok = np.array_equal(srt(t), srt(want_t)) and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+                    n_checks += 1
+                    if not ok:
+                        os.makedirs("gpurun_out", exist_ok=True)
+                        np.savez("gpurun_out/fuzz_fail.npz", co=co, s=s, e=e, f=f, regions=regions)
+                        print("MISMATCH iteration", it, "strategy", strat, "mode", mode, "invert", inv, "flags", flags,
+                              "n_chr", n_chr, "R", R, "nq", nq, "shape", shape, "span", span, flush=True)
+                        sys.exit(1)
+    b.close()
+    ix.close()
+print("fuzz ok: %d iterations, %d passes checked, %.0f s" % (iters, n_checks, time.time() - t0))
