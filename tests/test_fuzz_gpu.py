@@ -15,3 +15,10 @@ def test_fuzz_parity_short(seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "25", str(seed)], cwd=ROOT,
                        capture_output=True, timeout=600)
     assert r.returncode == 0 and b"fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_fuzz_lines_short():
+    """tools/fuzz_lines.py: Join B, covered bases and depth against their definitions on random inputs."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_lines.py"), "40", "7"], cwd=ROOT,
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
