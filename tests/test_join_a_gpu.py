@@ -423,3 +423,42 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
             used.append([name for kid, name in engine.KERNEL_NAMES.items() if b.kernel_ms(kid)[1]])
             assert np.array_equal(b.counts(), want_c)
         assert used[0] == ["k_join_slots"] and used[1] == [want_second]
+
+
+@pytest.mark.parametrize("shift", [0, 1, 3])
+def test_device_resident_regions_aligned_and_unaligned(shift):
+    """The zero-copy path of bench.py: three device-resident u32 columns borrowed by pointer.  k_join_slots reads them
+    with 16-byte loads when it can; columns that start `shift` elements into an allocation are not 16-byte aligned and
+    take the scalar loads."""
+    torch = pytest.importorskip("torch")
+    roots = synth.gencode_like_roots(2000, seed=31, chroms=synth.SMALL2)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    regions = synth.synth_bed(10_001, seed=32, chroms=synth.SMALL2, width=(1, 4000), edge_frac=0.05, roots=roots)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    dev = torch.device("cuda", 0)
+    cols = []
+    for c in range(3):
+        t = torch.zeros(len(regions) + 8, dtype=torch.int32, device=dev)
+        t[shift:shift + len(regions)] = torch.from_numpy(np.ascontiguousarray(regions[:, c]).view(np.int32)).to(dev)
+        cols.append(t)
+    torch.cuda.synchronize()
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions_device(*(t.data_ptr() + 4 * shift for t in cols), len(regions), keep=cols)
+    by_chr = np.argsort(regions[:, 0], kind="stable")
+    for strategy in STRATEGIES:
+        for mode in OverlapMode:
+            want_t, want_c = oix.query_features(regions, int(mode), False)
+            b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS, strategy)
+            b.wait()
+            c, off, fids = b.counts(), b.offsets(), b.fids()
+            assert np.array_equal(c, want_c) and b.total_hits == len(want_t)
+            wc = want_c.astype(np.int64)
+            qid = np.repeat(np.arange(len(regions), dtype=np.int64), wc)
+            within = np.arange(len(qid), dtype=np.int64) - np.repeat(np.cumsum(wc) - wc, wc)
+            got = np.stack([qid, fids[off[:-1].astype(np.int64)[qid] + within].astype(np.int64)], axis=1)
+            want = np.stack([np.repeat(by_chr, wc[by_chr]), want_t[:, 0].astype(np.int64)], axis=1)
+            srt = lambda a: a[np.lexsort((a[:, 1], a[:, 0]))]  # noqa: E731
+            assert np.array_equal(srt(got), srt(want))
+    b.close()
+    ix.close()
