@@ -161,6 +161,12 @@ class QueryBatch:
     def total_hits(self) -> int:
         return lib().gffx_hip_batch_total_hits(self._h)
 
+    def device_pointers(self):
+        """(counts, fids, triples) device addresses of the last pass (0 where not produced): for consumers on the GPU."""
+        L = lib()
+        return (L.gffx_hip_batch_device_counts(self._h) or 0, L.gffx_hip_batch_device_fids(self._h) or 0,
+                L.gffx_hip_batch_device_triples(self._h) or 0)
+
     def counts(self) -> np.ndarray:
         out = np.empty(max(self.n_queries, 1), dtype=np.uint32)
         check(lib().gffx_hip_batch_copy_counts(self._h, _p(out)))
@@ -304,6 +310,11 @@ def segments_covered(seg_seq, seg_start, seg_end, regions, n_seq: int, device: i
     out = np.zeros(max(len(q), 1), dtype=np.uint32)
     check(lib().gffx_hip_segments_covered(device, len(q), _p(q), _p(s), _p(e), _p(r), r.shape[0], int(n_seq), _p(out)))
     return out[: len(q)]
+
+
+def warmup(device: int = 0) -> None:
+    """Pay the process's one-off HIP costs now (gffx_hip_warmup); optional."""
+    check(lib().gffx_hip_warmup(int(device)))
 
 
 def query_features(index_data: TreeIndexData, regions, mode: int = OverlapMode.Overlap,

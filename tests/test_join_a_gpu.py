@@ -462,3 +462,40 @@ def test_device_resident_regions_aligned_and_unaligned(shift):
             assert np.array_equal(srt(got), srt(want))
     b.close()
     ix.close()
+
+
+def test_warmup_reserve_hits_and_device_result_pointers():
+    """The optional / zero-copy corners of the ABI: gffx_hip_warmup, a pair reservation that makes the capacity replay
+    unnecessary, and the device addresses of the results (read back here with hipMemcpy)."""
+    import ctypes
+
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    engine.warmup(0)
+    roots = synth.gencode_like_roots(500, seed=41, chroms=synth.SMALL2)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    regions = synth.synth_bed(3000, seed=42, chroms=synth.SMALL2, width=(1, 200_000))  # ~30 pairs per region
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    want_t, want_c = oix.query_features(regions, 2, False)
+    assert len(want_t) > 4 * len(regions)  # more than the default first guess of 2 pairs per region
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    for reserve in (0, len(want_t) + 10):
+        b = engine.QueryBatch(ix, len(regions))
+        assert b.n_queries == 0
+        b.set_regions(regions)
+        assert b.n_queries == len(regions)
+        if reserve:
+            b.reserve_hits(reserve)
+        b.run(OverlapMode.Overlap, False, engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_OFFSETS)
+        b.wait()
+        assert b.total_hits == len(want_t) and np.array_equal(b.counts(), want_c)
+        d_counts, d_fids, d_triples = b.device_pointers()
+        assert d_counts and d_fids and d_triples
+        host = np.empty(len(regions), np.uint32)
+        assert hip.hipMemcpy(host.ctypes.data, d_counts, host.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        assert np.array_equal(host, want_c)
+        hf = np.empty(len(want_t), np.uint32)
+        assert hip.hipMemcpy(hf.ctypes.data, d_fids, hf.nbytes, 2) == 0
+        assert np.array_equal(hf, b.fids())
+        b.close()
+    ix.close()
