@@ -427,24 +427,30 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
 
 @pytest.mark.parametrize("shift", [0, 1, 3])
 def test_device_resident_regions_aligned_and_unaligned(shift):
-    """The zero-copy path of bench.py: three device-resident u32 columns borrowed by pointer.  k_join_slots reads them
+    """The zero-copy path of bench.py: three device-resident u32 columns borrowed by pointer (allocated here with
+    hipMalloc through ctypes).  k_join_slots reads them
     with 16-byte loads when it can; columns that start `shift` elements into an allocation are not 16-byte aligned and
     take the scalar loads."""
-    torch = pytest.importorskip("torch")
+    import ctypes
+
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
     roots = synth.gencode_like_roots(2000, seed=31, chroms=synth.SMALL2)
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
     regions = synth.synth_bed(10_001, seed=32, chroms=synth.SMALL2, width=(1, 4000), edge_frac=0.05, roots=roots)
     oix = ob.OracleIndex.from_roots(co, s, e, f)
     ix = engine.TreeIndexData.from_roots(co, s, e, f)
-    dev = torch.device("cuda", 0)
     cols = []
     for c in range(3):
-        t = torch.zeros(len(regions) + 8, dtype=torch.int32, device=dev)
-        t[shift:shift + len(regions)] = torch.from_numpy(np.ascontiguousarray(regions[:, c]).view(np.int32)).to(dev)
-        cols.append(t)
-    torch.cuda.synchronize()
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), 4 * (len(regions) + 8)) == 0
+        col = np.ascontiguousarray(regions[:, c])
+        assert hip.hipMemcpy(p.value + 4 * shift, col.ctypes.data, col.nbytes, 1) == 0  # hipMemcpyHostToDevice
+        cols.append(p)
     b = engine.QueryBatch(ix, len(regions))
-    b.set_regions_device(*(t.data_ptr() + 4 * shift for t in cols), len(regions), keep=cols)
+    b.set_regions_device(*(p.value + 4 * shift for p in cols), len(regions))
     by_chr = np.argsort(regions[:, 0], kind="stable")
     for strategy in STRATEGIES:
         for mode in OverlapMode:
@@ -462,6 +468,8 @@ def test_device_resident_regions_aligned_and_unaligned(shift):
             assert np.array_equal(srt(got), srt(want))
     b.close()
     ix.close()
+    for p in cols:
+        hip.hipFree(p)
 
 
 def test_warmup_reserve_hits_and_device_result_pointers():
