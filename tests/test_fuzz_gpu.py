@@ -22,3 +22,10 @@ def test_fuzz_lines_short():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_lines.py"), "40", "7"], cwd=ROOT,
                        capture_output=True, timeout=600)
     assert r.returncode == 0 and b"fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_fuzz_cli_short():
+    """tools/fuzz_cli.py: index + intersect / depth / coverage with random inputs and flags against the oracle's commands."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "5", "9"], cwd=ROOT,
+                       capture_output=True, timeout=900)
+    assert r.returncode == 0 and b"fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
