@@ -19,6 +19,7 @@
 #include "join_a_kernels.hpp"
 #include "join_fused_kernels.hpp"
 #include "join_slot_kernels.hpp"
+#include "join_win_kernels.hpp"
 #include "partition_kernels.hpp"
 #include "tile_join_kernels.hpp"
 
@@ -69,6 +70,136 @@ static int dev_upload(T **p, const std::vector<T> &v) {
     return GFFX_OK;
 }
 
+
+// Window index (gffx_device.hpp, join_win_kernels.hpp): per seqid ~GFFX_HIP_WIN_PER_ENTRY windows per root (a power of
+// two wide), widened until the lists total <= 8 per root; the line of window b lists, by ascending start, the roots with
+// start < (b+1) << shift and end + wmax > b << shift.  `start` / `aux` are the sorted arrays of the index.
+static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
+                              const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
+                              std::vector<uint4> &win_pos, std::vector<uint4> &spill) {
+    meta.assign(n_chr + 1, make_uint4(0, 0, 0, 0));  // (+ one zero entry: a kernel may read one past the end)
+    win.clear(), win_pos.clear(), spill.clear();
+    const uint64_t per_entry = (uint64_t)env_long("GFFX_HIP_WIN_PER_ENTRY", 1, 1, 16);
+    const uint64_t wmax_min = (uint64_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
+    auto win_wmax = [&](uint32_t shift) {  // widest region the lines answer: 16 Ki, but between 1/4 and 4 windows
+        const uint64_t w = 1ull << shift;
+        return std::max<uint64_t>(w >> 2, std::min<uint64_t>(wmax_min, w << 2));
+    };
+    std::vector<uint32_t> len, fill;
+    uint64_t total_win = 0;
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        if (hi == lo) continue;
+        const uint64_t max_end = std::max(h_aux[hi - 1].x, h_aux[hi - 1].y);
+        const uint64_t budget = std::max<uint64_t>(per_entry * (hi - lo), 16);
+        uint32_t shift = 0;
+        uint64_t wmax = 0, ns = 0;
+        for (;; shift++) {
+            wmax = win_wmax(shift);
+            ns = ((max_end + wmax) >> shift) + 1;
+            if (ns > budget && shift < 40) continue;
+            uint64_t total = 0;  // list entries over all windows at this width
+            for (uint32_t i = lo; i < hi && total <= 8ull * (hi - lo) + 1024; i++) {
+                const uint64_t first = (uint64_t)h_start[i] >> shift;
+                const uint64_t last = std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift);
+                if (last >= first) total += last - first + 1;  // (an interval with end < start lists itself nowhere)
+            }
+            if (total <= 8ull * (hi - lo) + 1024 || shift >= 40) break;
+        }
+        if (shift > 31) shift = 31, wmax = win_wmax(31), ns = ((max_end + wmax) >> 31) + 1;
+        wmax = std::min<uint64_t>(wmax, 0xFFFFFFFFull);
+        if (total_win + ns >= (1ull << 25)) return fail(GFFX_E_INVALID, "index too large for the window directory");
+        const uint32_t base = (uint32_t)total_win;
+        total_win += ns;
+        meta[c] = make_uint4(base, (uint32_t)ns, shift, (uint32_t)wmax);
+        auto first_w = [&](uint32_t i) { return ((uint64_t)h_start[i] >> shift); };
+        auto last_w = [&](uint32_t i) { return std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift); };
+        len.assign(ns, 0);
+        for (uint32_t i = lo; i < hi; i++)
+            for (uint64_t b = first_w(i); b <= last_w(i) && last_w(i) >= first_w(i); b++) len[b]++;
+        // a line = 16 words {hdr, start x 5, end x 5, fid (or position) x 5}; absent entries: start = 0xFFFFFFFF
+        win.resize(4 * total_win, make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
+        win_pos.resize(4 * total_win, make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
+        uint32_t *ww = reinterpret_cast<uint32_t *>(win.data()), *wp = reinterpret_cast<uint32_t *>(win_pos.data());
+        for (uint64_t b = 0; b < ns; b++) {
+            uint32_t n = len[b];
+            uint64_t off = 0;
+            if (n > kWinMaxList || (n > kWinInline && spill.size() + (n - kWinInline) >= (1ull << 24))) {
+                n = 255;  // dense window (or the 24-bit spill offsets are used up): exact sweep
+            } else if (n > kWinInline) {
+                off = spill.size();
+                spill.resize(spill.size() + (n - kWinInline));
+            }
+            uint32_t *l = ww + 16 * ((size_t)base + b), *lp = wp + 16 * ((size_t)base + b);
+            l[0] = lp[0] = n | (uint32_t)(off << 8);
+            for (int j = 1; j <= 5; j++) l[j] = lp[j] = 0xFFFFFFFFu;  // starts
+            for (int j = 6; j < 16; j++) l[j] = lp[j] = 0;            // ends, fids / positions
+        }
+        fill.assign(ns, 0);
+        for (uint32_t i = lo; i < hi; i++) {  // ascending start: the lists come out sorted
+            if (last_w(i) < first_w(i)) continue;
+            for (uint64_t b = first_w(i); b <= last_w(i); b++) {
+                uint32_t *l = ww + 16 * ((size_t)base + b), *lp = wp + 16 * ((size_t)base + b);
+                if ((l[0] & 255u) == 255u) continue;
+                const uint32_t j = fill[b]++;
+                if (j < kWinInline) {
+                    l[1 + j] = lp[1 + j] = h_start[i];
+                    l[6 + j] = lp[6 + j] = h_aux[i].x;
+                    l[11 + j] = h_aux[i].w;
+                    lp[11 + j] = i;
+                } else {
+                    spill[(l[0] >> 8) + j - kWinInline] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
+                }
+            }
+        }
+    }
+    return GFFX_OK;
+}
+
+// Coverage filter of the window index (gffx_device.hpp): the smallest cell size whose bitmap fits GFFX_HIP_WIN_FILTER_KB
+// (default 24 KB of LDS per block; 48 KB measured 1.5 % faster at 10 M regions, 1.5 % slower at 1 M), but never so small that a region the lines answer (width <= wmax) spans more than 32 cells.
+static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
+                                const std::vector<uint4> &h_aux, const std::vector<uint4> &win_meta, std::vector<uint32_t> &bits,
+                                std::vector<uint2> &fmeta, uint32_t &fshift) {
+    fmeta.assign(n_chr + 1, make_uint2(0, 0));
+    bits.clear();
+    fshift = 0;
+    const uint64_t budget_bits = (uint64_t)env_long("GFFX_HIP_WIN_FILTER_KB", 24, 0, 120) * 1024 * 8;
+    if (!budget_bits) return;
+    auto cells_of = [&](uint32_t c, uint32_t sh) -> uint64_t {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        if (hi == lo) return 0;
+        const uint64_t max_end = std::max(h_aux[hi - 1].x, h_aux[hi - 1].y);
+        return (max_end >> sh) + 1;
+    };
+    uint32_t wmax_all = 1;
+    for (uint32_t c = 0; c < n_chr; c++) wmax_all = std::max(wmax_all, win_meta[c].w);
+    uint32_t sh = 0;
+    while (sh < 31 && ((uint64_t)wmax_all >> sh) + 2 > 32) sh++;  // a region of width <= wmax touches <= (wmax >> sh) + 2 cells
+    for (; sh < 32; sh++) {
+        uint64_t tot = 0;
+        for (uint32_t c = 0; c < n_chr; c++) tot += (cells_of(c, sh) + 31) / 32 * 32;
+        if (tot <= budget_bits) break;
+    }
+    if (sh >= 32) return;
+    fshift = sh;
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        const uint64_t nc = cells_of(c, sh);
+        if (!nc) continue;
+        const uint32_t base = (uint32_t)bits.size() * 32u;
+        fmeta[c] = make_uint2(base, (uint32_t)nc);
+        bits.resize(bits.size() + (nc + 31) / 32, 0u);
+        for (uint32_t i = lo; i < hi; i++) {
+            if (h_aux[i].x <= h_start[i]) continue;  // an empty or reversed interval overlaps nothing (start < qe && end > qs with qs < qe)
+            const uint64_t a = (uint64_t)h_start[i] >> sh, b = ((uint64_t)h_aux[i].x - 1) >> sh;
+            for (uint64_t x = a; x <= b && x < nc; x++) bits[(base + x) >> 5] |= 1u << ((base + x) & 31);
+        }
+    }
+    bits.push_back(0u);                           // (the kernel reads word pairs)
+    while (bits.size() & 3u) bits.push_back(0u);  // (... and stages the bitmap 16 bytes at a time)
+}
+
 }  // namespace gffx
 
 using namespace gffx;
@@ -84,6 +215,11 @@ struct gffx_hip_index {
     uint4 *d_slot_meta = nullptr, *d_slots = nullptr, *d_spill = nullptr;  // slot index (join_slot_kernels.hpp)
     uint32_t *d_slot_pos = nullptr;
     uint64_t n_slots = 0, n_spill = 0;
+    uint4 *d_win_meta = nullptr, *d_win = nullptr, *d_win_pos = nullptr, *d_win_spill = nullptr;  // window index (join_win_kernels.hpp)
+    uint32_t n_win = 0;
+    uint32_t *d_win_filter = nullptr;
+    uint2 *d_win_fmeta = nullptr;
+    uint32_t win_fwords = 0, win_fshift = 0;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
     uint32_t *d_cell_base = nullptr;
     uint16_t *d_cell_tile = nullptr;
@@ -105,6 +241,15 @@ struct gffx_hip_index {
         v.slots = d_slots;
         v.spill = d_spill;
         v.slot_pos = d_slot_pos;
+        v.win_meta = d_win_meta;
+        v.win = d_win;
+        v.win_pos = d_win_pos;
+        v.win_spill = d_win_spill;
+        v.n_win = n_win;
+        v.win_filter = d_win_filter;
+        v.win_fmeta = d_win_fmeta;
+        v.win_fwords = win_fwords;
+        v.win_fshift = win_fshift;
         v.n_chr = n_chr;
         v.n_roots = n_roots;
         return v;
@@ -131,11 +276,17 @@ struct gffx_hip_batch {
     // outputs / workspace
     uint32_t *d_counts = nullptr;
     unsigned long long *d_block_sums = nullptr;
-    unsigned long long *d_status = nullptr;     // [0] error bits; partitioned strategy: [1] kept pairs
+    unsigned long long *d_status = nullptr;     // [0] error bits; partitioned strategy: [1] kept pairs; [2], [3] the alternating
+                                                // pair cursors of the one-kernel strategies; [4] regions that took the exact
+                                                // sweep (windows strategy); [5], [6] scratch cursors of a second (bitmap) pass
+    static constexpr int kStatusWords = 8;
     unsigned long long *h_status = nullptr;     // pinned: [0] error bits, [1] pair cursor / [1..] block sums
     static constexpr uint32_t kMaxBlocks = 8192;
     uint32_t *d_fids = nullptr, *d_triples = nullptr, *d_bitmap = nullptr;
     unsigned long long *d_offsets = nullptr;
+    uint32_t *d_offsets32 = nullptr;            // GFFX_OUT_OFFSETS32
+    uint32_t *d_slabs = nullptr;                // windows strategy, root-bitmap passes: one LDS bitmap image per block
+    uint32_t slab_blocks = 0;
     uint64_t cap_fids = 0, cap_triples = 0;
     uint64_t reserve = 0;
     // partitioned strategy workspace (allocated on first use)
@@ -147,6 +298,7 @@ struct gffx_hip_batch {
     int cursor_phase = 0;
     int fused_phase = 0;            // which of d_status[2..3] the next fused pass uses as its pair cursor
     int fused_word = 2;             // ... and the one the last fused pass used
+    uint64_t slow_seen_win = 0;     // windows strategy: the device's exact-sweep counter at the last wait
     uint64_t slow_seen = 0;         // slots strategy: the device's slow-lane counter at the last wait
     uint64_t slots_passes = 0;      // ... and the slot passes enqueued since
     bool mostly_slow = false;       // ... > 1/4 of the regions took the slow lane: AUTO uses the sweep kernel
@@ -291,8 +443,11 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
                 ns = ((max_end + wmax) >> shift) + 1;
                 if (ns > budget && shift < 40) continue;
                 uint64_t total = 0;  // list entries over all windows at this width
-                for (uint32_t i = lo; i < hi && total <= 8ull * (hi - lo) + 1024; i++)
-                    total += std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift) - ((uint64_t)h_start[i] >> shift) + 1;
+                for (uint32_t i = lo; i < hi && total <= 8ull * (hi - lo) + 1024; i++) {
+                    const uint64_t fw = (uint64_t)h_start[i] >> shift;
+                    const uint64_t lw = std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift);
+                    if (lw >= fw) total += lw - fw + 1;  // (an interval with end < start lists itself nowhere)
+                }
                 if (total <= 8ull * (hi - lo) + 1024 || shift >= 40) break;
             }
             if (shift > 31) shift = 31, wmax = slot_wmax(31), ns = ((max_end + wmax) >> 31) + 1;
@@ -340,6 +495,13 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     }
     ix->n_slots = slots.size() / 2;
     ix->n_spill = spill.size();
+    std::vector<uint4> win_meta, win, win_pos, win_spill;
+    if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill)) return wrc;
+    ix->n_win = (uint32_t)(win.size() / 4);
+    std::vector<uint32_t> win_filter;
+    std::vector<uint2> win_fmeta;
+    build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);
+    ix->win_fwords = (uint32_t)win_filter.size();
 
     // Partitioned strategy: cells of 2^cshift bp (<= kMaxCells in total, >= 1 per seqid) merged into
     // tiles of <= kTileEntries entries; per tile a 1024-bin u16 directory over start (gffx_device.hpp).
@@ -434,6 +596,9 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
         (rc = dev_upload(&ix->d_slot_meta, slot_meta)) || (rc = dev_upload(&ix->d_slots, slots)) ||
         (rc = dev_upload(&ix->d_spill, spill)) || (rc = dev_upload(&ix->d_slot_pos, slot_pos)) ||
+        (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = dev_upload(&ix->d_win, win)) ||
+        (rc = dev_upload(&ix->d_win_pos, win_pos)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
+        (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_fmeta, win_fmeta)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -457,6 +622,12 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_slots);
     (void)hipFree(ix->d_spill);
     (void)hipFree(ix->d_slot_pos);
+    (void)hipFree(ix->d_win_meta);
+    (void)hipFree(ix->d_win);
+    (void)hipFree(ix->d_win_pos);
+    (void)hipFree(ix->d_win_spill);
+    (void)hipFree(ix->d_win_filter);
+    (void)hipFree(ix->d_win_fmeta);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);
     (void)hipFree(ix->d_tile_meta);
@@ -488,11 +659,11 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(GFFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     if ((rc = dev_alloc(&b->d_counts, max_queries)) || (rc = dev_alloc(&b->d_block_sums, gffx_hip_batch::kMaxBlocks)) ||
-        (rc = dev_alloc(&b->d_status, 4))) {
+        (rc = dev_alloc(&b->d_status, gffx_hip_batch::kStatusWords))) {
         gffx_hip_batch_destroy(b.release());
         return rc;
     }
-    GFFX_HIP_TRY(hipMemset(b->d_status, 0, 4 * sizeof(unsigned long long)));
+    GFFX_HIP_TRY(hipMemset(b->d_status, 0, gffx_hip_batch::kStatusWords * sizeof(unsigned long long)));
     GFFX_HIP_TRY(hipDeviceSynchronize());  // NULL-stream memset vs the batch's non-blocking stream
     e = hipHostMalloc((void **)&b->h_status, (1 + gffx_hip_batch::kMaxBlocks) * sizeof(unsigned long long),
                       hipHostMallocDefault);
@@ -521,6 +692,8 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     (void)hipFree(b->d_triples);
     (void)hipFree(b->d_bitmap);
     (void)hipFree(b->d_offsets);
+    (void)hipFree(b->d_offsets32);
+    (void)hipFree(b->d_slabs);
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_cursor);
     (void)hipFree(b->d_q_rec);
@@ -927,7 +1100,139 @@ static int run_slots(gffx_hip_batch *b) {
     return GFFX_OK;
 }
 
-static bool one_kernel(int strategy) { return strategy == GFFX_STRATEGY_FUSED || strategy == GFFX_STRATEGY_SLOTS; }
+
+// ------------------------------------------------------------------------------------ windows strategy
+
+constexpr uint32_t kWinMaxLds = 80 * 1024;  // two blocks per CU share 160 KB
+
+template <int MODE, bool INV, bool AOS, bool ML, int OUT>
+static void launch_win3(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, uint32_t stage_words, uint32_t fwords,
+                        uint32_t lds) {
+    static bool big_lds = false;  // beyond the default 64 KB of dynamic LDS a kernel has to opt in, once
+    if (lds > 64 * 1024 && !big_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_win<MODE, INV, AOS, ML, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinMaxLds);
+        big_lds = true;
+    }
+    hipLaunchKernelGGL((k_join_win<MODE, INV, AOS, ML, OUT>), dim3(grid), dim3(kWinThreads), lds, b->stream, b->ix->view(), b->q,
+                       (unsigned long long)b->nq, o, vec_ok, stage_words, fwords);
+}
+
+template <int MODE, bool INV, bool AOS, bool ML>
+static void launch_win(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, int out_kind, uint32_t stage_words,
+                       uint32_t fwords, uint32_t lds) {
+    if (out_kind == 3)
+        launch_win3<MODE, INV, AOS, ML, 3>(b, grid, o, vec_ok, stage_words, fwords, lds);
+    else if (out_kind == 2)
+        launch_win3<MODE, INV, AOS, ML, 2>(b, grid, o, vec_ok, stage_words, fwords, lds);
+    else
+        launch_win3<MODE, INV, AOS, ML, 1>(b, grid, o, vec_ok, stage_words, fwords, lds);
+}
+
+// dynamic LDS of k_join_win: scratch + stage (root_fids or the LDS bitmap) + per-thread strips + coverage filter + seqid tables
+static uint32_t win_lds_bytes(const gffx_hip_index *ix, uint32_t stage_words, uint32_t fwords, bool ml) {
+    return 80 + 4 * stage_words + 4 * kWinStash * kWinThreads + 4 * fwords + (ml ? (ix->n_chr + 1) * 24 : 0);
+}
+
+static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
+    const gffx_hip_index *ix = b->ix;
+    WinOut o{};
+    o.counts = b->d_counts;
+    o.err = reinterpret_cast<uint32_t *>(b->d_status);
+    o.slow = b->d_status + (second ? 6 : 4);  // (a second pass over the same regions must not count them twice)
+    if (second) {
+        o.pair_cursor = b->d_status + 5;
+        o.pair_cursor_next = b->d_status + 6;
+    } else {
+        b->fused_word = 2 + b->fused_phase;
+        o.pair_cursor = b->d_status + b->fused_word;
+        o.pair_cursor_next = b->d_status + 2 + (b->fused_phase ^ 1);
+        b->fused_phase ^= 1;
+    }
+    const bool ml = meta_bytes(ix) <= kMetaLdsBytes;
+    const uint64_t rounds = (b->nq + kWinChunk - 1) / kWinChunk;
+    uint32_t grid, stage_words;
+    if (out_kind == 3) {
+        const uint32_t words = (ix->n_roots + 31) / 32;
+        // LDS-private bitmap when it fits next to the rest within the default 64 KB of dynamic LDS
+        const bool bm_lds = words && win_lds_bytes(ix, (words + 3) / 4 * 4, 0, ml) <= kWinMaxLds;
+        grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_BITMAP_BLOCKS", 512, 1, 4096));
+        stage_words = bm_lds ? (words + 3) / 4 * 4 : 0;
+        o.bitmap = b->d_bitmap;
+        if (bm_lds) {
+            if (b->slab_blocks < grid) {
+                if (b->d_slabs) GFFX_HIP_TRY(hipFree(b->d_slabs));
+                b->d_slabs = nullptr;
+                b->slab_blocks = 0;
+                const uint32_t want = std::max<uint32_t>(grid, 512);
+                int rc = dev_alloc(&b->d_slabs, (size_t)want * words);
+                if (rc) return rc;
+                b->slab_blocks = want;
+            }
+            o.slabs = b->d_slabs;
+            o.bm_words = words;
+        }
+    } else {
+        o.offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr;
+        o.offsets32 = (b->flags & GFFX_OUT_OFFSETS32) ? b->d_offsets32 : nullptr;
+        o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
+        o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
+        uint64_t cap = UINT64_MAX;
+        if (o.fids) cap = std::min(cap, b->cap_fids);
+        if (o.triples) cap = std::min(cap, b->cap_triples);
+        o.capacity = cap;
+        grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", 1024, 1, 65535));
+        stage_words = out_kind == 1 ? kWinStage : 0;
+    }
+    // the coverage filter rides along when everything still fits half a CU's LDS
+    uint32_t fwords = (ix->win_fwords + 3) / 4 * 4;
+    if (fwords < 4 || win_lds_bytes(ix, stage_words, fwords, ml) > kWinMaxLds) fwords = 0;
+    const uint32_t lds = win_lds_bytes(ix, stage_words, fwords, ml);
+    const bool aos = b->q.aos != nullptr;
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int vec_ok = aos ? al(b->q.aos) : (al(b->q.chr) && al(b->q.start) && al(b->q.end));
+    ProfEvent pe;
+    prof_begin(b, GFFX_K_WINDOWS, &pe);
+#define GFFX_CASE2(M, I, A, L) \
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) launch_win<M, I, A, L>(b, grid, o, vec_ok, out_kind, stage_words, fwords, lds);
+#define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
+    GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
+    GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
+    GFFX_CASE(2, false, false) GFFX_CASE(2, false, true) GFFX_CASE(2, true, false) GFFX_CASE(2, true, true)
+#undef GFFX_CASE
+#undef GFFX_CASE2
+    prof_end(b, &pe);
+    GFFX_HIP_TRY(hipGetLastError());
+    if (out_kind == 3 && o.slabs) {
+        const uint32_t words = o.bm_words;
+        prof_begin(b, GFFX_K_BITMAP_OR, &pe);
+        hipLaunchKernelGGL(k_bitmap_or, dim3((words + 63) / 64, 16), dim3(1024), 0, b->stream, b->d_slabs, grid, words, b->d_bitmap);
+        prof_end(b, &pe);
+        GFFX_HIP_TRY(hipGetLastError());
+    }
+    return GFFX_OK;
+}
+
+// One pass = the pair outputs (root_fids and / or triples; offsets) and, when asked for, the root bitmap as a pass of its
+// own over the position copy of the window table (the CLI asks for the bitmap alone: one pass).
+static int run_windows(gffx_hip_batch *b) {
+    const bool want_bitmap = b->flags & GFFX_OUT_ROOT_BITMAP;
+    const bool want_pairs = b->flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32);
+    if (want_bitmap && !(b->flags & GFFX_OUT_BITMAP_KEEP))
+        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
+    b->slots_passes++;
+    int rc;
+    if (want_pairs || !want_bitmap) {
+        if ((rc = run_windows_pass(b, (b->flags & GFFX_OUT_TRIPLES) ? 2 : 1, false))) return rc;
+        if (want_bitmap && (rc = run_windows_pass(b, 3, true))) return rc;
+        return GFFX_OK;
+    }
+    return run_windows_pass(b, 3, false);
+}
+
+static bool one_kernel(int strategy) {
+    return strategy == GFFX_STRATEGY_FUSED || strategy == GFFX_STRATEGY_SLOTS || strategy == GFFX_STRATEGY_WINDOWS;
+}
 
 // AUTO: the slot kernel, unless the last waited pass over these regions sent most of them down its slow lane
 // (wide queries / dense windows): then the sweep kernel, which interleaves those chains, serves the batch.
@@ -936,10 +1241,10 @@ static int pick_strategy(const gffx_hip_batch *b, int strategy) {
     if (strategy == GFFX_STRATEGY_SORTED) return part_ok ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_DIRECT;
     if (strategy != GFFX_STRATEGY_AUTO) return strategy;
     // GFFX_HIP_AUTO_STRATEGY overrides for experiments
-    const long forced = env_long("GFFX_HIP_AUTO_STRATEGY", 0, 1, 4);
+    const long forced = env_long("GFFX_HIP_AUTO_STRATEGY", 0, 1, 5);
     if (forced == GFFX_STRATEGY_SORTED) return part_ok ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_FUSED;
     if (forced) return (int)forced;
-    return b->mostly_slow ? GFFX_STRATEGY_FUSED : GFFX_STRATEGY_SLOTS;
+    return b->mostly_slow ? GFFX_STRATEGY_FUSED : GFFX_STRATEGY_WINDOWS;
 }
 
 extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags,
@@ -947,7 +1252,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: batch is NULL");
     if (!b->have_regions) return fail(GFFX_E_STATE, "gffx_hip_batch_run: no regions set");
     if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad mode %d", mode);
-    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_SLOTS)
+    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_WINDOWS)
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad strategy %d", strategy);
     if (strategy == GFFX_STRATEGY_SORTED && (!b->ix->partition_ok || b->max_q >= (1ull << 32)))
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: the partitioned strategy needs <= %u seqids / genome cells "
@@ -957,6 +1262,11 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     b->invert = invert ? 1 : 0;
     b->flags = out_flags | GFFX_OUT_COUNTS;
     b->strategy = pick_strategy(b, strategy);
+    if ((out_flags & (GFFX_OUT_OFFSETS32 | GFFX_OUT_BITMAP_KEEP)) && b->strategy != GFFX_STRATEGY_WINDOWS) {
+        if (strategy != GFFX_STRATEGY_AUTO)
+            return fail(GFFX_E_INVALID, "gffx_hip_batch_run: GFFX_OUT_OFFSETS32 / GFFX_OUT_BITMAP_KEEP need the windows strategy (or AUTO)");
+        b->strategy = GFFX_STRATEGY_WINDOWS;  // (AUTO's sweep-kernel choice is a speed matter only)
+    }
     b->ran = true;
     b->waited = false;
     b->total = 0;
@@ -966,11 +1276,13 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         if (!b->d_offsets && (rc = dev_alloc(&b->d_offsets, b->max_q + 1))) return rc;
         if (nq == 0) GFFX_HIP_TRY(hipMemsetAsync(b->d_offsets, 0, sizeof(unsigned long long), b->stream));
     }
-    if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !b->d_bitmap &&
-        (rc = dev_alloc(&b->d_bitmap, ((size_t)b->ix->n_roots + 31) / 32 + 1)))
-        return rc;
+    if ((b->flags & GFFX_OUT_OFFSETS32) && !b->d_offsets32 && (rc = dev_alloc(&b->d_offsets32, b->max_q + 4))) return rc;
+    if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !b->d_bitmap) {
+        if ((rc = dev_alloc(&b->d_bitmap, ((size_t)b->ix->n_roots + 31) / 32 + 1))) return rc;
+        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));  // (GFFX_OUT_BITMAP_KEEP on a first pass)
+    }
     if (nq == 0) {
-        if (b->flags & GFFX_OUT_ROOT_BITMAP)
+        if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !(b->flags & GFFX_OUT_BITMAP_KEEP))
             GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
         b->n_blocks = 0;
         return GFFX_OK;
@@ -980,9 +1292,10 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want && (rc = grow(&b->d_fids, &b->cap_fids, want, 1))) return rc;
         if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want && (rc = grow(&b->d_triples, &b->cap_triples, want, 3)))
             return rc;
-        return b->strategy == GFFX_STRATEGY_SORTED ? run_partitioned(b)
-               : b->strategy == GFFX_STRATEGY_SLOTS ? run_slots(b)
-                                                    : run_fused(b);
+        return b->strategy == GFFX_STRATEGY_SORTED    ? run_partitioned(b)
+               : b->strategy == GFFX_STRATEGY_SLOTS   ? run_slots(b)
+               : b->strategy == GFFX_STRATEGY_WINDOWS ? run_windows(b)
+                                                      : run_fused(b);
     }
     // contiguous chunk of queries per block, a multiple of the block size; <= 2048 blocks
     const uint64_t tiles = (nq + kJoinThreads - 1) / kJoinThreads;
@@ -1035,7 +1348,8 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     }
     const bool part = b->strategy == GFFX_STRATEGY_SORTED, fused = one_kernel(b->strategy);
     // error word + the pair cursors in one copy; block sums of the direct strategy
-    GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, gffx_hip_batch::kStatusWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const unsigned long long h_slow_win = b->h_status[4];  // (h_status[1..] is overwritten by the block sums below)
     if (!part && !fused)
         GFFX_HIP_TRY(hipMemcpy(b->h_status + 1, b->d_block_sums, b->n_blocks * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost));
@@ -1055,6 +1369,12 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         b->slow_seen = slow_now;
         b->slots_passes = 0;
     }
+    if (b->strategy == GFFX_STRATEGY_WINDOWS) {  // regions the passes since the last wait sent to the exact sweep (own 64-bit word)
+        const uint64_t passes = std::max<uint64_t>(b->slots_passes, 1);
+        b->mostly_slow = (h_slow_win - b->slow_seen_win) / passes > b->nq / 4;
+        b->slow_seen_win = h_slow_win;
+        b->slots_passes = 0;
+    }
     b->total = 0;
     if (part)
         b->total = b->h_status[1];
@@ -1071,18 +1391,29 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         if ((rc = grow(&b->d_triples, &b->cap_triples, b->total + b->total / 8, 3))) return rc;
         replay = true;
     }
+    if ((b->flags & GFFX_OUT_OFFSETS32) && b->total >= (1ull << 32))
+        return fail(GFFX_E_INVALID, "gffx_hip_batch_wait: %llu kept pairs do not fit GFFX_OUT_OFFSETS32; run with GFFX_OUT_OFFSETS",
+                    (unsigned long long)b->total);
     if ((part || fused) && (b->flags & GFFX_OUT_OFFSETS)) {
         const unsigned long long tot = b->total;  // offsets[nq] = number of pairs, as in the direct path
         GFFX_HIP_TRY(hipMemcpy(b->d_offsets + b->nq, &tot, sizeof tot, hipMemcpyHostToDevice));
     }
     if (replay) {
         // the partitioned strategy counts and emits in one kernel: the whole pass runs again
-        if ((rc = part ? run_partitioned(b) : b->strategy == GFFX_STRATEGY_SLOTS ? run_slots(b) : fused ? run_fused(b) : enqueue_emit(b)))
-            return rc;
+        const uint32_t keep_flags = b->flags;
+        if (b->strategy == GFFX_STRATEGY_WINDOWS) b->flags |= GFFX_OUT_BITMAP_KEEP;  // (the first attempt already set every bit)
+        rc = part ? run_partitioned(b) : b->strategy == GFFX_STRATEGY_SLOTS ? run_slots(b) : b->strategy == GFFX_STRATEGY_WINDOWS ? run_windows(b) : fused ? run_fused(b) : enqueue_emit(b);
+        b->flags = keep_flags;
+        if (rc) return rc;
         if ((rc = gffx_hip_batch_sync(b))) return rc;
         if (b->strategy == GFFX_STRATEGY_SLOTS) {  // the replay counted its slow-lane queries again: not news
             GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, sizeof(unsigned long long), hipMemcpyDeviceToHost));
             b->slow_seen = b->h_status[0] >> 32;
+            b->slots_passes = 0;
+        }
+        if (b->strategy == GFFX_STRATEGY_WINDOWS) {
+            GFFX_HIP_TRY(hipMemcpy(b->h_status + 4, b->d_status + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            b->slow_seen_win = b->h_status[4];
             b->slots_passes = 0;
         }
     }
@@ -1121,6 +1452,12 @@ extern "C" int gffx_hip_batch_copy_offsets(gffx_hip_batch *b, uint64_t *host) {
     int rc = need_waited(b, "gffx_hip_batch_copy_offsets", GFFX_OUT_OFFSETS);
     if (rc || (rc = need_input_order(b))) return rc;
     GFFX_HIP_TRY(hipMemcpy(host, b->d_offsets, (b->nq + 1) * 8, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_copy_offsets32(gffx_hip_batch *b, uint32_t *host) {
+    int rc = need_waited(b, "gffx_hip_batch_copy_offsets32", GFFX_OUT_OFFSETS32);
+    if (rc) return rc;
+    if (b->nq) GFFX_HIP_TRY(hipMemcpy(host, b->d_offsets32, b->nq * 4, hipMemcpyDeviceToHost));
     return GFFX_OK;
 }
 extern "C" int gffx_hip_batch_copy_query_records(gffx_hip_batch *b, uint32_t *rows, uint32_t *counts,
@@ -1173,6 +1510,12 @@ extern "C" const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *b)
     // input order; NULL while a partitioned pass has not been un-permuted (GFFX_OUT_EMIT_ORDER)
     if (!b || (b->strategy == GFFX_STRATEGY_SORTED && !b->unpermuted)) return nullptr;
     return b->d_counts;
+}
+extern "C" const uint32_t *gffx_hip_batch_device_offsets32(const gffx_hip_batch *b) {
+    return (b && (b->flags & GFFX_OUT_OFFSETS32)) ? b->d_offsets32 : nullptr;
+}
+extern "C" const uint64_t *gffx_hip_batch_device_offsets(const gffx_hip_batch *b) {
+    return (b && (b->flags & GFFX_OUT_OFFSETS)) ? reinterpret_cast<const uint64_t *>(b->d_offsets) : nullptr;
 }
 extern "C" const uint32_t *gffx_hip_batch_device_fids(const gffx_hip_batch *b) {
     return (b && (b->flags & GFFX_OUT_FIDS)) ? b->d_fids : nullptr;

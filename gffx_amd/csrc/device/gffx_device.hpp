@@ -78,6 +78,22 @@ struct IndexView {
     const uint4 *slots;
     const uint4 *spill;
     const uint32_t *slot_pos;
+    // Window index (join_win_kernels.hpp): as the slot index, but one 64-byte LINE per window holding up to 5 entries
+    // as words {n | spill << 8, start x 5, end x 5, root_fid x 5}; win_pos is a copy with index positions in place of
+    // the root_fids (root-bitmap passes); win_spill[spill + j - 5] = {start, end, root_fid, position} of entry j >= 5.
+    //   win_meta[seqid] = {first window, windows, shift, wmax}
+    const uint4 *win_meta;
+    const uint4 *win;
+    const uint4 *win_pos;
+    const uint4 *win_spill;
+    uint32_t n_win;
+    // Coverage filter of the window index (staged in LDS by k_join_win): the genome in cells of 2^win_fshift bp, one bit per
+    // cell = "some root overlaps the cell".  A region whose cells are all clear has no hit and reads no index line.
+    //   win_fmeta[seqid] = {first bit (a multiple of 32), cells}     (0 cells: no filter for the seqid)
+    const uint32_t *win_filter;
+    const uint2 *win_fmeta;
+    uint32_t win_fwords;  // 0 = no filter
+    uint32_t win_fshift;
     uint32_t n_chr;
     uint32_t n_roots;
 };

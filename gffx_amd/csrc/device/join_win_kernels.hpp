@@ -1,0 +1,479 @@
+// join_win_kernels.hpp -- Join A over the WINDOW index ("windows" strategy, AUTO's choice): regions in input order,
+// count + emit in one kernel, ONE 64-byte index line per region in the usual case.  Same result set as
+// join_a_kernels.hpp (utils/tree.rs:110 + intersect.rs:145-161).
+//
+// What a random index access costs on gfx950 was measured with tools/gather_ubench.hip: ~2.65 CU-cycles per L2
+// request (the XCD's L2 channels are the limit: bypassing L1 with sc1 changes nothing, a quad of lanes sharing one
+// 64-byte piece is no cheaper than four lanes on four lines), + ~0.5 cycles for every further 16-byte load that hits the
+// line just requested.  So a region should touch ONE line, with everything it needs in it:
+//   every seqid is cut into windows of 2^shift bp (~1 per root); the LINE of window b lists, by ascending start, every
+//   root that can overlap a region of width <= wmax whose last base lies in the window
+//   (start < (b+1) << shift and end + wmax > b << shift), as
+//       word 0        n | spill << 8      n = list length; 255 = dense window (take the exact sweep)
+//       words 1..5    start of entries 0..4     (0xFFFFFFFF for an absent entry: never < qe)
+//       words 6..10   end   of entries 0..4
+//       words 11..15  root_fid of entries 0..4  (the "pos" copy of the table carries index positions instead: root bitmap)
+//   entries 5.. of the 3 % longer lists are 16-byte records {start, end, root_fid, position} at win_spill[spill ...].
+// Region (qs, qe) with 0 < qe - qs <= wmax: four 16-byte buffer loads of line (qe-1) >> shift, all in flight at once for the
+// thread's 4 regions (no dependent second gather), five exact tests (start < qe && end > qs, mode predicate, invert).
+// The main path is branch-free: a region the table cannot serve reads from beyond the buffer (a buffer load out of range
+// returns zeros without touching memory: an empty line).  What the line cannot answer -- the tail of a list longer than 5,
+// dense windows, regions wider than wmax, qs >= qe rows (the reference keeps them) -- is handled by the thread AFTER the main
+// path in ONE loop over its deferred regions (list tail from win_spill, or the exact skip-link sweep of join_a_kernels.hpp),
+// so the rare code exists once, not once per unrolled region: ~1/4 of the instructions of join_slot_kernels.hpp.
+// Reservation as in the fused kernel (block scan + one returning atomicAdd per 2048-region round), but the atomic is
+// issued BEFORE the round's root_fids are staged in LDS, so its latency (the same-address atomics of 489 rounds
+// serialise at ~90 per us) hides behind the staging; the root_fids leave as full lines.
+// Root-bitmap passes (what the CLI runs, intersect.rs:598-615) read the "pos" copy of the table and set bits in an
+// LDS-private bitmap (no reservation, no scan); every block writes its bitmap to its own slab and k_bitmap_or folds the
+// slabs into the batch's bitmap -- no global atomics at all.
+// Roofline bound: HBM.  Algorithmic bytes per region: 12 in + 4 + 4*h out.
+#pragma once
+#include "join_fused_kernels.hpp"
+
+#ifndef GFFX_WIN_THREADS
+#define GFFX_WIN_THREADS 512
+#endif
+#ifndef GFFX_WIN_MIN_WAVES
+#define GFFX_WIN_MIN_WAVES 4
+#endif
+// tools/kbench.hip builds ablated variants to price the kernel's parts (-DGFFX_WIN_ABL_NOGATHER: no index line is read,
+// _NODEFER: list tails / sweeps are skipped, _NOATOMIC: no pair reservation); they give wrong results and are never built
+// into the library.
+
+namespace gffx {
+
+constexpr int kWinThreads = GFFX_WIN_THREADS;
+constexpr uint32_t kWinChunk = kWinThreads * 4;  // regions per round: one uint4 of every region column per thread
+constexpr uint32_t kWinStage = 2 * kWinChunk;    // root_fids of a round staged in LDS so that they leave as full lines
+constexpr uint32_t kWinInline = 5;               // list entries inside the 64-byte line
+constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (n = 255)
+constexpr uint32_t kWinStash = 4;                // per thread: kept root_fids of list tails / sweeps wait here (LDS) for the emit
+
+typedef uint32_t gffx_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned long long gffx_v2ul __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 win_nt_load4(const uint32_t *p) {
+    const gffx_v4u v = GFFX_NT_LOAD(reinterpret_cast<const gffx_v4u *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void win_nt_store4(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    gffx_v4u v;
+    v.x = a, v.y = b, v.z = c, v.w = d;
+    GFFX_NT_STORE(v, reinterpret_cast<gffx_v4u *>(p));
+}
+__device__ __forceinline__ void win_nt_store2(unsigned long long *p, unsigned long long a, unsigned long long b) {
+    gffx_v2ul v;
+    v.x = a, v.y = b;
+    GFFX_NT_STORE(v, reinterpret_cast<gffx_v2ul *>(p));
+}
+
+// Block barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and store of the
+// wave (s_waitcnt vmcnt(0)): the next round's region prefetch and this round's result stores would be waited for at every
+// barrier.  Nothing in k_join_win is handed from wave to wave through global memory, so LDS ordering is all it needs.
+__device__ __forceinline__ void win_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int MODE, bool INVERT>
+__device__ __forceinline__ bool win_test(uint32_t s, uint32_t e, uint32_t qs, uint32_t qe) {
+    return s < qe && e > qs && keep_pair<MODE, INVERT>(s, e, qs, qe);
+}
+
+struct WinOut {
+    uint32_t *counts;               // nq, input order
+    unsigned long long *offsets;    // nq, input order: start of the region's pair segment (or nullptr)
+    uint32_t *offsets32;            // the same as u32 (GFFX_OUT_OFFSETS32; or nullptr)
+    uint32_t *fids, *triples;
+    uint32_t *bitmap;               // OUT == 3 without an LDS bitmap: global words (atomicOr)
+    uint32_t *slabs;                // OUT == 3 with an LDS bitmap: gridDim.x slabs of bm_words words
+    uint32_t bm_words;              // words of the root bitmap; 0 = no LDS bitmap
+    uint32_t *err;                  // bit0 = chr out of range
+    unsigned long long *slow;       // regions that took the exact sweep (AUTO's heuristic)
+    unsigned long long *pair_cursor;       // kept pairs of this pass (zero on entry)
+    unsigned long long *pair_cursor_next;  // the other cursor word: zeroed here for the next pass
+    unsigned long long capacity;
+};
+
+constexpr uint32_t kWinNoLine = 0x80000000u;  // byte offset beyond every window table (< 2^31 bytes): reads as zeros
+
+// a[k] for a per-lane k without making `a` addressable (an indexed private array would live in scratch memory)
+__device__ __forceinline__ uint32_t win_sel(const uint32_t (&a)[4], int k) {
+    return (a[0] & (k == 0 ? ~0u : 0u)) | (a[1] & (k == 1 ? ~0u : 0u)) | (a[2] & (k == 2 ? ~0u : 0u)) | (a[3] & (k == 3 ? ~0u : 0u));
+}
+
+// what the 64-byte line does not hold of one DEFERRED region: the tail (entries 5..) of its list, or -- wide / empty-width
+// region, dense window -- every kept pair by the exact sweep.  f(start, end, root_fid, position); `start` is only valid when
+// the mode predicate or the caller (NEED_START) reads it.
+template <int MODE, bool INVERT, bool NEED_START, typename F>
+__device__ __forceinline__ void win_rest(const IndexView &ix, bool sweep, uint32_t chr, uint32_t qs, uint32_t qe, uint32_t hdr,
+                                         F &&f) {
+    if (sweep) {
+        for_each_kept<MODE, INVERT>(ix, ix.chr_meta[chr], qs, qe, [&](uint32_t j, uint32_t s, const uint4 &a) {
+            f((NEED_START && MODE == GFFX_MODE_OVERLAP) ? ix.start[j] : s, a.x, a.w, j);
+            return true;
+        });
+    } else {
+        const uint32_t n = hdr & 255u;
+        const uint4 *sp = ix.win_spill + (hdr >> 8);
+        for (uint32_t j = kWinInline; j < n; j += 4) {  // four records in flight (99.9 % of the tails end here)
+            uint4 x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                x[t] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+                if (j + t < n) x[t] = sp[j - kWinInline + t];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (win_test<MODE, INVERT>(x[t].x, x[t].y, qs, qe)) f(x[t].x, x[t].y, x[t].z, x[t].w);
+        }
+    }
+}
+
+// OUT: 1 = counts (+ offsets) and root_fids when out.fids is set (bench / depth), 2 = triples (+ root_fids),
+//      3 = root bitmap only (the CLI's pass)
+template <int MODE, bool INVERT, bool AOS, bool META_LDS, int OUT>
+__global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(IndexView ix, QueryView q, unsigned long long nq,
+                                                                               WinOut out, int vec_ok, uint32_t stage_words,
+                                                                               uint32_t fwords) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *s_scratch = reinterpret_cast<uint32_t *>(smem);                       // wave totals
+    unsigned long long *s_base = reinterpret_cast<unsigned long long *>(smem + 64);  // 8 B
+    uint32_t *s_fids = reinterpret_cast<uint32_t *>(smem + 80);                      // stage_words: root_fid stage / LDS bitmap
+    uint32_t *s_stash = s_fids + stage_words + kWinStash * threadIdx.x;              // this thread's kWinStash words
+    uint32_t *s_filter = s_fids + stage_words + kWinStash * kWinThreads;             // fwords (a multiple of 4): coverage filter
+    uint4 *s_meta = reinterpret_cast<uint4 *>(s_filter + fwords);                    // n_chr + 1 (META_LDS)
+    uint2 *s_fmeta = reinterpret_cast<uint2 *>(s_meta + ix.n_chr + 1);               // n_chr + 1 (META_LDS)
+    const bool bm_lds = OUT == 3 && out.bm_words != 0;
+    constexpr bool kPrefetch = OUT != 2;  // (the triples pass keeps every line word alive: no registers to spare)
+
+    uint32_t qc[4], qs[4], qe[4];     // this round's 4 consecutive regions of the thread
+    uint32_t nqc[4], nqs[4], nqe[4];  // the next round's: loaded while this round reserves and emits
+    auto load_round = [&](unsigned long long r, uint32_t (&qc)[4], uint32_t (&qs)[4], uint32_t (&qe)[4]) {
+        const unsigned long long i0 = r * kWinChunk + 4ull * threadIdx.x;
+        if (vec_ok && i0 + 4 <= nq) {
+            if (AOS) {
+                const uint32_t *p = q.aos + 3ull * i0;
+                const uint4 a = win_nt_load4(p), b = win_nt_load4(p + 4), c = win_nt_load4(p + 8);
+                qc[0] = a.x, qs[0] = a.y, qe[0] = a.z;
+                qc[1] = a.w, qs[1] = b.x, qe[1] = b.y;
+                qc[2] = b.z, qs[2] = b.w, qe[2] = c.x;
+                qc[3] = c.y, qs[3] = c.z, qe[3] = c.w;
+            } else {
+                const uint4 c = win_nt_load4(q.chr + i0), s = win_nt_load4(q.start + i0), e = win_nt_load4(q.end + i0);
+                qc[0] = c.x, qc[1] = c.y, qc[2] = c.z, qc[3] = c.w;
+                qs[0] = s.x, qs[1] = s.y, qs[2] = s.z, qs[3] = s.w;
+                qe[0] = e.x, qe[1] = e.y, qe[2] = e.z, qe[3] = e.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                qc[k] = 0xFFFFFFFFu;  // "no region"
+                qs[k] = qe[k] = 0;
+                if (i0 + k < nq) load_query<AOS>(q, i0 + k, qc[k], qs[k], qe[k]);
+            }
+        }
+    };
+    const unsigned long long n_rounds = (nq + kWinChunk - 1) / kWinChunk;
+    if (blockIdx.x < n_rounds) load_round(blockIdx.x, nqc, nqs, nqe);  // in flight while the seqid table is staged
+    const uint4 *cm;  // seqid -> {first window, windows, shift, wmax}; entry n_chr is all zero ("no windows")
+    const uint2 *fmeta;  // seqid -> {first filter bit, cells}
+    if (META_LDS) {
+        for (uint32_t i = threadIdx.x; i <= ix.n_chr; i += kWinThreads) s_meta[i] = ix.win_meta[i], s_fmeta[i] = ix.win_fmeta[i];
+        cm = s_meta;
+        fmeta = s_fmeta;
+    } else {
+        cm = ix.win_meta;
+        fmeta = ix.win_fmeta;
+    }
+    for (uint32_t x = threadIdx.x; x < fwords / 4; x += kWinThreads)  // the coverage filter: 16 bytes per thread and trip
+        reinterpret_cast<uint4 *>(s_filter)[x] = reinterpret_cast<const uint4 *>(ix.win_filter)[x];
+    if (bm_lds)
+        for (uint32_t x = threadIdx.x; x < out.bm_words; x += kWinThreads) s_fids[x] = 0;
+    win_barrier();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out.pair_cursor_next = 0ull;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the index lines: buffer loads (32-bit offsets from one scalar base: no 64-bit address arithmetic per gather;
+    // an offset beyond the table reads zeros)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(OUT == 3 ? ix.win_pos : ix.win), 0, (uint32_t)(ix.n_win * 64u), 0x00020000);
+    auto set_bit = [&](uint32_t p) {
+        if (bm_lds)
+            atomicOr(&s_fids[p >> 5], 1u << (p & 31));
+        else if (!(__hip_atomic_load(&out.bitmap[p >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (p & 31) & 1u))
+            atomicOr(&out.bitmap[p >> 5], 1u << (p & 31));
+    };
+    uint32_t bad = 0;
+    uint32_t n_slow = 0;
+    unsigned long long kept_total = 0;  // OUT == 3: this thread's kept pairs over all rounds
+
+    GFFX_STAMP(4, 0);
+    for (unsigned long long r = blockIdx.x; r < n_rounds; r += gridDim.x) {
+        const unsigned long long i0 = r * kWinChunk + 4ull * threadIdx.x;  // this thread's 4 consecutive regions
+        if (!kPrefetch && r != blockIdx.x) load_round(r, nqc, nqs, nqe);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) qc[k] = nqc[k], qs[k] = nqs[k], qe[k] = nqe[k];
+        // ---- one index line per region: 4 x 16 bytes, the loads of all four regions in flight together; no branches
+        uint32_t sweep = 0;  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
+        uint32_t off[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool inb = qc[k] < ix.n_chr;
+            bad |= (!inb && i0 + k < nq) ? 1u : 0u;
+            const uint32_t ci = inb ? qc[k] : ix.n_chr;
+            const uint4 m = cm[ci];
+            const bool live = m.y != 0 && !(MODE == GFFX_MODE_OVERLAP && INVERT);  // (invert ^ true: nothing is ever kept)
+            const bool fits = qe[k] > qs[k] && qe[k] - qs[k] <= m.w;
+            const uint32_t b = (qe[k] - 1) >> m.z;  // (beyond the last window nothing can reach the region)
+            bool cov = true;
+            if (fwords) {  // kernel-uniform: is any cell the region touches covered by a root?  (clear = no hit, exactly)
+                const uint2 fm = fmeta[ci];
+                const uint32_t last = fm.y - 1;  // (cells beyond the seqid's last: clamped, i.e. conservative)
+                const uint32_t a2 = min(qs[k] >> ix.win_fshift, last), b2 = min((qe[k] - 1) >> ix.win_fshift, last);
+                const uint32_t bit = fm.x + a2, w = min(bit >> 5, fwords - 2);
+                const unsigned long long v = (((unsigned long long)s_filter[w + 1] << 32) | s_filter[w]) >> (bit & 31);
+                cov = (v & ((2ull << min(b2 - a2, 31u)) - 1ull)) != 0;  // (a region the lines answer spans <= 32 cells)
+            }
+#if defined(GFFX_WIN_ABL_NOGATHER)
+            off[k] = (live && fits && b < m.y && cov && qs[k] == 0xFFFFFFF0u) ? (m.x + b) * 64u : kWinNoLine;
+#else
+            off[k] = (live && fits && b < m.y && cov) ? (m.x + b) * 64u : kWinNoLine;
+#endif
+            sweep |= (live && !fits) ? 1u << k : 0u;
+        }
+        // (the header words first: list tails can be fetched while the rest of the lines is still on its way)
+        gffx_v4u w0[4], w1[4], w2[4], w3[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w0[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w2[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 32, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w3[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 48, 0, 0);
+        if (r == blockIdx.x) GFFX_STAMP(4, 1);
+        // ---- the rare rest, one region at a time: list tails and exact sweeps (count; a bitmap pass also sets the bits).
+        // The first kWinStash kept root_fids wait in the thread's LDS strip: the emit below then walks nothing again.
+        uint32_t hdr[4], tc[4] = {0, 0, 0, 0};
+        uint32_t deferred = sweep, n_rest = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hdr[k] = w0[k].x;
+            const uint32_t n = hdr[k] & 255u;
+            deferred |= n > kWinInline ? 1u << k : 0u;
+            sweep |= n == 255u ? 1u << k : 0u;  // dense window: its line is empty
+        }
+#if defined(GFFX_WIN_ABL_NODEFER)
+        deferred = 0;
+#endif
+        if (deferred) {
+            n_slow += __popc(sweep);
+            uint32_t d = deferred;
+            while (d) {
+                const int k = __ffs(d) - 1;
+                d &= d - 1;
+                uint32_t c = 0;
+                win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
+                                              [&](uint32_t, uint32_t, uint32_t fid, uint32_t p) {
+                                                  if (OUT == 1 && n_rest < kWinStash) s_stash[n_rest] = fid;
+                                                  ++n_rest;
+                                                  ++c;
+                                                  if (OUT == 3) set_bit(p);
+                                              });
+                tc[0] += k == 0 ? c : 0u;
+                tc[1] += k == 1 ? c : 0u;
+                tc[2] += k == 2 ? c : 0u;
+                tc[3] += k == 3 ? c : 0u;
+            }
+        }
+        // ---- five exact tests per region
+        uint32_t cnt[4], mask[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t mk = 0;
+            mk |= win_test<MODE, INVERT>(w0[k].y, w1[k].z, qs[k], qe[k]) ? 1u : 0u;
+            mk |= win_test<MODE, INVERT>(w0[k].z, w1[k].w, qs[k], qe[k]) ? 2u : 0u;
+            mk |= win_test<MODE, INVERT>(w0[k].w, w2[k].x, qs[k], qe[k]) ? 4u : 0u;
+            mk |= win_test<MODE, INVERT>(w1[k].x, w2[k].y, qs[k], qe[k]) ? 8u : 0u;
+            mk |= win_test<MODE, INVERT>(w1[k].y, w2[k].z, qs[k], qe[k]) ? 16u : 0u;
+            mask[k] = mk;
+            cnt[k] = __popc(mk) + tc[k];
+        }
+        if (kPrefetch && r + gridDim.x < n_rounds) load_round(r + gridDim.x, nqc, nqs, nqe);
+        if (r == blockIdx.x) GFFX_STAMP(4, 2);
+        const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        if (OUT == 3) {
+            // ---- root bitmap: no reservation; counts out, bits set
+            kept_total += mine;
+            if (i0 + 4 <= nq) {
+                win_nt_store4(out.counts + i0, cnt[0], cnt[1], cnt[2], cnt[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (i0 + k < nq) out.counts[i0 + k] = cnt[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // (the "pos" copy of the table: positions where the root_fids are)
+                if (mask[k] & 1u) set_bit(w2[k].w);
+                if (mask[k] & 2u) set_bit(w3[k].x);
+                if (mask[k] & 4u) set_bit(w3[k].y);
+                if (mask[k] & 8u) set_bit(w3[k].z);
+                if (mask[k] & 16u) set_bit(w3[k].w);
+            }
+            continue;
+        }
+        // ---- reserve the round's pair segment: block scan + ONE returning atomicAdd, issued before the staging
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        win_barrier();  // s_scratch / s_base / the stage of the previous round are no longer read
+        if (lane == 63) s_scratch[wave] = inc;
+        win_barrier();
+        uint32_t wbase = 0, btotal = 0;
+#pragma unroll
+        for (int x = 0; x < kWinThreads / 64; ++x) {
+            const uint32_t v = s_scratch[x];
+            if (x < wave) wbase += v;
+            btotal += v;
+        }
+        unsigned long long got = 0;
+#if defined(GFFX_WIN_ABL_NOATOMIC)
+        got = r * 1400ull;
+#else
+        if (threadIdx.x == 0 && btotal) got = atomicAdd(out.pair_cursor, (unsigned long long)btotal);
+#endif
+        const uint32_t lp0 = wbase + inc - mine;  // this thread's first pair inside the round's segment
+        const uint32_t lpk[4] = {lp0, lp0 + cnt[0], lp0 + cnt[0] + cnt[1], lp0 + cnt[0] + cnt[1] + cnt[2]};
+        if (r == blockIdx.x) GFFX_STAMP(4, 3);
+        // ---- counts (input order, 16 bytes per thread); root_fids of the round into the LDS stage by final position
+        if (i0 + 4 <= nq) {
+            win_nt_store4(out.counts + i0, cnt[0], cnt[1], cnt[2], cnt[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k < nq) out.counts[i0 + k] = cnt[k];
+        }
+        const bool want_fids = out.fids != nullptr;
+        const bool staged = OUT == 1 && want_fids && btotal <= stage_words;  // block-uniform
+        if (OUT == 1 && staged) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t m = mask[k], lp = lpk[k];
+                if (m & 1u) s_fids[lp] = w2[k].w;
+                if (m & 2u) s_fids[lp + (m & 1u)] = w3[k].x;
+                if (m & 4u) s_fids[lp + __popc(m & 3u)] = w3[k].y;
+                if (m & 8u) s_fids[lp + __popc(m & 7u)] = w3[k].z;
+                if (m & 16u) s_fids[lp + __popc(m & 15u)] = w3[k].w;
+            }
+            uint32_t d = deferred, taken = 0;
+            while (d) {  // list tails / sweeps, now that their places are known: from the strip, or (rare) walked again
+                const int k = __ffs(d) - 1;
+                d &= d - 1;
+                uint32_t e = win_sel(lpk, k) + __popc(win_sel(mask, k));
+                if (n_rest <= kWinStash) {
+                    for (uint32_t t = win_sel(tc, k); t; --t) s_fids[e++] = s_stash[taken++];
+                } else {
+                    win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
+                                                  [&](uint32_t, uint32_t, uint32_t fid, uint32_t) { s_fids[e++] = fid; });
+                }
+            }
+        }
+        if (threadIdx.x == 0) s_base[0] = got;
+        win_barrier();
+        const unsigned long long seg = s_base[0];
+        {  // offsets: 16 bytes per thread and array
+            const unsigned long long pos = seg + lp0;
+            if (i0 + 4 <= nq) {
+                if (out.offsets) {
+                    win_nt_store2(out.offsets + i0, pos, pos + cnt[0]);
+                    win_nt_store2(out.offsets + i0 + 2, pos + cnt[0] + cnt[1], pos + cnt[0] + cnt[1] + cnt[2]);
+                }
+                if (out.offsets32) {
+                    const uint32_t p32 = (uint32_t)pos;
+                    win_nt_store4(out.offsets32 + i0, p32, p32 + cnt[0], p32 + cnt[0] + cnt[1], p32 + cnt[0] + cnt[1] + cnt[2]);
+                }
+            } else {
+                unsigned long long o = pos;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (i0 + k < nq) {
+                        if (out.offsets) out.offsets[i0 + k] = o;
+                        if (out.offsets32) out.offsets32[i0 + k] = (uint32_t)o;
+                    }
+                    o += cnt[k];
+                }
+            }
+        }
+        if (staged) {  // the round's root_fids leave as full lines
+            for (uint32_t x = threadIdx.x; x < btotal; x += kWinThreads)
+                if (seg + x < out.capacity) GFFX_NT_STORE(s_fids[x], out.fids + seg + x);
+        } else if (OUT == 2 || want_fids) {  // triples, or more root_fids than the stage holds: straight to global memory
+            auto put = [&](unsigned long long o, uint32_t s, uint32_t e, uint32_t fid) {
+                if (o >= out.capacity) return;
+                if (want_fids) out.fids[o] = fid;
+                if (OUT == 2 && out.triples) {
+                    uint32_t *tr = out.triples + 3ull * o;
+                    tr[0] = fid, tr[1] = s, tr[2] = e;
+                }
+            };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned long long o = seg + lpk[k];
+                const uint32_t m = mask[k];
+                if (m & 1u) put(o++, w0[k].y, w1[k].z, w2[k].w);
+                if (m & 2u) put(o++, w0[k].z, w1[k].w, w3[k].x);
+                if (m & 4u) put(o++, w0[k].w, w2[k].x, w3[k].y);
+                if (m & 8u) put(o++, w1[k].x, w2[k].y, w3[k].z);
+                if (m & 16u) put(o++, w1[k].y, w2[k].z, w3[k].w);
+            }
+            uint32_t d = deferred;
+            while (d) {
+                const int k = __ffs(d) - 1;
+                d &= d - 1;
+                unsigned long long o = seg + win_sel(lpk, k) + __popc(win_sel(mask, k));
+                win_rest<MODE, INVERT, OUT == 2>(ix, sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
+                                                 [&](uint32_t s, uint32_t e, uint32_t fid, uint32_t) { put(o++, s, e, fid); });
+            }
+        }
+        if (r == blockIdx.x) GFFX_STAMP(4, 4);
+    }
+    if (bad) atomicOr(out.err, 1u);
+    if (OUT == 3) {
+        // kept pairs of the pass: one atomic per block; the LDS bitmap goes to this block's slab
+        const unsigned long long t = wave_reduce_add(kept_total);
+        win_barrier();
+        if (threadIdx.x == 0) s_base[0] = 0;
+        win_barrier();
+        if (lane == 0 && t) atomicAdd(s_base, t);
+        win_barrier();
+        if (threadIdx.x == 0 && s_base[0]) atomicAdd(out.pair_cursor, s_base[0]);
+        if (bm_lds)
+            for (uint32_t x = threadIdx.x; x < out.bm_words; x += kWinThreads) out.slabs[(size_t)blockIdx.x * out.bm_words + x] = s_fids[x];
+    }
+    // how many regions took the exact sweep (the host moves a batch that is mostly such regions to the sweep kernel)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64);
+    if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow);
+}
+
+// folds the per-block bitmap slabs of a root-bitmap pass into the batch's bitmap (OR: a streaming caller accumulates
+// chunk after chunk without clearing).  Block (x, y) = 64 words x the y-th sixteenth of the slabs, 16 slab shares per word
+// inside the block; one atomicOr per non-zero word and block.
+__global__ __launch_bounds__(1024) void k_bitmap_or(const uint32_t *slabs, uint32_t n_slabs, uint32_t words, uint32_t *bitmap) {
+    __shared__ uint32_t s_part[1024];
+    const uint32_t w = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const uint32_t per = (n_slabs + gridDim.y - 1) / gridDim.y;
+    const uint32_t s0 = blockIdx.y * per, s1 = min(n_slabs, s0 + per);
+    uint32_t acc = 0;
+    if (w < words)
+        for (uint32_t s = s0 + g; s < s1; s += 16) acc |= slabs[(size_t)s * words + w];
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && w < words) {
+#pragma unroll
+        for (int x = 1; x < 16; ++x) acc |= s_part[threadIdx.x + 64 * x];
+        if (acc) atomicOr(&bitmap[w], acc);
+    }
+}
+
+}  // namespace gffx

@@ -30,11 +30,14 @@ class OverlapMode(enum.IntEnum):
 
 
 OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS, OUT_EMIT_ORDER = 1, 2, 4, 8, 16, 32
-STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED, STRATEGY_FUSED, STRATEGY_SLOTS = 0, 1, 2, 3, 4
+OUT_OFFSETS32, OUT_BITMAP_KEEP = 64, 128
+STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED, STRATEGY_FUSED, STRATEGY_SLOTS, STRATEGY_WINDOWS = 0, 1, 2, 3, 4, 5
 K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE, K_FUSED_DIRECT, K_DEPTH, K_SLOTS = 0, 1, 2, 3, 4, 5, 6, 7, 8
+K_WINDOWS, K_BITMAP_OR = 9, 10
 KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_partition",
                 K_LINES: "k_lines_exists", K_FUSED: "k_tile_join", K_UNPERMUTE: "k_unpermute",
-                K_FUSED_DIRECT: "k_join_fused", K_DEPTH: "k_depth_regions", K_SLOTS: "k_join_slots"}
+                K_FUSED_DIRECT: "k_join_fused", K_DEPTH: "k_depth_regions", K_SLOTS: "k_join_slots",
+                K_WINDOWS: "k_join_win", K_BITMAP_OR: "k_bitmap_or"}
 
 
 def device_count() -> int:
@@ -176,6 +179,12 @@ class QueryBatch:
         out = np.empty(self.n_queries + 1, dtype=np.uint64)
         check(lib().gffx_hip_batch_copy_offsets(self._h, out.ctypes.data_as(u64p)))
         return out
+
+    def offsets32(self) -> np.ndarray:
+        """Segment starts as u32 (OUT_OFFSETS32), nq entries."""
+        out = np.empty(max(self.n_queries, 1), dtype=np.uint32)
+        check(lib().gffx_hip_batch_copy_offsets32(self._h, _p(out)))
+        return out[: self.n_queries]
 
     def query_records(self, with_offsets: bool = True):
         """(rows, counts, offsets) in emission order: rows[i] = input row of the i-th served query."""

@@ -73,6 +73,12 @@ enum gffx_out {
                                  Direct strategy: the exclusive prefix of the counts (CSR in input order).
                                  Partitioned strategy: segments follow the order in which genome tiles were
                                  served, so the offsets are explicit -- they still tile [0, pairs) exactly. */
+    GFFX_OUT_OFFSETS32 = 64,  /* the same segment starts as u32 (nq entries), for callers that know the pass keeps
+                                 fewer than 2^32 pairs (the engine checks: _wait fails with GFFX_E_INVALID otherwise);
+                                 halves the bytes the offsets cost.  Windows strategy only (AUTO picks it). */
+    GFFX_OUT_BITMAP_KEEP = 128, /* with GFFX_OUT_ROOT_BITMAP: do not clear the batch's bitmap first -- a caller that streams a
+                                 BED file chunk by chunk through one batch accumulates the unique roots of all chunks
+                                 (commands/intersect.rs:598-615 dedups over the whole file) */
     GFFX_OUT_EMIT_ORDER = 32  /* partitioned strategy: leave the per-query results in emission order
                                  ({input row, count, offset} records: gffx_hip_batch_copy_query_records) and
                                  skip the scatter into input-order arrays; _copy_counts / _copy_offsets then
@@ -87,6 +93,11 @@ enum gffx_strategy {
     GFFX_STRATEGY_FUSED = 3,  /* queries in input order, ONE kernel: interleaved gathers from the L2-resident
                                  index, count + emit per block round; counts / offsets in input order, pair
                                  segments in the order rounds reserve them (offsets explicit) */
+    GFFX_STRATEGY_WINDOWS = 5, /* AUTO's choice.  One 64-byte index LINE per region: the line of the genome window the
+                                 region ends in lists up to 5 candidate roots {start, end, root_fid}; longer lists, dense
+                                 windows, wide and empty-width regions are deferred to an LDS work list inside the round
+                                 and served exactly (list walk / skip-link sweep).  Root-bitmap passes set bits in an
+                                 LDS-private bitmap.  Output contract as FUSED. */
     GFFX_STRATEGY_SLOTS = 4   /* as FUSED, but over the slot index: one 32-byte gather per region answers the
                                  usual case (precomputed candidate list of the window the region ends in);
                                  wide regions and dense windows take the exact sweep in their lane */
@@ -102,7 +113,9 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
     GFFX_K_FUSED_DIRECT = 6,
     GFFX_K_DEPTH = 7,
     GFFX_K_SLOTS = 8,
-    GFFX_K__COUNT = 9
+    GFFX_K_WINDOWS = 9,
+    GFFX_K_BITMAP_OR = 10,
+    GFFX_K__COUNT = 11
 };
 
 typedef struct gffx_hip_index gffx_hip_index;
@@ -162,6 +175,7 @@ uint64_t gffx_hip_batch_n_queries(const gffx_hip_batch *);
 uint64_t gffx_hip_batch_total_hits(const gffx_hip_batch *);
 int gffx_hip_batch_copy_counts(gffx_hip_batch *, uint32_t *host /* nq */);
 int gffx_hip_batch_copy_offsets(gffx_hip_batch *, uint64_t *host /* nq+1 */);
+int gffx_hip_batch_copy_offsets32(gffx_hip_batch *, uint32_t *host /* nq */); /* GFFX_OUT_OFFSETS32 */
 /* per-query records in emission order: rows[i] = input row, counts[i] = kept pairs, offsets[i] = start of
  * its segment in fids / triples (needs GFFX_OUT_OFFSETS); any pointer may be NULL; nq entries each */
 int gffx_hip_batch_copy_query_records(gffx_hip_batch *, uint32_t *rows, uint32_t *counts, uint64_t *offsets);
@@ -172,6 +186,8 @@ int gffx_hip_batch_copy_root_bitmap(gffx_hip_batch *, uint64_t *host, uint64_t n
 /* device views of the same buffers (NULL if not produced), for zero-copy consumers */
 const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *);
 const uint32_t *gffx_hip_batch_device_fids(const gffx_hip_batch *);
+const uint64_t *gffx_hip_batch_device_offsets(const gffx_hip_batch *);
+const uint32_t *gffx_hip_batch_device_offsets32(const gffx_hip_batch *);
 const uint32_t *gffx_hip_batch_device_triples(const gffx_hip_batch *);
 /* pre-size the pair buffers (pairs); avoids the capacity replay on the first run */
 int gffx_hip_batch_reserve_hits(gffx_hip_batch *, uint64_t n_pairs);

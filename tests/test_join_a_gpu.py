@@ -13,7 +13,8 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 FLAGS = engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS
-STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_SLOTS]
+STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_SLOTS,
+              engine.STRATEGY_WINDOWS]
 
 
 def _sorted_rows(t):
@@ -366,10 +367,11 @@ def test_full_size_c2_properties(nq, strategy):
         assert np.array_equal(res[(int(mode), False)][sel], want_c)
 
 
+@pytest.mark.parametrize("strategy", [engine.STRATEGY_SLOTS, engine.STRATEGY_WINDOWS])
 @pytest.mark.parametrize("mode", list(OverlapMode))
 @pytest.mark.parametrize("invert", [False, True])
-def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert):
-    """The slot index answers regions of width <= wmax from a window's candidate list; everything else -- wide
+def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert, strategy):
+    """The slot / window index answers regions of width <= wmax from a window's candidate list; everything else -- wide
     regions, start >= end, windows with more than kSlotMaxList candidates -- walks the sweep in its lane.  A mix
     of all of them in one batch, odd batch sizes (partial last thread / round), against the oracle."""
     rng = np.random.default_rng(11)
@@ -399,7 +401,7 @@ def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert):
         regions[dense, 0] = 0
         regions[dense, 1] = rng.integers(495_000, 525_000, int(dense.sum()))
         regions[dense, 2] = regions[dense, 1] + rng.integers(1, 4000, int(dense.sum()))
-        _check(roots2, regions, mode, invert, soa=bool(nq & 1), strategy=engine.STRATEGY_SLOTS)
+        _check(roots2, regions, mode, invert, soa=bool(nq & 1), strategy=strategy)
 
 
 def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
@@ -410,7 +412,7 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
     wide = synth.synth_bed(5000, seed=1, chroms=synth.SMALL2, width=(200_000, 900_000))
     narrow = synth.synth_bed(5000, seed=2, chroms=synth.SMALL2, width=(100, 5000))
     b = engine.QueryBatch(ix, 5000)
-    for regions, want_second in ((wide, "k_join_fused"), (narrow, "k_join_slots")):
+    for regions, want_second in ((wide, "k_join_fused"), (narrow, "k_join_win")):
         b.set_regions(regions)
         _, want_c = oix.query_features(regions, 2, False)
         used = []
@@ -422,7 +424,42 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
             b.set_profiling(False)
             used.append([name for kid, name in engine.KERNEL_NAMES.items() if b.kernel_ms(kid)[1]])
             assert np.array_equal(b.counts(), want_c)
-        assert used[0] == ["k_join_slots"] and used[1] == [want_second]
+        assert used[0] == ["k_join_win"] and used[1] == [want_second]
+
+
+def test_offsets32_and_bitmap_accumulation():
+    """GFFX_OUT_OFFSETS32: the segment starts as u32 equal the u64 ones.  GFFX_OUT_BITMAP_KEEP: a caller that streams a
+    BED file chunk by chunk through one batch ends with the unique roots of the whole file (intersect.rs:598-615)."""
+    roots = synth.gencode_like_roots(5000, seed=3)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    regions = synth.synth_bed(30011, seed=8, edge_frac=0.02, roots=roots)
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)
+    for mode in OverlapMode:
+        want_t, want_c = oix.query_features(regions, int(mode), False)
+        b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32)
+        b.wait()
+        off, off32 = b.offsets(), b.offsets32()
+        assert np.array_equal(b.counts(), want_c) and np.array_equal(off[:-1], off32.astype(np.uint64))
+        f2 = b.fids()
+        got = np.sort(np.concatenate([f2[int(o):int(o) + int(c)] for o, c in zip(off32[:500], want_c[:500])]))
+        one_t, _ = oix.query_features(regions[:500], int(mode), False)
+        assert np.array_equal(got, np.sort(one_t[:, 0]))
+        # three chunks through one batch, the bitmap kept between them
+        seen = np.zeros(0, dtype=np.uint32)
+        for ci, chunk in enumerate(np.array_split(regions, 3)):
+            b.set_regions(chunk)
+            b.run(mode, False, engine.OUT_ROOT_BITMAP | (engine.OUT_BITMAP_KEEP if ci else 0))
+            b.wait()
+            ct, _ = oix.query_features(chunk, int(mode), False)
+            seen = np.union1d(seen, ct[:, 0])
+            assert np.array_equal(b.unique_roots(), seen)
+        assert np.array_equal(seen, np.unique(want_t[:, 0]))
+        b.set_regions(regions)
+    b.close()
+    ix.close()
 
 
 @pytest.mark.parametrize("shift", [0, 1, 3])

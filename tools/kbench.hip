@@ -123,8 +123,8 @@ int main(int argc, char **argv) {
         gffx_hip_batch_sync(b);
     }
     gffx_hip_batch_set_profiling(b, 0);
-    const char *names[] = {"join_count", "join_emit", "partition", "lines", "tile_join", "unpermute", "join_fused", "depth", "join_slots"};
-    for (int k = 0; k < 9; k++) {
+    const char *names[] = {"join_count", "join_emit", "partition", "lines", "tile_join", "unpermute", "join_fused", "depth", "join_slots", "join_win", "bitmap_or"};
+    for (int k = 0; k < 11; k++) {
         double t;
         uint64_t n;
         gffx_hip_batch_kernel_ms(b, k, &t, &n);
@@ -132,7 +132,7 @@ int main(int argc, char **argv) {
     }
 #if GFFX_STAMPS
     // one more pass, then dump the phase stamps of the LAST kernel that stamped
-    for (int which = 2; which < 4; which++) {
+    for (int which = 2; which < 5; which++) {
         std::vector<unsigned long long> z(8192 * 16, 0);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z.data(), z.size() * 8);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sel), &which, sizeof(int));
