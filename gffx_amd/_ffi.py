@@ -48,6 +48,7 @@ SIGNATURES = {
     "gffx_hip_batch_device_counts": (vp, [vp]),
     "gffx_hip_batch_device_fids": (vp, [vp]),
     "gffx_hip_batch_device_triples": (vp, [vp]),
+    "gffx_hip_batch_device_regions": (vp, [vp]),
     "gffx_hip_batch_device_offsets": (vp, [vp]),
     "gffx_hip_batch_device_offsets32": (vp, [vp]),
     "gffx_hip_batch_reserve_hits": (C.c_int, [vp, C.c_uint64]),
@@ -59,7 +60,11 @@ SIGNATURES = {
     "gffx_hip_lines_create": (C.c_int, [C.c_int, C.c_uint64, u32p, u32p, u32p, C.POINTER(vp)]),
     "gffx_hip_lines_destroy": (None, [vp]),
     "gffx_hip_lines_test": (C.c_int, [vp, u32p, C.c_uint64, C.c_uint32, C.c_int, u8p]),
+    "gffx_hip_lines_test_device": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_int, u8p]),
     "gffx_hip_lines_last_kernel_ms": (C.c_double, [vp]),
+    "gffx_hip_lines_last_prep_ms": (C.c_double, [vp]),
+    "gffx_hip_lines_copy_tables": (C.c_int, [vp, u64p, u32p, u32p, u32p, u32p]),
+    "gffx_hip_lines_copy_dirs": (C.c_int, [vp, u64p, u32p, u32p, u32p]),
     "gffx_hip_segments_covered": (C.c_int, [C.c_int, C.c_uint64, u32p, u32p, u32p, u32p, C.c_uint64, C.c_uint32, u32p]),
     "gffx_hip_depth_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, u64p, u32p, u32p, u32p, C.c_uint32, u32p,
                                         C.POINTER(vp)]),

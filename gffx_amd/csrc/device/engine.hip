@@ -1511,6 +1511,7 @@ extern "C" const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *b)
     if (!b || (b->strategy == GFFX_STRATEGY_SORTED && !b->unpermuted)) return nullptr;
     return b->d_counts;
 }
+extern "C" const uint32_t *gffx_hip_batch_device_regions(const gffx_hip_batch *b) { return (b && b->have_regions) ? b->q.aos : nullptr; }
 extern "C" const uint32_t *gffx_hip_batch_device_offsets32(const gffx_hip_batch *b) {
     return (b && (b->flags & GFFX_OUT_OFFSETS32)) ? b->d_offsets32 : nullptr;
 }

@@ -3,7 +3,7 @@
 // gff_line_overlaps_queries; called for every non-comment line of every hit block, :284-321).
 //
 // The reference scans all regions of the seqid linearly per line: O(lines x regions_of_seqid),
-// its dominant cost.  Here the regions of a seqid are sorted by start once per run and three
+// its dominant cost.  Here the regions are radix-sorted ON THE DEVICE by (seqid, start, end) once per run (radix_sort.hpp) and three
 // monotone helper arrays make each mode a couple of binary searches.  With (s, e) the RAW
 // column-4/5 integers of the line (1-based closed, no swap: intersect.rs:475-489) and the regions'
 // raw (qs, qe) (no s<e check: intersect.rs:223-225):
@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "gffx_device.hpp"
+#include "radix_sort.hpp"
 
 namespace gffx {
 
@@ -149,6 +150,160 @@ __global__ __launch_bounds__(256) void k_lines_exists(LinesView L, RegionsView R
     keep[i] = k;
 }
 
+
+// ---- region tables on the device (what the reference builds per run as `query_ivmap`, intersect.rs:621-633) --------------
+// The records {seqid, qs, qe} are radix-sorted by (seqid, qs, qe) (radix_sort.hpp); q_off, QS, PM, SM come from that order,
+// QE from a second sort by (seqid, qe); the two bin directories are filled from the sorted arrays.  All kernels below are
+// one thread per region.
+
+// q_off[c] = first sorted position of seqid c (n_seq + 1 entries): every boundary thread fills the seqids it skips over
+__global__ __launch_bounds__(256) void k_b_offsets(const uint32_t *rec, unsigned long long n, uint32_t n_seq, unsigned long long *q_off) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = min(rec[3 * i], n_seq);  // (a seqid out of range is reported by the sort's histogram kernel)
+    const long long prev = i ? (long long)min(rec[3 * (i - 1)], n_seq) : -1;
+    for (long long c = prev + 1; c <= (long long)s; ++c) q_off[c] = i;
+    if (i + 1 == n)
+        for (uint32_t c = s + 1; c <= n_seq; ++c) q_off[c] = n;
+}
+
+// column w of the sorted records; head[i] = 1 where a seqid's run starts (forward) / ends (backward scans)
+__global__ __launch_bounds__(256) void k_b_columns(const uint32_t *rec, unsigned long long n, uint32_t *qs, uint32_t *qe_by_qs,
+                                                   uint8_t *head_fwd, uint8_t *head_bwd) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = rec[3 * i];
+    qs[i] = rec[3 * i + 1];
+    qe_by_qs[i] = rec[3 * i + 2];
+    head_fwd[i] = (i == 0 || rec[3 * (i - 1)] != s) ? 1 : 0;
+    head_bwd[i] = (i + 1 == n || rec[3 * (i + 1)] != s) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_b_column2(const uint32_t *rec, unsigned long long n, uint32_t *out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = rec[3 * i + 2];
+}
+
+// Segmented inclusive scan, one level: MAXOP ? running max : running min; BACKWARD scans from the end (element x of the
+// scan is array element n-1-x).  head[x'] = 1 starts a new segment.  Blocks of 1024 elements; the block's last value and
+// "has a head" flag go to agg / agg_head (the next level scans those), k_b_scan_apply folds the carries back in.
+constexpr int kScanBlock = 1024;
+template <bool MAXOP>
+__device__ __forceinline__ uint32_t scan_op(uint32_t a, uint32_t b) {
+    return MAXOP ? max(a, b) : min(a, b);
+}
+template <bool MAXOP, bool BACKWARD>
+__global__ __launch_bounds__(kScanBlock) void k_b_scan_local(const uint32_t *val, const uint8_t *head, unsigned long long n, uint32_t *out,
+                                                             uint32_t *agg, uint8_t *agg_head) {
+    __shared__ uint32_t s_v[kScanBlock / 64];
+    __shared__ uint32_t s_f[kScanBlock / 64];
+    const unsigned long long x = (unsigned long long)blockIdx.x * kScanBlock + threadIdx.x;
+    const bool live = x < n;
+    const unsigned long long i = BACKWARD ? n - 1 - (live ? x : 0) : x;
+    uint32_t v = live ? val[i] : (MAXOP ? 0u : 0xFFFFFFFFu);
+    uint32_t f = live ? head[i] : 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t pv = __shfl_up(v, o, 64), pf = __shfl_up(f, o, 64);
+        if (lane >= o) {
+            if (!f) v = scan_op<MAXOP>(pv, v);
+            f |= pf;
+        }
+    }
+    if (lane == 63) s_v[wave] = v, s_f[wave] = f;
+    __syncthreads();
+    // carry of the preceding waves of the block: the value of the segment still open where this wave starts
+    // (serial over <= 15 wave totals; a wave that holds a head restarts it)
+    uint32_t cv = 0, cf = 0;
+    for (int w = 0; w < wave; ++w) {
+        cv = (w == 0 || s_f[w]) ? s_v[w] : scan_op<MAXOP>(cv, s_v[w]);
+        cf |= s_f[w];
+    }
+    if (wave > 0 && !f) v = scan_op<MAXOP>(cv, v);
+    f |= cf;
+    if (live) out[i] = v;
+    if (threadIdx.x == kScanBlock - 1 || x + 1 == n) {
+        if (live) agg[blockIdx.x] = v, agg_head[blockIdx.x] = (uint8_t)(f ? 1 : 0);
+    }
+}
+// fold the scanned block carries in: an element before the first head of its block continues the previous blocks' segment
+template <bool MAXOP, bool BACKWARD>
+__global__ __launch_bounds__(kScanBlock) void k_b_scan_apply(const uint8_t *head, unsigned long long n, uint32_t *out, const uint32_t *agg_scanned) {
+    __shared__ uint32_t s_any[kScanBlock / 64];
+    if (blockIdx.x == 0) return;
+    const unsigned long long x = (unsigned long long)blockIdx.x * kScanBlock + threadIdx.x;
+    const bool live = x < n;
+    const unsigned long long i = BACKWARD ? n - 1 - (live ? x : 0) : x;
+    const uint32_t f = live ? head[i] : 1u;
+    // "a head at or before me inside the block": inclusive OR-scan
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(f != 0);
+    const bool before_in_wave = (m & ((2ull << lane) - 1ull)) != 0;
+    if (lane == 0) s_any[wave] = m != 0;
+    __syncthreads();
+    bool seen = before_in_wave;
+    for (int w = 0; w < wave; ++w) seen |= s_any[w] != 0;
+    if (live && !seen) out[i] = scan_op<MAXOP>(agg_scanned[blockIdx.x - 1], out[i]);
+}
+
+// per seqid: the directory geometry {shift, nb} over max(largest start, largest end) and the directory's place d_off
+__global__ __launch_bounds__(256) void k_b_dir_meta(const unsigned long long *q_off, const uint32_t *qs, const uint32_t *qe, uint32_t n_seq,
+                                                    uint2 *d_meta, unsigned long long *d_off) {
+    __shared__ unsigned long long s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    // seqids in chunks of 256: sizes, then a serial prefix by thread 0 (n_seq is small)
+    for (uint32_t c0 = 0; c0 < n_seq; c0 += 256) {
+        const uint32_t c = c0 + threadIdx.x;
+        uint32_t size = 0;
+        if (c < n_seq) {
+            const unsigned long long lo = q_off[c], hi = q_off[c + 1];
+            uint2 m = make_uint2(0, 0);
+            if (hi > lo) {
+                const uint32_t vmax = max(qs[hi - 1], qe[hi - 1]);
+                const unsigned long long budget = max(2ull * (hi - lo), 16ull);
+                uint32_t shift = 0;
+                while ((((unsigned long long)vmax >> shift) + 1) > budget) shift++;
+                m = make_uint2(shift, (vmax >> shift) + 1);
+                size = m.y + 1;
+            }
+            d_meta[c] = m;
+        }
+        __shared__ uint32_t s_size[256];
+        s_size[threadIdx.x] = size;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long run = s_run;
+            for (uint32_t k = 0; k < 256 && c0 + k < n_seq; ++k) {
+                d_off[c0 + k] = run;
+                run += s_size[k];
+            }
+            s_run = run;
+            if (c0 + 256 >= n_seq) d_off[n_seq] = run;
+        }
+        __syncthreads();
+    }
+    if (n_seq == 0 && threadIdx.x == 0) d_off[0] = 0;
+}
+
+// dir[d_off[c] + b] = first sorted position of seqid c whose value >= b << shift, b = 0..nb (nb: the seqid's end)
+__global__ __launch_bounds__(256) void k_b_dir_fill(const uint32_t *val, const uint32_t *rec /* seqid of element i */, unsigned long long n,
+                                                    uint32_t n_seq, const unsigned long long *q_off, const unsigned long long *d_off, const uint2 *d_meta,
+                                                    uint32_t *dir) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = rec[3 * i];
+    if (c >= n_seq) return;  // (reported by the sort's histogram kernel)
+    const unsigned long long lo = q_off[c], hi = q_off[c + 1];
+    const uint2 m = d_meta[c];
+    uint32_t *d = dir + d_off[c];
+    const uint32_t b = val[i] >> m.x;
+    const long long bprev = i > lo ? (long long)(val[i - 1] >> m.x) : -1;
+    for (long long x = bprev + 1; x <= (long long)b; ++x) d[x] = (uint32_t)i;
+    if (i + 1 == hi)
+        for (uint32_t x = b + 1; x <= m.y; ++x) d[x] = (uint32_t)hi;
+}
+
 }  // namespace gffx
 
 using namespace gffx;
@@ -160,7 +315,23 @@ struct gffx_hip_lines {
     uint8_t *d_keep = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;  // bracket k_lines_exists of the last _test
-    double last_kernel_ms = 0.0;
+    hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // ... and the device preparation of the region tables
+    double last_kernel_ms = 0.0, last_prep_ms = 0.0;
+    // region tables of the last _test (grow-only device buffers)
+    uint64_t cap_q = 0, cap_seq = 0, cap_work = 0, cap_dir = 0;
+    uint32_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_c = nullptr;  // 3 u32 per region: input / sort ping-pong / kept (seqid, qs, qe) order
+    uint32_t *d_tab = nullptr;       // QS, PM, SM, QE, E (qe in qs order): 5 x cap_q
+    uint8_t *d_head = nullptr;       // 2 x cap_q
+    uint32_t *d_scan = nullptr;      // carries of the scan levels
+    uint8_t *d_scan_head = nullptr;
+    uint32_t *d_work = nullptr;      // sort work space
+    unsigned long long *d_qoff = nullptr, *d_doff = nullptr;  // cap_seq + 1
+    uint2 *d_dmeta = nullptr;
+    uint32_t *d_dir = nullptr;       // 2 x cap_dir
+    uint32_t *d_err = nullptr;
+    uint64_t last_nq = 0;
+    uint32_t last_n_seq = 0;
+    bool last_dir = false;
 };
 
 template <typename T>
@@ -169,16 +340,35 @@ static int dalloc(T **p, size_t n) {
     GFFX_HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
     return GFFX_OK;
 }
+template <typename T>
+static int regrow(T **p, size_t n) {
+    if (*p) GFFX_HIP_TRY(hipFree(*p));
+    return dalloc(p, n);
+}
 
 extern "C" void gffx_hip_lines_destroy(gffx_hip_lines *L) {
     if (!L) return;
     (void)hipSetDevice(L->device);
+    if (L->stream) (void)hipStreamSynchronize(L->stream);
     (void)hipFree(L->d_seq);
     (void)hipFree(L->d_start);
     (void)hipFree(L->d_end);
     (void)hipFree(L->d_keep);
-    if (L->ev_a) (void)hipEventDestroy(L->ev_a);
-    if (L->ev_b) (void)hipEventDestroy(L->ev_b);
+    (void)hipFree(L->d_rec_a);
+    (void)hipFree(L->d_rec_b);
+    (void)hipFree(L->d_rec_c);
+    (void)hipFree(L->d_tab);
+    (void)hipFree(L->d_head);
+    (void)hipFree(L->d_scan);
+    (void)hipFree(L->d_scan_head);
+    (void)hipFree(L->d_work);
+    (void)hipFree(L->d_qoff);
+    (void)hipFree(L->d_doff);
+    (void)hipFree(L->d_dmeta);
+    (void)hipFree(L->d_dir);
+    (void)hipFree(L->d_err);
+    for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_p0, L->ev_p1})
+        if (e) (void)hipEventDestroy(e);
     if (L->stream) (void)hipStreamDestroy(L->stream);
     delete L;
 }
@@ -202,11 +392,10 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
     L->n = n_lines;
     int rc;
     if ((rc = dalloc(&L->d_seq, n_lines)) || (rc = dalloc(&L->d_start, n_lines)) ||
-        (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)))
+        (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)) || (rc = dalloc(&L->d_err, 4)))
         return rc;
     GFFX_HIP_TRY(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
-    GFFX_HIP_TRY(hipEventCreate(&L->ev_a));
-    GFFX_HIP_TRY(hipEventCreate(&L->ev_b));
+    for (hipEvent_t *e : {&L->ev_a, &L->ev_b, &L->ev_p0, &L->ev_p1}) GFFX_HIP_TRY(hipEventCreate(e));
     if (n_lines) {
         GFFX_HIP_TRY(hipMemcpyAsync(L->d_seq, seq, n_lines * 4, hipMemcpyHostToDevice, L->stream));
         GFFX_HIP_TRY(hipMemcpyAsync(L->d_start, start, n_lines * 4, hipMemcpyHostToDevice, L->stream));
@@ -217,157 +406,182 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
     return GFFX_OK;
 }
 
-extern "C" int gffx_hip_lines_test(gffx_hip_lines *L, const uint32_t *regions, uint64_t nq,
-                                   uint32_t n_seq, int mode, uint8_t *keep_host) {
-    if (!L) return fail(GFFX_E_INVALID, "gffx_hip_lines_test: lines is NULL");
-    if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_lines_test: bad mode %d", mode);
-    if (nq && !regions) return fail(GFFX_E_INVALID, "gffx_hip_lines_test: regions is NULL");
-    if (L->n && !keep_host) return fail(GFFX_E_INVALID, "gffx_hip_lines_test: keep_host is NULL");
-    for (uint64_t i = 0; i < nq; i++)
-        if (regions[3 * i] >= n_seq)
-            return fail(GFFX_E_CHR_RANGE, "gffx_hip_lines_test: region %llu has chr %u >= %u",
-                        (unsigned long long)i, regions[3 * i], n_seq);
-    GFFX_HIP_TRY(hipSetDevice(L->device));
-    // Region preparation: bucket by seqid, sort by start, prefix max / suffix min of the ends,
-    // sorted ends.  Host-side for now (std::sort); the device radix sort replaces it.
-    std::vector<unsigned long long> q_off(n_seq + 1, 0);
-    for (uint64_t i = 0; i < nq; i++) q_off[regions[3 * i] + 1]++;
-    for (uint32_t c = 0; c < n_seq; c++) q_off[c + 1] += q_off[c];
-    std::vector<uint64_t> key(nq);  // (qs << 32 | qe) grouped by seqid
-    {
-        std::vector<unsigned long long> cur(q_off.begin(), q_off.end() - 1);
-        for (uint64_t i = 0; i < nq; i++)
-            key[cur[regions[3 * i]]++] = ((uint64_t)regions[3 * i + 1] << 32) | regions[3 * i + 2];
-    }
-    std::vector<uint32_t> qs(nq), pm(nq), sm(nq), qe(nq);
-    auto prep_seq = [&](uint32_t c) {
-        const uint64_t lo = q_off[c], hi = q_off[c + 1];
-        if (hi == lo) return;
-        std::sort(key.begin() + lo, key.begin() + hi);
-        uint32_t m = 0;
-        for (uint64_t i = lo; i < hi; i++) {
-            qs[i] = (uint32_t)(key[i] >> 32);
-            qe[i] = (uint32_t)key[i];
-            m = std::max(m, qe[i]);
-            pm[i] = m;
-        }
-        m = UINT32_MAX;
-        for (uint64_t i = hi; i-- > lo;) {
-            m = std::min(m, qe[i]);
-            sm[i] = m;
-        }
-        std::sort(qe.begin() + lo, qe.begin() + hi);
-    };
-    {  // the seqids are independent: host threads take them largest first (80 ms -> ~10 ms per 1 M regions)
-        std::vector<uint32_t> by_size(n_seq);
-        for (uint32_t c = 0; c < n_seq; c++) by_size[c] = c;
-        std::sort(by_size.begin(), by_size.end(),
-                  [&](uint32_t a, uint32_t b) { return q_off[a + 1] - q_off[a] > q_off[b + 1] - q_off[b]; });
-        unsigned hw = std::thread::hardware_concurrency();
-        const unsigned n_thr = nq < 50000 ? 1u : std::max(1u, std::min({hw ? hw : 1u, 16u, n_seq}));
-        std::atomic<uint32_t> next{0};
-        auto work = [&]() {
-            for (;;) {
-                const uint32_t k = next.fetch_add(1);
-                if (k >= n_seq) return;
-                prep_seq(by_size[k]);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-    }
-    // directories over the sorted starts / ends (see RegionsView); positions are u32: skipped for >= 2^32 regions
-    std::vector<unsigned long long> dir_off(n_seq + 1, 0);
-    std::vector<uint2> dir_meta(n_seq, make_uint2(0, 0));
-    std::vector<uint32_t> dir_qs, dir_qe;
-    const bool use_dir = nq > 0 && nq < 0xFFFFFFFFull;
-    if (use_dir) {
-        for (uint32_t c = 0; c < n_seq; c++) {
-            const uint64_t lo = q_off[c], hi = q_off[c + 1];
-            dir_off[c + 1] = dir_off[c];
-            if (hi == lo) continue;
-            const uint32_t vmax = std::max(qs[hi - 1], qe[hi - 1]);
-            const uint64_t budget = std::max<uint64_t>(2 * (hi - lo), 16);
-            uint32_t shift = 0;
-            while ((((uint64_t)vmax >> shift) + 1) > budget) shift++;
-            const uint32_t nb = (vmax >> shift) + 1;
-            dir_meta[c] = make_uint2(shift, nb);
-            uint64_t ps = lo, pe = lo;
-            for (uint32_t b = 0; b < nb; b++) {
-                const uint64_t edge = (uint64_t)b << shift;
-                while (ps < hi && qs[ps] < edge) ps++;
-                while (pe < hi && qe[pe] < edge) pe++;
-                dir_qs.push_back((uint32_t)ps);
-                dir_qe.push_back((uint32_t)pe);
-            }
-            dir_qs.push_back((uint32_t)hi);
-            dir_qe.push_back((uint32_t)hi);
-            dir_off[c + 1] = dir_qs.size();
-        }
-    }
-    unsigned long long *d_off = nullptr, *d_doff = nullptr;
-    uint32_t *d_q = nullptr, *d_dir = nullptr;
-    uint2 *d_dmeta = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_off);
-        (void)hipFree(d_q);
-        (void)hipFree(d_doff);
-        (void)hipFree(d_dir);
-        (void)hipFree(d_dmeta);
-    };
+static int lines_reserve(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int sort_passes) {
     int rc;
-    if ((rc = dalloc(&d_off, n_seq + 1)) || (rc = dalloc(&d_q, 4 * nq)) || (rc = dalloc(&d_doff, n_seq + 1)) ||
-        (rc = dalloc(&d_dir, 2 * dir_qs.size())) || (rc = dalloc(&d_dmeta, n_seq))) {
-        cleanup();
-        return rc;
+    if (nq > L->cap_q) {
+        const uint64_t cap = nq + nq / 8 + 1024;
+        const size_t blocks = (size_t)((cap + kScanBlock - 1) / kScanBlock) + 2;
+        if ((rc = regrow(&L->d_rec_a, 3 * cap)) || (rc = regrow(&L->d_rec_b, 3 * cap)) || (rc = regrow(&L->d_rec_c, 3 * cap)) ||
+            (rc = regrow(&L->d_tab, 5 * cap)) || (rc = regrow(&L->d_head, 2 * cap)) || (rc = regrow(&L->d_scan, 4 * blocks)) ||
+            (rc = regrow(&L->d_scan_head, 2 * blocks)))
+            return rc;
+        L->cap_q = cap;
+        L->cap_dir = 0;
     }
-#define GFFX_TRY_C(expr)                                                                       \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess) {                                                                \
-            cleanup();                                                                         \
-            return fail(GFFX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));            \
-        }                                                                                      \
-    } while (0)
-    GFFX_TRY_C(hipMemcpyAsync(d_off, q_off.data(), (n_seq + 1) * 8, hipMemcpyHostToDevice, L->stream));
+    const uint64_t want_dir = 2 * L->cap_q + 17ull * (n_seq + 1) + 64;
+    if (want_dir > L->cap_dir) {
+        if ((rc = regrow(&L->d_dir, 2 * want_dir))) return rc;
+        L->cap_dir = want_dir;
+    }
+    if (n_seq + 1 > L->cap_seq) {
+        const uint64_t cap = n_seq + 1 + 64;
+        if ((rc = regrow(&L->d_qoff, cap + 1)) || (rc = regrow(&L->d_doff, cap + 1)) || (rc = regrow(&L->d_dmeta, cap))) return rc;
+        L->cap_seq = cap;
+    }
+    const uint64_t want_work = DeviceSort::work_words(L->cap_q, sort_passes);
+    if (want_work > L->cap_work) {
+        if ((rc = regrow(&L->d_work, want_work))) return rc;
+        L->cap_work = want_work;
+    }
+    return GFFX_OK;
+}
+
+// one direction of the segmented scans: local blocks, the carries (recursively), fold back
+template <bool MAXOP, bool BACKWARD>
+static int seg_scan(gffx_hip_lines *L, const uint32_t *val, const uint8_t *head, uint64_t n, uint32_t *out) {
+    // level 0 over the elements; level 1 over the block carries (forward from here on: the carries already are in scan order)
+    const uint32_t b0 = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
+    uint32_t *agg0 = L->d_scan, *agg0s = L->d_scan + b0 + 1;
+    uint8_t *h0 = L->d_scan_head;
+    hipLaunchKernelGGL((k_b_scan_local<MAXOP, BACKWARD>), dim3(b0), dim3(kScanBlock), 0, L->stream, val, head, (unsigned long long)n, out, agg0, h0);
+    if (b0 > 1) {
+        const uint32_t b1 = (b0 + kScanBlock - 1) / kScanBlock;
+        uint32_t *agg1 = agg0s + b0 + 1, *agg1s = agg1 + b1 + 1;
+        uint8_t *h1 = h0 + b0 + 1;
+        hipLaunchKernelGGL((k_b_scan_local<MAXOP, false>), dim3(b1), dim3(kScanBlock), 0, L->stream, agg0, h0, (unsigned long long)b0, agg0s, agg1, h1);
+        if (b1 > 1) {  // > 1 M blocks = > 10^9 regions never happens (the sort refuses 2^30), two carry levels are enough up to 2^30
+            hipLaunchKernelGGL((k_b_scan_local<MAXOP, false>), dim3(1), dim3(kScanBlock), 0, L->stream, agg1, h1, (unsigned long long)b1, agg1s,
+                               agg1s + b1 + 1, h1 + b1 + 1);
+            hipLaunchKernelGGL((k_b_scan_apply<MAXOP, false>), dim3(b1), dim3(kScanBlock), 0, L->stream, h0, (unsigned long long)b0, agg0s, agg1s);
+        }
+        hipLaunchKernelGGL((k_b_scan_apply<MAXOP, BACKWARD>), dim3(b0), dim3(kScanBlock), 0, L->stream, head, (unsigned long long)n, out, agg0s);
+    }
+    GFFX_HIP_TRY(hipGetLastError());
+    return GFFX_OK;
+}
+
+// Region tables from the records in d_rec_a (AoS {seqid, qs, qe}, any order), then k_lines_exists.
+static int lines_run(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int mode, uint8_t *keep_host) {
+    const unsigned long long n = nq;
+    const uint32_t g256 = (uint32_t)((n + 255) / 256);
+    int seq_bytes = 1;
+    while (seq_bytes < 4 && (n_seq > (1u << (8 * seq_bytes)))) seq_bytes++;
+    SortPlan p1{}, p2{};
+    for (int b = 0; b < 4; ++b) p1.word[p1.n_passes] = 2, p1.shift[p1.n_passes++] = (uint8_t)(8 * b);
+    for (int b = 0; b < 4; ++b) p1.word[p1.n_passes] = 1, p1.shift[p1.n_passes++] = (uint8_t)(8 * b);
+    for (int b = 0; b < seq_bytes; ++b) p1.word[p1.n_passes] = 0, p1.shift[p1.n_passes++] = (uint8_t)(8 * b);
+    for (int b = 0; b < 4; ++b) p2.word[p2.n_passes] = 2, p2.shift[p2.n_passes++] = (uint8_t)(8 * b);
+    for (int b = 0; b < seq_bytes; ++b) p2.word[p2.n_passes] = 0, p2.shift[p2.n_passes++] = (uint8_t)(8 * b);
+    uint32_t *qs = L->d_tab, *pm = qs + L->cap_q, *sm = pm + L->cap_q, *qe = sm + L->cap_q, *eq = qe + L->cap_q;
+    const bool use_dir = nq > 0;
+    GFFX_HIP_TRY(hipEventRecord(L->ev_p0, L->stream));
+    GFFX_HIP_TRY(hipMemsetAsync(L->d_err, 0, 16, L->stream));
+    GFFX_HIP_TRY(hipMemsetAsync(L->d_qoff, 0, (n_seq + 1) * 8, L->stream));
+    GFFX_HIP_TRY(hipMemsetAsync(L->d_doff, 0, (n_seq + 1) * 8, L->stream));
     if (nq) {
-        GFFX_TRY_C(hipMemcpyAsync(d_q, qs.data(), nq * 4, hipMemcpyHostToDevice, L->stream));
-        GFFX_TRY_C(hipMemcpyAsync(d_q + nq, pm.data(), nq * 4, hipMemcpyHostToDevice, L->stream));
-        GFFX_TRY_C(hipMemcpyAsync(d_q + 2 * nq, sm.data(), nq * 4, hipMemcpyHostToDevice, L->stream));
-        GFFX_TRY_C(hipMemcpyAsync(d_q + 3 * nq, qe.data(), nq * 4, hipMemcpyHostToDevice, L->stream));
+        uint32_t *s1 = nullptr, *s2 = nullptr;
+        int rc = DeviceSort::run(L->stream, L->d_rec_a, L->d_rec_b, n, p1, n_seq, L->d_work, L->d_err, &s1);
+        if (rc) return rc;
+        // keep the (seqid, qs, qe) order: the second sort needs both ping-pong buffers
+        GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_c, s1, n * 12, hipMemcpyDeviceToDevice, L->stream));
+        hipLaunchKernelGGL(k_b_offsets, dim3(g256), dim3(256), 0, L->stream, L->d_rec_c, n, n_seq, L->d_qoff);
+        hipLaunchKernelGGL(k_b_columns, dim3(g256), dim3(256), 0, L->stream, L->d_rec_c, n, qs, eq, L->d_head, L->d_head + L->cap_q);
+        if ((rc = seg_scan<true, false>(L, eq, L->d_head, nq, pm))) return rc;               // PM: running max of the ends
+        if ((rc = seg_scan<false, true>(L, eq, L->d_head + L->cap_q, nq, sm))) return rc;     // SM: running min from the right
+        if (s1 != L->d_rec_a) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, s1, n * 12, hipMemcpyDeviceToDevice, L->stream));
+        if ((rc = DeviceSort::run(L->stream, L->d_rec_a, L->d_rec_b, n, p2, n_seq, L->d_work, L->d_err, &s2))) return rc;
+        hipLaunchKernelGGL(k_b_column2, dim3(g256), dim3(256), 0, L->stream, s2, n, qe);
+        hipLaunchKernelGGL(k_b_dir_meta, dim3(1), dim3(256), 0, L->stream, L->d_qoff, qs, qe, n_seq, L->d_dmeta, L->d_doff);
+        hipLaunchKernelGGL(k_b_dir_fill, dim3(g256), dim3(256), 0, L->stream, qs, L->d_rec_c, n, n_seq, L->d_qoff, L->d_doff, L->d_dmeta, L->d_dir);
+        hipLaunchKernelGGL(k_b_dir_fill, dim3(g256), dim3(256), 0, L->stream, qe, s2, n, n_seq, L->d_qoff, L->d_doff, L->d_dmeta, L->d_dir + L->cap_dir);
+        GFFX_HIP_TRY(hipGetLastError());
     }
-    if (use_dir) {
-        GFFX_TRY_C(hipMemcpyAsync(d_doff, dir_off.data(), (n_seq + 1) * 8, hipMemcpyHostToDevice, L->stream));
-        GFFX_TRY_C(hipMemcpyAsync(d_dmeta, dir_meta.data(), n_seq * sizeof(uint2), hipMemcpyHostToDevice, L->stream));
-        GFFX_TRY_C(hipMemcpyAsync(d_dir, dir_qs.data(), dir_qs.size() * 4, hipMemcpyHostToDevice, L->stream));
-        GFFX_TRY_C(hipMemcpyAsync(d_dir + dir_qs.size(), dir_qe.data(), dir_qe.size() * 4, hipMemcpyHostToDevice, L->stream));
-    }
+    GFFX_HIP_TRY(hipEventRecord(L->ev_p1, L->stream));
     if (L->n) {
         LinesView lv{L->d_seq, L->d_start, L->d_end, (unsigned long long)L->n};
-        RegionsView rv{d_off, d_q, d_q + nq, d_q + 2 * nq, d_q + 3 * nq,
-                       use_dir ? d_dir : nullptr, use_dir ? d_dir + dir_qs.size() : nullptr, d_doff, d_dmeta, n_seq};
+        RegionsView rv{L->d_qoff, qs, pm, sm, qe, use_dir ? L->d_dir : nullptr, use_dir ? L->d_dir + L->cap_dir : nullptr,
+                       L->d_doff, L->d_dmeta, n_seq};
         const unsigned blocks = (unsigned)((L->n + 255) / 256);
-        GFFX_TRY_C(hipEventRecord(L->ev_a, L->stream));
+        GFFX_HIP_TRY(hipEventRecord(L->ev_a, L->stream));
         if (mode == GFFX_MODE_CONTAINED)
             hipLaunchKernelGGL((k_lines_exists<GFFX_MODE_CONTAINED>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
         else if (mode == GFFX_MODE_CONTAINS_REGION)
             hipLaunchKernelGGL((k_lines_exists<GFFX_MODE_CONTAINS_REGION>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
         else
             hipLaunchKernelGGL((k_lines_exists<GFFX_MODE_OVERLAP>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
-        GFFX_TRY_C(hipGetLastError());
-        GFFX_TRY_C(hipEventRecord(L->ev_b, L->stream));
-        GFFX_TRY_C(hipMemcpyAsync(keep_host, L->d_keep, L->n, hipMemcpyDeviceToHost, L->stream));
+        GFFX_HIP_TRY(hipGetLastError());
+        GFFX_HIP_TRY(hipEventRecord(L->ev_b, L->stream));
+        GFFX_HIP_TRY(hipMemcpyAsync(keep_host, L->d_keep, L->n, hipMemcpyDeviceToHost, L->stream));
     }
-    GFFX_TRY_C(hipStreamSynchronize(L->stream));
-    if (L->n) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, L->ev_a, L->ev_b) == hipSuccess) L->last_kernel_ms = ms;
-    }
-#undef GFFX_TRY_C
-    cleanup();
+    uint32_t h_err[4] = {0, 0, 0, 0};
+    GFFX_HIP_TRY(hipMemcpyAsync(h_err, L->d_err, 16, hipMemcpyDeviceToHost, L->stream));
+    GFFX_HIP_TRY(hipStreamSynchronize(L->stream));
+    float ms = 0.f;
+    if (L->n && hipEventElapsedTime(&ms, L->ev_a, L->ev_b) == hipSuccess) L->last_kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, L->ev_p0, L->ev_p1) == hipSuccess) L->last_prep_ms = ms;
+    L->last_nq = nq;
+    L->last_n_seq = n_seq;
+    L->last_dir = use_dir;
+    if (h_err[0] & 2u)
+        return fail(GFFX_E_CHR_RANGE, "gffx_hip_lines_test: a region has chr >= %u", n_seq);
+    if (h_err[0] & 4u) return fail(GFFX_E_HIP, "gffx_hip_lines_test: the device sort timed out waiting for an earlier tile");
     return GFFX_OK;
 }
+
+static int lines_check(gffx_hip_lines *L, const void *regions, uint64_t nq, int mode, const uint8_t *keep_host, const char *who) {
+    if (!L) return fail(GFFX_E_INVALID, "%s: lines is NULL", who);
+    if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "%s: bad mode %d", who, mode);
+    if (nq && !regions) return fail(GFFX_E_INVALID, "%s: regions is NULL", who);
+    if (L->n && !keep_host) return fail(GFFX_E_INVALID, "%s: keep_host is NULL", who);
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_lines_test(gffx_hip_lines *L, const uint32_t *regions, uint64_t nq,
+                                   uint32_t n_seq, int mode, uint8_t *keep_host) {
+    int rc = lines_check(L, regions, nq, mode, keep_host, "gffx_hip_lines_test");
+    if (rc) return rc;
+    GFFX_HIP_TRY(hipSetDevice(L->device));
+    if ((rc = lines_reserve(L, nq, n_seq, 9 + 3))) return rc;
+    if (nq) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, regions, nq * 12, hipMemcpyHostToDevice, L->stream));
+    return lines_run(L, nq, n_seq, mode, keep_host);
+}
+
+// the same with the regions already in HBM (AoS triples, e.g. the batch Join A uploaded: gffx_hip_batch_device_regions)
+extern "C" int gffx_hip_lines_test_device(gffx_hip_lines *L, const uint32_t *d_regions, uint64_t nq,
+                                          uint32_t n_seq, int mode, uint8_t *keep_host) {
+    int rc = lines_check(L, d_regions, nq, mode, keep_host, "gffx_hip_lines_test_device");
+    if (rc) return rc;
+    GFFX_HIP_TRY(hipSetDevice(L->device));
+    if ((rc = lines_reserve(L, nq, n_seq, 9 + 3))) return rc;
+    if (nq) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, d_regions, nq * 12, hipMemcpyDeviceToDevice, L->stream));
+    return lines_run(L, nq, n_seq, mode, keep_host);
+}
+
+// The region tables of the last _test, for parity tests: q_off (n_seq + 1), then QS, PM, SM, QE (nq each).
+extern "C" int gffx_hip_lines_copy_tables(gffx_hip_lines *L, uint64_t *q_off, uint32_t *qs, uint32_t *pm, uint32_t *sm, uint32_t *qe) {
+    if (!L) return fail(GFFX_E_INVALID, "gffx_hip_lines_copy_tables: lines is NULL");
+    GFFX_HIP_TRY(hipSetDevice(L->device));
+    const uint64_t nq = L->last_nq;
+    if (q_off) GFFX_HIP_TRY(hipMemcpy(q_off, L->d_qoff, (L->last_n_seq + 1) * 8, hipMemcpyDeviceToHost));
+    uint32_t *host[4] = {qs, pm, sm, qe};
+    for (int t = 0; t < 4; ++t)
+        if (host[t] && nq) GFFX_HIP_TRY(hipMemcpy(host[t], L->d_tab + (size_t)t * L->cap_q, nq * 4, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+// ... and the two bin directories: d_off (n_seq + 1), shift_nb (2 per seqid), dir_qs / dir_qe (d_off[n_seq] each)
+extern "C" int gffx_hip_lines_copy_dirs(gffx_hip_lines *L, uint64_t *d_off, uint32_t *shift_nb, uint32_t *dir_qs, uint32_t *dir_qe) {
+    if (!L) return fail(GFFX_E_INVALID, "gffx_hip_lines_copy_dirs: lines is NULL");
+    GFFX_HIP_TRY(hipSetDevice(L->device));
+    std::vector<unsigned long long> off(L->last_n_seq + 1, 0);
+    GFFX_HIP_TRY(hipMemcpy(off.data(), L->d_doff, off.size() * 8, hipMemcpyDeviceToHost));
+    if (d_off)
+        for (size_t i = 0; i < off.size(); i++) d_off[i] = off[i];
+    if (shift_nb && L->last_n_seq) GFFX_HIP_TRY(hipMemcpy(shift_nb, L->d_dmeta, (size_t)L->last_n_seq * 8, hipMemcpyDeviceToHost));
+    const uint64_t total = off.back();
+    if (dir_qs && total) GFFX_HIP_TRY(hipMemcpy(dir_qs, L->d_dir, total * 4, hipMemcpyDeviceToHost));
+    if (dir_qe && total) GFFX_HIP_TRY(hipMemcpy(dir_qe, L->d_dir + L->cap_dir, total * 4, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+extern "C" double gffx_hip_lines_last_prep_ms(const gffx_hip_lines *L) { return L ? L->last_prep_ms : 0.0; }
 
 extern "C" double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *L) { return L ? L->last_kernel_ms : 0.0; }

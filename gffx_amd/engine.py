@@ -164,6 +164,11 @@ class QueryBatch:
     def total_hits(self) -> int:
         return lib().gffx_hip_batch_total_hits(self._h)
 
+    @property
+    def device_regions(self) -> int:
+        """Device address of the batch's own AoS copy of the regions (0 unless set_regions uploaded them)."""
+        return lib().gffx_hip_batch_device_regions(self._h) or 0
+
     def device_pointers(self):
         """(counts, fids, triples) device addresses of the last pass (0 where not produced): for consumers on the GPU."""
         L = lib()
@@ -267,10 +272,37 @@ class LineTable:
                                         keep.ctypes.data_as(_ffi.u8p)))
         return keep[: self.n].astype(bool)
 
+    def test_device(self, d_regions: int, nq: int, n_seq: int, mode: int = OverlapMode.Overlap) -> np.ndarray:
+        """The same with the regions already in HBM as AoS triples (``QueryBatch.device_regions``)."""
+        keep = np.zeros(max(self.n, 1), dtype=np.uint8)
+        check(lib().gffx_hip_lines_test_device(self._h, d_regions, int(nq), int(n_seq), int(mode),
+                                               keep.ctypes.data_as(_ffi.u8p)))
+        return keep[: self.n].astype(bool)
+
     @property
     def last_kernel_ms(self) -> float:
         """HIP-event duration of k_lines_exists in the last ``test`` call."""
         return lib().gffx_hip_lines_last_kernel_ms(self._h)
+
+    @property
+    def last_prep_ms(self) -> float:
+        """HIP-event duration of the device preparation of the region tables (radix sorts, scans, directories)."""
+        return lib().gffx_hip_lines_last_prep_ms(self._h)
+
+    def tables(self, nq: int, n_seq: int):
+        """Region tables of the last ``test``: dict(q_off, qs, pm, sm, qe, d_off, shift_nb, dir_qs, dir_qe)."""
+        u64p = _ffi.u64p
+        q_off = np.zeros(n_seq + 1, dtype=np.uint64)
+        tabs = [np.zeros(max(nq, 1), dtype=np.uint32) for _ in range(4)]
+        check(lib().gffx_hip_lines_copy_tables(self._h, q_off.ctypes.data_as(u64p), *[_p(t) for t in tabs]))
+        d_off = np.zeros(n_seq + 1, dtype=np.uint64)
+        shift_nb = np.zeros((max(n_seq, 1), 2), dtype=np.uint32)
+        check(lib().gffx_hip_lines_copy_dirs(self._h, d_off.ctypes.data_as(u64p), _p(shift_nb), None, None))
+        total = int(d_off[-1])
+        dq, de = np.zeros(max(total, 1), dtype=np.uint32), np.zeros(max(total, 1), dtype=np.uint32)
+        check(lib().gffx_hip_lines_copy_dirs(self._h, None, None, _p(dq), _p(de)))
+        return dict(q_off=q_off, qs=tabs[0][:nq], pm=tabs[1][:nq], sm=tabs[2][:nq], qe=tabs[3][:nq], d_off=d_off,
+                    shift_nb=shift_nb[:n_seq], dir_qs=dq[:total], dir_qe=de[:total])
 
 
 class DepthTable:

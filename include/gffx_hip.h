@@ -189,6 +189,8 @@ const uint32_t *gffx_hip_batch_device_fids(const gffx_hip_batch *);
 const uint64_t *gffx_hip_batch_device_offsets(const gffx_hip_batch *);
 const uint32_t *gffx_hip_batch_device_offsets32(const gffx_hip_batch *);
 const uint32_t *gffx_hip_batch_device_triples(const gffx_hip_batch *);
+/* the batch's own device copy of the regions as AoS triples (after _set_regions_host; NULL for SoA / borrowed regions) */
+const uint32_t *gffx_hip_batch_device_regions(const gffx_hip_batch *);
 /* pre-size the pair buffers (pairs); avoids the capacity replay on the first run */
 int gffx_hip_batch_reserve_hits(gffx_hip_batch *, uint64_t n_pairs);
 
@@ -218,8 +220,21 @@ void gffx_hip_lines_destroy(gffx_hip_lines *);
  * n_seq = number of seqids; keep_host receives n_lines bytes (0/1). */
 int gffx_hip_lines_test(gffx_hip_lines *, const uint32_t *regions, uint64_t nq, uint32_t n_seq,
                         int mode, uint8_t *keep_host);
+/* the same with the regions already in HBM as AoS triples (e.g. gffx_hip_batch_device_regions of the batch Join A ran on) */
+int gffx_hip_lines_test_device(gffx_hip_lines *, const uint32_t *d_regions, uint64_t nq, uint32_t n_seq,
+                               int mode, uint8_t *keep_host);
 /* HIP-event duration (ms) of k_lines_exists in the last _test call, on the table's own stream */
 double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *);
+/* ... and of the device preparation of the region tables before it: radix sort by (seqid, start, end) and by (seqid, end),
+ * running max / min of the ends, bin directories (the reference builds `query_ivmap` on the CPU: intersect.rs:621-633) */
+double gffx_hip_lines_last_prep_ms(const gffx_hip_lines *);
+/* The region tables of the last _test, for parity checks: q_off (n_seq + 1 entries), then per region in (seqid, start,
+ * end) order: QS = start, PM = running max of `end` inside the seqid, SM = running min of `end` from the seqid's last
+ * region backwards, and QE = the ends sorted per seqid.  Any pointer may be NULL. */
+int gffx_hip_lines_copy_tables(gffx_hip_lines *, uint64_t *q_off, uint32_t *qs, uint32_t *pm, uint32_t *sm, uint32_t *qe);
+/* ... and the bin directories over QS and QE: d_off (n_seq + 1), shift_nb ({shift, bins} per seqid), dir_qs / dir_qe
+ * (d_off[n_seq] entries each; dir[d_off[c] + b] = first position of seqid c whose value >= b << shift). */
+int gffx_hip_lines_copy_dirs(gffx_hip_lines *, uint64_t *d_off, uint32_t *shift_nb, uint32_t *dir_qs, uint32_t *dir_qe);
 
 /* ---- `gffx depth` with a BED source: compute_hit_depth / compute_root_depth (commands/depth.rs:121-293) --
  * The host parses every root BLOCK once (the byte range of a .gof record; for a root_fid with several

@@ -79,3 +79,96 @@ def test_gencode_like_lines_against_sampled_oracle():
     for m in OverlapMode:
         want = _oracle_keep(seq[sel], s[sel], e[sel], regions, 25, m)
         assert np.array_equal(keep[m][sel], want), m
+
+
+def _host_tables(regions, n_seq):
+    """The region tables as the definition builds them (numpy): (seqid, start, end) order, running max / min of the
+    ends inside a seqid, the ends sorted per seqid, and the two bin directories (~2 bins per region, >= 16)."""
+    r = regions[np.lexsort((regions[:, 2], regions[:, 1], regions[:, 0]))]
+    n = len(r)
+    q_off = np.concatenate([[0], np.cumsum(np.bincount(r[:, 0], minlength=n_seq))]).astype(np.uint64)
+    qs, e = r[:, 1].copy(), r[:, 2].copy()
+    pm, sm, qe = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    d_off = np.zeros(n_seq + 1, np.uint64)
+    shift_nb = np.zeros((n_seq, 2), np.uint32)
+    dq, de = [], []
+    for c in range(n_seq):
+        lo, hi = int(q_off[c]), int(q_off[c + 1])
+        d_off[c + 1] = d_off[c]
+        if hi == lo:
+            continue
+        pm[lo:hi] = np.maximum.accumulate(e[lo:hi])
+        sm[lo:hi] = np.minimum.accumulate(e[lo:hi][::-1])[::-1]
+        qe[lo:hi] = np.sort(e[lo:hi])
+        vmax = int(max(qs[hi - 1], qe[hi - 1]))
+        budget = max(2 * (hi - lo), 16)
+        shift = 0
+        while (vmax >> shift) + 1 > budget:
+            shift += 1
+        nb = (vmax >> shift) + 1
+        shift_nb[c] = (shift, nb)
+        edges = np.arange(nb + 1, dtype=np.uint64) << np.uint64(shift)
+        dq.append(lo + np.searchsorted(qs[lo:hi].astype(np.uint64), edges, "left"))
+        de.append(lo + np.searchsorted(qe[lo:hi].astype(np.uint64), edges, "left"))
+        dq[-1][-1] = de[-1][-1] = hi  # the last entry is the seqid's end
+        d_off[c + 1] = d_off[c] + nb + 1
+    cat = lambda x: np.concatenate(x).astype(np.uint32) if x else np.zeros(0, np.uint32)  # noqa: E731
+    return dict(q_off=q_off, qs=qs, pm=pm, sm=sm, qe=qe, d_off=d_off, shift_nb=shift_nb, dir_qs=cat(dq), dir_qe=cat(de))
+
+
+@pytest.mark.parametrize("case", ["tiny", "ties", "tile_edges", "many_seqids", "extremes", "bed_1m"])
+def test_device_region_tables_equal_the_host_definition(case):
+    """The device preparation (radix sort by (seqid, start, end) and by (seqid, end), segmented running max / min, bin
+    directories: radix_sort.hpp, join_b.hip) gives bit-identical tables to the numpy definition."""
+    rng = np.random.default_rng(hash(case) % 1000)
+    if case == "tiny":
+        n_seq, regions = 3, np.array([[2, 5, 9], [0, 7, 7], [2, 1, 3], [0, 7, 2], [2, 5, 1]], np.uint32)
+    elif case == "ties":
+        n_seq, n = 5, 20000
+        regions = np.stack([rng.integers(0, n_seq, n), rng.integers(0, 40, n), rng.integers(0, 40, n)], axis=1).astype(np.uint32)
+    elif case == "tile_edges":
+        n_seq = 7
+        regions = None
+    elif case == "many_seqids":
+        n_seq, n = 3000, 50000  # two radix passes over the seqid
+        regions = np.stack([rng.integers(0, n_seq, n), rng.integers(0, 1 << 20, n), rng.integers(0, 1 << 20, n)], axis=1).astype(np.uint32)
+        regions[regions[:, 0] % 7 == 3, 0] = 11  # empty seqids and one big one
+    elif case == "extremes":
+        n_seq, n = 2, 5000
+        regions = np.stack([rng.integers(0, n_seq, n), rng.integers(0, 1 << 32, n), rng.integers(0, 1 << 32, n)], axis=1).astype(np.uint32)
+        regions[:5] = [[0, 0xFFFFFFFF, 0xFFFFFFFF], [1, 0, 0], [0, 0xFFFFFFFF, 0], [1, 0, 0xFFFFFFFF], [0, 0x80000000, 0x7FFFFFFF]]
+    else:
+        roots = synth.gencode_like_roots(63000, seed=42)
+        n_seq, regions = 25, synth.synth_bed(1_000_000, seed=1001)
+    lt = engine.LineTable(np.zeros(4, np.uint32), np.arange(4, dtype=np.uint32), np.arange(4, dtype=np.uint32) + 3)
+    sizes = [2047, 2048, 2049, 4096, 6145] if case == "tile_edges" else [None]
+    for size in sizes:
+        if size is not None:
+            regions = np.stack([rng.integers(0, n_seq, size), rng.integers(0, 100000, size), rng.integers(0, 100000, size)],
+                               axis=1).astype(np.uint32)
+        lt.test(regions, n_seq, OverlapMode.Overlap)
+        got, want = lt.tables(len(regions), n_seq), _host_tables(regions, n_seq)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (case, size, k)
+    if case == "bed_1m":
+        assert lt.last_prep_ms < 5.0, lt.last_prep_ms  # (the host preparation it replaces took ~10 ms per 1 M regions)
+    lt.close()
+
+
+def test_lines_test_on_the_regions_join_a_uploaded():
+    """gffx_hip_lines_test_device: Join B over the AoS copy of the regions that the Join A batch already holds in HBM."""
+    roots = synth.gencode_like_roots(3000, seed=4)
+    regions = synth.synth_bed(20000, seed=12, edge_frac=0.02, roots=roots)
+    co = roots["chr_offsets"]
+    ix = engine.TreeIndexData.from_roots(co, roots["start"], roots["end"], roots["fid"])
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)
+    b.run(OverlapMode.Overlap, False, engine.OUT_ROOT_BITMAP)
+    b.wait()
+    chr_of = np.repeat(np.arange(len(co) - 1), np.diff(co)).astype(np.uint32)
+    lt = engine.LineTable(chr_of, roots["start"] + 1, roots["end"])
+    for mode in OverlapMode:
+        assert np.array_equal(lt.test_device(b.device_regions, len(regions), len(co) - 1, mode), lt.test(regions, len(co) - 1, mode))
+    b.close()
+    lt.close()
+    ix.close()
