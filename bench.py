@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- BED overlap queries/sec against a GRCh38-scale GFF index on N MI355X.
 
-One "step" = one pass of the intersect hot path (Join A: regions x root intervals -> per-region
-kept counts + segment offsets in input order, and the root_fids of every kept pair) over one batch
-of synthetic BED regions that is already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: 1 M synthetic BED regions
-(seed 1001, chr ~ length, width U[100,10000], unsorted) x a GENCODE/GRCh38-shaped index
-(25 seqids, ~63 k root genes of a ~3.4 M-line annotation, seed 42), --overlap mode.
-For N>1 the global batch is N x 1 M regions, sharded by chromosome bucket over the ranks
-(gffx_amd.shard, LPT with splitting; index replicated); the only collective is the RCCL
-all-gather of per-rank hit counts, once per job: it is timed on its own (config.exchange_ms) after the K
-timed steps; --exchange final-timed puts it inside the timed region, per-step issues it after every step.
+One "step" = one pass of the intersect hot path (Join A: regions x root intervals -> per-region kept counts and u32
+segment offsets in input order, and the root_fids of every kept pair) over one batch of synthetic BED regions that is
+already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: 1 M synthetic BED regions (seed 1001, chr ~ length,
+width U[100,10000], unsorted) x a GENCODE/GRCh38-shaped index (25 seqids, ~63 k root genes of a ~3.4 M-line annotation,
+seed 42), --overlap mode.
 
-Steps are issued round-robin to --inflight (default 2) QueryBatch objects -- each with its own HIP
-stream and result buffers, all reading the same resident regions -- so the launch ramp / drain of one
-pass overlaps the next pass (34 -> 47 G regions/s on one MI355X); --inflight 1 gives strictly serial
-passes.  The roofline object is computed from single-pass kernel durations either way.
+The JSON line carries, next to the contract's fields:
+  value / ms_per_step   K steps issued round-robin to --inflight (default 2) QueryBatch objects (own HIP stream and result
+                        buffers each, the same resident regions): the launch ramp / drain of one pass overlaps the next.
+                        The pipeline is warmed (2 x inflight passes, synced) immediately before the timed region.
+  serial                the same K steps with ONE batch: strictly serial passes (what profiles/*kernel_stats* shows)
+  roofline              dominant kernel, HIP-event durations of serial back-to-back launches on the engine's stream
+  roofline_10m          the same for a 10 M-region batch (seed 1002)
+  cli_pass              the pass the CLI runs (root bitmap only) at 1 M and 10 M regions, next to the root_fid pass
+  t_xfer                host regions in (pinned), counts + root_fids back on the host: two batches double-buffered
+  t_e2e                 the `gffx` CLI on a 3.5 M-line synthetic GFF3 x the 1 M-row BED: wall clock + its stage timers
+  join_b                Join B (k_lines_exists over a 3.4 M-line table) with the device-built region tables
+  cpu_baseline          the oracle's Join A on 1 thread (the reference is serial there), + all cores, + Join B on all cores
+
+For N>1 (launched by torch.distributed.run, one rank per GPU) --scaling weak (default) gives every rank 1 M regions of an
+N x 1 M batch sharded by chromosome bucket (gffx_amd.shard, LPT with splitting; index replicated); --scaling strong shards
+BASELINE configs[3]'s 100 M regions over the N ranks.  The only collective is the RCCL all-gather of per-rank hit counts,
+once per job: --exchange final-timed puts it inside the timed region (default for --scaling strong).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -23,9 +32,12 @@ passes.  The roofline object is computed from single-pass kernel durations eithe
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -43,54 +55,26 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--queries-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = --queries-per-gpu regions per rank; strong = --strong-total regions (configs[3]: 100 M) "
+                         "sharded over the ranks, the hit-count all-gather inside the timed region")
+    ap.add_argument("--strong-total", type=int, default=100_000_000)
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
-    ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused", "slots"])
+    ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused", "slots", "windows"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
-    ap.add_argument("--no-offsets", action="store_true",
-                    help="fused / partitioned strategy: do not write every region's segment offset")
-    ap.add_argument("--input-order", action="store_true",
-                    help="partitioned strategy: also scatter the per-region records into input-order arrays "
-                         "inside the pass (k_unpermute); default leaves them as {row, count, offset} records")
-    ap.add_argument("--presort", default="none", choices=["none", "chr_end", "bucket"],
+    ap.add_argument("--offsets", default="u32", choices=["u32", "u64", "none"],
+                    help="per-region segment offsets written by the pass (u32 needs the windows strategy / auto)")
+    ap.add_argument("--presort", default="none", choices=["none", "chr_end"],
                     help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
-    ap.add_argument("--exchange", default="final", choices=["final", "final-timed", "per-step"],
-                    help="N>1: all-gather the per-rank hit counts once at the end of the timed region (default, "
-                         "north_star's 'final hit-count all-gather') or after every step (latency-bound)")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="batches in flight per GPU: steps are issued round-robin to this many QueryBatch objects "
-                         "(own HIP stream and buffers each, same resident regions), so one pass's ramp/drain overlaps "
-                         "the next pass; 1 = strictly serial passes")
-    ap.add_argument("--depth", action="store_true",
-                    help="additionally time the `gffx depth` join (k_depth_regions) on the same regions against a "
-                         "GENCODE-shaped line table (~3.4 M lines) and report it as an extra \"depth\" object")
-    ap.add_argument("--join-b", action="store_true",
-                    help="additionally time Join B (k_lines_exists: every line of a GENCODE-shaped line table against "
-                         "all regions of its seqid) and report it as an extra \"join_b\" object")
+    ap.add_argument("--exchange", default=None, choices=["final", "final-timed", "per-step"])
+    ap.add_argument("--inflight", type=int, default=2)
+    ap.add_argument("--quick", action="store_true", help="headline + roofline + cpu_baseline only (skip the extra legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--cpu-allcore", action="store_true",
-                    help="also report the oracle's Join A with the batch split over all host cores (tools/cpu_allcore.py, "
-                         "run as a child process) as \"cpu_allcore\" -- a fairer CPU upper bound, not the reference's behaviour")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     return ap.parse_args()
 
 
-def cpu_baseline(roots, regions, mode, budget_s):
-    """Oracle (C restatement of the reference's serial tree walk, intersect.rs:124-166) timed on
-    this host: 1 thread, like the reference.  Bounded sample of the same workload."""
-    from oracle import binding as ob
-
-    oix = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
-    n = len(regions)
-    oix.query_features(regions[: min(n, 20000)], mode, False)  # warm
-    done, t_used, hits = 0, 0.0, 0
-    reps = 0
-    while t_used < budget_s and reps < 400:
-        t0 = time.perf_counter()
-        t, _ = oix.query_features(regions, mode, False)
-        t_used += time.perf_counter() - t0
-        done += n
-        hits = len(t)
-        reps += 1
+def host_info():
     model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -99,78 +83,204 @@ def cpu_baseline(roots, regions, mode, budget_s):
                 break
     except OSError:
         pass
-    return {"value": done / t_used, "unit": "queries/s", "cores": 1, "kind": "port",
-            "host": {"cpu": model, "nproc": os.cpu_count()},
-            "sample": "%d x the full %d-region batch of this workload, Join A only (pointer-based centered "
-                      "interval tree, serial, as commands/intersect.rs:124-166); C restatement, not the Rust binary"
-                      % (reps, n),
+    return {"cpu": model, "nproc": os.cpu_count()}
+
+
+def cpu_baseline(roots, regions, mode, budget_s):
+    """Oracle (C restatement of the reference's serial tree walk, intersect.rs:124-166) timed on this host: 1 thread,
+    like the reference.  Bounded sample of the same workload."""
+    from oracle import binding as ob
+
+    oix = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    n = len(regions)
+    oix.query_features(regions[: min(n, 20000)], mode, False)  # warm
+    done, t_used, hits, reps = 0, 0.0, 0, 0
+    while t_used < budget_s and reps < 400:
+        t0 = time.perf_counter()
+        t, _ = oix.query_features(regions, mode, False)
+        t_used += time.perf_counter() - t0
+        done += n
+        hits = len(t)
+        reps += 1
+    return {"value": done / t_used, "unit": "queries/s", "cores": 1, "kind": "port", "host": host_info(),
+            "sample": "%d x the full %d-region batch of this workload, Join A only (pointer-based centered interval tree, "
+                      "serial, as commands/intersect.rs:124-166); C restatement, not the Rust binary" % (reps, n),
             "pairs_per_batch": hits}
 
 
-def depth_leg(engine, synth, roots, batch, mode, nq, pairs):
-    """`gffx depth` (BASELINE configs[4]'s command, reference semantics: per-feature-ID region counts):
-    k_depth_regions over the pairs of an Overlap pass, HIP-event time per 1 M-region batch."""
-    tab = synth.gencode_like_block_table(roots)
-    table = engine.DepthTable(tab["n_groups"], tab["block_line_off"], tab["line_start"], tab["line_end"],
-                              tab["line_group"], tab["block_of_fid"])
-    flags = engine.OUT_FIDS | engine.OUT_OFFSETS
-    batch.run(2, False, flags, 0)
-    batch.wait()
-    table.accumulate(batch)  # warm
-    batch.set_profiling(True)
-    batch.reset_profile()
-    reps = 10
-    for _ in range(reps):
-        table.accumulate(batch)
-    batch.set_profiling(False)
-    ms, n = batch.kernel_ms(engine.K_DEPTH)
-    d, _, _ = table.results()
-    lines = int(tab["block_line_off"][-1])
-    pair_lines = float(np.diff(tab["block_line_off"]).mean()) * pairs  # (pair, block line) tests per batch
-    us = 1e3 * ms / max(n, 1)
-    return {"kernel": "k_depth_regions", "avg_us": us, "regions_per_s": nq / (us * 1e-6),
-            "line_table": {"lines": lines, "groups": tab["n_groups"], "blocks": len(tab["block_line_off"]) - 1},
-            "pair_line_tests_per_batch": pair_lines,
-            "achieved_GBps": 12.0 * pair_lines / (us * 1e-6) / 1e9,
-            "depth_sum_check": int(d.sum() // (reps + 1)),
-            "note": "12 B per (pair, block line) read; reference: commands/depth.rs:121-217 (it re-parses a root's "
-                    "block text for every batch that touches it)"}
+def child_json(argv):
+    """CPU legs that fork worker pools run as child processes (nothing forks from a process that initialised the GPU)."""
+    r = subprocess.run([sys.executable] + argv, capture_output=True, text=True)
+    try:
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        return {"error": (r.stderr or r.stdout)[-300:]}
 
 
-def join_b_leg(engine, synth, roots, regions, mode):
-    """Join B (commands/intersect.rs:500-521 for every line of the annotation): k_lines_exists, HIP-event time."""
-    tab = synth.gencode_like_block_table(roots)
-    per_block = np.diff(tab["block_line_off"]).astype(np.int64)
-    chr_of_root = np.repeat(np.arange(len(roots["chr_offsets"]) - 1), np.diff(roots["chr_offsets"]))
-    seq = np.repeat(chr_of_root, per_block).astype(np.uint32)
-    lt = engine.LineTable(seq, tab["line_start"] + 1, tab["line_end"])  # raw 1-based closed columns 4/5
-    n_seq = len(roots["chr_offsets"]) - 1
-    kept = lt.test(regions, n_seq, mode)  # warm
-    us = []
-    for _ in range(5):
-        lt.test(regions, n_seq, mode)
-        us.append(1e3 * lt.last_kernel_ms)
-    avg = float(np.mean(us))
-    # CPU beside it: the reference scans ALL regions of the line's seqid per line (intersect.rs:500-521);
-    # the oracle's literal scan on a bounded sample of lines, 1 thread
-    from oracle import binding as ob
-    order = np.argsort(regions[:, 0], kind="stable")
-    r = regions[order]
-    off = np.concatenate([[0], np.cumsum(np.bincount(r[:, 0], minlength=n_seq))])
-    pick = np.random.default_rng(5).choice(lt.n, size=400, replace=False)
-    raw_s, raw_e = tab["line_start"] + 1, tab["line_end"]
+class Pass:
+    """K passes over resident regions, round-robin over `inflight` batches."""
+
+    def __init__(self, engine, ix, dev_cols, nq, inflight, mode, out_flags, strategy):
+        self.engine, self.mode, self.flags, self.strategy = engine, mode, out_flags, strategy
+        self.batches = []
+        for _ in range(max(1, inflight)):
+            bb = engine.QueryBatch(ix, max(nq, 1))
+            bb.set_regions_device(dev_cols[0].data_ptr(), dev_cols[1].data_ptr(), dev_cols[2].data_ptr(), nq, keep=dev_cols)
+            self.batches.append(bb)
+        self.issued = 0
+
+    def step(self):
+        self.batches[self.issued % len(self.batches)].run(self.mode, False, self.flags, self.strategy)
+        self.issued += 1
+
+    def sync(self):
+        for bb in self.batches:
+            bb.sync()
+
+    def size_and_warm(self, warmup):
+        """First pass sizes the pair buffers (a capacity replay can only happen here); returns the pass's kept pairs."""
+        b0 = self.batches[0]
+        b0.run(self.mode, False, self.flags, self.strategy)
+        b0.wait()
+        pairs = b0.total_hits
+        for bb in self.batches[1:]:
+            bb.reserve_hits(pairs + pairs // 8 + 1024)
+            bb.run(self.mode, False, self.flags, self.strategy)
+            bb.wait()
+        for _ in range(warmup * len(self.batches)):
+            self.step()
+        self.sync()
+        return pairs
+
+    def timed(self, steps, barrier, torch):
+        # warm the pipeline immediately before the timed region: >= 2 x inflight passes, drained
+        for _ in range(2 * len(self.batches)):
+            self.step()
+        self.sync()
+        self.issued = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.sync()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def check(self, pairs):
+        """Every batch's sticky error flag and pair total, once, outside the timed region."""
+        for bb in self.batches:
+            bb.wait()
+            assert bb.total_hits == pairs, (bb.total_hits, pairs)
+
+    def kernel_us(self, n_prof):
+        """HIP-event durations per kernel: serial launches back to back on batch 0's stream."""
+        b0 = self.batches[0]
+        b0.set_profiling(True)
+        b0.reset_profile()
+        for _ in range(n_prof):
+            b0.run(self.mode, False, self.flags, self.strategy)
+        b0.sync()
+        b0.set_profiling(False)
+        kern = {}
+        for kid, name in self.engine.KERNEL_NAMES.items():
+            ms, n = b0.kernel_ms(kid)
+            if n:
+                kern[name] = {"avg_us": 1e3 * ms / n, "launches_per_step": n / n_prof}
+        return kern
+
+    def close(self):
+        for bb in self.batches:
+            bb.close()
+
+
+def roofline_obj(kern, nq, pairs, out_b, note, traffic=None):
+    h_bar = pairs / max(nq, 1)
+    bytes_per_query = 12.0 + 4.0 + out_b * h_bar  # SURVEY.md 8(d): regions in, count out, pairs out
+    pass_us = sum(k["avg_us"] * k["launches_per_step"] for k in kern.values())
+    dominant = max(kern.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches_per_step"])[0] if kern else None
+    achieved = (bytes_per_query * nq) / (pass_us * 1e-6) / 1e9 if pass_us > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_copy_ceiling": achieved / 6300.0, "traffic": traffic, "dominant_kernel": dominant,
+            "regions_per_launch": nq, "pairs_per_region": h_bar, "algorithmic_bytes_per_pass": bytes_per_query * nq,
+            "pass_kernel_us": pass_us, "kernels": kern, "note": note}
+
+
+def to_dev(torch, regions, dev):
+    t = torch.from_numpy(np.ascontiguousarray(regions).view(np.int32))  # u32 bit patterns
+    return tuple(t[:, k].contiguous().to(dev) for k in range(3))
+
+
+def xfer_leg(engine, torch, ix, regions, mode, pairs, reps=8):
+    """T_xfer: regions start in pinned host memory, counts + root_fids end in pinned host memory.  Two batches
+    double-buffered: the copies of one overlap the kernel of the other (they run on the batches' own streams)."""
+    nq = len(regions)
+    L = engine.lib()
+    pin_in = torch.from_numpy(np.ascontiguousarray(regions).view(np.int32)).pin_memory()
+    cap = pairs + pairs // 8 + 1024
+    pin_counts = [torch.empty(nq, dtype=torch.int32).pin_memory() for _ in range(2)]
+    pin_fids = [torch.empty(cap, dtype=torch.int32).pin_memory() for _ in range(2)]
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    bs = [engine.QueryBatch(ix, nq) for _ in range(2)]
+    flags = engine.OUT_FIDS | engine.OUT_OFFSETS32
+
+    def one(k):
+        b = bs[k]
+        engine.check(L.gffx_hip_batch_set_regions_host(b._h, ctypes.cast(pin_in.data_ptr(), u32p), nq))
+        b.run(mode, False, flags, 0)
+
+    def collect(k):
+        b = bs[k]
+        b.wait()
+        engine.check(L.gffx_hip_batch_copy_counts(b._h, ctypes.cast(pin_counts[k].data_ptr(), u32p)))
+        engine.check(L.gffx_hip_batch_copy_fids(b._h, ctypes.cast(pin_fids[k].data_ptr(), u32p)))
+        return b.total_hits
+
+    for k in range(2):
+        bs[k].reserve_hits(cap)
+        one(k)
+        collect(k)
     t0 = time.perf_counter()
-    for i in pick.tolist():
-        c = int(seq[i])
-        ob.line_predicate(int(raw_s[i]), int(raw_e[i]), r[off[c]:off[c + 1], 1], r[off[c]:off[c + 1], 2], mode)
-    cpu_s = time.perf_counter() - t0
-    return {"kernel": "k_lines_exists", "avg_us": avg,
-            "cpu_baseline": {"value": len(pick) / cpu_s, "unit": "lines/s", "cores": 1, "kind": "port",
-                             "sample": "%d random lines, literal scan of all regions of the line's seqid" % len(pick)}, "lines": int(lt.n), "regions": int(len(regions)),
-            "lines_per_s": lt.n / (avg * 1e-6), "achieved_GBps": 13.0 * lt.n / (avg * 1e-6) / 1e9,
-            "kept_lines": int(kept.sum()),
-            "note": "13 B per line (seq, start, end in; keep flag out); the regions' sort / prefix-max tables are "
-                    "prepared on the host per call and are not in this time"}
+    one(0)
+    for i in range(1, reps):
+        one(i & 1)
+        got = collect((i - 1) & 1)
+    got = collect((reps - 1) & 1)
+    dt = (time.perf_counter() - t0) / reps
+    assert got == pairs
+    for b in bs:
+        b.close()
+    moved = 12.0 * nq + 4.0 * nq + 4.0 * pairs
+    return {"ms_per_batch": 1e3 * dt, "value": nq / dt, "unit": "queries/s", "regions": nq,
+            "pcie_GBps": moved / dt / 1e9,
+            "note": "pinned host regions -> HBM, pass, counts + root_fids -> pinned host; two batches double-buffered; "
+                    "never the headline value (PCIe Gen5 x16 bounds it at ~63 GB/s)"}
+
+
+def e2e_leg(synth, roots, regions, tmp):
+    """T_e2e: the product CLI, end to end, on text inputs: GENCODE-shaped GFF3 (~3.5 M lines) x the 1 M-row BED."""
+    gff, bed = os.path.join(tmp, "anno.gff"), os.path.join(tmp, "q.bed")
+    n_lines = synth.write_gff3_fast(gff, roots)
+    synth.write_bed_fast(bed, regions, roots["names"])
+    G = os.path.join(ROOT, "gffx_amd", "bin", "gffx")
+    t0 = time.perf_counter()
+    subprocess.run([G, "index", "-i", gff], check=True, capture_output=True)
+    t_index = time.perf_counter() - t0
+    out = {"gff_lines": n_lines, "gff_MB": os.path.getsize(gff) / 1e6, "bed_rows": len(regions), "index_s": t_index, "runs": {}}
+    for name, extra in (("intersect", []), ("intersect -e", ["-e"])):
+        best, stages, size = None, "", 0
+        for _ in range(2):  # (second run: page cache warm)
+            t0 = time.perf_counter()
+            r = subprocess.run([G, "intersect", "-v", "-i", gff, "-b", bed, "-o", os.path.join(tmp, "out.gff")] + extra,
+                               capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            if best is None or dt < best:
+                best = dt
+                stages = [ln.strip() for ln in r.stderr.splitlines() if "[TIMER]" in ln]
+                size = os.path.getsize(os.path.join(tmp, "out.gff"))
+        out["runs"][name] = {"wall_s": best, "regions_per_s": len(regions) / best, "output_MB": size / 1e6, "stages": stages}
+    return out
 
 
 def main():
@@ -184,6 +294,8 @@ def main():
                   file=sys.stderr)
             sys.exit(2)
         args.gpus = world
+    if args.exchange is None:
+        args.exchange = "final-timed" if (args.scaling == "strong" and world > 1) else "final"
 
     import torch
     import torch.distributed as dist
@@ -193,8 +305,8 @@ def main():
     if not torch.cuda.is_available() or engine.device_count() < 1:
         print("bench.py: no MI355X visible; the engine has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    # GFFX_BENCH_BACKEND=gloo lets the N>1 plumbing be exercised on a 1-GPU box (all ranks share
-    # device 0); the driver's runs use nccl (= RCCL over xGMI), one rank per GPU.
+    # GFFX_BENCH_BACKEND=gloo lets the N>1 plumbing be exercised on a 1-GPU box (all ranks share device 0); the driver's
+    # runs use nccl (= RCCL over xGMI), one rank per GPU.
     backend = os.environ.get("GFFX_BENCH_BACKEND", "nccl")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
@@ -205,147 +317,97 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = dev if backend == "nccl" else None  # gloo gathers CPU tensors
 
     mode = {"contained": 0, "contains_region": 1, "overlap": 2}[args.mode]
-    strategy = {"auto": 0, "direct": 1, "sorted": 2, "fused": 3, "slots": 4}[args.strategy]
+    strategy = {"auto": 0, "direct": 1, "sorted": 2, "fused": 3, "slots": 4, "windows": 5}[args.strategy]
     out_flags = {"counts": engine.OUT_COUNTS, "fids": engine.OUT_FIDS, "triples": engine.OUT_TRIPLES}[args.out]
-    if args.strategy != "direct" and args.out != "counts" and not args.no_offsets:
-        out_flags |= engine.OUT_OFFSETS  # segments follow the order rounds / tiles were served: offsets are explicit
-    if args.strategy == "sorted" and not args.input_order:
+    if args.strategy != "direct" and args.out != "counts":
+        out_flags |= {"u32": engine.OUT_OFFSETS32, "u64": engine.OUT_OFFSETS, "none": 0}[args.offsets]
+    if args.strategy == "sorted":
         out_flags |= engine.OUT_EMIT_ORDER
+    out_b = {"counts": 0.0, "fids": 4.0, "triples": 12.0}[args.out]
 
     # ---- synthetic inputs (identical on every rank; each rank keeps its shard)
     roots = synth.gencode_like_roots(63000, seed=42)
     n_chr = len(roots["chr_offsets"]) - 1
-    nq_global = args.queries_per_gpu * world
-    regions_all = synth.synth_bed(nq_global, seed=1001)
+    strong = args.scaling == "strong" and world > 1
+    if strong:
+        nq_global, seed, cfg = args.strong_total, 1003, "configs[3]"
+    else:
+        nq_global, seed, cfg = args.queries_per_gpu * world, 1001, "configs[1]"
+    regions_all = synth.synth_bed(nq_global, seed=seed)
     if world > 1:
-        rows = shard.shard_rows(regions_all, n_chr, world, rank)
-        regions = np.ascontiguousarray(regions_all[rows])
+        regions = np.ascontiguousarray(regions_all[shard.shard_rows(regions_all, n_chr, world, rank)])
     else:
         regions = regions_all
+    del regions_all
     if args.presort == "chr_end":
-        regions = regions[np.lexsort((regions[:, 2], regions[:, 0]))]
-    elif args.presort == "bucket":  # (chr, end >> 21) buckets, input order inside a bucket
-        key = (regions[:, 0].astype(np.int64) << 11) | (regions[:, 2].astype(np.int64) >> 21)
-        regions = regions[np.argsort(key, kind="stable")]
-    regions = np.ascontiguousarray(regions)
+        regions = np.ascontiguousarray(regions[np.lexsort((regions[:, 2], regions[:, 0]))])
     nq = len(regions)
 
     ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"],
                                          roots["names"], device=dev_index)
-    # regions resident in HBM as SoA u32 (torch owns the memory; the engine borrows the pointers)
-    t_regions = torch.from_numpy(np.ascontiguousarray(regions).view(np.int32))  # u32 bit patterns
-    d_chr = t_regions[:, 0].contiguous().to(dev)
-    d_start = t_regions[:, 1].contiguous().to(dev)
-    d_end = t_regions[:, 2].contiguous().to(dev)
+    cols = to_dev(torch, regions, dev)  # regions resident in HBM as SoA u32 (torch owns the memory; the engine borrows the pointers)
     torch.cuda.synchronize()
-    batches = []
-    for _ in range(max(1, args.inflight)):
-        bb = engine.QueryBatch(ix, max(nq, 1))
-        bb.set_regions_device(d_chr.data_ptr(), d_start.data_ptr(), d_end.data_ptr(), nq,
-                              keep=(d_chr, d_start, d_end))
-        batches.append(bb)
-    batch = batches[0]
-    issued = [0]
-
-    coll_dev = dev if backend == "nccl" else None  # gloo gathers CPU tensors
-
-    def step():
-        batches[issued[0] % len(batches)].run(mode, False, out_flags, strategy)
-        issued[0] += 1
-
-    def sync_all():
-        for bb in batches:
-            bb.sync()
-
-    def exchange():
-        # the path's one exchange step: all-gather of per-rank (queries, kept pairs)
-        if world > 1 and args.exchange == "per-step":
-            batch.wait()
-            return shard.allgather_hit_counts(nq, batch.total_hits, device=coll_dev)
-        return None
-
-    # sizing pass (also the parity-relevant total), then warmup
-    step()
-    batch.wait()
-    pairs = batch.total_hits
-    for _ in range(args.warmup * len(batches)):
-        step()
-        exchange()
-    for bb in batches:  # (sizes every batch's pair buffers: a capacity replay can only happen here)
-        if bb is batch or args.warmup > 0:
-            bb.wait()
-    issued[0] = 0
-    if world > 1:  # the collective's first call sets up its channels: not part of the job's steady state
-        shard.allgather_hit_counts(nq, pairs, device=coll_dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        exchange()
-    if world > 1 and args.exchange == "final-timed":
-        sync_all()
-        batch.wait()  # the job's one exchange step, inside the timed region
-        shard.allgather_hit_counts(nq, batch.total_hits, device=coll_dev)
+    run = Pass(engine, ix, cols, nq, args.inflight, mode, out_flags, strategy)
+    pairs = run.size_and_warm(args.warmup)
+    if world > 1:  # the collective's first call sets up its channels: not part of the job's steady state
+        shard.allgather_hit_counts(nq, pairs, device=coll_dev)
+
+    # ---- the timed region: exactly K steps between barrier + synchronize, MAX over ranks
+    if world > 1 and args.exchange != "final":
+        for _ in range(2 * len(run.batches)):
+            run.step()
+        run.sync()
+        run.issued = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run.step()
+            if args.exchange == "per-step":
+                run.batches[(run.issued - 1) % len(run.batches)].wait()
+                shard.allgather_hit_counts(nq, pairs, device=coll_dev)
+        run.sync()
+        if args.exchange == "final-timed":  # the job's one exchange step, inside the timed region
+            run.batches[0].wait()
+            shard.allgather_hit_counts(nq, run.batches[0].total_hits, device=coll_dev)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     else:
-        sync_all()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0  # this rank's K steps (+ the exchange); MAX over ranks below
+        elapsed = run.timed(args.steps, barrier, torch)
     barrier()
+    run.check(pairs)
     exchange_ms = None
     if world > 1:
-        # the job's ONE exchange step (north_star: the final hit-count all-gather): once per job, not per step, so it is
-        # timed on its own (--exchange final-timed puts it inside the K-step region, per-step runs one per step)
-        batch.wait()
         tx = time.perf_counter()
-        shard.allgather_hit_counts(nq, batch.total_hits, device=coll_dev)
+        counts = shard.allgather_hit_counts(nq, pairs, device=coll_dev)
         torch.cuda.synchronize()
         exchange_ms = 1e3 * (time.perf_counter() - tx)
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        counts = shard.allgather_hit_counts(nq, pairs, device=coll_dev)
         nq_total, pairs_total = int(counts[:, 0].sum()), int(counts[:, 1].sum())
     else:
         nq_total, pairs_total = nq, pairs
-    sync_all()
-    batch.wait()
-    issued[0] = 0  # the profiled loop below runs on batch 0 only, one pass at a time
-
-    # ---- per-kernel durations, HIP events on the engine's own stream (separate profiled loop)
-    batch.set_profiling(True)
-    batch.reset_profile()
-    n_prof = max(5, min(args.steps, 30))
-    for _ in range(n_prof):  # back to back on the engine's stream, one event pair per launch, one sync at the end
-        batch.run(mode, False, out_flags, strategy)
-    batch.sync()
-    batch.set_profiling(False)
-    kern = {}
-    for kid, name in engine.KERNEL_NAMES.items():
-        ms, n = batch.kernel_ms(kid)
-        if n:
-            kern[name] = {"avg_us": 1e3 * ms / n, "launches_per_step": n / n_prof}
 
     result = None
     if rank == 0:
-        h_bar = pairs / max(nq, 1)
-        out_b = {"counts": 0.0, "fids": 4.0, "triples": 12.0}[args.out]
-        bytes_per_query = 12.0 + 4.0 + out_b * h_bar  # regions in, count out, pairs out
-        pass_us = sum(k["avg_us"] * k["launches_per_step"] for k in kern.values())
-        dominant = max(kern.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches_per_step"])[0] if kern else None
-        achieved = (bytes_per_query * nq) / (pass_us * 1e-6) / 1e9 if pass_us > 0 else 0.0
+        kern = run.kernel_us(max(5, min(args.steps, 30)))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_pass")
+                tj = json.load(open(tpath))
+                traffic = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_pass"), "kernel": tj.get("kernel"),
+                           "measured_at_commit": tj.get("commit"), "source": "profiles/traffic_latest.json (rocprofv3 --pmc "
+                           "FETCH_SIZE / WRITE_SIZE passes; NOT measured by this run)"}
             except Exception:
                 traffic = None
         result = {
@@ -357,26 +419,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: %d synthetic BED regions per GPU (seed 1001) x GENCODE/GRCh38-shaped "
-                            "index (25 seqids, %d root genes, seed 42), --%s, regions resident in HBM as u32 SoA"
-                            % (args.queries_per_gpu, ix.n_roots, args.mode),
+                "workload": "BASELINE %s: %d synthetic BED regions %s (seed %d) x GENCODE/GRCh38-shaped index (25 seqids, %d root "
+                            "genes, seed 42), --%s, regions resident in HBM as u32 SoA"
+                            % (cfg, nq_global if strong else args.queries_per_gpu, "in total" if strong else "per GPU", seed,
+                               ix.n_roots, args.mode),
                 "regions_total": nq_total,
                 "kept_pairs_total": pairs_total,
-                "pairs_per_region": h_bar,
-                "outputs": {"direct": "per-region counts (input order) + %s in CSR order" % args.out,
-                            "sorted": "per-region {row, count, offset} records in tile order%s + %s"
-                                      % (" and input-order counts/offsets" if args.input_order else "", args.out),
-                            }.get(args.strategy,
-                                  "per-region counts%s (input order) + %s, segments in round order"
-                                  % ("" if args.no_offsets or args.out == "counts" else " and segment offsets", args.out)),
+                "pairs_per_region": pairs_total / max(nq_total, 1),
+                "outputs": "per-region counts%s (input order) + %s, segments in round order"
+                           % ({"u32": " and u32 segment offsets", "u64": " and u64 segment offsets", "none": ""}[args.offsets]
+                              if args.out != "counts" else "", args.out),
                 "strategy": args.strategy,
                 "presort": args.presort,
-                "batches_in_flight": len(batches),
+                "batches_in_flight": len(run.batches),
                 "sharding": ("chromosome buckets, LPT with splitting; index replicated; all-gather of hit counts "
                              + {"per-step": "after every step (inside the timed region)",
                                 "final-timed": "once per job, inside the timed region",
@@ -384,43 +444,89 @@ def main():
                             if world > 1 else "none (1 GPU)",
                 "exchange_ms": exchange_ms,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "frac_of_copy_ceiling": achieved / 6300.0,  # also against the measured ~6.3 TB/s copy ceiling
-                "traffic": traffic,
-                "kernel": "+".join(sorted(kern)) if kern else None,
-                "dominant_kernel": dominant,
-                "algorithmic_bytes_per_pass": bytes_per_query * nq,
-                "pass_kernel_us": pass_us,
-                "kernels": kern,
-                "note": "achieved = (12 B region + 4 B count + 4 B x pairs/region) x regions / summed HIP-event "
-                        "durations of the pass's kernels on the engine's stream (rank 0)",
-            },
+            "roofline": roofline_obj(kern, nq, pairs, out_b,
+                                     "achieved = (12 B region + 4 B count + 4 B x pairs/region) x regions / summed HIP-event "
+                                     "durations of the pass's kernels, serial launches on the engine's stream (rank 0)", traffic),
         }
-        if args.depth:
-            result["depth"] = depth_leg(engine, synth, roots, batch, mode, nq, pairs)
-        if args.join_b:
-            result["join_b"] = join_b_leg(engine, synth, roots, regions, mode)
-        if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(roots, regions, mode, args.cpu_seconds)
-        elif not args.no_cpu_baseline:
-            result["cpu_baseline"] = None
-        if args.cpu_allcore and world == 1:
-            import subprocess
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_allcore.py"), str(nq), str(mode), "5"],
-                               capture_output=True, text=True)
-            try:
-                result["cpu_allcore"] = json.loads(r.stdout.strip().splitlines()[-1])
-            except Exception:
-                result["cpu_allcore"] = {"error": (r.stderr or r.stdout)[-300:]}
+    if world == 1:
+        # ---- strictly serial passes (one batch, one stream): what the committed rocprofv3 kernel stats show
+        ser = Pass(engine, ix, cols, nq, 1, mode, out_flags, strategy)
+        ser.size_and_warm(1)
+        el = ser.timed(args.steps, barrier, torch)
+        ser.check(pairs)
+        result["serial"] = {"ms_per_step": 1e3 * el / args.steps, "value": nq * args.steps / el, "unit": "queries/s",
+                            "batches_in_flight": 1}
+        ser.close()
+    if world == 1 and not args.quick:
+        # ---- the pass the CLI runs: root bitmap only (commands/intersect.rs:598-615 needs the unique roots, nothing else)
+        cli = {}
+        bm = Pass(engine, ix, cols, nq, 1, mode, engine.OUT_ROOT_BITMAP, strategy)
+        bm.size_and_warm(1)
+        kb = bm.kernel_us(10)
+        cli["1m"] = {"bitmap_pass_us": sum(k["avg_us"] * k["launches_per_step"] for k in kb.values()), "kernels": kb,
+                     "fids_pass_us": result["roofline"]["pass_kernel_us"]}
+        bm.close()
+        # ---- 10 M regions (seed 1002): roofline of the same pass, and the CLI's pass
+        reg10 = synth.synth_bed(10_000_000, seed=1002)
+        cols10 = to_dev(torch, reg10, dev)
+        p10 = Pass(engine, ix, cols10, len(reg10), 1, mode, out_flags, strategy)
+        pairs10 = p10.size_and_warm(1)
+        k10 = p10.kernel_us(10)
+        result["roofline_10m"] = roofline_obj(k10, len(reg10), pairs10, out_b, "10 M synthetic BED regions (seed 1002), same pass")
+        p10.close()
+        bm10 = Pass(engine, ix, cols10, len(reg10), 1, mode, engine.OUT_ROOT_BITMAP, strategy)
+        bm10.size_and_warm(1)
+        kb10 = bm10.kernel_us(5)
+        cli["10m"] = {"bitmap_pass_us": sum(k["avg_us"] * k["launches_per_step"] for k in kb10.values()), "kernels": kb10,
+                      "fids_pass_us": result["roofline_10m"]["pass_kernel_us"]}
+        bm10.close()
+        result["cli_pass"] = cli
+        del cols10, reg10
+        # ---- transfers included, and the product CLI end to end
+        result["t_xfer"] = xfer_leg(engine, torch, ix, regions, mode, pairs)
+        try:
+            with tempfile.TemporaryDirectory(prefix="gffx_bench_") as tmp:
+                result["t_e2e"] = e2e_leg(synth, roots, regions, tmp)
+        except Exception as exc:  # the headline must not die with an auxiliary leg
+            result["t_e2e"] = {"error": repr(exc)[:300]}
+        result["join_b"] = join_b_leg(engine, synth, roots, regions, mode)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline(roots, regions, mode, args.cpu_seconds)
+        if not args.quick:
+            cb["join_a_allcore"] = child_json([os.path.join(ROOT, "tools", "cpu_allcore.py"), str(nq), str(mode), "4"])
+            cb["join_b_allcore"] = child_json([os.path.join(ROOT, "tools", "cpu_joinb_allcore.py"), str(nq), str(mode), "6"])
+        result["cpu_baseline"] = cb
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def join_b_leg(engine, synth, roots, regions, mode):
+    """Join B (commands/intersect.rs:500-521 for every line of the annotation): device preparation of the region tables
+    (radix sorts, running max / min, directories) + k_lines_exists, HIP-event times."""
+    tab = synth.gencode_like_block_table(roots)
+    per_block = np.diff(tab["block_line_off"]).astype(np.int64)
+    chr_of_root = np.repeat(np.arange(len(roots["chr_offsets"]) - 1), np.diff(roots["chr_offsets"]))
+    seq = np.repeat(chr_of_root, per_block).astype(np.uint32)
+    lt = engine.LineTable(seq, tab["line_start"] + 1, tab["line_end"])  # raw 1-based closed columns 4/5
+    n_seq = len(roots["chr_offsets"]) - 1
+    kept = lt.test(regions, n_seq, mode)  # warm
+    us, prep = [], []
+    for _ in range(5):
+        lt.test(regions, n_seq, mode)
+        us.append(1e3 * lt.last_kernel_ms)
+        prep.append(1e3 * lt.last_prep_ms)
+    avg = float(np.mean(us))
+    out = {"kernel": "k_lines_exists", "avg_us": avg, "prep_us": float(np.mean(prep)), "lines": int(lt.n), "regions": int(len(regions)),
+           "lines_per_s": lt.n / (avg * 1e-6), "achieved_GBps": 13.0 * lt.n / (avg * 1e-6) / 1e9, "kept_lines": int(kept.sum()),
+           "note": "13 B per line (seq, start, end in; keep flag out); prep_us = the region tables built on the device per call "
+                   "(k_radix_hist/_pass x 14, segmented scans, directories; was ~10 ms on the host)"}
+    lt.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -14,6 +14,8 @@ All randomness is numpy PCG64 with the seed given by the caller.
 """
 from __future__ import annotations
 
+import os
+import subprocess
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -223,3 +225,51 @@ def write_gff3(path: str, roots: Dict[str, np.ndarray], seed: int = 7, tx_per_ge
             # reversed coordinates on a child (core.rs:107 swaps them for the index only)
             w("%s\tsynth\texon\t900\t850\t.\t+\t.\tID=rev.e0;Parent=gene%06d" % (last, gi - 1))
     return n_lines
+
+
+# ---- fast text writers (tools/synth_text.c, built by __graft_entry__.build()): 3.4 M GFF lines / 100 M BED rows in seconds
+_SYNTH_TEXT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "synth_text")
+
+
+def build_synth_text() -> str:
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "synth_text.c")
+    if not os.path.exists(_SYNTH_TEXT) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_SYNTH_TEXT)):
+        os.makedirs(os.path.dirname(_SYNTH_TEXT), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-o", _SYNTH_TEXT, src, "-lm"])
+    return _SYNTH_TEXT
+
+
+def _write_names(path: str, names: Sequence[str]) -> None:
+    with open(path, "w") as f:
+        f.write("".join(n + "\n" for n in names))
+
+
+def write_gff3_fast(path: str, roots: Dict[str, np.ndarray], tx_per_gene: float = 4.0, exons_per_tx: float = 8.0,
+                    seed: int = 7) -> int:
+    """GENCODE-shaped GFF3 around ``roots`` (gene + mRNA + exon/CDS lines; ~54 lines per gene at the defaults, i.e.
+    ~3.4 M lines for 63 k genes).  Returns the number of lines."""
+    tool = build_synth_text()
+    tmp = path + ".roots.bin"
+    with open(tmp, "wb") as f:
+        co = np.ascontiguousarray(roots["chr_offsets"], dtype=np.uint32)
+        np.array([len(co) - 1, len(roots["start"])], dtype=np.uint32).tofile(f)
+        co.tofile(f)
+        np.ascontiguousarray(roots["start"], dtype=np.uint32).tofile(f)
+        np.ascontiguousarray(roots["end"], dtype=np.uint32).tofile(f)
+    _write_names(path + ".names", roots["names"])
+    out = subprocess.check_output([tool, "gff", tmp, path + ".names", path, str(tx_per_gene), str(exons_per_tx), str(seed)])
+    os.remove(tmp)
+    os.remove(path + ".names")
+    return int(out.strip())
+
+
+def write_bed_fast(path: str, regions: np.ndarray, names: Sequence[str]) -> None:
+    tool = build_synth_text()
+    tmp = path + ".regions.bin"
+    with open(tmp, "wb") as f:
+        np.array([len(regions)], dtype=np.uint64).tofile(f)
+        np.ascontiguousarray(regions, dtype=np.uint32).tofile(f)
+    _write_names(path + ".names", names)
+    subprocess.check_call([tool, "bed", tmp, path + ".names", path])
+    os.remove(tmp)
+    os.remove(path + ".names")
