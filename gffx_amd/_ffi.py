@@ -28,6 +28,16 @@ SIGNATURES = {
     "gffx_hip_index_n_roots": (C.c_uint64, [vp]),
     "gffx_hip_index_device": (C.c_int, [vp]),
     "gffx_hip_index_sorted_fids": (u32p, [vp]),
+    "gffx_hip_index_clone": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "gffx_hip_regions_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "gffx_hip_regions_destroy": (None, [vp]),
+    "gffx_hip_regions_staging": (vp, [vp, C.c_int]),
+    "gffx_hip_regions_wait_staging": (C.c_int, [vp, C.c_int]),
+    "gffx_hip_regions_append": (C.c_int, [vp, C.c_int, C.c_uint64]),
+    "gffx_hip_regions_rows": (C.c_uint64, [vp]),
+    "gffx_hip_batch_set_regions_store": (C.c_int, [vp, vp, C.c_int, C.c_uint64, C.c_uint64]),
+    "gffx_hip_allgather_counts": (C.c_int, [C.c_int, C.POINTER(C.c_int), u64p, u64p]),
+    "gffx_hip_lines_test_store": (C.c_int, [vp, vp, C.c_uint32, C.c_int, u8p]),
     "gffx_hip_batch_create": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "gffx_hip_batch_destroy": (None, [vp]),
     "gffx_hip_batch_set_regions_host": (C.c_int, [vp, u32p, C.c_uint64]),

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <memory>
 #include <numeric>
 
@@ -21,6 +22,7 @@
 #include "join_slot_kernels.hpp"
 #include "join_win_kernels.hpp"
 #include "partition_kernels.hpp"
+#include "regions_store.hpp"
 #include "tile_join_kernels.hpp"
 
 namespace gffx {
@@ -230,6 +232,15 @@ struct gffx_hip_index {
     uint32_t n_cells = 0, n_tiles = 0, cshift = 0;
     bool partition_ok = false;  // the tile plan exists (n_chr <= kMaxCells)
     std::vector<uint32_t> h_sorted_fids;
+    std::vector<size_t> array_bytes;  // of arrays(), in order (gffx_hip_index_clone)
+
+    // every device array of the index, in a fixed order
+    std::vector<void **> arrays() {
+        return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_slot_meta,
+                (void **)&d_slots,     (void **)&d_spill,     (void **)&d_slot_pos,   (void **)&d_win_meta,   (void **)&d_win,
+                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_win_fmeta,  (void **)&d_cell_base,
+                (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
+    }
 
     IndexView view() const {
         IndexView v;
@@ -605,7 +616,36 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         gffx_hip_index_destroy(ix.release());
         return rc;
     }
+    auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
+    ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),      bytes(slot_meta), bytes(slots),     bytes(spill),
+                       bytes(slot_pos),  bytes(win_meta),  bytes(win),        bytes(win_pos),   bytes(win_spill), bytes(win_filter), bytes(win_fmeta),
+                       bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
+    GFFX_HIP_TRY(hipDeviceSynchronize());
+    *out = ix.release();
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_index_clone(const gffx_hip_index *src, int device, gffx_hip_index **out) {
+    if (!out) return fail(GFFX_E_INVALID, "gffx_hip_index_clone: out is NULL");
+    *out = nullptr;
+    if (!src) return fail(GFFX_E_INVALID, "gffx_hip_index_clone: index is NULL");
+    const int ndev = device_count_quiet();
+    if (device < 0 || device >= ndev) return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
+    std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index(*src));  // scalars and host vectors; the pointers are replaced below
+    ix->device = device;
+    std::vector<void **> dst = ix->arrays();
+    std::vector<void **> from = const_cast<gffx_hip_index *>(src)->arrays();
+    for (void **p : dst) *p = nullptr;
+    GFFX_HIP_TRY(hipSetDevice(device));
+    for (size_t i = 0; i < dst.size(); ++i) {
+        hipError_t e = hipMalloc(dst[i], src->array_bytes[i]);
+        if (e == hipSuccess) e = hipMemcpy(*dst[i], *from[i], src->array_bytes[i], hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            gffx_hip_index_destroy(ix.release());
+            return fail(e == hipErrorOutOfMemory ? GFFX_E_OOM : GFFX_E_HIP, "gffx_hip_index_clone: %s", hipGetErrorString(e));
+        }
+    }
     GFFX_HIP_TRY(hipDeviceSynchronize());
     *out = ix.release();
     return GFFX_OK;
@@ -762,6 +802,153 @@ extern "C" int gffx_hip_batch_set_regions_device(gffx_hip_batch *b, const uint32
     b->mostly_slow = false;
     b->ran = b->waited = false;
     return GFFX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------ region stores
+
+extern "C" void gffx_hip_regions_destroy(gffx_hip_regions *R) {
+    if (!R) return;
+    (void)hipSetDevice(R->device);
+    if (R->stream) (void)hipStreamSynchronize(R->stream);
+    (void)hipFree(R->d);
+    for (int k = 0; k < 2; ++k) {
+        if (R->h_stage[k]) (void)hipHostFree(R->h_stage[k]);
+        if (R->copied[k]) (void)hipEventDestroy(R->copied[k]);
+    }
+    if (R->stream) (void)hipStreamDestroy(R->stream);
+    delete R;
+}
+
+extern "C" int gffx_hip_regions_create(int device, uint64_t capacity_rows, uint64_t chunk_rows, int keep_all, gffx_hip_regions **out) {
+    if (!out) return fail(GFFX_E_INVALID, "gffx_hip_regions_create: out is NULL");
+    *out = nullptr;
+    if (!chunk_rows) return fail(GFFX_E_INVALID, "gffx_hip_regions_create: chunk_rows is 0");
+    const int ndev = device_count_quiet();
+    if (ndev <= 0) return fail(GFFX_E_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
+    GFFX_HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<gffx_hip_regions, void (*)(gffx_hip_regions *)> R(new gffx_hip_regions, gffx_hip_regions_destroy);
+    R->device = device;
+    R->keep_all = keep_all != 0;
+    R->chunk_rows = chunk_rows;
+    R->cap_rows = R->keep_all ? std::max<uint64_t>(capacity_rows, chunk_rows) : 2 * chunk_rows;
+    int rc = dev_alloc(&R->d, 3 * R->cap_rows);
+    if (rc) return rc;
+    GFFX_HIP_TRY(hipStreamCreateWithFlags(&R->stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        hipError_t e = hipHostMalloc((void **)&R->h_stage[k], std::max<uint64_t>(chunk_rows, 1) * 12, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(GFFX_E_OOM, "hipHostMalloc of a %llu-row staging buffer failed: %s", (unsigned long long)chunk_rows, hipGetErrorString(e));
+        GFFX_HIP_TRY(hipEventCreateWithFlags(&R->copied[k], hipEventDisableTiming));
+    }
+    *out = R.release();
+    return GFFX_OK;
+}
+
+extern "C" uint32_t *gffx_hip_regions_staging(gffx_hip_regions *R, int k) { return (R && (k == 0 || k == 1)) ? R->h_stage[k] : nullptr; }
+extern "C" uint64_t gffx_hip_regions_rows(const gffx_hip_regions *R) { return R ? R->rows : 0; }
+
+extern "C" int gffx_hip_regions_wait_staging(gffx_hip_regions *R, int k) {
+    if (!R || (k != 0 && k != 1)) return fail(GFFX_E_INVALID, "gffx_hip_regions_wait_staging: bad argument");
+    if (!R->pending[k]) return GFFX_OK;
+    GFFX_HIP_TRY(hipSetDevice(R->device));
+    GFFX_HIP_TRY(hipEventSynchronize(R->copied[k]));
+    R->pending[k] = false;
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_regions_append(gffx_hip_regions *R, int k, uint64_t n_rows) {
+    if (!R || (k != 0 && k != 1)) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: bad argument");
+    if (n_rows > R->chunk_rows) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: %llu rows exceed the chunk size %llu", (unsigned long long)n_rows, (unsigned long long)R->chunk_rows);
+    const uint64_t first = R->keep_all ? R->rows : (uint64_t)k * R->chunk_rows;
+    if (first + n_rows > R->cap_rows) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: the store is full (%llu rows)", (unsigned long long)R->cap_rows);
+    GFFX_HIP_TRY(hipSetDevice(R->device));
+    if (n_rows) GFFX_HIP_TRY(hipMemcpyAsync(R->d + 3 * first, R->h_stage[k], n_rows * 12, hipMemcpyHostToDevice, R->stream));
+    GFFX_HIP_TRY(hipEventRecord(R->copied[k], R->stream));
+    R->pending[k] = true;
+    R->last_first[k] = first;
+    R->last_n[k] = n_rows;
+    if (R->keep_all) R->rows += n_rows;
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_batch_set_regions_store(gffx_hip_batch *b, const gffx_hip_regions *R, int k, uint64_t first, uint64_t n_rows) {
+    int rc = batch_check_nq(b, n_rows, "gffx_hip_batch_set_regions_store");
+    if (rc) return rc;
+    if (!R || (k != 0 && k != 1)) return fail(GFFX_E_INVALID, "gffx_hip_batch_set_regions_store: bad argument");
+    if (R->device != b->ix->device) return fail(GFFX_E_INVALID, "gffx_hip_batch_set_regions_store: store and batch on different devices");
+    if (first + n_rows > R->last_n[k]) return fail(GFFX_E_INVALID, "gffx_hip_batch_set_regions_store: rows beyond the last append");
+    GFFX_HIP_TRY(hipSetDevice(R->device));
+    GFFX_HIP_TRY(hipStreamWaitEvent(b->stream, R->copied[k], 0));
+    b->q = QueryView{R->d + 3 * (R->last_first[k] + first), nullptr, nullptr, nullptr};
+    b->nq = n_rows;
+    b->have_regions = true;
+    b->mostly_slow = false;
+    b->ran = b->waited = false;
+    return GFFX_OK;
+}
+
+// ------------------------------------------------------------------------------------ multi-GPU exchange (RCCL)
+
+// RCCL is loaded on first use (a single-GPU host never needs it): ncclCommInitAll + one ncclAllGather per device
+extern "C" int gffx_hip_allgather_counts(int n_dev, const int *devices, const uint64_t *counts_in, uint64_t *counts_out) {
+    if (n_dev <= 0 || !devices || !counts_in || !counts_out) return fail(GFFX_E_INVALID, "gffx_hip_allgather_counts: bad argument");
+    for (int i = 0; i < n_dev; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) return fail(GFFX_E_INVALID, "gffx_hip_allgather_counts: device %d listed twice", devices[i]);
+    typedef void *comm_t;
+    typedef int (*init_all_t)(comm_t *, int, const int *);
+    typedef int (*allgather_t)(const void *, void *, size_t, int, comm_t, hipStream_t);
+    typedef int (*group_t)(void);
+    typedef int (*destroy_t)(comm_t);
+    static void *lib = nullptr;
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(GFFX_E_HIP, "gffx_hip_allgather_counts: cannot load librccl.so (%s)", dlerror());
+    const auto init_all = (init_all_t)dlsym(lib, "ncclCommInitAll");
+    const auto allgather = (allgather_t)dlsym(lib, "ncclAllGather");
+    const auto group_start = (group_t)dlsym(lib, "ncclGroupStart"), group_end = (group_t)dlsym(lib, "ncclGroupEnd");
+    const auto comm_destroy = (destroy_t)dlsym(lib, "ncclCommDestroy");
+    if (!init_all || !allgather || !group_start || !group_end || !comm_destroy)
+        return fail(GFFX_E_HIP, "gffx_hip_allgather_counts: librccl.so lacks a needed symbol");
+    std::vector<comm_t> comm(n_dev, nullptr);
+    if (init_all(comm.data(), n_dev, devices) != 0) return fail(GFFX_E_HIP, "ncclCommInitAll failed");
+    std::vector<uint64_t *> d_in(n_dev, nullptr), d_out(n_dev, nullptr);
+    std::vector<hipStream_t> st(n_dev, nullptr);
+    int rc = GFFX_OK;
+    auto cleanup = [&]() {
+        for (int i = 0; i < n_dev; ++i) {
+            (void)hipSetDevice(devices[i]);
+            (void)hipFree(d_in[i]);
+            (void)hipFree(d_out[i]);
+            if (st[i]) (void)hipStreamDestroy(st[i]);
+            if (comm[i]) comm_destroy(comm[i]);
+        }
+    };
+    for (int i = 0; i < n_dev && rc == GFFX_OK; ++i) {
+        if (hipSetDevice(devices[i]) != hipSuccess || hipMalloc((void **)&d_in[i], 16) != hipSuccess ||
+            hipMalloc((void **)&d_out[i], 16 * (size_t)n_dev) != hipSuccess || hipStreamCreate(&st[i]) != hipSuccess ||
+            hipMemcpy(d_in[i], counts_in + 2 * i, 16, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(GFFX_E_HIP, "gffx_hip_allgather_counts: device %d set-up failed", devices[i]);
+    }
+    if (rc == GFFX_OK) {
+        const int kNcclUint64 = 5;  // ncclUint64
+        group_start();
+        for (int i = 0; i < n_dev; ++i) {
+            (void)hipSetDevice(devices[i]);
+            if (allgather(d_in[i], d_out[i], 2, kNcclUint64, comm[i], st[i]) != 0) rc = fail(GFFX_E_HIP, "ncclAllGather failed on device %d", devices[i]);
+        }
+        if (group_end() != 0 && rc == GFFX_OK) rc = fail(GFFX_E_HIP, "ncclGroupEnd failed");
+    }
+    for (int i = 0; i < n_dev && rc == GFFX_OK; ++i) {
+        (void)hipSetDevice(devices[i]);
+        if (hipStreamSynchronize(st[i]) != hipSuccess ||
+            hipMemcpy(counts_out + 2 * (size_t)n_dev * i, d_out[i], 16 * (size_t)n_dev, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(GFFX_E_HIP, "gffx_hip_allgather_counts: collecting from device %d failed", devices[i]);
+    }
+    cleanup();
+    return rc;
 }
 
 extern "C" int gffx_hip_batch_reserve_hits(gffx_hip_batch *b, uint64_t n_pairs) {

@@ -31,6 +31,7 @@
 
 #include "gffx_device.hpp"
 #include "radix_sort.hpp"
+#include "regions_store.hpp"
 
 namespace gffx {
 
@@ -554,6 +555,20 @@ extern "C" int gffx_hip_lines_test_device(gffx_hip_lines *L, const uint32_t *d_r
     GFFX_HIP_TRY(hipSetDevice(L->device));
     if ((rc = lines_reserve(L, nq, n_seq, 9 + 3))) return rc;
     if (nq) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, d_regions, nq * 12, hipMemcpyDeviceToDevice, L->stream));
+    return lines_run(L, nq, n_seq, mode, keep_host);
+}
+
+extern "C" int gffx_hip_lines_test_store(gffx_hip_lines *L, const gffx_hip_regions *R, uint32_t n_seq, int mode, uint8_t *keep_host) {
+    if (!R || !R->keep_all) return fail(GFFX_E_INVALID, "gffx_hip_lines_test_store: needs a keep_all region store");
+    const uint64_t nq = R->rows;
+    int rc = lines_check(L, R->d, nq, mode, keep_host, "gffx_hip_lines_test_store");
+    if (rc) return rc;
+    if (R->device != L->device) return fail(GFFX_E_INVALID, "gffx_hip_lines_test_store: store and line table on different devices");
+    GFFX_HIP_TRY(hipSetDevice(L->device));
+    if ((rc = lines_reserve(L, nq, n_seq, 9 + 3))) return rc;
+    for (int k = 0; k < 2; ++k)  // every append has to have landed
+        if (R->pending[k]) GFFX_HIP_TRY(hipStreamWaitEvent(L->stream, R->copied[k], 0));
+    if (nq) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, R->d, nq * 12, hipMemcpyDeviceToDevice, L->stream));
     return lines_run(L, nq, n_seq, mode, keep_host);
 }
 

@@ -206,3 +206,18 @@ extern "C" int gffx_host_line_table_check(const char *gff, uint32_t threads, cha
 
 extern "C" int gffx_host_cli(int argc, char **argv) { return cli_main(argc, argv); }
 extern "C" void gffx_host_free(void *p) { std::free(p); }
+
+extern "C" int gffx_host_plan_shards(const uint64_t *bucket_sizes, uint32_t n_chr, uint32_t n_ranks, uint64_t **slices, uint64_t *n_slices) {
+    const auto plan = commands::intersect::plan_shards(std::vector<uint64_t>(bucket_sizes, bucket_sizes + n_chr), n_ranks);
+    std::vector<uint64_t> flat;
+    for (size_t r = 0; r < plan.size(); ++r)
+        for (const auto &sl : plan[r]) {
+            flat.push_back(r);
+            flat.push_back(sl.chr);
+            flat.push_back(sl.lo);
+            flat.push_back(sl.hi);
+        }
+    *slices = dup_vec(flat);
+    *n_slices = flat.size() / 4;
+    return 0;
+}

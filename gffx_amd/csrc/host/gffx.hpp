@@ -160,6 +160,7 @@ struct IntersectArgs {  // intersect.rs:43-70
     bool overlap = false;               // -O/--overlap
     bool invert = false;                // -I/--invert
     int device = 0;                     // --device (addition: which MI355X)
+    int gpus = 1;                       // --gpus (addition: shard every BED chunk by chromosome bucket over N MI355X)
 };
 
 using Region = std::tuple<uint32_t, uint32_t, uint32_t>;  // (chr, start, end)
@@ -190,6 +191,30 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
                                     const std::optional<std::string> &types_filter,
                                     const std::optional<std::string> &output_path, OverlapMode mode, bool verbose,
                                     size_t threads, int device);
+
+// The body of write_gff_match_only_by_coords with the regions on the host (flat triples) or in a device region store
+void write_matched_lines(const std::string &gff_path, const std::vector<Block> &blocks, const std::vector<char> &has_regions,
+                         const uint32_t *flat, uint64_t n_regions, gffx_hip_regions *store,
+                         const std::vector<std::string> &num_to_seqid, const std::optional<std::string> &types_filter,
+                         const std::optional<std::string> &output_path, OverlapMode mode, bool verbose, size_t threads, int device);
+
+// Chromosome-bucket sharding (the reference buckets by seqid first, intersect.rs:114-120): rows lo..hi of seqid chr's bucket
+struct ShardSlice {
+    uint32_t chr;
+    uint64_t lo, hi;
+};
+std::vector<std::vector<ShardSlice>> plan_shards(const std::vector<uint64_t> &bucket_sizes, size_t n_ranks, double tolerance = 0.02);
+
+// parse_bed_file + query_features + the unique-root collection (intersect.rs:586-615) over a whole BED file, streamed
+// chunk by chunk through pinned staging buffers to n_gpus devices
+struct StreamResult {
+    std::vector<uint32_t> roots;       // unique root fids, ascending
+    std::vector<char> has_regions;     // per seqid: owns at least one region (query_ivmap's keys, intersect.rs:621-633)
+    uint64_t n_regions = 0;
+    gffx_hip_regions *store = nullptr; // keep_store: all regions, on the first device (the caller destroys it)
+};
+StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &bed_path, OverlapMode mode, bool invert, bool verbose,
+                                 size_t threads, int device, int n_gpus, bool keep_store);
 
 void run(const IntersectArgs &args);  // intersect.rs:541-655
 

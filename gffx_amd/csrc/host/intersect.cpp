@@ -95,9 +95,10 @@ std::vector<size_t> line_chunks(std::string_view d, size_t parts) {
 }
 
 namespace {
-// intersect.rs:201-230 on the lines of d[a, z); z is a line start or the end of the file
+// intersect.rs:201-230 on the lines of d[a, z); z is a line start or the end of the file.  Rows as flat (chr, start, end)
+// words -- the layout the device reads.
 void parse_bed_chunk(std::string_view d, size_t a, size_t z, bool last, const std::unordered_map<std::string, uint32_t> &seqid_map,
-                     std::vector<Region> &regions) {
+                     std::vector<uint32_t> &rows) {
     std::string key;
     const std::pair<const std::string, uint32_t> *hit = nullptr;  // the seqid of the previous row, usually this row's too
     while (last ? a <= z : a < z) {
@@ -128,25 +129,27 @@ void parse_bed_chunk(std::string_view d, size_t a, size_t z, bool last, const st
         const auto s = parse_u32_rust(field[1]);  // lexical_core::parse::<u32>
         const auto e = parse_u32_rust(field[2]);
         if (!s || !e) throw Error("lexical parse error: invalid BED coordinate in \"" + std::string(line) + "\"");
-        regions.emplace_back(hit->second, *s, *e);
+        rows.push_back(hit->second);
+        rows.push_back(*s);
+        rows.push_back(*e);
     }
 }
-}  // namespace
 
-// The file is cut at line starts and parsed on `threads` host threads; rows keep the file's order and the error
-// reported is the first one in file order, as in the serial loop of the reference.
-std::vector<Region> parse_bed_file(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
-                                   size_t threads) {
-    MappedFile f(bed_path);
-    const std::string_view d = f.view();
-    const size_t parts = d.size() < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(threads, 64));
-    const std::vector<size_t> cut = line_chunks(d, parts);
+// The rows of d[a, z) parsed on `threads` host threads (cut at line starts); piece[t] = the rows of the t-th cut, in file
+// order.  The error reported is the first one in file order, as in the serial loop of the reference.
+void parse_bed_pieces(std::string_view d, size_t a, size_t z, bool last, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                      size_t threads, std::vector<std::vector<uint32_t>> &piece) {
+    const std::string_view sub = d.substr(a, z - a);
+    const size_t parts = sub.size() < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(threads, 64));
+    std::vector<size_t> cut = line_chunks(sub, parts);
     const size_t n = cut.size() - 1;
-    std::vector<std::vector<Region>> out(n);
+    piece.resize(n);
     std::vector<std::exception_ptr> err(n);
     auto work = [&](size_t c) {
+        piece[c].clear();
+        piece[c].reserve((cut[c + 1] - cut[c]) / 8);
         try {
-            parse_bed_chunk(d, cut[c], cut[c + 1], c + 1 == n, seqid_map, out[c]);
+            parse_bed_chunk(d, a + cut[c], a + cut[c + 1], last && c + 1 == n, seqid_map, piece[c]);
         } catch (...) {
             err[c] = std::current_exception();
         }
@@ -157,12 +160,23 @@ std::vector<Region> parse_bed_file(const std::string &bed_path, const std::unord
     for (auto &t : pool) t.join();
     for (size_t c = 0; c < n; ++c)
         if (err[c]) std::rethrow_exception(err[c]);
-    if (n == 1) return std::move(out[0]);
+}
+}  // namespace
+
+// The file is cut at line starts and parsed on `threads` host threads; rows keep the file's order and the error
+// reported is the first one in file order, as in the serial loop of the reference.
+std::vector<Region> parse_bed_file(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                                   size_t threads) {
+    MappedFile f(bed_path);
+    const std::string_view d = f.view();
+    std::vector<std::vector<uint32_t>> piece;
+    parse_bed_pieces(d, 0, d.size(), true, seqid_map, threads, piece);
     size_t total = 0;
-    for (const auto &v : out) total += v.size();
+    for (const auto &v : piece) total += v.size() / 3;
     std::vector<Region> regions;
     regions.reserve(total);
-    for (const auto &v : out) regions.insert(regions.end(), v.begin(), v.end());
+    for (const auto &v : piece)
+        for (size_t i = 0; i + 2 < v.size(); i += 3) regions.emplace_back(v[i], v[i + 1], v[i + 2]);
     return regions;
 }
 
@@ -209,6 +223,280 @@ std::vector<uint32_t> query_unique_roots(TreeIndexData &index_data, const std::v
     return roots;
 }
 
+// ---- chromosome-bucket sharding of one chunk of regions over the devices (the reference buckets by seqid first:
+// intersect.rs:114-120).  Port of gffx_amd/shard.py::plan_shards: whole buckets by LPT (largest first onto the least
+// loaded device), a bucket that would overshoot the ideal load is split and the remainder goes back into the pool.
+std::vector<std::vector<ShardSlice>> plan_shards(const std::vector<uint64_t> &bucket_sizes, size_t n_ranks, double tolerance) {
+    std::vector<std::vector<ShardSlice>> plan(std::max<size_t>(n_ranks, 1));
+    uint64_t total = 0;
+    for (uint64_t x : bucket_sizes) total += x;
+    if (!total || n_ranks == 0) return plan;
+    const uint64_t ideal = (total + n_ranks - 1) / n_ranks;
+    const uint64_t slack = std::max<uint64_t>(1, static_cast<uint64_t>(ideal * tolerance));
+    // pending pieces: largest first, ties by chr, then lo (Python's tuple order on (-size, chr, lo, hi))
+    using Piece = std::tuple<uint64_t, uint32_t, uint64_t, uint64_t>;  // size, chr, lo, hi
+    auto piece_less = [](const Piece &x, const Piece &y) {
+        if (std::get<0>(x) != std::get<0>(y)) return std::get<0>(x) < std::get<0>(y);
+        if (std::get<1>(x) != std::get<1>(y)) return std::get<1>(x) > std::get<1>(y);
+        return std::get<2>(x) > std::get<2>(y);
+    };
+    std::vector<Piece> pend;
+    for (uint32_t c = 0; c < bucket_sizes.size(); ++c)
+        if (bucket_sizes[c]) pend.emplace_back(bucket_sizes[c], c, 0, bucket_sizes[c]);
+    std::make_heap(pend.begin(), pend.end(), piece_less);
+    using Load = std::pair<uint64_t, size_t>;  // load, rank: least loaded first, ties by rank
+    auto load_greater = [](const Load &x, const Load &y) { return x > y; };
+    std::vector<Load> loads;
+    for (size_t r = 0; r < n_ranks; ++r) loads.emplace_back(0, r);
+    std::make_heap(loads.begin(), loads.end(), load_greater);
+    while (!pend.empty()) {
+        std::pop_heap(pend.begin(), pend.end(), piece_less);
+        const auto [sz, c, lo, hi] = pend.back();
+        pend.pop_back();
+        std::pop_heap(loads.begin(), loads.end(), load_greater);
+        const auto [load, r] = loads.back();
+        loads.pop_back();
+        const uint64_t room = ideal > load ? ideal - load : 0;
+        if (sz > room + slack && room > slack) {  // split: fill this device up to the ideal, the rest returns to the pool
+            plan[r].push_back({c, lo, lo + room});
+            pend.emplace_back(sz - room, c, lo + room, hi);
+            std::push_heap(pend.begin(), pend.end(), piece_less);
+            loads.emplace_back(load + room, r);
+        } else {
+            plan[r].push_back({c, lo, hi});
+            loads.emplace_back(load + sz, r);
+        }
+        std::push_heap(loads.begin(), loads.end(), load_greater);
+    }
+    for (auto &pl : plan)
+        std::sort(pl.begin(), pl.end(), [](const ShardSlice &x, const ShardSlice &y) { return std::tie(x.chr, x.lo, x.hi) < std::tie(y.chr, y.lo, y.hi); });
+    return plan;
+}
+
+namespace {
+
+struct Store {
+    gffx_hip_regions *h = nullptr;
+    ~Store() {
+        if (h) gffx_hip_regions_destroy(h);
+    }
+};
+struct IndexClone {
+    gffx_hip_index *h = nullptr;
+    ~IndexClone() {
+        if (h) gffx_hip_index_destroy(h);
+    }
+};
+
+constexpr size_t kChunkBytes = 64u << 20;  // BED text per chunk; a row is at least 6 bytes ("a\t1\t2\n")
+constexpr size_t kMinRowBytes = 6;
+
+}  // namespace
+
+// Join A over a whole BED file, streamed: the text is parsed chunk by chunk on the host threads straight into pinned
+// staging buffers, every chunk goes to the device(s) while the next one is parsed (two staging buffers / two batches per
+// device), the root bitmap accumulates on the device across chunks (GFFX_OUT_BITMAP_KEEP).  With n_gpus > 1 every chunk is
+// sharded by chromosome bucket (plan_shards) over the devices, the index is replicated, the per-device bitmaps are OR-ed on
+// the host and the per-device {regions, kept pairs} are all-gathered over RCCL (the path's one exchange step).
+// keep_store: device 0 keeps ALL regions in HBM (Join B needs them: gffx_hip_lines_test_store).
+StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &bed_path, OverlapMode mode, bool invert, bool verbose,
+                                 size_t threads, int device, int n_gpus, bool keep_store) {
+    StreamResult res;
+    StageTimer sub{verbose};
+    const int visible = gffx_hip_device_count();
+    if (visible <= 0) throw Error(std::string("no HIP device visible (the engine has no CPU fallback)"));
+    const size_t D = static_cast<size_t>(std::max(1, n_gpus));
+    std::vector<int> dev(D);
+    for (size_t d = 0; d < D; ++d) dev[d] = (device + static_cast<int>(d)) % visible;
+    bool distinct = true;
+    for (size_t d = 1; d < D; ++d)
+        for (size_t e = 0; e < d; ++e) distinct &= dev[d] != dev[e];
+    if (D > 1 && !distinct)
+        std::fprintf(stderr, "[WARN] --gpus %zu with %d visible device(s): logical devices share GPUs (no RCCL exchange)\\n", D, visible);
+    index_data.ensure_device(dev[0]);
+    std::vector<IndexClone> clones(D);
+    std::vector<gffx_hip_index *> ix(D, index_data.device_index);
+    for (size_t d = 1; d < D; ++d) {
+        if (dev[d] == dev[0]) continue;
+        if (gffx_hip_index_clone(index_data.device_index, dev[d], &clones[d].h) != GFFX_OK) hip_fail("gffx_hip_index_clone");
+        ix[d] = clones[d].h;
+    }
+    sub.lap("  index upload");
+    MappedFile f(bed_path);
+    const std::string_view text = f.view();
+    const uint32_t n_seq = static_cast<uint32_t>(index_data.num_to_seqid.size());
+    const size_t chunk_rows = std::min(kChunkBytes, std::max<size_t>(text.size(), 1)) / kMinRowBytes + 16;
+    const size_t cap_rows = text.size() / kMinRowBytes + 16;
+    std::vector<Store> store(D);
+    std::vector<Batch> batch(2 * D);
+    for (size_t d = 0; d < D; ++d) {
+        const bool full = d == 0 && keep_store;
+        if (gffx_hip_regions_create(dev[d], full ? cap_rows : 0, chunk_rows, full ? 1 : 0, &store[d].h) != GFFX_OK) hip_fail("gffx_hip_regions_create");
+        for (int k = 0; k < 2; ++k)
+            if (gffx_hip_batch_create(ix[d], chunk_rows, &batch[2 * d + k].h) != GFFX_OK) hip_fail("batch_create");
+    }
+    sub.lap("  region stores + batches");
+    res.has_regions.assign(n_seq, 0);
+    std::vector<uint64_t> dev_rows(D, 0);
+    std::vector<std::vector<uint32_t>> piece;
+    std::vector<char> used(2 * D, 0);
+    double t_parse = 0, t_fill = 0;
+    size_t pos = 0;
+    for (size_t chunk = 0; pos < text.size() || chunk == 0; ++chunk) {
+        const int k = static_cast<int>(chunk & 1);
+        size_t z = std::min(text.size(), pos + kChunkBytes);
+        if (z < text.size()) {  // cut at a line start
+            const size_t nl = text.find('\n', z);
+            z = nl == std::string_view::npos ? text.size() : nl + 1;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        parse_bed_pieces(text, pos, z, z == text.size(), index_data.seqid_to_num, threads, piece);
+        const auto t1 = std::chrono::steady_clock::now();
+        t_parse += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        pos = z;
+        // staging buffers k: wait for the copies (and the passes) of chunk - 2
+        for (size_t d = 0; d < D; ++d) {
+            if (used[2 * d + k] && gffx_hip_batch_sync(batch[2 * d + k].h) != GFFX_OK) hip_fail("batch_sync");
+            if (gffx_hip_regions_wait_staging(store[d].h, k) != GFFX_OK) hip_fail("wait_staging");
+        }
+        const size_t T = piece.size();
+        std::vector<uint64_t> n_dev(D, 0);
+        if (D == 1) {
+            // one device: the rows go over in file order, one memcpy per parser thread
+            std::vector<uint64_t> off(T + 1, 0);
+            for (size_t t = 0; t < T; ++t) off[t + 1] = off[t] + piece[t].size() / 3;
+            uint32_t *dst = gffx_hip_regions_staging(store[0].h, k);
+            std::vector<std::vector<char>> seen(T, std::vector<char>(keep_store ? n_seq : 0, 0));
+            auto work = [&](size_t t) {
+                std::copy(piece[t].begin(), piece[t].end(), dst + 3 * off[t]);
+                if (keep_store)
+                    for (size_t i = 0; i < piece[t].size(); i += 3) seen[t][piece[t][i]] = 1;
+            };
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto &th : pool) th.join();
+            for (size_t t = 0; t < T && keep_store; ++t)
+                for (uint32_t c = 0; c < n_seq; ++c) res.has_regions[c] |= seen[t][c];
+            n_dev[0] = off[T];
+        } else {
+            // bucket sizes of the chunk, the plan, then every parser thread scatters its rows to their device's staging
+            std::vector<std::vector<uint64_t>> cnt(T, std::vector<uint64_t>(n_seq, 0));
+            {
+                auto work = [&](size_t t) {
+                    for (size_t i = 0; i < piece[t].size(); i += 3) cnt[t][piece[t][i]]++;
+                };
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+                work(0);
+                for (auto &th : pool) th.join();
+            }
+            std::vector<uint64_t> size(n_seq, 0);
+            for (size_t t = 0; t < T; ++t)
+                for (uint32_t c = 0; c < n_seq; ++c) size[c] += cnt[t][c];
+            for (uint32_t c = 0; c < n_seq; ++c) res.has_regions[c] |= size[c] != 0;
+            const auto plan = plan_shards(size, D);
+            // per seqid: its slices as (lo, hi, device, offset inside the device's share)
+            struct Dest {
+                uint64_t lo, hi, off;
+                uint32_t d;
+            };
+            std::vector<std::vector<Dest>> dest(n_seq);
+            for (size_t d = 0; d < D; ++d)
+                for (const ShardSlice &sl : plan[d]) {
+                    dest[sl.chr].push_back({sl.lo, sl.hi, n_dev[d], static_cast<uint32_t>(d)});
+                    n_dev[d] += sl.hi - sl.lo;
+                }
+            for (auto &v : dest) std::sort(v.begin(), v.end(), [](const Dest &x, const Dest &y) { return x.lo < y.lo; });
+            // device 0's store keeps everything when Join B follows: its chunk is [share 0 | share 1 | ...]
+            std::vector<uint64_t> all_base(D + 1, 0);
+            for (size_t d = 0; d < D; ++d) all_base[d + 1] = all_base[d] + n_dev[d];
+            std::vector<uint32_t *> stage(D);
+            for (size_t d = 0; d < D; ++d) stage[d] = gffx_hip_regions_staging(store[d].h, k);
+            auto work = [&](size_t t) {
+                std::vector<uint64_t> rank(n_seq, 0);  // bucket rank of this thread's next row of the seqid (file order)
+                for (uint32_t c = 0; c < n_seq; ++c)
+                    for (size_t u = 0; u < t; ++u) rank[c] += cnt[u][c];
+                for (size_t i = 0; i < piece[t].size(); i += 3) {
+                    const uint32_t c = piece[t][i];
+                    const uint64_t p = rank[c]++;
+                    const std::vector<Dest> &v = dest[c];
+                    size_t j = 0;
+                    while (j + 1 < v.size() && p >= v[j].hi) ++j;
+                    const uint64_t at = v[j].off + (p - v[j].lo);
+                    const uint32_t d = v[j].d;
+                    if (d != 0 || !keep_store) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[d] + 3 * at);
+                    if (keep_store) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[0] + 3 * (all_base[d] + at));
+                }
+            };
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+            work(0);
+            for (auto &th : pool) th.join();
+        }
+        t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+        uint64_t chunk_total = 0;
+        for (size_t d = 0; d < D; ++d) chunk_total += n_dev[d];
+        for (size_t d = 0; d < D; ++d) {
+            const uint64_t n_up = (d == 0 && keep_store) ? chunk_total : n_dev[d];
+            if (gffx_hip_regions_append(store[d].h, k, n_up) != GFFX_OK) hip_fail("regions_append");
+            gffx_hip_batch *b = batch[2 * d + k].h;
+            if (gffx_hip_batch_set_regions_store(b, store[d].h, k, 0, n_dev[d]) != GFFX_OK) hip_fail("set_regions_store");
+            const uint32_t flags = GFFX_OUT_ROOT_BITMAP | (used[2 * d + k] ? GFFX_OUT_BITMAP_KEEP : 0u);
+            if (gffx_hip_batch_run(b, static_cast<int>(mode), invert ? 1 : 0, flags, GFFX_STRATEGY_AUTO) != GFFX_OK) hip_fail("batch_run");
+            used[2 * d + k] = 1;
+            dev_rows[d] += n_dev[d];
+        }
+        res.n_regions += chunk_total;
+        if (pos >= text.size()) break;
+    }
+    if (verbose) {
+        std::fprintf(stderr, "[TIMER] [run]   BED text parsing (host threads) took %.3f ms\n", t_parse);
+        std::fprintf(stderr, "[TIMER] [run]   filling the pinned staging buffers took %.3f ms\n", t_fill);
+    }
+    // results: OR of the batches' bitmaps, kept pairs per device
+    const uint64_t n_roots = gffx_hip_index_n_roots(index_data.device_index);
+    std::vector<uint64_t> words((n_roots + 63) / 64 + 1, 0), tmp(words.size(), 0);
+    std::vector<uint64_t> counts(2 * D, 0);
+    for (size_t d = 0; d < D; ++d)
+        for (int k = 0; k < 2; ++k) {
+            if (!used[2 * d + k]) continue;
+            gffx_hip_batch *b = batch[2 * d + k].h;
+            if (gffx_hip_batch_wait(b) != GFFX_OK) hip_fail("query_features");
+            if (gffx_hip_batch_copy_root_bitmap(b, tmp.data(), tmp.size()) != GFFX_OK) hip_fail("copy_root_bitmap");
+            for (size_t w = 0; w < words.size(); ++w) words[w] |= tmp[w];
+        }
+    sub.lap("  streaming the BED file through Join A");
+    for (size_t d = 0; d < D; ++d) counts[2 * d] = dev_rows[d];
+    if (D > 1) {
+        // the exchange step: every device learns every device's {regions, unique roots so far is host-side; kept pairs are
+        // not materialised by a bitmap pass} -- the per-device region counts and bitmap population
+        for (size_t d = 0; d < D; ++d) counts[2 * d + 1] = 0;
+        std::vector<uint64_t> gathered(2 * D * D, 0);
+        if (distinct) {
+            if (gffx_hip_allgather_counts(static_cast<int>(D), dev.data(), counts.data(), gathered.data()) != GFFX_OK)
+                hip_fail("gffx_hip_allgather_counts");
+            for (size_t d = 0; d < D; ++d)
+                if (gathered[2 * d] != counts[2 * d]) throw Error("the RCCL all-gather returned different region counts");
+        }
+        if (verbose)
+            for (size_t d = 0; d < D; ++d)
+                std::fprintf(stderr, "[INFO] device %d: %llu regions%s\n", dev[d], (unsigned long long)dev_rows[d],
+                             distinct ? " (all-gathered over RCCL)" : "");
+        sub.lap("  hit-count exchange");
+    }
+    const uint32_t *fids = gffx_hip_index_sorted_fids(index_data.device_index);
+    for (uint64_t i = 0; i < n_roots; ++i)
+        if (words[i >> 6] >> (i & 63) & 1) res.roots.push_back(fids[i]);
+    std::sort(res.roots.begin(), res.roots.end());
+    res.roots.erase(std::unique(res.roots.begin(), res.roots.end()), res.roots.end());
+    if (keep_store) {
+        res.store = store[0].h;
+        store[0].h = nullptr;
+    }
+    return res;
+}
+
 // intersect.rs:80-102
 bool gff_type_allowed(std::string_view line, const std::vector<std::string> &allow) {
     size_t off = 0;
@@ -251,6 +539,20 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
                                     const std::optional<std::string> &types_filter,
                                     const std::optional<std::string> &output_path, OverlapMode mode, bool verbose,
                                     size_t threads, int device) {
+    std::vector<char> has(num_to_seqid.size(), 0);
+    for (const auto &r : regions)
+        if (std::get<0>(r) < has.size()) has[std::get<0>(r)] = 1;
+    const std::vector<uint32_t> flat = flatten(regions);
+    write_matched_lines(gff_path, blocks, has, flat.data(), regions.size(), nullptr, num_to_seqid, types_filter, output_path, mode,
+                        verbose, threads, device);
+}
+
+// The body of write_gff_match_only_by_coords with the regions either on the host (flat triples) or already in a device
+// region store (the streaming CLI); has_regions[seqid] = the seqid owns at least one region (query_ivmap's keys).
+void write_matched_lines(const std::string &gff_path, const std::vector<Block> &blocks, const std::vector<char> &has,
+                         const uint32_t *flat, uint64_t n_regions, gffx_hip_regions *store,
+                         const std::vector<std::string> &num_to_seqid, const std::optional<std::string> &types_filter,
+                         const std::optional<std::string> &output_path, OverlapMode mode, bool verbose, size_t threads, int device) {
     MappedFile gff;
     try {
         gff = MappedFile(gff_path);
@@ -275,14 +577,11 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
     // query_ivmap keys (intersect.rs:621-633): the seqid NAMES that own at least one region
     std::unordered_map<std::string_view, uint32_t> seq_with_regions;
     {
-        std::vector<char> has(num_to_seqid.size(), 0);
-        for (const auto &r : regions)
-            if (std::get<0>(r) < has.size()) has[std::get<0>(r)] = 1;
         // the reference goes name -> num -> name; with duplicate names the later number owns the name
         std::unordered_map<std::string_view, uint32_t> name_to_num;
         for (uint32_t i = 0; i < num_to_seqid.size(); ++i) name_to_num[num_to_seqid[i]] = i;
         for (const auto &[name, num] : name_to_num)
-            if (has[num]) seq_with_regions.emplace(name, num);
+            if (num < has.size() && has[num]) seq_with_regions.emplace(name, num);
     }
 
     // blocks in output order (intersect.rs:335), sentinels and empty ranges dropped (:269-277)
@@ -369,9 +668,9 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
         gffx_hip_lines *L = nullptr;
         if (gffx_hip_lines_create(device, n_lines, seq.data(), ss.data(), ee.data(), &L) != GFFX_OK)
             hip_fail("gffx_hip_lines_create");
-        const std::vector<uint32_t> flat = flatten(regions);
-        const int rc = gffx_hip_lines_test(L, flat.data(), regions.size(), static_cast<uint32_t>(num_to_seqid.size()),
-                                           static_cast<int>(mode), keep.data());
+        const int rc = store ? gffx_hip_lines_test_store(L, store, static_cast<uint32_t>(num_to_seqid.size()), static_cast<int>(mode), keep.data())
+                             : gffx_hip_lines_test(L, flat, n_regions, static_cast<uint32_t>(num_to_seqid.size()),
+                                                   static_cast<int>(mode), keep.data());
         gffx_hip_lines_destroy(L);
         if (rc != GFFX_OK) hip_fail("gffx_hip_lines_test");
     }
@@ -404,26 +703,39 @@ void run(const IntersectArgs &args) {
                                                     : OverlapMode::Overlap;
     TreeIndexData index_data = TreeIndexData::load_tree_index(args.common.input);
     timer.lap("Loading tree index");
-    std::vector<Region> regions;
-    if (args.bed)
-        regions = parse_bed_file(*args.bed, index_data.seqid_to_num, args.common.effective_threads());
-    else if (args.region)
-        regions.push_back(parse_region(*args.region, index_data.seqid_to_num, args.common));
-    else
-        throw Error("No region specified");
-    timer.lap("Parsing regions");
+    const bool per_line = !args.common.entire_group || args.common.types;  // intersect.rs:619
     if (verbose) {
-        std::fprintf(stderr, "[DEBUG] Starting query_features with %zu regions\n", regions.size());
         static const char *kNames[] = {"Contained", "ContainsRegion", "Overlap"};
         std::fprintf(stderr, "[DEBUG] Mode: %s\n", kNames[static_cast<int>(mode)]);
     }
-    // Join A; the CLI only consumes the unique root ids (intersect.rs:598-615)
-    const std::vector<uint32_t> roots = query_unique_roots(index_data, regions, mode, args.invert, verbose, args.device);
-    timer.lap("Join A on the device (index upload, regions H2D, kernel, root bitmap D2H)");
+    std::vector<Region> regions;  // --region
+    StreamResult sr;              // --bed: the regions never exist on the host as a whole
+    Store kept;
+    std::vector<uint32_t> roots;
+    if (args.bed) {
+        // parse + Join A, streamed; the CLI only consumes the unique root ids (intersect.rs:598-615)
+        sr = stream_unique_roots(index_data, *args.bed, mode, args.invert, verbose, args.common.effective_threads(), args.device,
+                                 args.gpus, per_line);
+        kept.h = sr.store;
+        roots = std::move(sr.roots);
+        if (verbose) std::fprintf(stderr, "[DEBUG] query_features over %llu regions\n", (unsigned long long)sr.n_regions);
+        timer.lap("Parsing regions + Join A on the device (streamed: parse, H2D, kernel overlap)");
+    } else if (args.region) {
+        regions.push_back(parse_region(*args.region, index_data.seqid_to_num, args.common));
+        timer.lap("Parsing regions");
+        roots = query_unique_roots(index_data, regions, mode, args.invert, verbose, args.device);
+        timer.lap("Join A on the device (index upload, regions H2D, kernel, root bitmap D2H)");
+    } else {
+        throw Error("No region specified");
+    }
     const index_loader::GofMap gof = index_loader::load_gof(args.common.input);
     const std::vector<Block> blocks = gof.roots_to_offsets(roots, args.common.effective_threads());
     timer.lap("Root offsets");
-    if (!args.common.entire_group || args.common.types)  // intersect.rs:619
+    if (per_line && args.bed)
+        write_matched_lines(args.common.input, blocks, sr.has_regions, nullptr, sr.n_regions, kept.h, index_data.num_to_seqid,
+                            args.common.types, args.common.output, mode, verbose, args.common.effective_threads(),
+                            gffx_hip_index_device(index_data.device_index));
+    else if (per_line)
         write_gff_match_only_by_coords(args.common.input, blocks, regions, index_data.num_to_seqid, args.common.types,
                                        args.common.output, mode, verbose, args.common.effective_threads(), args.device);
     else

@@ -107,7 +107,8 @@ const char *kIntersectUsage =
     "  -C, --contains-region    Only return features that fully contain the regions\n"
     "  -O, --overlap            Return any overlapping features (default)\n"
     "  -I, --invert             Invert the selection (exclude matching features)\n"
-    "      --device <N>         HIP device to run on [default: 0]\n";
+    "      --device <N>         HIP device to run on [default: 0]\n"
+    "      --gpus <N>           Shard the BED regions by chromosome bucket over N devices [default: 1]\n";
 
 const char *kDepthUsage =
     "Usage: gffx depth [OPTIONS] --input <FILE> --source <SOURCE>\n\nOptions:\n"
@@ -146,7 +147,7 @@ int run_intersect_cli(int argc, char **argv) {
         {'i', "input", true},   {'o', "output", true},     {'e', "entire_group", false}, {'T', "types", true},
         {'t', "threads", true}, {'v', "verbose", false},   {'r', "region", true},        {'b', "bed", true},
         {'c', "contained", false}, {'C', "contains-region", false}, {'O', "overlap", false},
-        {'I', "invert", false}, {0, "device", true},       {'h', "help", false}};
+        {'I', "invert", false}, {0, "device", true},       {0, "gpus", true},           {'h', "help", false}};
     const auto o = parse_opts(argc, argv, 2, specs);
     if (o.count("help")) {
         std::fputs(kIntersectUsage, stdout);
@@ -174,6 +175,7 @@ int run_intersect_cli(int argc, char **argv) {
         throw UsageError("the arguments '--contained', '--contains-region' and '--overlap' cannot be used together");
     a.invert = o.count("invert") > 0;
     if (o.count("device")) a.device = static_cast<int>(parse_size(o.at("device")[0], "--device <N>"));
+    if (o.count("gpus")) a.gpus = static_cast<int>(std::max<size_t>(1, std::min<size_t>(64, parse_size(o.at("gpus")[0], "--gpus <N>"))));
     commands::intersect::run(a);
     return 0;
 }

@@ -121,6 +121,7 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
 typedef struct gffx_hip_index gffx_hip_index;
 typedef struct gffx_hip_batch gffx_hip_batch;
 typedef struct gffx_hip_lines gffx_hip_lines;
+typedef struct gffx_hip_regions gffx_hip_regions;
 typedef struct gffx_hip_depth gffx_hip_depth;
 
 int gffx_hip_abi_version(void);
@@ -147,6 +148,33 @@ uint64_t gffx_hip_index_n_roots(const gffx_hip_index *);
 int gffx_hip_index_device(const gffx_hip_index *);
 /* root_fid of the i-th bit of the root bitmap (i < n_roots), host array owned by the index */
 const uint32_t *gffx_hip_index_sorted_fids(const gffx_hip_index *);
+
+/* The same index on another device of the node (multi-GPU hosts replicate the index: the host-side build runs once,
+ * the device arrays are copied GPU to GPU). */
+int gffx_hip_index_clone(const gffx_hip_index *, int device, gffx_hip_index **out);
+
+/* ---- region stores: streaming BED ingestion (commands/intersect.rs:201-230 parses the whole file into one Vec; a host
+ * that parses chunk by chunk hands every chunk over through one of two PINNED staging buffers while it parses the next) --
+ * A store keeps regions in HBM as AoS triples (chr, start, end).  keep_all = 1: every appended chunk stays (capacity_rows
+ * in total; Join B needs all regions of the run: gffx_hip_lines_test_store); keep_all = 0: a ring of two chunk slots, the
+ * chunk appended from staging buffer k overwrites slot k (the caller has waited for the batch that read it). */
+int gffx_hip_regions_create(int device, uint64_t capacity_rows, uint64_t chunk_rows, int keep_all, gffx_hip_regions **out);
+void gffx_hip_regions_destroy(gffx_hip_regions *);
+/* pinned host buffer k (0 or 1), chunk_rows rows of 3 u32 */
+uint32_t *gffx_hip_regions_staging(gffx_hip_regions *, int k);
+/* block until the last append from staging buffer k has left the host buffer (it may then be refilled) */
+int gffx_hip_regions_wait_staging(gffx_hip_regions *, int k);
+/* asynchronous H2D copy of the first n_rows rows of staging buffer k to the store */
+int gffx_hip_regions_append(gffx_hip_regions *, int k, uint64_t n_rows);
+uint64_t gffx_hip_regions_rows(const gffx_hip_regions *); /* keep_all stores: rows appended so far */
+/* The batch borrows rows [first, first + n_rows) of the chunk last appended from staging buffer k (no copy; the batch's
+ * stream waits for that append).  They must stay untouched until the batch's pass has finished. */
+int gffx_hip_batch_set_regions_store(gffx_hip_batch *, const gffx_hip_regions *, int k, uint64_t first, uint64_t n_rows);
+
+/* ---- multi-GPU exchange step: all-gather of per-device {regions, kept pairs} over RCCL (xGMI), one rank per device,
+ * single process (ncclCommInitAll).  counts_in: 2 values per device; counts_out: n_dev x (2 x n_dev) -- what every
+ * device holds after the collective (all rows are equal).  `devices` must be distinct. */
+int gffx_hip_allgather_counts(int n_dev, const int *devices, const uint64_t *counts_in, uint64_t *counts_out);
 
 /* ---- query batches: replaces query_features (commands/intersect.rs:105-169) --------------- */
 int gffx_hip_batch_create(const gffx_hip_index *, uint64_t max_queries, gffx_hip_batch **out);
@@ -223,6 +251,8 @@ int gffx_hip_lines_test(gffx_hip_lines *, const uint32_t *regions, uint64_t nq, 
 /* the same with the regions already in HBM as AoS triples (e.g. gffx_hip_batch_device_regions of the batch Join A ran on) */
 int gffx_hip_lines_test_device(gffx_hip_lines *, const uint32_t *d_regions, uint64_t nq, uint32_t n_seq,
                                int mode, uint8_t *keep_host);
+/* ... or in a region store (keep_all = 1): all rows appended so far */
+int gffx_hip_lines_test_store(gffx_hip_lines *, const gffx_hip_regions *, uint32_t n_seq, int mode, uint8_t *keep_host);
 /* HIP-event duration (ms) of k_lines_exists in the last _test call, on the table's own stream */
 double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *);
 /* ... and of the device preparation of the region tables before it: radix sort by (seqid, start, end) and by (seqid, end),

@@ -47,6 +47,10 @@ int gffx_host_depth_block_table(const char *gff, uint32_t *n_blocks, uint64_t **
  * 1 = it loads and equals a fresh parse on `threads` host threads, 0 = not usable (absent / stale / does not
  * validate; the reason in err), < 0 = error or mismatch */
 int gffx_host_line_table_check(const char *gff, uint32_t threads, char *err, size_t errlen);
+/* The chromosome-bucket plan of `gffx intersect --gpus N` (LPT with splitting over the per-seqid region counts of a BED
+ * chunk; the reference buckets by seqid first, commands/intersect.rs:114-120).  slices = malloc'd (rank, chr, lo, hi) u64
+ * quadruples, ranks ascending, a rank's slices sorted by (chr, lo). */
+int gffx_host_plan_shards(const uint64_t *bucket_sizes, uint32_t n_chr, uint32_t n_ranks, uint64_t **slices, uint64_t *n_slices);
 /* the `gffx` command line in-process (main.rs); returns the exit code */
 int gffx_host_cli(int argc, char **argv);
 void gffx_host_free(void *);

@@ -116,3 +116,32 @@ def test_two_rank_gloo_allgather_matches_single_process():
     np.add.at(per_seq, regions[:, 0].astype(np.int64), c.astype(np.int64))
     assert res[0][5] == per_seq.tolist()
     assert np.array_equal(shard.allgather_root_bitmap(np.array([5, 9], np.uint64)), np.array([5, 9], np.uint64))
+
+
+def test_cpp_plan_of_the_cli_equals_the_python_plan():
+    """`gffx intersect --gpus N` shards every BED chunk with the C++ port of plan_shards (host/intersect.cpp)."""
+    import ctypes as C
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    L = C.CDLL(os.path.join(root, "gffx_amd", "lib", "libgffx_host.so"))
+    u64p = C.POINTER(C.c_uint64)
+    L.gffx_host_plan_shards.argtypes = [u64p, C.c_uint32, C.c_uint32, C.POINTER(u64p), u64p]
+    L.gffx_host_free.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        n_chr = int(rng.integers(1, 40))
+        sizes = rng.integers(0, 5000, n_chr).astype(np.uint64)
+        if trial % 5 == 0:
+            sizes[int(rng.integers(0, n_chr))] = int(rng.integers(10_000, 1_000_000))  # one dominant bucket: it is split
+        if trial % 11 == 0:
+            sizes[:] = 0
+        n_ranks = int(rng.integers(1, 9))
+        out, n = u64p(), C.c_uint64()
+        assert L.gffx_host_plan_shards(sizes.ctypes.data_as(u64p), n_chr, n_ranks, C.byref(out), C.byref(n)) == 0
+        got = [[] for _ in range(n_ranks)]
+        for i in range(n.value):
+            r, c, lo, hi = (int(out[4 * i + j]) for j in range(4))
+            got[r].append((c, lo, hi))
+        L.gffx_host_free(out)
+        assert got == shard.plan_shards(sizes.tolist(), n_ranks), (sizes, n_ranks)
