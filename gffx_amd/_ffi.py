@@ -34,6 +34,7 @@ SIGNATURES = {
     "gffx_hip_regions_staging": (vp, [vp, C.c_int]),
     "gffx_hip_regions_wait_staging": (C.c_int, [vp, C.c_int]),
     "gffx_hip_regions_append": (C.c_int, [vp, C.c_int, C.c_uint64]),
+    "gffx_hip_regions_append_parts": (C.c_int, [vp, C.c_int, C.c_uint32, u64p, u64p]),
     "gffx_hip_regions_rows": (C.c_uint64, [vp]),
     "gffx_hip_batch_set_regions_store": (C.c_int, [vp, vp, C.c_int, C.c_uint64, C.c_uint64]),
     "gffx_hip_allgather_counts": (C.c_int, [C.c_int, C.POINTER(C.c_int), u64p, u64p]),

@@ -858,12 +858,27 @@ extern "C" int gffx_hip_regions_wait_staging(gffx_hip_regions *R, int k) {
 }
 
 extern "C" int gffx_hip_regions_append(gffx_hip_regions *R, int k, uint64_t n_rows) {
-    if (!R || (k != 0 && k != 1)) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: bad argument");
+    const uint64_t zero = 0;
+    return gffx_hip_regions_append_parts(R, k, 1, &zero, &n_rows);
+}
+
+extern "C" int gffx_hip_regions_append_parts(gffx_hip_regions *R, int k, uint32_t n_parts, const uint64_t *stage_first, const uint64_t *part_rows) {
+    if (!R || (k != 0 && k != 1) || (n_parts && (!stage_first || !part_rows))) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: bad argument");
+    uint64_t n_rows = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        if (stage_first[p] + part_rows[p] > R->chunk_rows) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: a piece lies outside the staging buffer");
+        n_rows += part_rows[p];
+    }
     if (n_rows > R->chunk_rows) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: %llu rows exceed the chunk size %llu", (unsigned long long)n_rows, (unsigned long long)R->chunk_rows);
     const uint64_t first = R->keep_all ? R->rows : (uint64_t)k * R->chunk_rows;
     if (first + n_rows > R->cap_rows) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: the store is full (%llu rows)", (unsigned long long)R->cap_rows);
     GFFX_HIP_TRY(hipSetDevice(R->device));
-    if (n_rows) GFFX_HIP_TRY(hipMemcpyAsync(R->d + 3 * first, R->h_stage[k], n_rows * 12, hipMemcpyHostToDevice, R->stream));
+    uint64_t at = first;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        if (part_rows[p])
+            GFFX_HIP_TRY(hipMemcpyAsync(R->d + 3 * at, R->h_stage[k] + 3 * stage_first[p], part_rows[p] * 12, hipMemcpyHostToDevice, R->stream));
+        at += part_rows[p];
+    }
     GFFX_HIP_TRY(hipEventRecord(R->copied[k], R->stream));
     R->pending[k] = true;
     R->last_first[k] = first;

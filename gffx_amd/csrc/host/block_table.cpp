@@ -10,6 +10,8 @@
 #include <exception>
 #include <thread>
 
+#include <sys/stat.h>
+
 #include "gffx.hpp"
 
 namespace gffx {
@@ -288,7 +290,7 @@ BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view g
 //      id_pool | chrom_pool        (little-endian, every section padded to 8 bytes)
 namespace {
 constexpr char kMagic[8] = {'G', 'F', 'F', 'X', 'L', 'S', 'O', 'A'};
-constexpr uint32_t kVersion = 1;
+constexpr uint32_t kVersion = 2;  // 2: the header binds the image to the .gof CONTENT and the GFF's mtime, not to sizes
 
 template <class T>
 void put_section(std::string &out, const T *p, size_t n) {
@@ -296,6 +298,31 @@ void put_section(std::string &out, const T *p, size_t n) {
     while (out.size() % 8) out.push_back('\0');
 }
 }  // namespace
+
+// What an image is valid for: the .gof records (FNV-1a over every field) and the GFF's size and modification time.  A
+// same-length edit of the GFF, a re-index by the reference's own `gffx index` (it rewrites .gof) or a copied file all
+// change it; the reader then parses the GFF, as the reference does on every run (depth.rs:131-152, coverage.rs:296-337).
+uint64_t line_table_key(const std::string &gff_path, const index_loader::GofMap &gof) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) {
+        for (int b = 0; b < 8; ++b) {
+            h ^= (v >> (8 * b)) & 255u;
+            h *= 1099511628211ull;
+        }
+    };
+    for (const auto &g : gof.entries) {
+        mix(static_cast<uint64_t>(g.feature_id) | (static_cast<uint64_t>(g.seqid_num) << 32));
+        mix(g.start_offset);
+        mix(g.end_offset);
+    }
+    struct stat st;
+    if (::stat(gff_path.c_str(), &st) == 0) {
+        mix(static_cast<uint64_t>(st.st_size));
+        mix(static_cast<uint64_t>(st.st_mtim.tv_sec));
+        mix(static_cast<uint64_t>(st.st_mtim.tv_nsec));
+    }
+    return h;
+}
 
 void write_block_table(const std::string &path, const BlockTable &t, uint64_t gff_bytes, uint64_t gof_bytes) {
     std::string out(kMagic, 8);
@@ -345,7 +372,7 @@ bool load_block_table(const std::string &path, uint64_t gff_bytes, uint64_t gof_
     uint32_t ver;
     std::memcpy(&ver, p + 8, 4);
     if (ver != kVersion) return why = "version " + std::to_string(ver), false;
-    if (rd64(16) != gff_bytes || rd64(24) != gof_bytes) return why = "stale (the GFF or its .gof changed size)", false;
+    if (rd64(16) != gff_bytes || rd64(24) != gof_bytes) return why = "stale (the GFF or its .gof changed since the image was written)", false;
     const uint64_t nb = rd64(32), nl = rd64(40), ng = rd64(48), ni = rd64(56), nf = rd64(64), nc = rd64(72), ib = rd64(80),
                    cb = rd64(88);
     if (nb >= 0xFFFFFFFFull || ng >= 0xFFFFFFFFull || ni > 0xFFFFFFFFull || nf > 0xFFFFFFFFull || nl > (1ull << 40) ||
@@ -395,7 +422,7 @@ bool load_block_table(const std::string &path, uint64_t gff_bytes, uint64_t gof_
 
 BlockTable load_or_build_block_table(const std::string &gff_path, const index_loader::GofMap &gof, std::string_view gff,
                                      size_t threads, bool verbose) {
-    const uint64_t gof_bytes = static_cast<uint64_t>(gof.entries.size()) * 24;
+    const uint64_t gof_bytes = line_table_key(gff_path, gof);  // (the header's second word: content key since version 2)
     BlockTable t;
     std::string why;
     const char *off = std::getenv("GFFX_LINE_TABLE");  // "parse" = ignore the image

@@ -190,7 +190,7 @@ extern "C" int gffx_host_line_table_check(const char *gff, uint32_t threads, cha
         const MappedFile text(gff);
         commands::depth::BlockTable img;
         std::string why;
-        if (!commands::depth::load_block_table(append_suffix(gff, ".lsoa"), text.size(), gof.entries.size() * 24ull, img, why)) {
+        if (!commands::depth::load_block_table(append_suffix(gff, ".lsoa"), text.size(), commands::depth::line_table_key(gff, gof), img, why)) {
             if (err && errlen) std::snprintf(err, errlen, "%s", why.c_str());
             return;
         }

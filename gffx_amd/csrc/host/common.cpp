@@ -57,7 +57,18 @@ struct OutFile {
     void write(const uint8_t *p, size_t n) {
         if (n && std::fwrite(p, 1, n, f) != n) throw Error("write failed");
     }
-    ~OutFile() {
+    // The reference propagates `writer.flush()?` (intersect.rs:405,425; common.rs:270): with a large stdio buffer most of
+    // the output is written here, so ENOSPC / EIO / a closed pipe must fail the run, not truncate the file silently.
+    void close() {
+        FILE *g = f;
+        f = nullptr;
+        if (!g) return;
+        const bool bad = std::fflush(g) != 0 || std::ferror(g);
+        if (owned && std::fclose(g) != 0) throw Error("write failed (closing the output)");
+        if (bad) throw Error("write failed (flushing the output)");
+    }
+    ~OutFile() {  // best effort only: the writers call close()
+        if (!f) return;
         if (owned)
             std::fclose(f);
         else
@@ -101,6 +112,7 @@ void write_gff_output(const std::string &gff_path, const std::vector<Block> &blo
         if (so >= eo || eo > file_len) continue;
         out.write(gff.data() + so, static_cast<size_t>(eo - so));
     }
+    out.close();
     if (verbose) std::fprintf(stderr, "Wrote %zu merged GFF block(s) with vectored I/O\n", merged.size());
 }
 

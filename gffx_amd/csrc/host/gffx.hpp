@@ -250,8 +250,10 @@ struct BlockTable {  // the device line table (include/gffx_hip.h "gffx depth") 
 // depth.rs:131-152 on every root block (the LAST .gof record of a root_fid): the lines that carry an ID
 BlockTable build_block_table(const index_loader::GofMap &gof, std::string_view gff, size_t threads = 1);
 // the same table as a flat image `<gff>.lsoa` (written by `gffx index`; block_table.cpp has the layout)
-void write_block_table(const std::string &path, const BlockTable &t, uint64_t gff_bytes, uint64_t gof_bytes);
-bool load_block_table(const std::string &path, uint64_t gff_bytes, uint64_t gof_bytes, BlockTable &t, std::string &why);
+// (gof_key = line_table_key(): FNV-1a of the .gof records + the GFF's size and mtime)
+uint64_t line_table_key(const std::string &gff_path, const index_loader::GofMap &gof);
+void write_block_table(const std::string &path, const BlockTable &t, uint64_t gff_bytes, uint64_t gof_key);
+bool load_block_table(const std::string &path, uint64_t gff_bytes, uint64_t gof_key, BlockTable &t, std::string &why);
 BlockTable load_or_build_block_table(const std::string &gff_path, const index_loader::GofMap &gof, std::string_view gff,
                                      size_t threads, bool verbose);
 void run(const DepthArgs &args);  // depth.rs:548-635

@@ -194,42 +194,11 @@ TreeIndexData::~TreeIndexData() {
     if (device_index) gffx_hip_index_destroy(device_index);
 }
 
-TreeIndexData TreeIndexData::load_tree_index(const std::string &gff) {
-    TreeIndexData t;
-    auto sqs = index_loader::load_sqs(gff);
-    t.num_to_seqid = std::move(sqs.first);
-    t.seqid_to_num = std::move(sqs.second);
-    // tree_index.rs:21-34: the reference's route is .rit/.rix.  Taken when both files are there and every
-    // image parses in the (unpinned) bincode layout; otherwise the .gof route below, which rebuilds the
-    // same multiset of intervals (index_builder/core.rs:170-186).  GFFX_TREE_INDEX=gof|rit forces one.
-    {
-        const char *force = std::getenv("GFFX_TREE_INDEX");
-        const bool want_rit = !force || std::string(force) != "gof";
-        const bool must_rit = force && std::string(force) == "rit";
-        if (want_rit) {
-            try {
-                auto trees = index_loader::load_region_index(append_suffix(gff, ".rit"), append_suffix(gff, ".rix"));
-                t.chr_offsets.assign(1, 0);
-                for (const auto &tr : trees) {  // tree i <-> seqid_num i (tree_index.rs:65-79)
-                    for (const auto &iv : tr) {
-                        t.start.push_back(iv.start);
-                        t.end.push_back(iv.end);
-                        t.root_fid.push_back(iv.root_fid);
-                    }
-                    t.chr_offsets.push_back(static_cast<uint32_t>(t.start.size()));
-                }
-                // seqids without a tree image (none in a builder-written index) get empty lists
-                while (t.chr_offsets.size() < t.num_to_seqid.size() + 1) t.chr_offsets.push_back(t.chr_offsets.back());
-                return t;
-            } catch (const Error &) {
-                if (must_rit) throw;
-                t.chr_offsets.clear();
-                t.start.clear();
-                t.end.clear();
-                t.root_fid.clear();
-            }
-        }
-    }
+namespace {
+
+// Interval lists from .gof + the root lines of the GFF: one (start, end, fid) per .gof record, parsed from the root's own
+// line with the builder's coordinate rules (index_builder/core.rs:102-109) -- exactly the trees' inputs (:170-186).
+void intervals_from_gof(const std::string &gff, TreeIndexData &t) {
     const index_loader::GofMap gof = index_loader::load_gof(gff);
     MappedFile text(gff);
     const std::string_view d = text.view();
@@ -274,6 +243,99 @@ TreeIndexData TreeIndexData::load_tree_index(const std::string &gff) {
             t.root_fid.push_back(f);
         }
         t.chr_offsets.push_back(static_cast<uint32_t>(t.start.size()));
+    }
+}
+
+
+// the per-seqid multisets of (start, end, root_fid) of two interval lists are equal
+bool same_intervals(const TreeIndexData &a, const TreeIndexData &b, std::string &why) {
+    if (a.chr_offsets.size() != b.chr_offsets.size()) {
+        why = "different number of seqids";
+        return false;
+    }
+    for (size_t c = 0; c + 1 < a.chr_offsets.size(); ++c) {
+        const size_t na = a.chr_offsets[c + 1] - a.chr_offsets[c], nb = b.chr_offsets[c + 1] - b.chr_offsets[c];
+        if (na != nb) {
+            why = "seqid " + std::to_string(c) + ": " + std::to_string(na) + " intervals in .rit, " + std::to_string(nb) + " root records in .gof";
+            return false;
+        }
+        std::vector<std::tuple<uint32_t, uint32_t, uint32_t>> x, y;
+        for (size_t i = a.chr_offsets[c]; i < a.chr_offsets[c + 1]; ++i) x.emplace_back(a.start[i], a.end[i], a.root_fid[i]);
+        for (size_t i = b.chr_offsets[c]; i < b.chr_offsets[c + 1]; ++i) y.emplace_back(b.start[i], b.end[i], b.root_fid[i]);
+        std::sort(x.begin(), x.end());
+        std::sort(y.begin(), y.end());
+        if (x != y) {
+            why = "seqid " + std::to_string(c) + ": the intervals differ from the root lines' columns 4/5 and feature ids";
+            return false;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+// tree_index.rs:21-34.  The reference's route is .rit/.rix; the byte layout of those images is a hypothesis here (SURVEY
+// App. A.2: no file written by the real `gffx index` has ever been read), so an image is never trusted on its own: the
+// interval lists are ALWAYS derived from .gof + the root lines of the GFF (1:1 with the builder's tree inputs), and a .rit
+// that parses is used only when it holds exactly the same intervals per seqid.  A .rit that is unreadable or disagrees is
+// reported with a [WARN] and ignored; absent images are not an event.  GFFX_TREE_INDEX=gof skips the images, =rit trusts
+// them as the reference does (every error of tree_index.rs:40-79 is then fatal).
+TreeIndexData TreeIndexData::load_tree_index(const std::string &gff) {
+    TreeIndexData t;
+    auto sqs = index_loader::load_sqs(gff);
+    t.num_to_seqid = std::move(sqs.first);
+    t.seqid_to_num = std::move(sqs.second);
+    const char *force = std::getenv("GFFX_TREE_INDEX");
+    const bool skip_rit = force && std::string(force) == "gof";
+    const bool must_rit = force && std::string(force) == "rit";
+    const std::string rit = append_suffix(gff, ".rit"), rix = append_suffix(gff, ".rix");
+    auto exists = [](const std::string &p) {
+        FILE *f = std::fopen(p.c_str(), "rb");
+        if (f) std::fclose(f);
+        return f != nullptr;
+    };
+    TreeIndexData from_rit;
+    bool have_rit = false;
+    if (!skip_rit && (must_rit || (exists(rit) && exists(rix)))) {
+        try {
+            auto trees = index_loader::load_region_index(rit, rix);
+            from_rit.chr_offsets.assign(1, 0);
+            for (const auto &tr : trees) {  // tree i <-> seqid_num i (tree_index.rs:65-79)
+                for (const auto &iv : tr) {
+                    from_rit.start.push_back(iv.start);
+                    from_rit.end.push_back(iv.end);
+                    from_rit.root_fid.push_back(iv.root_fid);
+                }
+                from_rit.chr_offsets.push_back(static_cast<uint32_t>(from_rit.start.size()));
+            }
+            // seqids without a tree image (none in a builder-written index) get empty lists
+            while (from_rit.chr_offsets.size() < t.num_to_seqid.size() + 1) from_rit.chr_offsets.push_back(from_rit.chr_offsets.back());
+            have_rit = true;
+        } catch (const Error &e) {
+            if (must_rit) throw;
+            std::fprintf(stderr, "[WARN] %s unusable (%s): the interval lists come from %s and the root lines instead\n", rit.c_str(),
+                         e.what(), append_suffix(gff, ".gof").c_str());
+        }
+    }
+    if (have_rit && must_rit) {
+        t.chr_offsets = std::move(from_rit.chr_offsets);
+        t.start = std::move(from_rit.start);
+        t.end = std::move(from_rit.end);
+        t.root_fid = std::move(from_rit.root_fid);
+        return t;
+    }
+    intervals_from_gof(gff, t);
+    if (have_rit) {
+        std::string why;
+        if (same_intervals(from_rit, t, why)) {  // the images are what the builder would have written: keep their order
+            t.chr_offsets = std::move(from_rit.chr_offsets);
+            t.start = std::move(from_rit.start);
+            t.end = std::move(from_rit.end);
+            t.root_fid = std::move(from_rit.root_fid);
+        } else {
+            std::fprintf(stderr, "[WARN] %s disagrees with %s (%s): ignoring the tree images\n", rit.c_str(),
+                         append_suffix(gff, ".gof").c_str(), why.c_str());
+        }
     }
     return t;
 }

@@ -7,6 +7,10 @@
 #include <chrono>
 #include <atomic>
 #include <cstdio>
+#include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 #include "gffx.hpp"
@@ -49,7 +53,18 @@ struct OutFile {
             f = stdout;
         }
     }
-    ~OutFile() {
+    // The reference propagates `writer.flush()?` (intersect.rs:405,425; common.rs:270): with a large stdio buffer most of
+    // the output is written here, so ENOSPC / EIO / a closed pipe must fail the run, not truncate the file silently.
+    void close() {
+        FILE *g = f;
+        f = nullptr;
+        if (!g) return;
+        const bool bad = std::fflush(g) != 0 || std::ferror(g);
+        if (owned && std::fclose(g) != 0) throw Error("write failed (closing the output)");
+        if (bad) throw Error("write failed (flushing the output)");
+    }
+    ~OutFile() {  // best effort only: the writers call close()
+        if (!f) return;
         if (owned)
             std::fclose(f);
         else
@@ -95,49 +110,110 @@ std::vector<size_t> line_chunks(std::string_view d, size_t parts) {
 }
 
 namespace {
+
+// seqid name -> number without a std::string per row: open addressing over FNV-1a of the field bytes (a BED file in random
+// order changes seqid on nearly every row; the reference pays a HashMap<String> probe there too, intersect.rs:219)
+class SeqidTable {
+  public:
+    explicit SeqidTable(const std::unordered_map<std::string, uint32_t> &m) {
+        size_t cap = 16;
+        while (cap < 4 * m.size() + 4) cap <<= 1;
+        slot_.assign(cap, Slot{nullptr, 0, 0, 0});
+        mask_ = cap - 1;
+        for (const auto &kv : m) {
+            const uint64_t h = hash(kv.first.data(), kv.first.size());
+            size_t i = h & mask_;
+            while (slot_[i].p) i = (i + 1) & mask_;
+            slot_[i] = Slot{kv.first.data(), static_cast<uint32_t>(kv.first.size()), kv.second, h};
+        }
+    }
+    static uint64_t hash(const char *p, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) h = (h ^ static_cast<unsigned char>(p[i])) * 1099511628211ull;
+        return h;
+    }
+    bool find(const char *p, size_t n, uint32_t &id) const {
+        const uint64_t h = hash(p, n);
+        for (size_t i = h & mask_; slot_[i].p; i = (i + 1) & mask_)
+            if (slot_[i].h == h && slot_[i].n == n && std::memcmp(slot_[i].p, p, n) == 0) {
+                id = slot_[i].id;
+                return true;
+            }
+        return false;
+    }
+
+  private:
+    struct Slot {
+        const char *p;
+        uint32_t n, id;
+        uint64_t h;
+    };
+    std::vector<Slot> slot_;
+    size_t mask_ = 0;
+};
+
+// lexical_core::parse::<u32>: optional '+', >= 1 digits, the whole field, no overflow
+inline bool field_u32(const char *p, const char *e, uint32_t &out) {
+    if (p < e && *p == '+') ++p;
+    if (p == e) return false;
+    uint64_t v = 0;
+    for (; p < e; ++p) {
+        const unsigned d = static_cast<unsigned char>(*p) - '0';
+        if (d > 9) return false;
+        v = v * 10 + d;
+        if (v > 0xFFFFFFFFull) return false;
+    }
+    out = static_cast<uint32_t>(v);
+    return true;
+}
+
 // intersect.rs:201-230 on the lines of d[a, z); z is a line start or the end of the file.  Rows as flat (chr, start, end)
-// words -- the layout the device reads.
-void parse_bed_chunk(std::string_view d, size_t a, size_t z, bool last, const std::unordered_map<std::string, uint32_t> &seqid_map,
-                     std::vector<uint32_t> &rows) {
-    std::string key;
-    const std::pair<const std::string, uint32_t> *hit = nullptr;  // the seqid of the previous row, usually this row's too
+// words -- the layout the device reads.  One pass per line: memchr for the newline, a word-wise scan for bytes >= 0x80 (only
+// then the full UTF-8 validation the reference's from_utf8 implies), the first three whitespace-separated fields.
+void parse_bed_chunk(std::string_view d, size_t a, size_t z, bool last, const SeqidTable &seqids, std::vector<uint32_t> &rows) {
+    const char *base = d.data();
     while (last ? a <= z : a < z) {
-        size_t nl = a < z ? d.find('\n', a) : std::string_view::npos;
-        if (nl == std::string_view::npos || nl >= z) nl = z;
-        const std::string_view line = d.substr(a, nl - a);
+        const char *nlp = a < z ? static_cast<const char *>(std::memchr(base + a, '\n', z - a)) : nullptr;
+        const size_t nl = nlp ? static_cast<size_t>(nlp - base) : z;
+        const char *p = base + a, *e = base + nl;
         a = nl + 1;
-        if (line.empty() || line[0] == '#') continue;
-        if (!utf8_valid(line)) throw Error("invalid utf-8 sequence in BED line");
-        std::string_view field[3];
+        if (p == e || *p == '#') continue;
+        {
+            uint64_t hi = 0;
+            const char *q = p;
+            for (; q + 8 <= e; q += 8) {
+                uint64_t w;
+                std::memcpy(&w, q, 8);
+                hi |= w;
+            }
+            for (; q < e; ++q) hi |= static_cast<unsigned char>(*q);
+            if ((hi & 0x8080808080808080ull) && !utf8_valid(std::string_view(p, static_cast<size_t>(e - p))))
+                throw Error("invalid utf-8 sequence in BED line");
+        }
+        const char *fb[3], *fe[3];
         int nf = 0;
-        size_t i = 0;
-        while (i < line.size() && nf < 3) {
-            while (i < line.size() && is_ascii_ws(static_cast<unsigned char>(line[i]))) ++i;
-            if (i >= line.size()) break;
-            size_t j = i;
-            while (j < line.size() && !is_ascii_ws(static_cast<unsigned char>(line[j]))) ++j;
-            field[nf++] = line.substr(i, j - i);
-            i = j;
+        const char *q = p;
+        while (q < e && nf < 3) {
+            while (q < e && is_ascii_ws(static_cast<unsigned char>(*q))) ++q;
+            if (q >= e) break;
+            fb[nf] = q;
+            while (q < e && !is_ascii_ws(static_cast<unsigned char>(*q))) ++q;
+            fe[nf++] = q;
         }
         if (nf < 3) continue;
-        if (!hit || hit->first != field[0]) {
-            key.assign(field[0]);
-            const auto it = seqid_map.find(key);
-            if (it == seqid_map.end()) continue;
-            hit = &*it;
-        }
-        const auto s = parse_u32_rust(field[1]);  // lexical_core::parse::<u32>
-        const auto e = parse_u32_rust(field[2]);
-        if (!s || !e) throw Error("lexical parse error: invalid BED coordinate in \"" + std::string(line) + "\"");
-        rows.push_back(hit->second);
-        rows.push_back(*s);
-        rows.push_back(*e);
+        uint32_t chr, s, en;
+        if (!seqids.find(fb[0], static_cast<size_t>(fe[0] - fb[0]), chr)) continue;
+        if (!field_u32(fb[1], fe[1], s) || !field_u32(fb[2], fe[2], en))  // lexical_core::parse::<u32>
+            throw Error("lexical parse error: invalid BED coordinate in \"" + std::string(p, static_cast<size_t>(e - p)) + "\"");
+        rows.push_back(chr);
+        rows.push_back(s);
+        rows.push_back(en);
     }
 }
 
 // The rows of d[a, z) parsed on `threads` host threads (cut at line starts); piece[t] = the rows of the t-th cut, in file
 // order.  The error reported is the first one in file order, as in the serial loop of the reference.
-void parse_bed_pieces(std::string_view d, size_t a, size_t z, bool last, const std::unordered_map<std::string, uint32_t> &seqid_map,
+void parse_bed_pieces(std::string_view d, size_t a, size_t z, bool last, const SeqidTable &seqid_map,
                       size_t threads, std::vector<std::vector<uint32_t>> &piece) {
     const std::string_view sub = d.substr(a, z - a);
     const size_t parts = sub.size() < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(threads, 64));
@@ -170,7 +246,7 @@ std::vector<Region> parse_bed_file(const std::string &bed_path, const std::unord
     MappedFile f(bed_path);
     const std::string_view d = f.view();
     std::vector<std::vector<uint32_t>> piece;
-    parse_bed_pieces(d, 0, d.size(), true, seqid_map, threads, piece);
+    parse_bed_pieces(d, 0, d.size(), true, SeqidTable(seqid_map), threads, piece);
     size_t total = 0;
     for (const auto &v : piece) total += v.size() / 3;
     std::vector<Region> regions;
@@ -303,6 +379,63 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
                                  size_t threads, int device, int n_gpus, bool keep_store) {
     StreamResult res;
     StageTimer sub{verbose};
+    MappedFile f(bed_path);
+    const std::string_view text = f.view();
+    const SeqidTable seqids(index_data.seqid_to_num);
+    // The parser runs ahead on its own thread (each chunk on `threads` workers) while this thread brings the devices up
+    // and then feeds them: a bounded queue of parsed chunks, in file order.
+    struct Parsed {
+        std::vector<std::vector<uint32_t>> piece;
+        bool last = false;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Parsed> queue;
+    std::exception_ptr parse_error;
+    bool stop = false;
+    double t_parse = 0, t_fill = 0;
+    std::thread producer([&] {
+        try {
+            size_t pos = 0;
+            for (bool first = true; pos < text.size() || first; first = false) {
+                size_t z = std::min(text.size(), pos + kChunkBytes);
+                if (z < text.size()) {  // cut at a line start
+                    const size_t nl = text.find('\n', z);
+                    z = nl == std::string_view::npos ? text.size() : nl + 1;
+                }
+                Parsed pc;
+                const auto t0 = std::chrono::steady_clock::now();
+                parse_bed_pieces(text, pos, z, z == text.size(), seqids, threads, pc.piece);
+                t_parse += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                pos = z;
+                pc.last = pos >= text.size();
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return queue.size() < 16 || stop; });  // (up to 1 GB of text ahead while the devices come up)
+                if (stop) return;
+                queue.push_back(std::move(pc));
+                cv.notify_all();
+                if (pos >= text.size()) break;
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            parse_error = std::current_exception();
+            cv.notify_all();
+        }
+    });
+    struct Joiner {  // the producer never outlives this frame, whatever throws
+        std::thread &t;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &stop;
+        ~Joiner() {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            if (t.joinable()) t.join();
+        }
+    } joiner{producer, mu, cv, stop};
     const int visible = gffx_hip_device_count();
     if (visible <= 0) throw Error(std::string("no HIP device visible (the engine has no CPU fallback)"));
     const size_t D = static_cast<size_t>(std::max(1, n_gpus));
@@ -312,7 +445,7 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
     for (size_t d = 1; d < D; ++d)
         for (size_t e = 0; e < d; ++e) distinct &= dev[d] != dev[e];
     if (D > 1 && !distinct)
-        std::fprintf(stderr, "[WARN] --gpus %zu with %d visible device(s): logical devices share GPUs (no RCCL exchange)\\n", D, visible);
+        std::fprintf(stderr, "[WARN] --gpus %zu with %d visible device(s): logical devices share GPUs (no RCCL exchange)\n", D, visible);
     index_data.ensure_device(dev[0]);
     std::vector<IndexClone> clones(D);
     std::vector<gffx_hip_index *> ix(D, index_data.device_index);
@@ -322,8 +455,6 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
         ix[d] = clones[d].h;
     }
     sub.lap("  index upload");
-    MappedFile f(bed_path);
-    const std::string_view text = f.view();
     const uint32_t n_seq = static_cast<uint32_t>(index_data.num_to_seqid.size());
     const size_t chunk_rows = std::min(kChunkBytes, std::max<size_t>(text.size(), 1)) / kMinRowBytes + 16;
     const size_t cap_rows = text.size() / kMinRowBytes + 16;
@@ -338,22 +469,20 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
     sub.lap("  region stores + batches");
     res.has_regions.assign(n_seq, 0);
     std::vector<uint64_t> dev_rows(D, 0);
-    std::vector<std::vector<uint32_t>> piece;
     std::vector<char> used(2 * D, 0);
-    double t_parse = 0, t_fill = 0;
-    size_t pos = 0;
-    for (size_t chunk = 0; pos < text.size() || chunk == 0; ++chunk) {
+    for (size_t chunk = 0;; ++chunk) {
         const int k = static_cast<int>(chunk & 1);
-        size_t z = std::min(text.size(), pos + kChunkBytes);
-        if (z < text.size()) {  // cut at a line start
-            const size_t nl = text.find('\n', z);
-            z = nl == std::string_view::npos ? text.size() : nl + 1;
+        Parsed pc;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !queue.empty() || parse_error; });
+            if (queue.empty()) std::rethrow_exception(parse_error);  // (chunks parsed before the error were still served, in order)
+            pc = std::move(queue.front());
+            queue.pop_front();
+            cv.notify_all();
         }
-        const auto t0 = std::chrono::steady_clock::now();
-        parse_bed_pieces(text, pos, z, z == text.size(), index_data.seqid_to_num, threads, piece);
+        std::vector<std::vector<uint32_t>> &piece = pc.piece;
         const auto t1 = std::chrono::steady_clock::now();
-        t_parse += std::chrono::duration<double, std::milli>(t1 - t0).count();
-        pos = z;
         // staging buffers k: wait for the copies (and the passes) of chunk - 2
         for (size_t d = 0; d < D; ++d) {
             if (used[2 * d + k] && gffx_hip_batch_sync(batch[2 * d + k].h) != GFFX_OK) hip_fail("batch_sync");
@@ -362,22 +491,28 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
         const size_t T = piece.size();
         std::vector<uint64_t> n_dev(D, 0);
         if (D == 1) {
-            // one device: the rows go over in file order, one memcpy per parser thread
+            // one device: the rows go over in file order; a few copy threads (memory-bound) take the pieces in turn
             std::vector<uint64_t> off(T + 1, 0);
             for (size_t t = 0; t < T; ++t) off[t + 1] = off[t] + piece[t].size() / 3;
             uint32_t *dst = gffx_hip_regions_staging(store[0].h, k);
-            std::vector<std::vector<char>> seen(T, std::vector<char>(keep_store ? n_seq : 0, 0));
-            auto work = [&](size_t t) {
-                std::copy(piece[t].begin(), piece[t].end(), dst + 3 * off[t]);
-                if (keep_store)
-                    for (size_t i = 0; i < piece[t].size(); i += 3) seen[t][piece[t][i]] = 1;
+            const size_t W = std::min<size_t>(T, 8);
+            std::vector<std::vector<char>> seen(W, std::vector<char>(keep_store ? n_seq : 0, 0));
+            std::atomic<size_t> next_piece{0};
+            auto work = [&](size_t w) {
+                for (;;) {
+                    const size_t t = next_piece.fetch_add(1);
+                    if (t >= T) return;
+                    std::memcpy(dst + 3 * off[t], piece[t].data(), piece[t].size() * 4);
+                    if (keep_store)
+                        for (size_t i = 0; i < piece[t].size(); i += 3) seen[w][piece[t][i]] = 1;
+                }
             };
             std::vector<std::thread> pool;
-            for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+            for (size_t w = 1; w < W; ++w) pool.emplace_back(work, w);
             work(0);
             for (auto &th : pool) th.join();
-            for (size_t t = 0; t < T && keep_store; ++t)
-                for (uint32_t c = 0; c < n_seq; ++c) res.has_regions[c] |= seen[t][c];
+            for (size_t w = 0; w < W && keep_store; ++w)
+                for (uint32_t c = 0; c < n_seq; ++c) res.has_regions[c] |= seen[w][c];
             n_dev[0] = off[T];
         } else {
             // bucket sizes of the chunk, the plan, then every parser thread scatters its rows to their device's staging
@@ -448,8 +583,9 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
             dev_rows[d] += n_dev[d];
         }
         res.n_regions += chunk_total;
-        if (pos >= text.size()) break;
+        if (pc.last) break;
     }
+    producer.join();  // (it pushed its last chunk)
     if (verbose) {
         std::fprintf(stderr, "[TIMER] [run]   BED text parsing (host threads) took %.3f ms\n", t_parse);
         std::fprintf(stderr, "[TIMER] [run]   filling the pinned staging buffers took %.3f ms\n", t_fill);
@@ -687,6 +823,7 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
         if (std::fwrite(gff.data() + a, 1, z - a, out.f) != z - a) throw Error("write failed");
         i = j;
     }
+    out.close();
     if (verbose) std::fprintf(stderr, "[INFO] match-only by coords completed; minput blocks %zu\n", blocks.size());
 }
 

@@ -254,8 +254,10 @@ int run_index_cli(int argc, char **argv) {
         const MappedFile text(input);
         unsigned hw = std::thread::hardware_concurrency();
         const auto t = commands::depth::build_block_table(gof, text.view(), std::min(hw ? hw : 1u, 12u));
-        commands::depth::write_block_table(append_suffix(input, ".lsoa"), t, text.size(), gof.entries.size() * 24ull);
+        commands::depth::write_block_table(append_suffix(input, ".lsoa"), t, text.size(), commands::depth::line_table_key(input, gof));
         if (verbose) std::printf("Line table image: %zu lines in %zu blocks.\n", t.line_start.size(), t.block_line_off.size() - 1);
+    } else {
+        std::remove(append_suffix(input, ".lsoa").c_str());  // an image of an earlier index run would be stale
     }
     if (verbose) std::printf("Index created successfully.\n");
     return 0;

@@ -166,6 +166,9 @@ uint32_t *gffx_hip_regions_staging(gffx_hip_regions *, int k);
 int gffx_hip_regions_wait_staging(gffx_hip_regions *, int k);
 /* asynchronous H2D copy of the first n_rows rows of staging buffer k to the store */
 int gffx_hip_regions_append(gffx_hip_regions *, int k, uint64_t n_rows);
+/* the same for a chunk that sits in staging buffer k in n_parts pieces (rows stage_first[p] .. + n_rows[p]: parser threads
+ * fill disjoint parts of the buffer); the pieces land back to back in the store and count as ONE append */
+int gffx_hip_regions_append_parts(gffx_hip_regions *, int k, uint32_t n_parts, const uint64_t *stage_first, const uint64_t *n_rows);
 uint64_t gffx_hip_regions_rows(const gffx_hip_regions *); /* keep_all stores: rows appended so far */
 /* The batch borrows rows [first, first + n_rows) of the chunk last appended from staging buffer k (no copy; the batch's
  * stream waits for that append).  They must stay untouched until the batch's pass has finished. */

@@ -14,6 +14,10 @@ pub struct gffx_hip_index {
     _p: [u8; 0],
 }
 #[repr(C)]
+pub struct gffx_hip_regions {
+    _p: [u8; 0],
+}
+#[repr(C)]
 pub struct gffx_hip_batch {
     _p: [u8; 0],
 }
@@ -62,6 +66,16 @@ extern "C" {
     pub fn gffx_hip_batch_set_regions_host(b: *mut gffx_hip_batch, regions: *const u32, nq: u64) -> c_int;
     pub fn gffx_hip_batch_run(b: *mut gffx_hip_batch, mode: c_int, invert: c_int, out_flags: u32, strategy: c_int) -> c_int;
     pub fn gffx_hip_batch_wait(b: *mut gffx_hip_batch) -> c_int;
+    pub fn gffx_hip_batch_sync(b: *mut gffx_hip_batch) -> c_int;
+    // streaming BED ingestion through pinned staging buffers, several GPUs
+    pub fn gffx_hip_regions_create(device: c_int, capacity_rows: u64, chunk_rows: u64, keep_all: c_int, out: *mut *mut gffx_hip_regions) -> c_int;
+    pub fn gffx_hip_regions_destroy(r: *mut gffx_hip_regions);
+    pub fn gffx_hip_regions_staging(r: *mut gffx_hip_regions, k: c_int) -> *mut u32;
+    pub fn gffx_hip_regions_wait_staging(r: *mut gffx_hip_regions, k: c_int) -> c_int;
+    pub fn gffx_hip_regions_append(r: *mut gffx_hip_regions, k: c_int, n_rows: u64) -> c_int;
+    pub fn gffx_hip_batch_set_regions_store(b: *mut gffx_hip_batch, r: *const gffx_hip_regions, k: c_int, first: u64, n_rows: u64) -> c_int;
+    pub fn gffx_hip_index_clone(ix: *const gffx_hip_index, device: c_int, out: *mut *mut gffx_hip_index) -> c_int;
+    pub fn gffx_hip_allgather_counts(n_dev: c_int, devices: *const c_int, counts_in: *const u64, counts_out: *mut u64) -> c_int;
     pub fn gffx_hip_batch_copy_root_bitmap(b: *mut gffx_hip_batch, host: *mut u64, n_words: u64) -> c_int;
     // depth (BED source)
     pub fn gffx_hip_depth_create(

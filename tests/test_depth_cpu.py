@@ -253,6 +253,23 @@ def test_line_table_image_roundtrip_stale_and_corrupt(host, tmp_path):
     with open(gff, "ab") as f:
         f.write(b"# trailing comment\n")
     assert host.gffx_host_line_table_check(gff.encode(), 2, err, len(err)) == 0 and b"stale" in err.value
+    # a same-LENGTH edit of the GFF (one coordinate digit of a child line), and a re-index that only rewrites .gof:
+    # sizes unchanged, the content key is not
+    gff3 = str(tmp_path / "u.gff")
+    synth.write_gff3(gff3, roots, seed=9)
+    assert subprocess.run([gffx, "index", "-i", gff3]).returncode == 0
+    assert host.gffx_host_line_table_check(gff3.encode(), 2, err, len(err)) == 1
+    data = bytearray(open(gff3, "rb").read())
+    at = data.index(b"\texon\t") + 6
+    data[at] = ord("1") if data[at] != ord("1") else ord("2")
+    st = os.stat(gff3)
+    open(gff3, "wb").write(bytes(data))
+    os.utime(gff3, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000))
+    assert os.path.getsize(gff3) == st.st_size
+    assert host.gffx_host_line_table_check(gff3.encode(), 2, err, len(err)) == 0 and b"stale" in err.value
+    # ... and re-indexing with the image switched off removes the old image instead of leaving it behind
+    assert subprocess.run([gffx, "index", "-i", gff3], env=dict(os.environ, GFFX_LINE_TABLE="off")).returncode == 0
+    assert not os.path.exists(gff3 + ".lsoa")
     # opt-out at index time
     gff2 = str(tmp_path / "t.gff")
     synth.write_gff3(gff2, roots, seed=9)

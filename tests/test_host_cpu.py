@@ -315,3 +315,51 @@ def test_bed_parsers_on_a_large_file_take_the_chunked_path(host, tmp_path, monke
     open(bed, "w").write("\n".join(text))
     assert host.gffx_host_parse_bed_file(gff.encode(), bed.encode(), C.byref(pr), C.byref(nr), e, len(e)) == -1
     assert b"firstbad" in e.value and b"secondbad" not in e.value
+
+
+def test_a_rit_that_parses_but_disagrees_with_gof_is_ignored_with_a_warning(host, tmp_path, monkeypatch, capfd):
+    """The byte layout of .rit is a hypothesis (no file of the real `gffx index` was ever read), so an image that parses is
+    only used when it holds exactly the intervals the .gof records + root lines give (per seqid: count, root_fid multiset,
+    columns 4/5).  A re-encoded image -- one coordinate changed, one interval dropped, a root_fid swapped between two
+    intervals -- is ignored with a [WARN] and the result equals the .gof route; a merely RE-ORDERED image is the same
+    multiset and is accepted."""
+    import struct
+
+    gff, _ = _make_gff(tmp_path, 5)
+    assert _build(host, gff)[0] == 0
+
+    def per_chr(t):
+        co, s, e, f = t
+        return [sorted(zip(s[co[c]:co[c + 1]].tolist(), e[co[c]:co[c + 1]].tolist(), f[co[c]:co[c + 1]].tolist())) for c in range(len(co) - 1)]
+
+    monkeypatch.setenv("GFFX_TREE_INDEX", "gof")
+    rc, via_gof = _host_tree_index(host, gff)
+    assert rc == 0
+    monkeypatch.delenv("GFFX_TREE_INDEX")
+    raw = bytearray(open(gff + ".rit", "rb").read())
+    # the first node of the first tree: tag(1) center(4) n(8) then n x (start, end, fid)
+    assert raw[0] == 1
+    n0 = struct.unpack_from("<Q", raw, 5)[0]
+    assert n0 >= 1
+    capfd.readouterr()
+    rc, ok = _host_tree_index(host, gff)
+    assert rc == 0 and per_chr(ok) == per_chr(via_gof) and "[WARN]" not in capfd.readouterr().err
+    cases = {}
+    x = bytearray(raw)
+    struct.pack_into("<I", x, 13 + 4, struct.unpack_from("<I", x, 13 + 4)[0] + 1)  # an end coordinate + 1
+    cases["coordinate"] = x
+    x = bytearray(raw)
+    struct.pack_into("<I", x, 13 + 8, struct.unpack_from("<I", x, 13 + 8)[0] ^ 0x40000)  # a root_fid nobody has
+    cases["root_fid"] = x
+    if n0 >= 2:
+        x = bytearray(raw)
+        a, b = bytes(x[13:25]), bytes(x[25:37])
+        x[13:25], x[25:37] = b, a  # two intervals of one node swapped: the same multiset
+        cases["reordered"] = x
+    for name, img in cases.items():
+        open(gff + ".rit", "wb").write(img)
+        rc, got = _host_tree_index(host, gff)
+        err = capfd.readouterr().err
+        assert rc == 0 and per_chr(got) == per_chr(via_gof), name
+        assert ("[WARN]" in err and "disagrees" in err) == (name != "reordered"), (name, err)
+    open(gff + ".rit", "wb").write(raw)

@@ -39,6 +39,24 @@ def main(path):
                 print("\n%s" % k)
                 last = k
             print("    %-40s dispatches=%-5d avg=%.1f" % (c, n, a))
+    # how much of the kernels' time overlaps another kernel (two batches in flight: streams interleave)
+    try:
+        iv = cur.execute("select start, end, name from kernels order by start").fetchall()
+    except sqlite3.Error:
+        iv = []
+    if len(iv) > 1:
+        busy = overlap = 0
+        span0, span1 = iv[0][0], max(r[1] for r in iv)
+        cur_end = iv[0][0]
+        n_over = 0
+        for (a, b, _), nxt in zip(iv, iv[1:] + [None]):
+            busy += b - a
+            if nxt is not None and nxt[0] < b:
+                n_over += 1
+                overlap += min(b, nxt[1]) - nxt[0]
+        print("\n## concurrency: %d kernels over a span of %.1f us; summed kernel time %.1f us; %d launches start before the "
+              "previous kernel ended (%.1f us of pairwise overlap); span / launches = %.2f us per launch"
+              % (len(iv), (span1 - span0) / 1e3, busy / 1e3, n_over, overlap / 1e3, (span1 - span0) / 1e3 / len(iv)))
     try:
         mc = cur.execute("select count(*), sum(size), avg(duration) from memory_copies").fetchone()
         if mc and mc[0]:

@@ -3,10 +3,15 @@
 (KiB per dispatch) -> HBM bytes per launch and per pass, corrected as MI355X_MICROARCH.md prescribes
 (separate --pmc passes; FETCH_SIZE doubled: gfx950 reports half the bytes of a wide read).
 
-    python tools/traffic_from_pmc.py gpurun_out/<tag>_pmc.txt k_join_fused [k_other ...] > profiles/traffic_latest.json
+    python tools/traffic_from_pmc.py gpurun_out/<tag>_pmc.txt k_join_win [k_other ...] > profiles/traffic_latest.json
+
+The file is stamped with the commit it was measured at (GFFX_COMMIT, else `git rev-parse`): bench.py prints that stamp next
+to the number, so a stale figure is visible as such.
 """
 import json
+import os
 import re
+import subprocess
 import sys
 
 
@@ -29,6 +34,14 @@ def main(path, kernels):
         out[k] = v
         total += b
     out["hbm_bytes_per_pass"] = total
+    out["kernel"] = "+".join(sorted(vals))
+    commit = os.environ.get("GFFX_COMMIT")
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+        except Exception:
+            commit = None
+    out["commit"] = commit
     out["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/profile_pmc.sh); per-dispatch "
                    "averages; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of a wide read); "
                    "the batch is re-read every pass, so Infinity-Cache hits are included (the guide: they are counted)")
