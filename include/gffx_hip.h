@@ -24,11 +24,17 @@
  *   a root interval iv of the query's seqid is a HIT iff  iv.start < q.end && iv.end > q.start
  *   (strict, half-open; u32 compares; q.start >= q.end rows are legal and evaluated as-is);
  *   keep = mode predicate(iv, q);  a (query, root) pair is emitted iff  invert ^ keep.
- * Output order: the pairs of one query are contiguous (its segment); inside a segment the order is
- * descending iv.start.  Direct strategy: segments in INPUT order (CSR).  Partitioned strategy:
- * segments in the order genome tiles were served, each query's offset given explicitly.  The
- * reference's own order is that of an FxHashMap walk plus a tree DFS and is unspecified as well;
- * the multiset of pairs is the contract.
+ * Output order: the pairs of one query are contiguous (its segment); WHERE the segments lie and the order inside a segment
+ * depend on the strategy, and only the multiset of pairs per query is the contract (the reference's own order is that of an
+ * FxHashMap walk plus a tree DFS and is unspecified as well):
+ *   DIRECT                 segments in INPUT order (CSR: offsets = exclusive prefix of the counts); inside a segment
+ *                          descending position in the seqid's start-sorted list (ties in start: later builder order first)
+ *   WINDOWS / SLOTS / FUSED  segments in the order in which 2048-region rounds reserve them (differs from run to run), the
+ *                          regions of a round in input order; every query's segment start is given explicitly
+ *                          (GFFX_OUT_OFFSETS / GFFX_OUT_OFFSETS32) and the segments tile [0, pairs) exactly.  Inside a segment:
+ *                          WINDOWS and SLOTS ascending list order (start, ties in builder order) for regions answered from the
+ *                          window's candidate list, descending for regions that took the exact sweep; FUSED descending
+ *   SORTED (partitioned)   segments in the order genome tiles were served, offsets explicit, inside a segment descending
  *
  * Threading: an index is immutable after creation and may be shared by threads; a batch owns
  * one HIP stream plus its buffers and must not be used from two threads at once.
@@ -86,7 +92,7 @@ enum gffx_out {
 };
 
 enum gffx_strategy {
-    GFFX_STRATEGY_AUTO = 0,   /* the engine picks: slots; fused for a batch of mostly wide regions */
+    GFFX_STRATEGY_AUTO = 0,   /* the engine picks: windows; fused for a batch of mostly wide regions */
     GFFX_STRATEGY_DIRECT = 1, /* queries in input order; bin directory + gathers from the L2-resident index */
     GFFX_STRATEGY_SORTED = 2, /* "partitioned": one-pass device radix partition of the batch by genome window,
                                  then a fused count+emit join served from LDS-staged index tiles */

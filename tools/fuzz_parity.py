@@ -10,7 +10,7 @@ from oracle import binding as ob
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-STRATS = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_SLOTS]
+STRATS = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_SLOTS, engine.STRATEGY_WINDOWS]
 t0 = time.time()
 n_checks = 0
 for it in range(iters):
@@ -70,11 +70,22 @@ for it in range(iters):
             for strat in STRATS:
                 if strat == engine.STRATEGY_SORTED and n_chr > 4000:
                     continue
-                for flags in (engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS):
+                flag_sets = [engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS]
+                if strat == engine.STRATEGY_WINDOWS:  # u32 offsets next to the u64 ones; the CLI's bitmap-only pass
+                    flag_sets += [engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_ROOT_BITMAP]
+                for flags in flag_sets:
                     b.run(mode, inv, flags, strat)
                     b.wait()
-                    c, off = b.counts(), b.offsets()
+                    c = b.counts()
                     ok = np.array_equal(c, want_c) and b.total_hits == len(want_t)
+                    if flags == engine.OUT_ROOT_BITMAP:
+                        ok = ok and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+                        n_checks += 1
+                        if ok:
+                            continue
+                    off = b.offsets() if ok or flags != engine.OUT_ROOT_BITMAP else None
+                    if ok and flags & engine.OUT_OFFSETS32:
+                        ok = np.array_equal(off[:-1], b.offsets32().astype(np.uint64))
                     if ok and flags & engine.OUT_FIDS:
                         got = np.stack([qid, b.fids()[off[:-1].astype(np.int64)[qid] + within].astype(np.int64)], axis=1)
                         ok = np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want_pairs)
