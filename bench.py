@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--exchange", default=None, choices=["final", "final-timed", "per-step"])
     ap.add_argument("--inflight", type=int, default=2)
     ap.add_argument("--quick", action="store_true", help="headline + roofline + cpu_baseline only (skip the extra legs)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic live (two child runs of this script under rocprofv3 --pmc, ~20 s)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     return ap.parse_args()
@@ -203,6 +206,51 @@ def roofline_obj(kern, nq, pairs, out_b, note, traffic=None):
             "frac_of_copy_ceiling": achieved / 6300.0, "traffic": traffic, "dominant_kernel": dominant,
             "regions_per_launch": nq, "pairs_per_region": h_bar, "algorithmic_bytes_per_pass": bytes_per_query * nq,
             "pass_kernel_us": pass_us, "kernels": kern, "note": note}
+
+
+def measure_traffic(args):
+    """roofline.traffic, measured by THIS run: HBM bytes per launch of the dominant kernel from the L2's fabric counters,
+    collected as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --kernel-trace --pmc`
+    passes (never combined with other trace domains), per-dispatch averages, FETCH_SIZE doubled (gfx950 reports half the
+    bytes of a wide read; for 16-byte gathers that makes the figure an upper bound).  Each pass is a child process running
+    this script with --traffic-child (the same workload, 12 serial passes)."""
+    import shutil
+    import sqlite3
+
+    if shutil.which("rocprofv3") is None:
+        return None
+    kib = {}
+    with tempfile.TemporaryDirectory(prefix="gffx_pmc_", dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "run", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--traffic-child", "--mode", args.mode, "--strategy", args.strategy,
+                   "--out", args.out, "--offsets", args.offsets, "--queries-per-gpu", str(args.queries_per_gpu)]
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            except Exception as exc:
+                return {"error": repr(exc)[:200]}
+            db = None
+            for dirpath, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("_results.db"):
+                        db = os.path.join(dirpath, f)
+            if r.returncode != 0 or db is None:
+                return {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-200:])}
+            rows = sqlite3.connect(db).execute(
+                "select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name",
+                (counter,)).fetchall()
+            rows = [x for x in rows if "k_join_" in x[0] or "k_tile_join" in x[0] or "k_partition" in x[0]]
+            if not rows:
+                return {"error": "no dispatch of a join kernel in the %s pass" % counter}
+            name, n, avg = max(rows, key=lambda x: x[1] * x[2])
+            kib[counter] = {"kernel": name.split("<")[0].replace("void ", ""), "dispatches": n, "avg_KiB": avg}
+    b = 2.0 * kib["FETCH_SIZE"]["avg_KiB"] * 1024 + kib["WRITE_SIZE"]["avg_KiB"] * 1024
+    return {"hbm_bytes_per_launch": b, "kernel": kib["FETCH_SIZE"]["kernel"], "FETCH_SIZE_KiB": kib["FETCH_SIZE"]["avg_KiB"],
+            "WRITE_SIZE_KiB": kib["WRITE_SIZE"]["avg_KiB"], "dispatches": kib["FETCH_SIZE"]["dispatches"],
+            "source": "measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate child "
+                      "passes; bytes = 2 x FETCH_SIZE + WRITE_SIZE (the doubling is calibrated for wide streaming reads: an "
+                      "upper bound for this kernel's 16-byte index gathers)"}
 
 
 def to_dev(torch, regions, dev):
@@ -356,6 +404,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.traffic_child:  # (under rocprofv3 --pmc: the workload, 12 serial passes, nothing else)
+        one = Pass(engine, ix, cols, nq, 1, mode, out_flags, strategy)
+        one.size_and_warm(0)
+        for _ in range(12):
+            one.step()
+        one.sync()
+        one.close()
+        return
     run = Pass(engine, ix, cols, nq, args.inflight, mode, out_flags, strategy)
     pairs = run.size_and_warm(args.warmup)
     if world > 1:  # the collective's first call sets up its channels: not part of the job's steady state
@@ -410,6 +466,12 @@ def main():
                            "FETCH_SIZE / WRITE_SIZE passes; NOT measured by this run)"}
             except Exception:
                 traffic = None
+        if world == 1 and not args.no_traffic and not args.quick:
+            live = measure_traffic(args)
+            if live and "error" not in live:
+                traffic = live
+            elif live and traffic is not None:
+                traffic["live_measurement_error"] = live["error"]
         result = {
             "metric": "BED overlap queries/sec vs GRCh38-scale GFF index at 1/2/4/8 MI355X",  # BASELINE.json
             "value": nq_total * args.steps / elapsed,

@@ -152,6 +152,13 @@ class SeqidTable {
     size_t mask_ = 0;
 };
 
+// u8::is_ascii_whitespace as a table (split_ascii_whitespace, intersect.rs:214): space, \t, \n, \x0C, \r
+struct WsTable {
+    bool t[256] = {};
+    constexpr WsTable() { t[' '] = t['\t'] = t['\n'] = t['\x0C'] = t['\r'] = true; }
+};
+constexpr WsTable kWs{};
+
 // lexical_core::parse::<u32>: optional '+', >= 1 digits, the whole field, no overflow
 inline bool field_u32(const char *p, const char *e, uint32_t &out) {
     if (p < e && *p == '+') ++p;
@@ -194,10 +201,10 @@ void parse_bed_chunk(std::string_view d, size_t a, size_t z, bool last, const Se
         int nf = 0;
         const char *q = p;
         while (q < e && nf < 3) {
-            while (q < e && is_ascii_ws(static_cast<unsigned char>(*q))) ++q;
+            while (q < e && kWs.t[static_cast<unsigned char>(*q)]) ++q;
             if (q >= e) break;
             fb[nf] = q;
-            while (q < e && !is_ascii_ws(static_cast<unsigned char>(*q))) ++q;
+            while (q < e && !kWs.t[static_cast<unsigned char>(*q)]) ++q;
             fe[nf++] = q;
         }
         if (nf < 3) continue;
