@@ -149,6 +149,12 @@ class QueryBatch:
             strategy: int = STRATEGY_AUTO) -> None:
         check(lib().gffx_hip_batch_run(self._h, int(mode), int(bool(invert)), int(out_flags), int(strategy)))
 
+    def timed_runs(self, mode: int, invert: bool, out_flags: int, strategy: int, n: int) -> float:
+        """n passes back to back between one pair of HIP events on the batch's stream; returns microseconds per pass."""
+        ms = C.c_double(0.0)
+        check(lib().gffx_hip_batch_timed_runs(self._h, int(mode), int(bool(invert)), int(out_flags), int(strategy), int(n), C.byref(ms)))
+        return 1e3 * ms.value / n
+
     def wait(self) -> None:
         check(lib().gffx_hip_batch_wait(self._h))
 

@@ -237,6 +237,10 @@ int gffx_hip_batch_reserve_hits(gffx_hip_batch *, uint64_t n_pairs);
 int gffx_hip_batch_set_profiling(gffx_hip_batch *, int enabled);
 int gffx_hip_batch_kernel_ms(gffx_hip_batch *, int kernel_id, double *total_ms, uint64_t *launches);
 int gffx_hip_batch_reset_profile(gffx_hip_batch *);
+/* n passes back to back on the batch's stream between ONE pair of HIP events (blocking): total_ms / n = the average
+ * launch-to-launch duration of a pass without an event pair per launch */
+int gffx_hip_batch_timed_runs(gffx_hip_batch *, int mode, int invert, uint32_t out_flags, int strategy, uint32_t n,
+                              double *total_ms);
 
 /* One-shot drop-in for query_features (commands/intersect.rs:105-111): host regions in, host
  * triples out (malloc'd by the library, release with gffx_hip_free_host). */
