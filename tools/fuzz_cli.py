@@ -38,6 +38,8 @@ with tempfile.TemporaryDirectory() as d:
             rc, msg = ob.intersect_run(gff, want_p, bed=bed, mode=mode, invert=inv, entire_group=eg, types=types)
             cmd = [G, "intersect", "-i", gff, "-b", bed, FLAG[mode], "-o", got_p, "-t", str(int(rng.choice([1, 3, 12])))]
             cmd += (["-I"] if inv else []) + (["-e"] if eg else []) + (["-T", types] if types is not None else [])
+            if rng.random() < 0.4:  # chromosome-bucket sharding over logical devices (they share the GPU of a 1-GPU box)
+                cmd += ["--gpus", str(int(rng.integers(2, 5)))]
             r = subprocess.run(cmd, capture_output=True)
             ok = (rc == 0) == (r.returncode == 0) and (rc != 0 or open(got_p, "rb").read() == open(want_p, "rb").read())
             n_cmp += 1
