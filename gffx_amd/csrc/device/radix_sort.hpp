@@ -6,7 +6,7 @@
 // LSD sequence c.byte0..3, b.byte0..3, a.byte0..k.  "Onesweep" structure:
 //   k_radix_hist   ONE read of the records builds the 256-bin histograms of ALL passes (per-block LDS histograms, one
 //                  global atomic per non-empty bin and block); k_radix_scan turns them into exclusive bin starts.
-//   k_radix_pass   one kernel per pass, one read + one write of the records: a block takes the next 2048-record tile by
+//   k_radix_pass   one kernel per pass, one read + one write of the records: a block takes the next 4096-record tile by
 //                  ticket (so an earlier tile always started earlier), ranks its records with wave64 ballots
 //                  (8 ballots give every lane the set of lanes with the same byte: rank = popcount below me, one LDS
 //                  counter update per distinct byte and step), and learns where its tile's run of every byte starts by
@@ -14,16 +14,16 @@
 //                  separate scan kernel, no second read.  Status words are single relaxed agent-scope 4-byte stores /
 //                  loads that carry their own flag (one granule: nothing to order); every spin is bounded and a timeout
 //                  sets the error word instead of hanging the GPU.
-// Stability: wave w of a tile ranks records [512 w, 512 w + 512) in order (step j holds records j*64 + lane), waves and
-// tiles are prefix-summed in order.  Roofline bound: HBM, 24 bytes per record and pass.
+// Stability: wave w of a tile ranks records [1024 w, 1024 w + 1024) in order (step j holds records j*64 + lane), waves and
+// tiles are prefix-summed in order; the LDS reorder keeps the rank order inside a byte's run.  Roofline bound: HBM, 24 bytes per record and pass.
 #pragma once
 #include "gffx_device.hpp"
 
 namespace gffx {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortItems = 8;
-constexpr uint32_t kSortTile = kSortThreads * kSortItems;  // 2048 records
+constexpr int kSortItems = 16;
+constexpr uint32_t kSortTile = kSortThreads * kSortItems;  // 4096 records (48 KB of LDS for the reorder)
 constexpr int kSortMaxPasses = 12;
 constexpr uint32_t kSortFlagAgg = 1u << 30, kSortFlagPrefix = 2u << 30, kSortValueMask = (1u << 30) - 1;
 
@@ -81,18 +81,25 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist) {
 }
 
 // one LSD pass: in -> out, stable by byte (word, shift).  status: n_tiles x 256 words, zero on entry; ticket: zero on entry.
+// The tile is reordered in LDS first (digit by digit, stable), so that a wave's 64 consecutive stores cover a few runs of
+// consecutive global records instead of 64 scattered 12-byte writes.
 __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in, uint32_t *out, unsigned long long n, int word,
                                                              int shift, const uint32_t *bin_start, uint32_t *status,
                                                              uint32_t *ticket, uint32_t *err) {
     __shared__ uint32_t s_cnt[kSortThreads / 64][256];  // per wave: records of the byte so far; then: first rank of the wave's run
     __shared__ uint32_t s_base[256];                     // where the tile's run of the byte starts in `out`
+    __shared__ uint32_t s_dstart[256];                   // ... and inside the tile (exclusive scan of the tile's byte counts)
+    __shared__ uint32_t s_wsum[kSortThreads / 64];
+    __shared__ uint32_t s_rec[kSortTile * 3];            // the tile, byte-sorted
     __shared__ uint32_t s_tile;
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     for (int i = threadIdx.x; i < (kSortThreads / 64) * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long base_i = (unsigned long long)tile * kSortTile + (unsigned long long)wave * (64 * kSortItems);
+    const unsigned long long tile_i = (unsigned long long)tile * kSortTile;
+    const unsigned long long base_i = tile_i + (unsigned long long)wave * (64 * kSortItems);
+    const uint32_t n_tile = (uint32_t)min((unsigned long long)kSortTile, n - tile_i);
     uint32_t r0[kSortItems], r1[kSortItems], r2[kSortItems], rank[kSortItems];
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
@@ -122,7 +129,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         rank[j] = pre + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    {  // thread = byte value: runs of the waves inside the tile, then the tile's place among the tiles (look-back)
+    {  // thread = byte value: runs of the waves inside the tile, the tile's place among the tiles (look-back), the byte's
+       // place inside the tile (block scan of the counts)
         const uint32_t d = threadIdx.x;
         uint32_t total = 0;
 #pragma unroll
@@ -131,6 +139,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
             s_cnt[w][d] = total;
             total += c;
         }
+        uint32_t inc = total;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
         uint32_t *st = status + (size_t)tile * 256 + d;
         __hip_atomic_store(st, total | (tile == 0 ? kSortFlagPrefix : kSortFlagAgg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
@@ -151,15 +166,27 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         }
         if (tile) __hip_atomic_store(st, ((excl + total) & kSortValueMask) | kSortFlagPrefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_base[d] = bin_start[d] + excl;
+        __syncthreads();
+        uint32_t wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
+        s_dstart[d] = wbase + inc - total;
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kSortItems; ++j) {
+    for (int j = 0; j < kSortItems; ++j) {  // into LDS at the record's place inside the byte-sorted tile
         if (base_i + j * 64 + lane >= n) continue;
         const uint32_t key = word == 0 ? r0[j] : word == 1 ? r1[j] : r2[j];
         const uint32_t d = (key >> shift) & 255u;
-        const unsigned long long pos = (unsigned long long)s_base[d] + s_cnt[wave][d] + rank[j];
-        out[3 * pos] = r0[j], out[3 * pos + 1] = r1[j], out[3 * pos + 2] = r2[j];
+        const uint32_t lp = s_dstart[d] + s_cnt[wave][d] + rank[j];
+        s_rec[3 * lp] = r0[j], s_rec[3 * lp + 1] = r1[j], s_rec[3 * lp + 2] = r2[j];
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < n_tile; x += kSortThreads) {
+        const uint32_t a = s_rec[3 * x], b = s_rec[3 * x + 1], c = s_rec[3 * x + 2];
+        const uint32_t key = word == 0 ? a : word == 1 ? b : c;
+        const uint32_t d = (key >> shift) & 255u;
+        const unsigned long long pos = (unsigned long long)s_base[d] + (x - s_dstart[d]);
+        out[3 * pos] = a, out[3 * pos + 1] = b, out[3 * pos + 2] = c;
     }
 }
 
@@ -178,7 +205,8 @@ struct DeviceSort {
         const size_t tiles = (size_t)((n + kSortTile - 1) / kSortTile);
         GFFX_HIP_TRY(hipMemsetAsync(work, 0, work_words(n, plan.n_passes) * 4, stream));
         uint32_t *hist = work, *tickets = work + (size_t)plan.n_passes * 256, *status = tickets + plan.n_passes + 16;
-        const uint32_t hgrid = (uint32_t)std::min<unsigned long long>((n + 255) / 256, 2048);
+        // (few blocks: every block ends with one global atomic per non-empty bin and pass)
+        const uint32_t hgrid = (uint32_t)std::max<unsigned long long>(1, std::min<unsigned long long>((n + 4095) / 4096, 256));
         hipLaunchKernelGGL(k_radix_hist, dim3(hgrid), dim3(256), 0, stream, buf_a, n, plan, hist, limit0, err);
         hipLaunchKernelGGL(k_radix_scan, dim3(plan.n_passes), dim3(256), 0, stream, hist);
         uint32_t *src = buf_a, *dst = buf_b;
