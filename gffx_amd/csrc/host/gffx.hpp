@@ -82,6 +82,9 @@ bool check_index_files_exist(const std::string &gff);                           
 
 using Block = std::tuple<uint32_t, uint64_t, uint64_t>;  // (root fid, start offset, end offset)
 
+// the copy-out of both writers: byte ranges (offset, length) of the mapped GFF, in order; files are written in parallel
+void write_segments(const uint8_t *base, const std::vector<std::pair<uint64_t, uint64_t>> &seg,
+                    const std::optional<std::string> &output_path, size_t threads);
 // common.rs:188-287: drop sentinel blocks, sort, merge touching/overlapping, copy out.
 void write_gff_output(const std::string &gff_path, const std::vector<Block> &blocks,
                       const std::optional<std::string> &output_path, bool verbose);

@@ -584,7 +584,7 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
             if (gffx_hip_regions_append(store[d].h, k, n_up) != GFFX_OK) hip_fail("regions_append");
             gffx_hip_batch *b = batch[2 * d + k].h;
             if (gffx_hip_batch_set_regions_store(b, store[d].h, k, 0, n_dev[d]) != GFFX_OK) hip_fail("set_regions_store");
-            const uint32_t flags = GFFX_OUT_ROOT_BITMAP | (used[2 * d + k] ? GFFX_OUT_BITMAP_KEEP : 0u);
+            const uint32_t flags = static_cast<uint32_t>(GFFX_OUT_ROOT_BITMAP) | (used[2 * d + k] ? static_cast<uint32_t>(GFFX_OUT_BITMAP_KEEP) : 0u);
             if (gffx_hip_batch_run(b, static_cast<int>(mode), invert ? 1 : 0, flags, GFFX_STRATEGY_AUTO) != GFFX_OK) hip_fail("batch_run");
             used[2 * d + k] = 1;
             dev_rows[d] += n_dev[d];
@@ -818,7 +818,7 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
         if (rc != GFFX_OK) hip_fail("gffx_hip_lines_test");
     }
 
-    OutFile out(output_path);
+    std::vector<std::pair<uint64_t, uint64_t>> seg;
     for (size_t i = 0; i < n_lines;) {  // kept lines that touch in the file leave as one write
         if (!keep[i]) {
             ++i;
@@ -826,11 +826,10 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
         }
         size_t j = i + 1;
         while (j < n_lines && keep[j] && ls[j] == le[j - 1]) ++j;
-        const uint64_t a = ls[i], z = le[j - 1];
-        if (std::fwrite(gff.data() + a, 1, z - a, out.f) != z - a) throw Error("write failed");
+        seg.emplace_back(ls[i], le[j - 1] - ls[i]);
         i = j;
     }
-    out.close();
+    write_segments(gff.data(), seg, output_path, threads);
     if (verbose) std::fprintf(stderr, "[INFO] match-only by coords completed; minput blocks %zu\n", blocks.size());
 }
 
