@@ -76,9 +76,12 @@ static int dev_upload(T **p, const std::vector<T> &v) {
 // Window index (gffx_device.hpp, join_win_kernels.hpp): per seqid ~GFFX_HIP_WIN_PER_ENTRY windows per root (a power of
 // two wide), widened until the lists total <= 8 per root; the line of window b lists, by ascending start, the roots with
 // start < (b+1) << shift and end + wmax > b << shift.  `start` / `aux` are the sorted arrays of the index.
-static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
-                              const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
-                              std::vector<uint4> &win_pos, std::vector<uint4> &spill) {
+// `coarsen` halves the windows per root (k times): the directory is addressed with 32-bit byte offsets below 2^31, i.e. at
+// most 2^25 lines -- an index with more roots than that gets wider windows (longer lists, more of them deferred), not a failure.
+// Returns 1 when the directory does not fit at this coarseness.
+static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
+                                 const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
+                                 std::vector<uint4> &win_pos, std::vector<uint4> &spill, uint32_t coarsen, uint64_t max_lines) {
     meta.assign(n_chr + 1, make_uint4(0, 0, 0, 0));  // (+ one zero entry: a kernel may read one past the end)
     win.clear(), win_pos.clear(), spill.clear();
     const uint64_t per_entry = (uint64_t)env_long("GFFX_HIP_WIN_PER_ENTRY", 1, 1, 16);
@@ -93,7 +96,7 @@ static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const
         const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
         if (hi == lo) continue;
         const uint64_t max_end = std::max(h_aux[hi - 1].x, h_aux[hi - 1].y);
-        const uint64_t budget = std::max<uint64_t>(per_entry * (hi - lo), 16);
+        const uint64_t budget = std::max<uint64_t>((per_entry * (hi - lo)) >> coarsen, 16);
         uint32_t shift = 0;
         uint64_t wmax = 0, ns = 0;
         for (;; shift++) {
@@ -110,7 +113,7 @@ static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const
         }
         if (shift > 31) shift = 31, wmax = win_wmax(31), ns = ((max_end + wmax) >> 31) + 1;
         wmax = std::min<uint64_t>(wmax, 0xFFFFFFFFull);
-        if (total_win + ns >= (1ull << 25)) return fail(GFFX_E_INVALID, "index too large for the window directory");
+        if (total_win + ns >= max_lines) return 1;
         const uint32_t base = (uint32_t)total_win;
         total_win += ns;
         meta[c] = make_uint4(base, (uint32_t)ns, shift, (uint32_t)wmax);
@@ -156,6 +159,18 @@ static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const
         }
     }
     return GFFX_OK;
+}
+
+static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
+                              const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
+                              std::vector<uint4> &win_pos, std::vector<uint4> &spill) {
+    // (GFFX_HIP_WIN_MAX_LINES: tests shrink the limit to reach the coarsening path with small indexes)
+    const uint64_t max_lines = (uint64_t)env_long("GFFX_HIP_WIN_MAX_LINES", 1l << 25, 64, 1l << 25);
+    for (uint32_t coarsen = 0; coarsen < 40; ++coarsen) {
+        const int rc = build_window_index_at(n_chr, chr_offsets, h_start, h_aux, meta, win, win_pos, spill, coarsen, max_lines);
+        if (rc <= 0) return rc;
+    }
+    return fail(GFFX_E_INVALID, "index too large for the window directory (%u seqids need more than 2^25 lines)", n_chr);
 }
 
 // Coverage filter of the window index (gffx_device.hpp): the smallest cell size whose bitmap fits GFFX_HIP_WIN_FILTER_KB

@@ -544,3 +544,44 @@ def test_warmup_reserve_hits_and_device_result_pointers():
         assert np.array_equal(hf, b.fids())
         b.close()
     ix.close()
+
+
+@pytest.mark.parametrize("n_roots", [300_000, 800_000])
+def test_many_roots_bitmap_beyond_the_default_lds(n_roots):
+    """The root bitmap of a root-bitmap pass lives in LDS while it fits: 300 k roots need more than the default 64 KB of
+    dynamic LDS (the kernel opts in), 800 k roots do not fit at all (test-before-set global atomics)."""
+    rng = np.random.default_rng(n_roots)
+    n_chr = 3
+    per = n_roots // n_chr
+    co = np.arange(n_chr + 1, dtype=np.uint32) * per
+    s = np.concatenate([np.sort(rng.integers(0, 400_000_000, per)) for _ in range(n_chr)]).astype(np.uint32)
+    e = (s + rng.integers(1, 3000, len(s))).astype(np.uint32)
+    f = (rng.permutation(len(s)) * 2 + 1).astype(np.uint32)
+    regions = np.stack([rng.integers(0, n_chr, 60_000), rng.integers(0, 400_000_000, 60_000), np.zeros(60_000, np.int64)], axis=1)
+    regions[:, 2] = regions[:, 1] + rng.integers(1, 9000, len(regions))
+    regions = regions.astype(np.uint32)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)
+    for mode in (OverlapMode.Overlap, OverlapMode.Contained):
+        want_t, want_c = oix.query_features(regions, int(mode), False)
+        b.run(mode, False, engine.OUT_ROOT_BITMAP)
+        b.wait()
+        assert np.array_equal(b.counts(), want_c) and b.total_hits == len(want_t)
+        assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+        b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS32 | engine.OUT_ROOT_BITMAP)
+        b.wait()
+        assert np.array_equal(np.sort(b.fids()), np.sort(want_t[:, 0])) and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    b.close()
+    ix.close()
+
+
+def test_window_directory_is_coarsened_not_refused(monkeypatch):
+    """An index whose window directory would exceed the 32-bit line addressing gets wider windows (longer lists, more of them
+    deferred or dense) instead of an error: forced here with a tiny limit."""
+    monkeypatch.setenv("GFFX_HIP_WIN_MAX_LINES", "300")
+    roots = synth.gencode_like_roots(6000, seed=31)
+    regions = synth.synth_bed(30_000, seed=32, edge_frac=0.02, roots=roots)
+    for mode in OverlapMode:
+        _check(roots, regions, mode, False, strategy=engine.STRATEGY_WINDOWS)
