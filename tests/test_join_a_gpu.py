@@ -580,7 +580,7 @@ def test_many_roots_bitmap_beyond_the_default_lds(n_roots):
 def test_window_directory_is_coarsened_not_refused(monkeypatch):
     """An index whose window directory would exceed the 32-bit line addressing gets wider windows (longer lists, more of them
     deferred or dense) instead of an error: forced here with a tiny limit."""
-    monkeypatch.setenv("GFFX_HIP_WIN_MAX_LINES", "300")
+    monkeypatch.setenv("GFFX_HIP_WIN_MAX_LINES", "1500")
     roots = synth.gencode_like_roots(6000, seed=31)
     regions = synth.synth_bed(30_000, seed=32, edge_frac=0.02, roots=roots)
     for mode in OverlapMode:
