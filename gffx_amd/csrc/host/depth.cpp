@@ -146,41 +146,102 @@ void run(const DepthArgs &args) {
     std::vector<uint64_t> depth(std::max<size_t>(n_groups, 1), 0);
     std::vector<uint32_t> mn(std::max<size_t>(n_groups, 1), 0xFFFFFFFFu), mx(std::max<size_t>(n_groups, 1), 0);
     if (!regions.empty()) {
-        index_data.ensure_device(args.device);
-        gffx_hip_depth *dt = nullptr;
-        if (gffx_hip_depth_create(args.device, n_groups, static_cast<uint32_t>(t.block_line_off.size() - 1),
-                                  t.block_line_off.data(), t.line_start.data(), t.line_end.data(), t.line_group.data(),
-                                  static_cast<uint32_t>(t.block_of_fid.size()), t.block_of_fid.data(), &dt) != GFFX_OK)
-            hip_fail("gffx_hip_depth_create");
-        struct Guard {
-            gffx_hip_depth *d;
+        // --gpus N: the BED rows go to the devices in batches, round robin (every per-group result is a sum / min / max over
+        // regions, so any partition of the rows gives the same rows out: depth.rs:264-291 merges its own batches the same
+        // way); index and line table are replicated; one host thread drives each device.
+        const int visible = gffx_hip_device_count();
+        if (visible <= 0) throw Error("no HIP device visible (the engine has no CPU fallback)");
+        const size_t D = static_cast<size_t>(std::max(1, args.gpus));
+        std::vector<int> dev(D);
+        for (size_t d = 0; d < D; ++d) dev[d] = (args.device + static_cast<int>(d)) % visible;
+        bool distinct = true;
+        for (size_t d = 1; d < D; ++d)
+            for (size_t e = 0; e < d; ++e) distinct &= dev[d] != dev[e];
+        if (D > 1 && !distinct)
+            std::fprintf(stderr, "[WARN] --gpus %zu with %d visible device(s): logical devices share GPUs (no RCCL exchange)\n", D, visible);
+        index_data.ensure_device(dev[0]);
+        struct PerDevice {
+            gffx_hip_index *ix = nullptr;  // clone (owned) unless it is the first device's
+            bool own_ix = false;
+            gffx_hip_depth *dt = nullptr;
             gffx_hip_batch *b = nullptr;
-            ~Guard() {
+            std::vector<uint64_t> depth;
+            std::vector<uint32_t> mn, mx;
+            uint64_t rows = 0;
+            std::string error;
+            ~PerDevice() {
                 if (b) gffx_hip_batch_destroy(b);
-                gffx_hip_depth_destroy(d);
+                if (dt) gffx_hip_depth_destroy(dt);
+                if (own_ix && ix) gffx_hip_index_destroy(ix);
             }
-        } guard{dt};
+        };
+        std::vector<PerDevice> pd(D);
         // regions stream through Join A in batches (the reference's BATCH_SIZE, depth.rs:24, only bounds memory:
         // every merge is min / max / sum)
         const size_t kBatch = 4u << 20;
         const size_t cap = std::min(regions.size(), kBatch);
-        if (gffx_hip_batch_create(index_data.device_index, cap, &guard.b) != GFFX_OK) hip_fail("gffx_hip_batch_create");
-        std::vector<uint32_t> flat;
-        for (size_t a = 0; a < regions.size(); a += kBatch) {
-            const size_t n = std::min(kBatch, regions.size() - a);
-            flat.resize(3 * n);
-            for (size_t i = 0; i < n; ++i) {
-                flat[3 * i] = std::get<0>(regions[a + i]);
-                flat[3 * i + 1] = std::get<1>(regions[a + i]);
-                flat[3 * i + 2] = std::get<2>(regions[a + i]);
+        auto device_work = [&](size_t d) {
+            PerDevice &P = pd[d];
+            auto fail_hip = [&](const char *what) { P.error = std::string(what) + ": " + gffx_hip_last_error(); };
+            P.ix = index_data.device_index;
+            if (dev[d] != dev[0]) {
+                if (gffx_hip_index_clone(index_data.device_index, dev[d], &P.ix) != GFFX_OK) return fail_hip("gffx_hip_index_clone");
+                P.own_ix = true;
             }
-            if (gffx_hip_batch_set_regions_host(guard.b, flat.data(), n) != GFFX_OK) hip_fail("set_regions");
-            if (gffx_hip_batch_run(guard.b, GFFX_MODE_OVERLAP, 0, GFFX_OUT_FIDS | GFFX_OUT_OFFSETS, GFFX_STRATEGY_AUTO) != GFFX_OK)
-                hip_fail("gffx_hip_batch_run");
-            if (gffx_hip_batch_wait(guard.b) != GFFX_OK) hip_fail("query_features");
-            if (gffx_hip_depth_accumulate(dt, guard.b) != GFFX_OK) hip_fail("gffx_hip_depth_accumulate");
+            if (gffx_hip_depth_create(dev[d], n_groups, static_cast<uint32_t>(t.block_line_off.size() - 1), t.block_line_off.data(),
+                                      t.line_start.data(), t.line_end.data(), t.line_group.data(),
+                                      static_cast<uint32_t>(t.block_of_fid.size()), t.block_of_fid.data(), &P.dt) != GFFX_OK)
+                return fail_hip("gffx_hip_depth_create");
+            if (gffx_hip_batch_create(P.ix, cap, &P.b) != GFFX_OK) return fail_hip("gffx_hip_batch_create");
+            std::vector<uint32_t> flat;
+            for (size_t a = d * kBatch; a < regions.size(); a += D * kBatch) {
+                const size_t n = std::min(kBatch, regions.size() - a);
+                flat.resize(3 * n);
+                for (size_t i = 0; i < n; ++i) {
+                    flat[3 * i] = std::get<0>(regions[a + i]);
+                    flat[3 * i + 1] = std::get<1>(regions[a + i]);
+                    flat[3 * i + 2] = std::get<2>(regions[a + i]);
+                }
+                if (gffx_hip_batch_set_regions_host(P.b, flat.data(), n) != GFFX_OK) return fail_hip("set_regions");
+                if (gffx_hip_batch_run(P.b, GFFX_MODE_OVERLAP, 0, GFFX_OUT_FIDS | GFFX_OUT_OFFSETS, GFFX_STRATEGY_AUTO) != GFFX_OK)
+                    return fail_hip("gffx_hip_batch_run");
+                if (gffx_hip_batch_wait(P.b) != GFFX_OK) return fail_hip("query_features");
+                if (gffx_hip_depth_accumulate(P.dt, P.b) != GFFX_OK) return fail_hip("gffx_hip_depth_accumulate");
+                P.rows += n;
+            }
+            P.depth.assign(std::max<size_t>(n_groups, 1), 0);
+            P.mn.assign(std::max<size_t>(n_groups, 1), 0xFFFFFFFFu);
+            P.mx.assign(std::max<size_t>(n_groups, 1), 0);
+            if (gffx_hip_depth_copy(P.dt, P.depth.data(), P.mn.data(), P.mx.data()) != GFFX_OK) return fail_hip("gffx_hip_depth_copy");
+        };
+        {
+            std::vector<std::thread> pool;
+            for (size_t d = 1; d < D; ++d) pool.emplace_back(device_work, d);
+            device_work(0);
+            for (auto &th : pool) th.join();
         }
-        if (gffx_hip_depth_copy(dt, depth.data(), mn.data(), mx.data()) != GFFX_OK) hip_fail("gffx_hip_depth_copy");
+        for (size_t d = 0; d < D; ++d)
+            if (!pd[d].error.empty()) throw Error(pd[d].error);
+        std::vector<uint64_t> counts(2 * D, 0);
+        for (size_t d = 0; d < D; ++d) {  // merge: sum of depths, min / max of the extents
+            const PerDevice &P = pd[d];
+            counts[2 * d] = P.rows;
+            for (uint32_t g = 0; g < n_groups; ++g) {
+                depth[g] += P.depth[g];
+                mn[g] = std::min(mn[g], P.mn[g]);
+                mx[g] = std::max(mx[g], P.mx[g]);
+                counts[2 * d + 1] += P.depth[g];
+            }
+        }
+        if (D > 1) {  // the exchange step: per-device {rows, group hits}, all-gathered over RCCL when the devices are distinct
+            std::vector<uint64_t> gathered(2 * D * D, 0);
+            if (distinct && gffx_hip_allgather_counts(static_cast<int>(D), dev.data(), counts.data(), gathered.data()) != GFFX_OK)
+                hip_fail("gffx_hip_allgather_counts");
+            if (verbose)
+                for (size_t d = 0; d < D; ++d)
+                    std::fprintf(stderr, "[INFO] device %d: %llu BED rows, %llu group hits%s\n", dev[d], (unsigned long long)counts[2 * d],
+                                 (unsigned long long)counts[2 * d + 1], distinct ? " (all-gathered over RCCL)" : "");
+        }
     }
     timer.lap("Join A + depth on the device (uploads, kernels, results D2H)");
     // merge the groups of an ID (depth.rs:264-291): min start, max end, summed depth; chrom from the first

@@ -234,6 +234,7 @@ struct DepthArgs {  // depth.rs:34-72
     size_t threads = 12;                // -t/--threads
     bool verbose = false;               // -v/--verbose
     int device = 0;                     // --device (addition)
+    int gpus = 1;                       // --gpus (addition: the BED rows in batches over N MI355X, results merged)
 };
 
 // depth.rs:450-495: the rows `depth` keeps from a BED file (its rules differ from intersect's parser)

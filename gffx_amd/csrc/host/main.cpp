@@ -118,7 +118,8 @@ const char *kDepthUsage =
     "      --bin-shift <BIN_SHIFT>  Bin width parameter (2^k bp) [default: 12]\n"
     "  -t, --threads <THREADS>      Number of threads for parallel processing [default: 12]\n"
     "  -v, --verbose                Enable verbose output\n"
-    "      --device <N>             HIP device to run on [default: 0]\n";
+    "      --device <N>             HIP device to run on [default: 0]\n"
+    "      --gpus <N>               Spread the BED rows over N devices [default: 1]\n";
 
 const char *kCoverageUsage =
     "Usage: gffx coverage [OPTIONS] --input <FILE> --source <SOURCE>\n\nOptions:\n"
@@ -183,7 +184,7 @@ int run_intersect_cli(int argc, char **argv) {
 int run_depth_cli(int argc, char **argv) {
     static const std::vector<OptSpec> specs = {{'i', "input", true},   {'s', "source", true},   {'o', "output", true},
                                                {0, "bin-shift", true}, {'t', "threads", true},  {'v', "verbose", false},
-                                               {0, "device", true},    {'h', "help", false}};
+                                               {0, "device", true},    {0, "gpus", true},       {'h', "help", false}};
     const auto o = parse_opts(argc, argv, 2, specs);
     if (o.count("help")) {
         std::fputs(kDepthUsage, stdout);
@@ -200,6 +201,7 @@ int run_depth_cli(int argc, char **argv) {
     if (o.count("threads")) a.threads = parse_size(o.at("threads")[0], "--threads <THREADS>");
     a.verbose = o.count("verbose") > 0;
     if (o.count("device")) a.device = static_cast<int>(parse_size(o.at("device")[0], "--device <N>"));
+    if (o.count("gpus")) a.gpus = static_cast<int>(std::max<size_t>(1, std::min<size_t>(64, parse_size(o.at("gpus")[0], "--gpus <N>"))));
     commands::depth::run(a);
     return 0;
 }

@@ -138,3 +138,26 @@ def test_depth_cli_rows_equal_the_oracle(tmp_path, seed, quirks, crlf):
     # unsupported sources fail like the reference (depth.rs:596-600)
     r = subprocess.run([GFFX, "depth", "-i", gff, "-s", str(tmp_path / "reads.txt")], capture_output=True)
     assert r.returncode == 1 and b"Unsupported file type" in r.stderr
+
+
+def test_depth_over_several_logical_devices_gives_the_same_rows(tmp_path):
+    """`gffx depth --gpus N` (configs[4]'s layout: the read intervals spread over the devices, index and line table replicated,
+    per-group results merged by sum / min / max): 9 M rows = three 4 M-row batches over 1, 2 and 3 logical devices (they share
+    the GPU of a 1-GPU box) give identical rows, equal to the oracle's."""
+    roots = synth.gencode_like_roots(3000, seed=8)
+    gff = str(tmp_path / "a.gff")
+    synth.write_gff3_fast(gff, roots, tx_per_gene=2.0, exons_per_tx=3.0)
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    regions = synth.synth_bed(9_000_000, seed=99)
+    bed = str(tmp_path / "reads.bed")
+    synth.write_bed_fast(bed, regions, roots["names"])
+    want = str(tmp_path / "want.tsv")
+    rc, msg = ob.depth_run(gff, bed, want)
+    assert rc == 0, msg
+    want_rows = _rows(open(want, "rb").read())
+    assert len(want_rows) > 1000
+    for n in (1, 2, 3):
+        out = str(tmp_path / ("got%d.tsv" % n))
+        r = subprocess.run([GFFX, "depth", "-v", "-i", gff, "-s", bed, "-o", out, "--gpus", str(n)], capture_output=True)
+        assert r.returncode == 0, r.stderr[-400:]
+        assert _rows(open(out, "rb").read()) == want_rows, n
