@@ -18,6 +18,7 @@ The JSON line carries, next to the contract's fields:
   t_xfer                host regions in (pinned), counts + root_fids back on the host: two batches double-buffered
   t_e2e                 the `gffx` CLI on a 3.5 M-line synthetic GFF3 x the 1 M-row BED: wall clock + its stage timers
   join_b                Join B (k_lines_exists over a 3.4 M-line table) with the device-built region tables
+  depth                 `gffx depth`'s kernel (k_depth_regions) on the same regions against a 3.4 M-line table
   cpu_baseline          the oracle's Join A on 1 thread (the reference is serial there), + all cores, + Join B on all cores
 
 For N>1 (launched by torch.distributed.run, one rank per GPU) --scaling weak (default) gives every rank 1 M regions of an
@@ -560,6 +561,7 @@ def main():
         except Exception as exc:  # the headline must not die with an auxiliary leg
             result["t_e2e"] = {"error": repr(exc)[:300]}
         result["join_b"] = join_b_leg(engine, synth, roots, regions, mode)
+        result["depth"] = depth_leg(engine, synth, roots, ix, cols, nq)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(roots, regions, mode, args.cpu_seconds)
         if not args.quick:
@@ -573,6 +575,37 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def depth_leg(engine, synth, roots, ix, cols, nq):
+    """`gffx depth` (BASELINE configs[4]'s command, reference semantics: per-feature-ID region counts): k_depth_regions over
+    the pairs of an Overlap pass, HIP-event time per 1 M-region batch."""
+    tab = synth.gencode_like_block_table(roots)
+    table = engine.DepthTable(tab["n_groups"], tab["block_line_off"], tab["line_start"], tab["line_end"],
+                              tab["line_group"], tab["block_of_fid"])
+    batch = engine.QueryBatch(ix, nq)
+    batch.set_regions_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), nq, keep=cols)
+    batch.run(2, False, engine.OUT_FIDS | engine.OUT_OFFSETS, 0)
+    batch.wait()
+    pairs = batch.total_hits
+    table.accumulate(batch)  # warm
+    batch.set_profiling(True)
+    batch.reset_profile()
+    reps = 10
+    for _ in range(reps):
+        table.accumulate(batch)
+    batch.set_profiling(False)
+    ms, n = batch.kernel_ms(engine.K_DEPTH)
+    d, _, _ = table.results()
+    pair_lines = float(np.diff(tab["block_line_off"]).mean()) * pairs  # (pair, block line) tests per batch
+    us = 1e3 * ms / max(n, 1)
+    batch.close()
+    return {"kernel": "k_depth_regions", "avg_us": us, "regions_per_s": nq / (us * 1e-6),
+            "line_table": {"lines": int(tab["block_line_off"][-1]), "groups": tab["n_groups"], "blocks": len(tab["block_line_off"]) - 1},
+            "pair_line_tests_per_batch": pair_lines, "achieved_GBps": 12.0 * pair_lines / (us * 1e-6) / 1e9,
+            "depth_sum_check": int(d.sum() // (reps + 1)),
+            "note": "12 B per (pair, block line) read; reference: commands/depth.rs:121-217 (it re-parses a root's block text "
+                    "for every batch that touches it)"}
 
 
 def join_b_leg(engine, synth, roots, regions, mode):
