@@ -74,45 +74,56 @@ static int dev_upload(T **p, const std::vector<T> &v) {
 
 
 // Window index (gffx_device.hpp, join_win_kernels.hpp): per seqid ~GFFX_HIP_WIN_PER_ENTRY windows per root (a power of
-// two wide), widened until the lists total <= 8 per root; the line of window b lists, by ascending start, the roots with
-// start < (b+1) << shift and end + wmax > b << shift.  `start` / `aux` are the sorted arrays of the index.
-// `coarsen` halves the windows per root (k times): the directory is addressed with 32-bit byte offsets below 2^31, i.e. at
-// most 2^25 lines -- an index with more roots than that gets wider windows (longer lists, more of them deferred), not a failure.
+// two wide, at most 2^15 bp: the lines hold 16-bit coordinates relative to the window); the line of window b lists, by
+// ascending start, the roots with start < (b+1) << shift and end + wmax > b << shift.  `start` / `aux` are the sorted
+// arrays of the index.  A seqid whose lists would be absurdly long at 2^15 bp (> 64 entries per root) gets NO windows but
+// meta {0, 1, 31, 0}: wmax = 0, so every region on it takes the exact sweep.
+// `coarsen` (k) halves the windows per root k times and, from k = 1 on, turns a seqid that would need windows wider than
+// 2^15 bp into a sweep-only one: the directory is addressed with 32-bit byte offsets below 2^31, at most 2^25 lines.
 // Returns 1 when the directory does not fit at this coarseness.
 static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
                                  const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
                                  std::vector<uint4> &win_pos, std::vector<uint4> &spill, uint32_t coarsen, uint64_t max_lines) {
     meta.assign(n_chr + 1, make_uint4(0, 0, 0, 0));  // (+ one zero entry: a kernel may read one past the end)
     win.clear(), win_pos.clear(), spill.clear();
-    const uint64_t per_entry = (uint64_t)env_long("GFFX_HIP_WIN_PER_ENTRY", 1, 1, 16);
+    const uint64_t per_entry = (uint64_t)env_long("GFFX_HIP_WIN_PER_ENTRY", 2, 1, 16);
     const uint64_t wmax_min = (uint64_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
-    auto win_wmax = [&](uint32_t shift) {  // widest region the lines answer: 16 Ki, but between 1/4 and 4 windows
-        const uint64_t w = 1ull << shift;
-        return std::max<uint64_t>(w >> 2, std::min<uint64_t>(wmax_min, w << 2));
+    auto win_wmax = [&](uint32_t shift) {  // widest region the lines answer: 16 Ki, but between 1/4 and 4 windows,
+        const uint64_t w = 1ull << shift;  // and W + wmax + 1 <= 65535 (16-bit relative coordinates)
+        return std::min<uint64_t>(std::max<uint64_t>(w >> 2, std::min<uint64_t>(wmax_min, w << 2)), 65534 - w);
     };
+    const uint4 sweep_only = make_uint4(0, 1, 31, 0);
     std::vector<uint32_t> len, fill;
     uint64_t total_win = 0;
     for (uint32_t c = 0; c < n_chr; c++) {
         const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
         if (hi == lo) continue;
         const uint64_t max_end = std::max(h_aux[hi - 1].x, h_aux[hi - 1].y);
-        const uint64_t budget = std::max<uint64_t>((per_entry * (hi - lo)) >> coarsen, 16);
-        uint32_t shift = 0;
-        uint64_t wmax = 0, ns = 0;
-        for (;; shift++) {
-            wmax = win_wmax(shift);
-            ns = ((max_end + wmax) >> shift) + 1;
-            if (ns > budget && shift < 40) continue;
-            uint64_t total = 0;  // list entries over all windows at this width
-            for (uint32_t i = lo; i < hi && total <= 8ull * (hi - lo) + 1024; i++) {
-                const uint64_t first = (uint64_t)h_start[i] >> shift;
-                const uint64_t last = std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift);
+        const uint64_t budget = std::max<uint64_t>((per_entry * (hi - lo)) >> coarsen, std::max<uint64_t>(16 >> coarsen, 1));
+        auto windows_at = [&](uint32_t sh) { return ((max_end + win_wmax(sh)) >> sh) + 1; };
+        auto entries_at = [&](uint32_t sh, uint64_t stop) {  // list entries over all windows at this width
+            const uint64_t wm = win_wmax(sh), ns = windows_at(sh);
+            uint64_t total = 0;
+            for (uint32_t i = lo; i < hi && total <= stop; i++) {
+                const uint64_t first = (uint64_t)h_start[i] >> sh;
+                const uint64_t last = std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wm - 1) >> sh);
                 if (last >= first) total += last - first + 1;  // (an interval with end < start lists itself nowhere)
             }
-            if (total <= 8ull * (hi - lo) + 1024 || shift >= 40) break;
+            return total;
+        };
+        uint32_t shift = 0;
+        while (shift < kWinMaxShift && windows_at(shift) > budget) shift++;
+        if (windows_at(shift) > budget && coarsen) {
+            meta[c] = sweep_only;
+            continue;
         }
-        if (shift > 31) shift = 31, wmax = win_wmax(31), ns = ((max_end + wmax) >> 31) + 1;
-        wmax = std::min<uint64_t>(wmax, 0xFFFFFFFFull);
+        const uint64_t want = 8ull * (hi - lo) + 1024, most = 64ull * (hi - lo) + 1024;
+        while (shift < kWinMaxShift && entries_at(shift, want) > want) shift++;
+        if (entries_at(shift, most) > most) {
+            meta[c] = sweep_only;
+            continue;
+        }
+        const uint64_t wmax = win_wmax(shift), ns = windows_at(shift), W = 1ull << shift;
         if (total_win + ns >= max_lines) return 1;
         const uint32_t base = (uint32_t)total_win;
         total_win += ns;
@@ -122,38 +133,41 @@ static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, co
         len.assign(ns, 0);
         for (uint32_t i = lo; i < hi; i++)
             for (uint64_t b = first_w(i); b <= last_w(i) && last_w(i) >= first_w(i); b++) len[b]++;
-        // a line = 16 words {hdr, start x 5, end x 5, fid (or position) x 5}; absent entries: start = 0xFFFFFFFF
-        win.resize(4 * total_win, make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
-        win_pos.resize(4 * total_win, make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu));
+        // a line = 8 words {coordinates x 4, root_fid (or position) x 4}, join_win_kernels.hpp
+        win.resize(2 * total_win, make_uint4(kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent));
+        win_pos.resize(2 * total_win, make_uint4(kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent));
         uint32_t *ww = reinterpret_cast<uint32_t *>(win.data()), *wp = reinterpret_cast<uint32_t *>(win_pos.data());
         for (uint64_t b = 0; b < ns; b++) {
             uint32_t n = len[b];
             uint64_t off = 0;
-            if (n > kWinMaxList || (n > kWinInline && spill.size() + (n - kWinInline) >= (1ull << 24))) {
+            if (n > kWinMaxList || (n > kWinInline && spill.size() + (n - kWinInlineTail) >= (1ull << 24))) {
                 n = 255;  // dense window (or the 24-bit spill offsets are used up): exact sweep
             } else if (n > kWinInline) {
                 off = spill.size();
-                spill.resize(spill.size() + (n - kWinInline));
+                spill.resize(spill.size() + (n - kWinInlineTail));
             }
-            uint32_t *l = ww + 16 * ((size_t)base + b), *lp = wp + 16 * ((size_t)base + b);
-            l[0] = lp[0] = n | (uint32_t)(off << 8);
-            for (int j = 1; j <= 5; j++) l[j] = lp[j] = 0xFFFFFFFFu;  // starts
-            for (int j = 6; j < 16; j++) l[j] = lp[j] = 0;            // ends, fids / positions
+            uint32_t *l = ww + 8 * ((size_t)base + b), *lp = wp + 8 * ((size_t)base + b);
+            for (int j = 0; j < 4; j++) l[j] = lp[j] = kWinAbsent, l[4 + j] = lp[4 + j] = 0;
+            if (n > kWinInline) l[3] = lp[3] = kWinTailMark, l[7] = lp[7] = n | (uint32_t)(off << 8);
         }
         fill.assign(ns, 0);
         for (uint32_t i = lo; i < hi; i++) {  // ascending start: the lists come out sorted
             if (last_w(i) < first_w(i)) continue;
             for (uint64_t b = first_w(i); b <= last_w(i); b++) {
-                uint32_t *l = ww + 16 * ((size_t)base + b), *lp = wp + 16 * ((size_t)base + b);
-                if ((l[0] & 255u) == 255u) continue;
+                uint32_t *l = ww + 8 * ((size_t)base + b), *lp = wp + 8 * ((size_t)base + b);
+                const bool tail = l[3] == kWinTailMark;
+                if (tail && (l[7] & 255u) == 255u) continue;
                 const uint32_t j = fill[b]++;
-                if (j < kWinInline) {
-                    l[1 + j] = lp[1 + j] = h_start[i];
-                    l[6 + j] = lp[6 + j] = h_aux[i].x;
-                    l[11 + j] = h_aux[i].w;
-                    lp[11 + j] = i;
+                if (j < (tail ? kWinInlineTail : kWinInline)) {
+                    // relative to b W - wmax; start clamped from below, end from above (outside every region the line serves)
+                    const int64_t org = (int64_t)(b * W) - (int64_t)wmax;
+                    const int64_t rs = std::max<int64_t>((int64_t)h_start[i] - org, 0);
+                    const int64_t re = std::min<int64_t>((int64_t)h_aux[i].x - org, (int64_t)(W + wmax + 1));
+                    l[j] = lp[j] = (uint32_t)rs | ((uint32_t)re << 16);
+                    l[4 + j] = h_aux[i].w;
+                    lp[4 + j] = i;
                 } else {
-                    spill[(l[0] >> 8) + j - kWinInline] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
+                    spill[(l[7] >> 8) + j - kWinInlineTail] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
                 }
             }
         }
@@ -523,7 +537,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     ix->n_spill = spill.size();
     std::vector<uint4> win_meta, win, win_pos, win_spill;
     if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill)) return wrc;
-    ix->n_win = (uint32_t)(win.size() / 4);
+    ix->n_win = (uint32_t)(win.size() / 2);
     std::vector<uint32_t> win_filter;
     std::vector<uint2> win_fmeta;
     build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);

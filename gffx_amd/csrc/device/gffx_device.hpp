@@ -78,9 +78,12 @@ struct IndexView {
     const uint4 *slots;
     const uint4 *spill;
     const uint32_t *slot_pos;
-    // Window index (join_win_kernels.hpp): as the slot index, but one 64-byte LINE per window holding up to 5 entries
-    // as words {n | spill << 8, start x 5, end x 5, root_fid x 5}; win_pos is a copy with index positions in place of
-    // the root_fids (root-bitmap passes); win_spill[spill + j - 5] = {start, end, root_fid, position} of entry j >= 5.
+    // Window index (join_win_kernels.hpp): windows of 2^shift bp (shift <= 15), one 32-byte LINE per window holding up to
+    // 4 entries as words {start_rel | end_rel << 16 x 4, root_fid x 4}, coordinates relative to (window start - wmax) and
+    // clamped to 16 bits; win_pos is a copy with index positions in place of the root_fids (root-bitmap and triples
+    // passes).  A longer list keeps 3 entries in the line, word 3 = 0xFFFFFFFF, word 7 = n | spill << 8 (n = 255: dense
+    // window, take the sweep) and win_spill[spill + j - 3] = {start, end, root_fid, position} of entry j >= 3.
+    // A seqid with meta {0, 1, 31, 0} has no windows: every region on it takes the exact sweep.
     //   win_meta[seqid] = {first window, windows, shift, wmax}
     const uint4 *win_meta;
     const uint4 *win;

@@ -1,24 +1,29 @@
 // join_win_kernels.hpp -- Join A over the WINDOW index ("windows" strategy, AUTO's choice): regions in input order,
-// count + emit in one kernel, ONE 64-byte index line per region in the usual case.  Same result set as
+// count + emit in one kernel, ONE 32-byte index line per region in the usual case.  Same result set as
 // join_a_kernels.hpp (utils/tree.rs:110 + intersect.rs:145-161).
 //
 // What a random index access costs on gfx950 was measured with tools/gather_ubench.hip: ~2.65 CU-cycles per L2
 // request (the XCD's L2 channels are the limit: bypassing L1 with sc1 changes nothing, a quad of lanes sharing one
 // 64-byte piece is no cheaper than four lanes on four lines), + ~0.5 cycles for every further 16-byte load that hits the
-// line just requested.  So a region should touch ONE line, with everything it needs in it:
-//   every seqid is cut into windows of 2^shift bp (~1 per root); the LINE of window b lists, by ascending start, every
-//   root that can overlap a region of width <= wmax whose last base lies in the window
-//   (start < (b+1) << shift and end + wmax > b << shift), as
-//       word 0        n | spill << 8      n = list length; 255 = dense window (take the exact sweep)
-//       words 1..5    start of entries 0..4     (0xFFFFFFFF for an absent entry: never < qe)
-//       words 6..10   end   of entries 0..4
-//       words 11..15  root_fid of entries 0..4  (the "pos" copy of the table carries index positions instead: root bitmap)
-//   entries 5.. of the 3 % longer lists are 16-byte records {start, end, root_fid, position} at win_spill[spill ...].
-// Region (qs, qe) with 0 < qe - qs <= wmax: four 16-byte buffer loads of line (qe-1) >> shift, all in flight at once for the
-// thread's 4 regions (no dependent second gather), five exact tests (start < qe && end > qs, mode predicate, invert).
+// line just requested (2.8 cycles for a 32-byte line, 4.1 for a 64-byte one).  So a region should touch ONE line, as
+// short as possible, with everything it needs in it:
+//   every seqid is cut into windows of W = 2^shift bp (shift <= 15, ~2 per root); the LINE of window b lists, by ascending
+//   start, every root that can overlap a region of width <= wmax whose last base lies in the window
+//   (start < (b+1) W and end + wmax > b W).  Such a region lies inside [b W - wmax + 1, (b+1) W], so coordinates RELATIVE
+//   to b W - wmax fit 16 bits (W + wmax + 1 <= 65535), a root's start clamped from below to 0 and its end from above to
+//   W + wmax + 1: every comparison of the predicates (start < qe, end > qs, start <=/>= qs, end <=/>= qe) has the same
+//   outcome on the clamped relative values as on the absolute ones (the clamps lie outside every such region).
+//       words 0..3    start_rel | end_rel << 16 of entries 0..3   (absent entry: 0x0000FFFF -- start 0xFFFF is never < qe)
+//       words 4..7    root_fid of entries 0..3  (the "pos" copy of the table carries index positions instead: root bitmap)
+//   a list longer than 4 keeps entries 0..2 in the line; word 3 = 0xFFFFFFFF marks it and word 7 = n | spill << 8:
+//   entries 3.. are 16-byte records {start, end, root_fid, position} (absolute) at win_spill[spill ...]; n = 255: dense
+//   window (take the exact sweep).
+// Region (qs, qe) with 0 < qe - qs <= wmax: two 16-byte buffer loads of line (qe-1) >> shift, all in flight at once for the
+// thread's 4 regions (no dependent second gather), four exact tests in relative coordinates.
 // The main path is branch-free: a region the table cannot serve reads from beyond the buffer (a buffer load out of range
-// returns zeros without touching memory: an empty line).  What the line cannot answer -- the tail of a list longer than 5,
-// dense windows, regions wider than wmax, qs >= qe rows (the reference keeps them) -- is handled by the thread AFTER the main
+// returns zeros without touching memory: an empty line).  What the line cannot answer -- the tail of a list longer than 4,
+// dense windows, regions wider than wmax, qs >= qe rows (the reference keeps them), seqids whose windows would be wider than
+// 2^15 bp -- is handled by the thread AFTER the main
 // path in ONE loop over its deferred regions (list tail from win_spill, or the exact skip-link sweep of join_a_kernels.hpp),
 // so the rare code exists once, not once per unrolled region: ~1/4 of the instructions of join_slot_kernels.hpp.
 // Reservation as in the fused kernel (block scan + one returning atomicAdd per 2048-region round), but the atomic is
@@ -46,7 +51,12 @@ namespace gffx {
 constexpr int kWinThreads = GFFX_WIN_THREADS;
 constexpr uint32_t kWinChunk = kWinThreads * 4;  // regions per round: one uint4 of every region column per thread
 constexpr uint32_t kWinStage = 2 * kWinChunk;    // root_fids of a round staged in LDS so that they leave as full lines
-constexpr uint32_t kWinInline = 5;               // list entries inside the 64-byte line
+constexpr uint32_t kWinLineBytes = 32;           // one index line: two 16-byte loads
+constexpr uint32_t kWinInline = 4;               // list entries inside the line when the whole list fits
+constexpr uint32_t kWinInlineTail = 3;           // ... when it does not: word 3 / word 7 mark and locate the tail
+constexpr uint32_t kWinMaxShift = 15;            // widest window: W + wmax + 1 must fit 16 bits
+constexpr uint32_t kWinTailMark = 0xFFFFFFFFu;   // word 3 of a line whose list continues in win_spill
+constexpr uint32_t kWinAbsent = 0x0000FFFFu;     // coordinate word of an absent entry
 constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (n = 255)
 constexpr uint32_t kWinStash = 4;                // per thread: kept root_fids of list tails / sweeps wait here (LDS) for the emit
 
@@ -99,7 +109,7 @@ __device__ __forceinline__ uint32_t win_sel(const uint32_t (&a)[4], int k) {
     return (a[0] & (k == 0 ? ~0u : 0u)) | (a[1] & (k == 1 ? ~0u : 0u)) | (a[2] & (k == 2 ? ~0u : 0u)) | (a[3] & (k == 3 ? ~0u : 0u));
 }
 
-// what the 64-byte line does not hold of one DEFERRED region: the tail (entries 5..) of its list, or -- wide / empty-width
+// what the line does not hold of one DEFERRED region: the tail (entries 3..) of its list, or -- wide / empty-width
 // region, dense window -- every kept pair by the exact sweep.  f(start, end, root_fid, position); `start` is only valid when
 // the mode predicate or the caller (NEED_START) reads it.
 template <int MODE, bool INVERT, bool NEED_START, typename F>
@@ -113,12 +123,12 @@ __device__ __forceinline__ void win_rest(const IndexView &ix, bool sweep, uint32
     } else {
         const uint32_t n = hdr & 255u;
         const uint4 *sp = ix.win_spill + (hdr >> 8);
-        for (uint32_t j = kWinInline; j < n; j += 4) {  // four records in flight (99.9 % of the tails end here)
+        for (uint32_t j = kWinInlineTail; j < n; j += 4) {  // four records in flight (99 % of the tails end here)
             uint4 x[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 x[t] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-                if (j + t < n) x[t] = sp[j - kWinInline + t];
+                if (j + t < n) x[t] = sp[j - kWinInlineTail + t];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
     // the index lines: buffer loads (32-bit offsets from one scalar base: no 64-bit address arithmetic per gather;
     // an offset beyond the table reads zeros)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(OUT == 3 ? ix.win_pos : ix.win), 0, (uint32_t)(ix.n_win * 64u), 0x00020000);
+        const_cast<uint4 *>(OUT != 1 ? ix.win_pos : ix.win), 0, (uint32_t)(ix.n_win * kWinLineBytes), 0x00020000);
     auto set_bit = [&](uint32_t p) {
         if (bm_lds)
             atomicOr(&s_fids[p >> 5], 1u << (p & 31));
@@ -210,9 +220,9 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
         if (!kPrefetch && r != blockIdx.x) load_round(r, nqc, nqs, nqe);
 #pragma unroll
         for (int k = 0; k < 4; ++k) qc[k] = nqc[k], qs[k] = nqs[k], qe[k] = nqe[k];
-        // ---- one index line per region: 4 x 16 bytes, the loads of all four regions in flight together; no branches
+        // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
         uint32_t sweep = 0;  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
-        uint32_t off[4];
+        uint32_t off[4], rel[4];  // rel: absolute -> line-relative coordinate (wmax - b W)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool inb = qc[k] < ix.n_chr;
@@ -232,22 +242,21 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
                 cov = (v & ((2ull << min(b2 - a2, 31u)) - 1ull)) != 0;  // (a region the lines answer spans <= 32 cells)
             }
 #if defined(GFFX_WIN_ABL_NOGATHER)
-            off[k] = (live && fits && b < m.y && cov && qs[k] == 0xFFFFFFF0u) ? (m.x + b) * 64u : kWinNoLine;
+            off[k] = (live && fits && b < m.y && cov && qs[k] == 0xFFFFFFF0u) ? (m.x + b) * kWinLineBytes : kWinNoLine;
 #else
-            off[k] = (live && fits && b < m.y && cov) ? (m.x + b) * 64u : kWinNoLine;
+            off[k] = (live && fits && b < m.y && cov) ? (m.x + b) * kWinLineBytes : kWinNoLine;
 #endif
+            rel[k] = m.w - (b << m.z);
             sweep |= (live && !fits) ? 1u << k : 0u;
         }
-        // (the header words first: list tails can be fetched while the rest of the lines is still on its way)
-        gffx_v4u w0[4], w1[4], w2[4], w3[4];
+        gffx_v4u wc[4], wf[4];  // coordinate words, root_fids (or positions)
+        // (scheduling fences: without them the compiler issues the fourth region's loads after WAITING for the first three)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w0[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+        for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w2[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 32, 0, 0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w3[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 48, 0, 0);
+        for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (r == blockIdx.x) GFFX_STAMP(4, 1);
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; a bitmap pass also sets the bits).
         // The first kWinStash kept root_fids wait in the thread's LDS strip: the emit below then walks nothing again.
@@ -255,10 +264,10 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
         uint32_t deferred = sweep, n_rest = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            hdr[k] = w0[k].x;
-            const uint32_t n = hdr[k] & 255u;
-            deferred |= n > kWinInline ? 1u << k : 0u;
-            sweep |= n == 255u ? 1u << k : 0u;  // dense window: its line is empty
+            const bool tail = wc[k].w == kWinTailMark;  // the list continues in win_spill; word 7 says where
+            hdr[k] = tail ? wf[k].w : 0u;
+            deferred |= tail ? 1u << k : 0u;
+            sweep |= (hdr[k] & 255u) == 255u ? 1u << k : 0u;  // dense window: its line is empty
         }
 #if defined(GFFX_WIN_ABL_NODEFER)
         deferred = 0;
@@ -283,16 +292,16 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
                 tc[3] += k == 3 ? c : 0u;
             }
         }
-        // ---- five exact tests per region
+        // ---- four exact tests per region, in the line's relative coordinates
         uint32_t cnt[4], mask[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            const uint32_t rqs = qs[k] + rel[k], rqe = qe[k] + rel[k];
             uint32_t mk = 0;
-            mk |= win_test<MODE, INVERT>(w0[k].y, w1[k].z, qs[k], qe[k]) ? 1u : 0u;
-            mk |= win_test<MODE, INVERT>(w0[k].z, w1[k].w, qs[k], qe[k]) ? 2u : 0u;
-            mk |= win_test<MODE, INVERT>(w0[k].w, w2[k].x, qs[k], qe[k]) ? 4u : 0u;
-            mk |= win_test<MODE, INVERT>(w1[k].x, w2[k].y, qs[k], qe[k]) ? 8u : 0u;
-            mk |= win_test<MODE, INVERT>(w1[k].y, w2[k].z, qs[k], qe[k]) ? 16u : 0u;
+            mk |= win_test<MODE, INVERT>(wc[k].x & 0xFFFFu, wc[k].x >> 16, rqs, rqe) ? 1u : 0u;
+            mk |= win_test<MODE, INVERT>(wc[k].y & 0xFFFFu, wc[k].y >> 16, rqs, rqe) ? 2u : 0u;
+            mk |= win_test<MODE, INVERT>(wc[k].z & 0xFFFFu, wc[k].z >> 16, rqs, rqe) ? 4u : 0u;
+            mk |= win_test<MODE, INVERT>(wc[k].w & 0xFFFFu, wc[k].w >> 16, rqs, rqe) ? 8u : 0u;  // (a tail mark never passes)
             mask[k] = mk;
             cnt[k] = __popc(mk) + tc[k];
         }
@@ -311,11 +320,10 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // (the "pos" copy of the table: positions where the root_fids are)
-                if (mask[k] & 1u) set_bit(w2[k].w);
-                if (mask[k] & 2u) set_bit(w3[k].x);
-                if (mask[k] & 4u) set_bit(w3[k].y);
-                if (mask[k] & 8u) set_bit(w3[k].z);
-                if (mask[k] & 16u) set_bit(w3[k].w);
+                if (mask[k] & 1u) set_bit(wf[k].x);
+                if (mask[k] & 2u) set_bit(wf[k].y);
+                if (mask[k] & 4u) set_bit(wf[k].z);
+                if (mask[k] & 8u) set_bit(wf[k].w);
             }
             continue;
         }
@@ -359,11 +367,10 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t m = mask[k], lp = lpk[k];
-                if (m & 1u) s_fids[lp] = w2[k].w;
-                if (m & 2u) s_fids[lp + (m & 1u)] = w3[k].x;
-                if (m & 4u) s_fids[lp + __popc(m & 3u)] = w3[k].y;
-                if (m & 8u) s_fids[lp + __popc(m & 7u)] = w3[k].z;
-                if (m & 16u) s_fids[lp + __popc(m & 15u)] = w3[k].w;
+                if (m & 1u) s_fids[lp] = wf[k].x;
+                if (m & 2u) s_fids[lp + (m & 1u)] = wf[k].y;
+                if (m & 4u) s_fids[lp + __popc(m & 3u)] = wf[k].z;
+                if (m & 8u) s_fids[lp + __popc(m & 7u)] = wf[k].w;
             }
             uint32_t d = deferred, taken = 0;
             while (d) {  // list tails / sweeps, now that their places are known: from the strip, or (rare) walked again
@@ -416,15 +423,23 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
                     tr[0] = fid, tr[1] = s, tr[2] = e;
                 }
             };
+            // an inline entry: the triples pass read the "pos" table and fetches the absolute interval by position
+            auto put_inline = [&](unsigned long long o, uint32_t x) {
+                if (OUT == 2) {
+                    const uint4 a = ix.aux[x];
+                    put(o, ix.start[x], a.x, a.w);
+                } else {
+                    put(o, 0, 0, x);
+                }
+            };
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 unsigned long long o = seg + lpk[k];
                 const uint32_t m = mask[k];
-                if (m & 1u) put(o++, w0[k].y, w1[k].z, w2[k].w);
-                if (m & 2u) put(o++, w0[k].z, w1[k].w, w3[k].x);
-                if (m & 4u) put(o++, w0[k].w, w2[k].x, w3[k].y);
-                if (m & 8u) put(o++, w1[k].x, w2[k].y, w3[k].z);
-                if (m & 16u) put(o++, w1[k].y, w2[k].z, w3[k].w);
+                if (m & 1u) put_inline(o++, wf[k].x);
+                if (m & 2u) put_inline(o++, wf[k].y);
+                if (m & 4u) put_inline(o++, wf[k].z);
+                if (m & 8u) put_inline(o++, wf[k].w);
             }
             uint32_t d = deferred;
             while (d) {
