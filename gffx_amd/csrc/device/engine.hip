@@ -206,7 +206,7 @@ static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, con
     uint32_t wmax_all = 1;
     for (uint32_t c = 0; c < n_chr; c++) wmax_all = std::max(wmax_all, win_meta[c].w);
     uint32_t sh = 0;
-    while (sh < 31 && ((uint64_t)wmax_all >> sh) + 2 > 32) sh++;  // a region of width <= wmax touches <= (wmax >> sh) + 2 cells
+    while (sh < 31 && ((uint64_t)wmax_all >> sh) + 2 > 31) sh++;  // a region of width <= wmax touches <= (wmax >> sh) + 2 cells (the kernel tests 31)
     for (; sh < 32; sh++) {
         uint64_t tot = 0;
         for (uint32_t c = 0; c < n_chr; c++) tot += (cells_of(c, sh) + 31) / 32 * 32;
@@ -249,7 +249,6 @@ struct gffx_hip_index {
     uint4 *d_win_meta = nullptr, *d_win = nullptr, *d_win_pos = nullptr, *d_win_spill = nullptr;  // window index (join_win_kernels.hpp)
     uint32_t n_win = 0;
     uint32_t *d_win_filter = nullptr;
-    uint2 *d_win_fmeta = nullptr;
     uint32_t win_fwords = 0, win_fshift = 0;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
     uint32_t *d_cell_base = nullptr;
@@ -267,7 +266,7 @@ struct gffx_hip_index {
     std::vector<void **> arrays() {
         return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_slot_meta,
                 (void **)&d_slots,     (void **)&d_spill,     (void **)&d_slot_pos,   (void **)&d_win_meta,   (void **)&d_win,
-                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_win_fmeta,  (void **)&d_cell_base,
+                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_cell_base,
                 (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
     }
 
@@ -287,7 +286,6 @@ struct gffx_hip_index {
         v.win_spill = d_win_spill;
         v.n_win = n_win;
         v.win_filter = d_win_filter;
-        v.win_fmeta = d_win_fmeta;
         v.win_fwords = win_fwords;
         v.win_fshift = win_fshift;
         v.n_chr = n_chr;
@@ -541,6 +539,8 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     std::vector<uint32_t> win_filter;
     std::vector<uint2> win_fmeta;
     build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);
+    // the kernel's seqid record: {first window, windows, shift | wmax << 8, first filter bit}
+    for (uint32_t c = 0; c <= n_chr; c++) win_meta[c] = make_uint4(win_meta[c].x, win_meta[c].y, win_meta[c].z | (win_meta[c].w << 8), win_fmeta[c].x);
     ix->win_fwords = (uint32_t)win_filter.size();
 
     // Partitioned strategy: cells of 2^cshift bp (<= kMaxCells in total, >= 1 per seqid) merged into
@@ -638,7 +638,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         (rc = dev_upload(&ix->d_spill, spill)) || (rc = dev_upload(&ix->d_slot_pos, slot_pos)) ||
         (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = dev_upload(&ix->d_win, win)) ||
         (rc = dev_upload(&ix->d_win_pos, win_pos)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
-        (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_fmeta, win_fmeta)) ||
+        (rc = dev_upload(&ix->d_win_filter, win_filter)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -647,7 +647,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     }
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
     ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),      bytes(slot_meta), bytes(slots),     bytes(spill),
-                       bytes(slot_pos),  bytes(win_meta),  bytes(win),        bytes(win_pos),   bytes(win_spill), bytes(win_filter), bytes(win_fmeta),
+                       bytes(slot_pos),  bytes(win_meta),  bytes(win),        bytes(win_pos),   bytes(win_spill), bytes(win_filter),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
     GFFX_HIP_TRY(hipDeviceSynchronize());
@@ -696,7 +696,6 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_win_pos);
     (void)hipFree(ix->d_win_spill);
     (void)hipFree(ix->d_win_filter);
-    (void)hipFree(ix->d_win_fmeta);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);
     (void)hipFree(ix->d_tile_meta);
@@ -1362,7 +1361,7 @@ static void launch_win(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int ve
 
 // dynamic LDS of k_join_win: scratch + stage (root_fids or the LDS bitmap) + per-thread strips + coverage filter + seqid tables
 static uint32_t win_lds_bytes(const gffx_hip_index *ix, uint32_t stage_words, uint32_t fwords, bool ml) {
-    return 80 + 4 * stage_words + 4 * kWinStash * kWinThreads + 4 * fwords + (ml ? (ix->n_chr + 1) * 24 : 0);
+    return 80 + 4 * stage_words + 4 * kWinStash * kWinThreads + 4 * fwords + (ml ? (ix->n_chr + 1) * 16 : 0);
 }
 
 static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {

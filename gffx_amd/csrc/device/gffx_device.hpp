@@ -84,7 +84,7 @@ struct IndexView {
     // passes).  A longer list keeps 3 entries in the line, word 3 = 0xFFFFFFFF, word 7 = n | spill << 8 (n = 255: dense
     // window, take the sweep) and win_spill[spill + j - 3] = {start, end, root_fid, position} of entry j >= 3.
     // A seqid with meta {0, 1, 31, 0} has no windows: every region on it takes the exact sweep.
-    //   win_meta[seqid] = {first window, windows, shift, wmax}
+    //   win_meta[seqid] = {first window, windows, shift | wmax << 8, first filter bit}
     const uint4 *win_meta;
     const uint4 *win;
     const uint4 *win_pos;
@@ -92,9 +92,8 @@ struct IndexView {
     uint32_t n_win;
     // Coverage filter of the window index (staged in LDS by k_join_win): the genome in cells of 2^win_fshift bp, one bit per
     // cell = "some root overlaps the cell".  A region whose cells are all clear has no hit and reads no index line.
-    //   win_fmeta[seqid] = {first bit (a multiple of 32), cells}     (0 cells: no filter for the seqid)
+    //   (a seqid's first bit, a multiple of 32, is word 3 of its win_meta record)
     const uint32_t *win_filter;
-    const uint2 *win_fmeta;
     uint32_t win_fwords;  // 0 = no filter
     uint32_t win_fshift;
     uint32_t n_chr;

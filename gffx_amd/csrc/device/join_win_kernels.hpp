@@ -46,6 +46,13 @@
 // _NODEFER: list tails / sweeps are skipped, _NOATOMIC: no pair reservation); they give wrong results and are never built
 // into the library.
 
+// tools/kbench.hip: phase stamps of one round per block (-DGFFX_STAMP_ROUND=n: the block's n-th round)
+#ifndef GFFX_STAMP_ROUND
+#define GFFX_STAMP_ROUND 0
+#endif
+#define GFFX_WIN_STAMP(slot) \
+    if (r == blockIdx.x + (unsigned long long)GFFX_STAMP_ROUND * gridDim.x) GFFX_STAMP(4, slot)
+
 namespace gffx {
 
 constexpr int kWinThreads = GFFX_WIN_THREADS;
@@ -81,6 +88,18 @@ __device__ __forceinline__ void win_nt_store2(unsigned long long *p, unsigned lo
 // wave (s_waitcnt vmcnt(0)): the next round's region prefetch and this round's result stores would be waited for at every
 // barrier.  Nothing in k_join_win is handed from wave to wave through global memory, so LDS ordering is all it needs.
 __device__ __forceinline__ void win_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// inclusive prefix sum over the wave's 64 lanes in 6 DPP adds (row shifts inside the rows of 16, then the row totals
+// broadcast to the rows above) -- no LDS round trips (__shfl_up is a ds_bpermute: six dependent ones per scan)
+__device__ __forceinline__ uint32_t win_wave_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
 
 template <int MODE, bool INVERT>
 __device__ __forceinline__ bool win_test(uint32_t s, uint32_t e, uint32_t qs, uint32_t qe) {
@@ -139,6 +158,11 @@ __device__ __forceinline__ void win_rest(const IndexView &ix, bool sweep, uint32
 
 // OUT: 1 = counts (+ offsets) and root_fids when out.fids is set (bench / depth), 2 = triples (+ root_fids),
 //      3 = root bitmap only (the CLI's pass)
+// Instruction diet (the pass is VALU-issue bound as much as memory bound: ~2 cycles per region and CU each): what is the
+// same for all lanes is kept scalar -- a round's base addresses (full rounds take a path without per-thread bounds checks),
+// the wave number, the round's pair segment; the filter test is an alignbit + bfe; the wave scan is 6 DPP adds; the next
+// round's regions are loaded into the registers of this round's as soon as the tests are done (the rare re-walks read
+// their region again from memory).
 template <int MODE, bool INVERT, bool AOS, bool META_LDS, int OUT>
 __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(IndexView ix, QueryView q, unsigned long long nq,
                                                                                WinOut out, int vec_ok, uint32_t stage_words,
@@ -150,29 +174,42 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
     uint32_t *s_stash = s_fids + stage_words + kWinStash * threadIdx.x;              // this thread's kWinStash words
     uint32_t *s_filter = s_fids + stage_words + kWinStash * kWinThreads;             // fwords (a multiple of 4): coverage filter
     uint4 *s_meta = reinterpret_cast<uint4 *>(s_filter + fwords);                    // n_chr + 1 (META_LDS)
-    uint2 *s_fmeta = reinterpret_cast<uint2 *>(s_meta + ix.n_chr + 1);               // n_chr + 1 (META_LDS)
     const bool bm_lds = OUT == 3 && out.bm_words != 0;
-    constexpr bool kPrefetch = OUT != 2;  // (the triples pass keeps every line word alive: no registers to spare)
+    const uint32_t tid = threadIdx.x, t4 = 4u * tid;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    uint32_t qc[4], qs[4], qe[4];     // this round's 4 consecutive regions of the thread
-    uint32_t nqc[4], nqs[4], nqe[4];  // the next round's: loaded while this round reserves and emits
-    auto load_round = [&](unsigned long long r, uint32_t (&qc)[4], uint32_t (&qs)[4], uint32_t (&qe)[4]) {
-        const unsigned long long i0 = r * kWinChunk + 4ull * threadIdx.x;
-        if (vec_ok && i0 + 4 <= nq) {
-            if (AOS) {
-                const uint32_t *p = q.aos + 3ull * i0;
-                const uint4 a = win_nt_load4(p), b = win_nt_load4(p + 4), c = win_nt_load4(p + 8);
-                qc[0] = a.x, qs[0] = a.y, qe[0] = a.z;
-                qc[1] = a.w, qs[1] = b.x, qe[1] = b.y;
-                qc[2] = b.z, qs[2] = b.w, qe[2] = c.x;
-                qc[3] = c.y, qs[3] = c.z, qe[3] = c.w;
-            } else {
-                const uint4 c = win_nt_load4(q.chr + i0), s = win_nt_load4(q.start + i0), e = win_nt_load4(q.end + i0);
-                qc[0] = c.x, qc[1] = c.y, qc[2] = c.z, qc[3] = c.w;
-                qs[0] = s.x, qs[1] = s.y, qs[2] = s.z, qs[3] = s.w;
-                qe[0] = e.x, qe[1] = e.y, qe[2] = e.z, qe[3] = e.w;
-            }
+    uint32_t qc[4], qs[4], qe[4];  // the round's 4 consecutive regions of the thread
+    // A round's regions: buffer loads from a descriptor of exactly the round's rows (scalar work), 16 bytes per thread and
+    // column at a fixed offset -- straight-line code: no per-thread bounds, and a round beyond the batch (the prefetch of the
+    // last rounds) reads zeros without touching memory.  Only the batch's last, partial round and unaligned columns take
+    // the element-wise path afterwards (uniform branch).
+    auto round_rsrc = [&](const uint32_t *col, unsigned long long first, uint32_t words) {
+        const unsigned long long left = first < nq ? nq - first : 0ull;
+        const uint32_t rows = (uint32_t)min(left, (unsigned long long)kWinChunk);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(col + words * first), 0, rows * 4u * words, 0x00020000);
+    };
+    auto load_round = [&](unsigned long long r) {
+        const unsigned long long base = r * kWinChunk;  // (uniform)
+        constexpr int kNt = 2;                           // (streamed once)
+        if (AOS) {
+            const __amdgpu_buffer_rsrc_t ra = round_rsrc(q.aos, base, 3);
+            const gffx_v4u a = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4, 0, kNt),
+                           b = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 16, 0, kNt),
+                           c = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 32, 0, kNt);
+            qc[0] = a.x, qs[0] = a.y, qe[0] = a.z;
+            qc[1] = a.w, qs[1] = b.x, qe[1] = b.y;
+            qc[2] = b.z, qs[2] = b.w, qe[2] = c.x;
+            qc[3] = c.y, qs[3] = c.z, qe[3] = c.w;
         } else {
+            const gffx_v4u c = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.chr, base, 1), 4u * t4, 0, kNt),
+                           s = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.start, base, 1), 4u * t4, 0, kNt),
+                           e = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.end, base, 1), 4u * t4, 0, kNt);
+            qc[0] = c.x, qc[1] = c.y, qc[2] = c.z, qc[3] = c.w;
+            qs[0] = s.x, qs[1] = s.y, qs[2] = s.z, qs[3] = s.w;
+            qe[0] = e.x, qe[1] = e.y, qe[2] = e.z, qe[3] = e.w;
+        }
+        if (base < nq && !(vec_ok && base + kWinChunk <= nq)) {
+            const unsigned long long i0 = base + t4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 qc[k] = 0xFFFFFFFFu;  // "no region"
@@ -182,24 +219,21 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
         }
     };
     const unsigned long long n_rounds = (nq + kWinChunk - 1) / kWinChunk;
-    if (blockIdx.x < n_rounds) load_round(blockIdx.x, nqc, nqs, nqe);  // in flight while the seqid table is staged
-    const uint4 *cm;  // seqid -> {first window, windows, shift, wmax}; entry n_chr is all zero ("no windows")
-    const uint2 *fmeta;  // seqid -> {first filter bit, cells}
+    if (blockIdx.x < n_rounds) load_round(blockIdx.x);  // in flight while the seqid table is staged
+    // seqid -> {first window, windows, shift | wmax << 8, first filter bit}; entry n_chr is all zero ("no windows")
+    const uint4 *cm;
     if (META_LDS) {
-        for (uint32_t i = threadIdx.x; i <= ix.n_chr; i += kWinThreads) s_meta[i] = ix.win_meta[i], s_fmeta[i] = ix.win_fmeta[i];
+        for (uint32_t i = tid; i <= ix.n_chr; i += kWinThreads) s_meta[i] = ix.win_meta[i];
         cm = s_meta;
-        fmeta = s_fmeta;
     } else {
         cm = ix.win_meta;
-        fmeta = ix.win_fmeta;
     }
-    for (uint32_t x = threadIdx.x; x < fwords / 4; x += kWinThreads)  // the coverage filter: 16 bytes per thread and trip
+    for (uint32_t x = tid; x < fwords / 4; x += kWinThreads)  // the coverage filter: 16 bytes per thread and trip
         reinterpret_cast<uint4 *>(s_filter)[x] = reinterpret_cast<const uint4 *>(ix.win_filter)[x];
     if (bm_lds)
-        for (uint32_t x = threadIdx.x; x < out.bm_words; x += kWinThreads) s_fids[x] = 0;
+        for (uint32_t x = tid; x < out.bm_words; x += kWinThreads) s_fids[x] = 0;
     win_barrier();
-    if (blockIdx.x == 0 && threadIdx.x == 0) *out.pair_cursor_next = 0ull;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && tid == 0) *out.pair_cursor_next = 0ull;
     // the index lines: buffer loads (32-bit offsets from one scalar base: no 64-bit address arithmetic per gather;
     // an offset beyond the table reads zeros)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -214,39 +248,39 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
     uint32_t n_slow = 0;
     unsigned long long kept_total = 0;  // OUT == 3: this thread's kept pairs over all rounds
 
-    GFFX_STAMP(4, 0);
     for (unsigned long long r = blockIdx.x; r < n_rounds; r += gridDim.x) {
-        const unsigned long long i0 = r * kWinChunk + 4ull * threadIdx.x;  // this thread's 4 consecutive regions
-        if (!kPrefetch && r != blockIdx.x) load_round(r, nqc, nqs, nqe);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) qc[k] = nqc[k], qs[k] = nqs[k], qe[k] = nqe[k];
+        const unsigned long long base = r * kWinChunk;  // (uniform) first region of the round
+        const bool full = base + kWinChunk <= nq;       // (uniform) every thread has its 4 regions
+        const unsigned long long i0 = base + t4;        // this thread's 4 consecutive regions
+        const uint32_t n_mine = full ? 4u : (i0 < nq ? (uint32_t)min(nq - i0, 4ull) : 0u);
+        GFFX_WIN_STAMP(0);
         // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
         uint32_t sweep = 0;  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
         uint32_t off[4], rel[4];  // rel: absolute -> line-relative coordinate (wmax - b W)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool inb = qc[k] < ix.n_chr;
-            bad |= (!inb && i0 + k < nq) ? 1u : 0u;
-            const uint32_t ci = inb ? qc[k] : ix.n_chr;
-            const uint4 m = cm[ci];
+            bad |= (!inb && (uint32_t)k < n_mine) ? 1u : 0u;
+            const uint4 m = cm[min(qc[k], ix.n_chr)];
+            const uint32_t shift = m.z & 31u, wmax = m.z >> 8;
             const bool live = m.y != 0 && !(MODE == GFFX_MODE_OVERLAP && INVERT);  // (invert ^ true: nothing is ever kept)
-            const bool fits = qe[k] > qs[k] && qe[k] - qs[k] <= m.w;
-            const uint32_t b = (qe[k] - 1) >> m.z;  // (beyond the last window nothing can reach the region)
+            const bool fits = qe[k] > qs[k] && qe[k] - qs[k] <= wmax;
+            const uint32_t b = (qe[k] - 1) >> shift;  // (beyond the last window nothing can reach the region)
             bool cov = true;
             if (fwords) {  // kernel-uniform: is any cell the region touches covered by a root?  (clear = no hit, exactly)
-                const uint2 fm = fmeta[ci];
-                const uint32_t last = fm.y - 1;  // (cells beyond the seqid's last: clamped, i.e. conservative)
-                const uint32_t a2 = min(qs[k] >> ix.win_fshift, last), b2 = min((qe[k] - 1) >> ix.win_fshift, last);
-                const uint32_t bit = fm.x + a2, w = min(bit >> 5, fwords - 2);
-                const unsigned long long v = (((unsigned long long)s_filter[w + 1] << 32) | s_filter[w]) >> (bit & 31);
-                cov = (v & ((2ull << min(b2 - a2, 31u)) - 1ull)) != 0;  // (a region the lines answer spans <= 32 cells)
+                // (no clamp to the seqid's cells: past them a region that fits has no hit whatever the bits there say, and
+                //  one that straddles the end only sees more set bits)
+                const uint32_t a2 = qs[k] >> ix.win_fshift, d = min(((qe[k] - 1) >> ix.win_fshift) - a2, 30u);
+                const uint32_t bit = m.w + a2, w = min(bit >> 5, fwords - 2);
+                const uint32_t v = __builtin_amdgcn_alignbit(s_filter[w + 1], s_filter[w], bit);  // 32 bits from `bit` on
+                cov = __builtin_amdgcn_ubfe(v, 0, d + 1) != 0;  // (a region the lines answer spans <= 31 cells)
             }
 #if defined(GFFX_WIN_ABL_NOGATHER)
             off[k] = (live && fits && b < m.y && cov && qs[k] == 0xFFFFFFF0u) ? (m.x + b) * kWinLineBytes : kWinNoLine;
 #else
             off[k] = (live && fits && b < m.y && cov) ? (m.x + b) * kWinLineBytes : kWinNoLine;
 #endif
-            rel[k] = m.w - (b << m.z);
+            rel[k] = wmax - (b << shift);
             sweep |= (live && !fits) ? 1u << k : 0u;
         }
         gffx_v4u wc[4], wf[4];  // coordinate words, root_fids (or positions)
@@ -257,7 +291,7 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
 #pragma unroll
         for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (r == blockIdx.x) GFFX_STAMP(4, 1);
+        GFFX_WIN_STAMP(1);
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; a bitmap pass also sets the bits).
         // The first kWinStash kept root_fids wait in the thread's LDS strip: the emit below then walks nothing again.
         uint32_t hdr[4], tc[4] = {0, 0, 0, 0};
@@ -305,18 +339,19 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
             mask[k] = mk;
             cnt[k] = __popc(mk) + tc[k];
         }
-        if (kPrefetch && r + gridDim.x < n_rounds) load_round(r + gridDim.x, nqc, nqs, nqe);
-        if (r == blockIdx.x) GFFX_STAMP(4, 2);
+        // the regions are done with: the next round's take their registers (a re-walk below reads its region again)
+        load_round(r + gridDim.x);
+        GFFX_WIN_STAMP(2);
         const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         if (OUT == 3) {
             // ---- root bitmap: no reservation; counts out, bits set
             kept_total += mine;
-            if (i0 + 4 <= nq) {
-                win_nt_store4(out.counts + i0, cnt[0], cnt[1], cnt[2], cnt[3]);
+            if (full) {
+                win_nt_store4(out.counts + base + t4, cnt[0], cnt[1], cnt[2], cnt[3]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (i0 + k < nq) out.counts[i0 + k] = cnt[k];
+                    if ((uint32_t)k < n_mine) out.counts[i0 + k] = cnt[k];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {  // (the "pos" copy of the table: positions where the root_fids are)
@@ -328,12 +363,7 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
             continue;
         }
         // ---- reserve the round's pair segment: block scan + ONE returning atomicAdd, issued before the staging
-        uint32_t inc = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += v;
-        }
+        const uint32_t inc = win_wave_scan(mine);
         win_barrier();  // s_scratch / s_base / the stage of the previous round are no longer read
         if (lane == 63) s_scratch[wave] = inc;
         win_barrier();
@@ -344,25 +374,33 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
             if (x < wave) wbase += v;
             btotal += v;
         }
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        btotal = __builtin_amdgcn_readfirstlane(btotal);
         unsigned long long got = 0;
 #if defined(GFFX_WIN_ABL_NOATOMIC)
         got = r * 1400ull;
 #else
-        if (threadIdx.x == 0 && btotal) got = atomicAdd(out.pair_cursor, (unsigned long long)btotal);
+        if (tid == 0 && btotal) got = atomicAdd(out.pair_cursor, (unsigned long long)btotal);
 #endif
         const uint32_t lp0 = wbase + inc - mine;  // this thread's first pair inside the round's segment
         const uint32_t lpk[4] = {lp0, lp0 + cnt[0], lp0 + cnt[0] + cnt[1], lp0 + cnt[0] + cnt[1] + cnt[2]};
-        if (r == blockIdx.x) GFFX_STAMP(4, 3);
+        GFFX_WIN_STAMP(3);
         // ---- counts (input order, 16 bytes per thread); root_fids of the round into the LDS stage by final position
-        if (i0 + 4 <= nq) {
-            win_nt_store4(out.counts + i0, cnt[0], cnt[1], cnt[2], cnt[3]);
+        if (full) {
+            win_nt_store4(out.counts + base + t4, cnt[0], cnt[1], cnt[2], cnt[3]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (i0 + k < nq) out.counts[i0 + k] = cnt[k];
+                if ((uint32_t)k < n_mine) out.counts[i0 + k] = cnt[k];
         }
         const bool want_fids = out.fids != nullptr;
         const bool staged = OUT == 1 && want_fids && btotal <= stage_words;  // block-uniform
+        // a deferred region's kept pairs once more, in list / sweep order (its registers are gone: read it again)
+        auto rewalk = [&](int k, auto &&f) {
+            uint32_t c_, s_, e_;
+            load_query<AOS>(q, i0 + k, c_, s_, e_);
+            win_rest<MODE, INVERT, OUT == 2>(ix, sweep >> k & 1u, c_, s_, e_, win_sel(hdr, k), f);
+        };
         if (OUT == 1 && staged) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -380,30 +418,32 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
                 if (n_rest <= kWinStash) {
                     for (uint32_t t = win_sel(tc, k); t; --t) s_fids[e++] = s_stash[taken++];
                 } else {
-                    win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
-                                                  [&](uint32_t, uint32_t, uint32_t fid, uint32_t) { s_fids[e++] = fid; });
+                    rewalk(k, [&](uint32_t, uint32_t, uint32_t fid, uint32_t) { s_fids[e++] = fid; });
                 }
             }
         }
-        if (threadIdx.x == 0) s_base[0] = got;
+        if (tid == 0) s_base[0] = got;
         win_barrier();
-        const unsigned long long seg = s_base[0];
+        unsigned long long seg = s_base[0];  // (uniform)
+        seg = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(seg >> 32)) << 32) |
+              __builtin_amdgcn_readfirstlane((uint32_t)seg);
+        GFFX_WIN_STAMP(4);
         {  // offsets: 16 bytes per thread and array
             const unsigned long long pos = seg + lp0;
-            if (i0 + 4 <= nq) {
+            if (full) {
                 if (out.offsets) {
-                    win_nt_store2(out.offsets + i0, pos, pos + cnt[0]);
-                    win_nt_store2(out.offsets + i0 + 2, pos + cnt[0] + cnt[1], pos + cnt[0] + cnt[1] + cnt[2]);
+                    win_nt_store2(out.offsets + base + t4, pos, pos + cnt[0]);
+                    win_nt_store2(out.offsets + base + t4 + 2, pos + cnt[0] + cnt[1], pos + cnt[0] + cnt[1] + cnt[2]);
                 }
                 if (out.offsets32) {
-                    const uint32_t p32 = (uint32_t)pos;
-                    win_nt_store4(out.offsets32 + i0, p32, p32 + cnt[0], p32 + cnt[0] + cnt[1], p32 + cnt[0] + cnt[1] + cnt[2]);
+                    const uint32_t p32 = (uint32_t)seg + lp0;
+                    win_nt_store4(out.offsets32 + base + t4, p32, p32 + cnt[0], p32 + cnt[0] + cnt[1], p32 + cnt[0] + cnt[1] + cnt[2]);
                 }
             } else {
                 unsigned long long o = pos;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (i0 + k < nq) {
+                    if ((uint32_t)k < n_mine) {
                         if (out.offsets) out.offsets[i0 + k] = o;
                         if (out.offsets32) out.offsets32[i0 + k] = (uint32_t)o;
                     }
@@ -412,8 +452,13 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
             }
         }
         if (staged) {  // the round's root_fids leave as full lines
-            for (uint32_t x = threadIdx.x; x < btotal; x += kWinThreads)
-                if (seg + x < out.capacity) GFFX_NT_STORE(s_fids[x], out.fids + seg + x);
+            uint32_t *dst = out.fids + seg;  // (uniform)
+            if (seg + btotal <= out.capacity) {
+                for (uint32_t x = tid; x < btotal; x += kWinThreads) GFFX_NT_STORE(s_fids[x], dst + x);
+            } else {
+                for (uint32_t x = tid; x < btotal; x += kWinThreads)
+                    if (seg + x < out.capacity) dst[x] = s_fids[x];
+            }
         } else if (OUT == 2 || want_fids) {  // triples, or more root_fids than the stage holds: straight to global memory
             auto put = [&](unsigned long long o, uint32_t s, uint32_t e, uint32_t fid) {
                 if (o >= out.capacity) return;
@@ -446,24 +491,23 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
                 const int k = __ffs(d) - 1;
                 d &= d - 1;
                 unsigned long long o = seg + win_sel(lpk, k) + __popc(win_sel(mask, k));
-                win_rest<MODE, INVERT, OUT == 2>(ix, sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
-                                                 [&](uint32_t s, uint32_t e, uint32_t fid, uint32_t) { put(o++, s, e, fid); });
+                rewalk(k, [&](uint32_t s, uint32_t e, uint32_t fid, uint32_t) { put(o++, s, e, fid); });
             }
         }
-        if (r == blockIdx.x) GFFX_STAMP(4, 4);
+        GFFX_WIN_STAMP(5);
     }
     if (bad) atomicOr(out.err, 1u);
     if (OUT == 3) {
         // kept pairs of the pass: one atomic per block; the LDS bitmap goes to this block's slab
         const unsigned long long t = wave_reduce_add(kept_total);
         win_barrier();
-        if (threadIdx.x == 0) s_base[0] = 0;
+        if (tid == 0) s_base[0] = 0;
         win_barrier();
         if (lane == 0 && t) atomicAdd(s_base, t);
         win_barrier();
-        if (threadIdx.x == 0 && s_base[0]) atomicAdd(out.pair_cursor, s_base[0]);
+        if (tid == 0 && s_base[0]) atomicAdd(out.pair_cursor, s_base[0]);
         if (bm_lds)
-            for (uint32_t x = threadIdx.x; x < out.bm_words; x += kWinThreads) out.slabs[(size_t)blockIdx.x * out.bm_words + x] = s_fids[x];
+            for (uint32_t x = tid; x < out.bm_words; x += kWinThreads) out.slabs[(size_t)blockIdx.x * out.bm_words + x] = s_fids[x];
     }
     // how many regions took the exact sweep (the host moves a batch that is mostly such regions to the sweep kernel)
 #pragma unroll
