@@ -200,8 +200,8 @@ static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, con
     auto cells_of = [&](uint32_t c, uint32_t sh) -> uint64_t {
         const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
         if (hi == lo) return 0;
-        const uint64_t max_end = std::max(h_aux[hi - 1].x, h_aux[hi - 1].y);
-        return (max_end >> sh) + 1;
+        const uint64_t max_pos = std::max<uint64_t>(std::max(h_aux[hi - 1].x, h_aux[hi - 1].y), h_start[hi - 1]);  // (starts ascend)
+        return (max_pos >> sh) + 1;
     };
     uint32_t wmax_all = 1;
     for (uint32_t c = 0; c < n_chr; c++) wmax_all = std::max(wmax_all, win_meta[c].w);
@@ -222,8 +222,10 @@ static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, con
         fmeta[c] = make_uint2(base, (uint32_t)nc);
         bits.resize(bits.size() + (nc + 31) / 32, 0u);
         for (uint32_t i = lo; i < hi; i++) {
-            if (h_aux[i].x <= h_start[i]) continue;  // an empty or reversed interval overlaps nothing (start < qe && end > qs with qs < qe)
-            const uint64_t a = (uint64_t)h_start[i] >> sh, b = ((uint64_t)h_aux[i].x - 1) >> sh;
+            // a region keeps the root only if start < qe && end > qs: it then holds a base of [start, end) -- or, for an EMPTY
+            // interval (end == start: the reference keeps it when qs < start < qe), the base `start`.  (end < start is outside
+            // the domain: the reference's IntervalTree::build never terminates on one, tree.rs:48-50.)
+            const uint64_t a = (uint64_t)h_start[i] >> sh, b = h_aux[i].x > h_start[i] ? ((uint64_t)h_aux[i].x - 1) >> sh : a;
             for (uint64_t x = a; x <= b && x < nc; x++) bits[(base + x) >> 5] |= 1u << ((base + x) & 31);
         }
     }

@@ -50,8 +50,13 @@
 #ifndef GFFX_STAMP_ROUND
 #define GFFX_STAMP_ROUND 0
 #endif
+#if defined(GFFX_STAMP_TIMELINE)  // slot k = start of the block's k-th round
+#define GFFX_WIN_STAMP(slot) \
+    if ((slot) == 0 && (r - blockIdx.x) / gridDim.x < 16) GFFX_STAMP(4, (int)((r - blockIdx.x) / gridDim.x))
+#else
 #define GFFX_WIN_STAMP(slot) \
     if (r == blockIdx.x + (unsigned long long)GFFX_STAMP_ROUND * gridDim.x) GFFX_STAMP(4, slot)
+#endif
 
 namespace gffx {
 

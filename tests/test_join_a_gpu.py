@@ -174,6 +174,19 @@ def test_edge_inputs(strategy):
                          [0, 0xFFFFFFFE, 0xFFFFFFFF], [0, 0x7FFFFFFF, 0x80000000]], np.uint32)
     for mode in OverlapMode:
         _check(roots3, regions3, mode, False, strategy=strategy)
+    # empty intervals (end == start) are kept whenever qs < start < qe (tree.rs:110 has no other condition) -- the coverage
+    # filter of the window index must not hide them.  (end < start is outside the domain: IntervalTree::build, tree.rs:48-50,
+    # never terminates on such an interval.)
+    roots4 = {"chr_offsets": np.array([0, 5], np.uint32),
+              "start": np.array([100, 5000, 70_000, 900_000, 2_000_000], np.uint32),
+              "end": np.array([100, 5000, 70_010, 900_000, 2_000_000], np.uint32),
+              "fid": np.array([1, 2, 4, 5, 6], np.uint32)}
+    regions4 = np.array([[0, 0, 200], [0, 100, 101], [0, 99, 100], [0, 99, 101], [0, 4980, 5010], [0, 4995, 5001], [0, 5000, 5001],
+                         [0, 890_000, 910_000], [0, 899_500, 900_001], [0, 1_999_999, 2_000_001], [0, 2_000_000, 2_000_001],
+                         [0, 0, 3_000_000]], np.uint32)
+    for mode in OverlapMode:
+        for inv in (False, True):
+            _check(roots4, regions4, mode, inv, strategy=strategy)
     # empty index
     ix0 = engine.TreeIndexData.from_roots([0], [], [], [])
     assert engine.query_features(ix0, np.zeros((0, 3), np.uint32)).shape == (0, 3)

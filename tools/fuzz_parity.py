@@ -39,6 +39,8 @@ for it in range(iters):
     f = rng.permutation(R).astype(np.uint32) * 3 + 1
     if R and rng.random() < 0.3:
         f[rng.integers(0, R, max(1, R // 10))] = f[0]  # duplicate fids
+    if R and rng.random() < 0.3:  # empty intervals (end == start): the reference keeps them when qs < start < qe
+        e = np.where(rng.random(R) < 0.05, s, e)  # (end < start is outside the domain: IntervalTree::build recurses forever, tree.rs:48-50)
     s, e = s.astype(np.uint32), e.astype(np.uint32)
     nq = int(rng.choice([1, 5, 63, 64, 65, 2047, 2048, 2049, 6000]))
     qc = rng.integers(0, n_chr, nq).astype(np.uint32)

@@ -133,7 +133,12 @@ int main(int argc, char **argv) {
         printf("%-34s %8.2f us per %u slots = %6.2f us per 1M slots, table %.2f MB, cycles/slot/CU @2.4GHz %.2f\n", name, us, m,
                us * 1e6 / m, n_slots * bytes_per_slot / 1e6, us * 2400.0 * 256 / m);
     };
-    for (int grid : {512, 1024}) {
+    std::vector<int> grids = {512, 1024};
+    if (argc > 3) {
+        grids.clear();
+        for (int a = 3; a < argc; a++) grids.push_back(atoi(argv[a]));
+    }
+    for (int grid : grids) {
         printf("grid %d x 512 threads\n", grid);
         run("A lane/slot 64B (4 x 16B)", [&] { hipLaunchKernelGGL(k_lane<4>, dim3(grid), dim3(512), 0, 0, d_tab, d_idx, m, d_out); }, 64);
         run("B lane/slot 32B (2 x 16B)", [&] { hipLaunchKernelGGL(k_lane<2>, dim3(grid), dim3(512), 0, 0, d_tab, d_idx, m, d_out); }, 32);

@@ -1,0 +1,109 @@
+// win_index_check.hip -- host-only check of the window index (engine.hip::build_window_index_at + the line format of
+// join_win_kernels.hpp): random indexes (seqids of 1 Kbp .. 4 Gbp, nested / empty / long roots), random regions that the
+// lines answer, all three modes.  Restates the kernel's use of a line on the CPU -- window of the region's last base,
+// 16-bit relative coordinates, the four inline tests, the list tail from win_spill -- and compares the kept root_fids with
+// a brute-force scan of the roots.  Runs without a GPU (tests/test_window_index_cpu.py); built by the Makefile of
+// gffx_amd/csrc into gffx_amd/bin/win_index_check.     usage: win_index_check [seed]
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include <set>
+#include "../gffx_amd/csrc/device/engine.hip"
+static bool keep(int mode, uint32_t s, uint32_t e, uint32_t qs, uint32_t qe) {
+    if (!(s < qe && e > qs)) return false;
+    if (mode == 0) return s >= qs && e <= qe;
+    if (mode == 1) return s <= qs && e >= qe;
+    return true;
+}
+int main(int argc, char **argv) {
+    uint64_t seed = argc > 1 ? atoll(argv[1]) : 1;
+    std::mt19937_64 rng(seed);
+    for (int iter = 0; iter < 200; iter++) {
+        uint32_t n_chr = 1 + rng() % 4;
+        std::vector<uint32_t> co(1, 0), start;
+        std::vector<uint4> aux;
+        for (uint32_t c = 0; c < n_chr; c++) {
+            uint32_t n = rng() % 300;
+            uint32_t span = (rng() % 3 == 0) ? 4000000000u : (1u << (10 + rng() % 18));
+            std::vector<std::pair<uint32_t, uint32_t>> g;
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t s = rng() % span;
+                uint32_t len = (rng() % 4 == 0) ? rng() % (span / 2 + 1) : rng() % 50000;
+                uint32_t e = (uint32_t)std::min<uint64_t>((uint64_t)s + len, 0xFFFFFFFFull);
+                if (rng() % 50 == 0) e = s;  // empty
+                g.push_back({s, e});
+            }
+            std::sort(g.begin(), g.end());
+            uint32_t pm = 0;
+            for (auto &x : g) {
+                pm = std::max(pm, x.second);
+                start.push_back(x.first);
+                aux.push_back(make_uint4(x.second, pm, 0, (uint32_t)start.size() * 7 + 3));
+            }
+            co.push_back((uint32_t)start.size());
+        }
+        std::vector<uint4> meta, win, wpos, spill;
+        int rc = gffx::build_window_index_at(n_chr, co.data(), start, aux, meta, win, wpos, spill, iter % 3 == 0 ? 1 : 0, 1 << 25);
+        if (rc) { printf("rc %d\n", rc); return 1; }
+        const uint32_t *ww = (const uint32_t *)win.data();
+        // the coverage filter as the kernel tests it: 32 bits from the region's first cell on, no clamp to the seqid's cells
+        std::vector<uint32_t> fbits;
+        std::vector<uint2> fmeta;
+        uint32_t fshift = 0;
+        gffx::build_window_filter(n_chr, co.data(), start, aux, meta, fbits, fmeta, fshift);
+        const uint32_t fwords = (uint32_t)fbits.size();
+        auto covered = [&](uint32_t c, uint32_t qs, uint32_t qe) {
+            if (fwords < 4) return true;
+            const uint32_t a2 = qs >> fshift, d = std::min<uint32_t>(((qe - 1) >> fshift) - a2, 30u);
+            const uint32_t bit = fmeta[c].x + a2, w = std::min<uint32_t>(bit >> 5, fwords - 2);
+            const uint64_t pair = ((uint64_t)fbits[w + 1] << 32) | fbits[w];
+            const uint32_t v = (uint32_t)(pair >> (bit & 31));
+            return (v & (uint32_t)((1ull << (d + 1)) - 1)) != 0;
+        };
+        for (int qi = 0; qi < 3000; qi++) {
+            uint32_t c = rng() % n_chr;
+            if (co[c + 1] == co[c]) continue;
+            uint32_t pick = co[c] + rng() % (co[c + 1] - co[c]);
+            uint32_t qs = (uint32_t)std::max<int64_t>(0, (int64_t)start[pick] + (int64_t)(rng() % 40000) - 20000);
+            uint32_t w = rng() % 3 == 0 ? rng() % 17000 : rng() % 2000;
+            uint32_t qe = (uint32_t)std::min<uint64_t>((uint64_t)qs + w, 0xFFFFFFFFull);
+            uint4 m = meta[c];
+            bool fits = qe > qs && qe - qs <= m.w;
+            if (!fits || m.y == 0) continue;
+            uint32_t b = (qe - 1) >> m.z;
+            for (int mode = 0; mode < 3; mode++) {
+                std::multiset<uint32_t> want, got;
+                for (uint32_t i = co[c]; i < co[c + 1]; i++)
+                    if (keep(mode, start[i], aux[i].x, qs, qe)) want.insert(aux[i].w);
+                bool skip = false;
+                if (!covered(c, qs, qe)) {
+                    if (!want.empty()) {
+                        printf("FILTER MISMATCH iter %d chr %u q [%u,%u) mode %d: %zu kept pairs behind a clear filter\n", iter, c, qs, qe, mode, want.size());
+                        return 1;
+                    }
+                    continue;
+                }
+                if (b < m.y) {
+                    const uint32_t *l = ww + 8 * ((size_t)m.x + b);
+                    uint32_t rel = m.w - (b << m.z);
+                    uint32_t rqs = qs + rel, rqe = qe + rel;
+                    for (int j = 0; j < 4; j++)
+                        if (keep(mode, l[j] & 0xFFFF, l[j] >> 16, rqs, rqe)) got.insert(l[4 + j]);
+                    if (l[3] == 0xFFFFFFFFu) {
+                        uint32_t n = l[7] & 255, sp = l[7] >> 8;
+                        if (n == 255) skip = true;
+                        else for (uint32_t j = 3; j < n; j++) { uint4 x = spill[sp + j - 3]; if (keep(mode, x.x, x.y, qs, qe)) got.insert(x.z); }
+                    }
+                }
+                if (!skip && want != got) {
+                    printf("MISMATCH iter %d chr %u q [%u,%u) mode %d want %zu got %zu shift %u wmax %u b %u\n", iter, c, qs, qe, mode, want.size(), got.size(), m.z, m.w, b);
+                    return 1;
+                }
+            }
+        }
+    }
+    printf("ok\n");
+    return 0;
+}
