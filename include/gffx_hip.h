@@ -99,11 +99,13 @@ enum gffx_strategy {
     GFFX_STRATEGY_FUSED = 3,  /* queries in input order, ONE kernel: interleaved gathers from the L2-resident
                                  index, count + emit per block round; counts / offsets in input order, pair
                                  segments in the order rounds reserve them (offsets explicit) */
-    GFFX_STRATEGY_WINDOWS = 5, /* AUTO's choice.  One 64-byte index LINE per region: the line of the genome window the
-                                 region ends in lists up to 5 candidate roots {start, end, root_fid}; longer lists, dense
-                                 windows, wide and empty-width regions are deferred to an LDS work list inside the round
-                                 and served exactly (list walk / skip-link sweep).  Root-bitmap passes set bits in an
-                                 LDS-private bitmap.  Output contract as FUSED. */
+    GFFX_STRATEGY_WINDOWS = 5, /* AUTO's choice.  One 32-byte index LINE per region: the line of the genome window
+                                 (<= 2^15 bp) the region ends in lists up to 4 candidate roots {start, end as 16-bit
+                                 window-relative coordinates, root_fid}; longer lists, dense windows, wide and
+                                 empty-width regions are deferred inside the round and served exactly (list tail /
+                                 skip-link sweep).  Root-bitmap passes set bits in an LDS-private bitmap.  Output
+                                 contract as FUSED.  Domain: end >= start for every root (an interval with end < start
+                                 never leaves the reference's IntervalTree::build, utils/tree.rs:48-50). */
     GFFX_STRATEGY_SLOTS = 4   /* as FUSED, but over the slot index: one 32-byte gather per region answers the
                                  usual case (precomputed candidate list of the window the region ends in);
                                  wide regions and dense windows take the exact sweep in their lane */
