@@ -195,7 +195,10 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
     };
     auto load_round = [&](unsigned long long r) {
         const unsigned long long base = r * kWinChunk;  // (uniform)
-        constexpr int kNt = 2;                           // (streamed once)
+#ifndef GFFX_WIN_REGION_AUX
+#define GFFX_WIN_REGION_AUX 2  // nt: streamed once
+#endif
+        constexpr int kNt = GFFX_WIN_REGION_AUX;
         if (AOS) {
             const __amdgpu_buffer_rsrc_t ra = round_rsrc(q.aos, base, 3);
             const gffx_v4u a = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4, 0, kNt),
