@@ -11,7 +11,8 @@ The JSON line carries, next to the contract's fields:
   value / ms_per_step   K steps issued round-robin to --inflight (default 2) QueryBatch objects (own HIP stream and result
                         buffers each, the same resident regions): the launch ramp / drain of one pass overlaps the next.
                         The pipeline is warmed (2 x inflight passes, synced) immediately before the timed region.
-  serial                the same K steps with ONE batch: strictly serial passes (what profiles/*kernel_stats* shows)
+  serial                the same K steps with ONE batch: strictly serial passes (what profiles/*kernel_stats* shows); the engine
+                        takes 1024-thread blocks for such a pass (roofline inside), 512-thread blocks while two batches are in flight
   roofline              dominant kernel, HIP-event durations of serial back-to-back launches on the engine's stream
   roofline_10m          the same for a 10 M-region batch (seed 1002)
   cli_pass              the pass the CLI runs (root bitmap only) at 1 M and 10 M regions, next to the root_fid pass
@@ -176,8 +177,19 @@ class Pass:
             bb.wait()
             assert bb.total_hits == pairs, (bb.total_hits, pairs)
 
-    def kernel_us(self, n_prof):
-        """HIP-event durations per kernel: serial launches back to back on batch 0's stream."""
+    def kernel_us(self, n_prof, block_threads=None):
+        """HIP-event durations per kernel: serial launches back to back on batch 0's stream.  block_threads: the block width
+        the measured passes must use (the engine takes 1024-thread blocks for a 0.5-2.5 M-region pass that runs ALONE and
+        512-thread blocks while another batch is in flight: serial passes measured for a timed region with two batches in
+        flight have to be told which kernel that region ran)."""
+        if block_threads:
+            os.environ["GFFX_HIP_WIN_THREADS"] = str(block_threads)
+        try:
+            return self._kernel_us(n_prof)
+        finally:
+            os.environ.pop("GFFX_HIP_WIN_THREADS", None)
+
+    def _kernel_us(self, n_prof):
         b0 = self.batches[0]
         b0.set_profiling(True)
         b0.reset_profile()
@@ -192,6 +204,7 @@ class Pass:
                 kern[name] = {"avg_us": 1e3 * ms / n, "launches_per_step": n / n_prof}
         # the same passes between ONE event pair: launch-to-launch average without the ~3 us an event pair per launch adds
         self.pass_us_one_event_pair = b0.timed_runs(self.mode, False, self.flags, self.strategy, max(n_prof, 20))
+        self.block_threads = b0.block_threads
         return kern
 
     def close(self):
@@ -199,7 +212,7 @@ class Pass:
             bb.close()
 
 
-def roofline_obj(kern, nq, pairs, out_b, note, traffic=None, one_pair_us=None):
+def roofline_obj(kern, nq, pairs, out_b, note, traffic=None, one_pair_us=None, block_threads=None):
     h_bar = pairs / max(nq, 1)
     bytes_per_query = 12.0 + 4.0 + out_b * h_bar  # regions in, count out, pairs out
     per_launch_us = sum(k["avg_us"] * k["launches_per_step"] for k in kern.values())
@@ -211,10 +224,11 @@ def roofline_obj(kern, nq, pairs, out_b, note, traffic=None, one_pair_us=None):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "frac_of_copy_ceiling": achieved / 6300.0, "traffic": traffic, "dominant_kernel": dominant,
             "regions_per_launch": nq, "pairs_per_region": h_bar, "algorithmic_bytes_per_pass": bytes_per_query * nq,
-            "pass_kernel_us": pass_us, "pass_kernel_us_event_pair_per_launch": per_launch_us, "kernels": kern, "note": note}
+            "pass_kernel_us": pass_us, "pass_kernel_us_event_pair_per_launch": per_launch_us, "kernels": kern,
+            "block_threads": block_threads, "note": note}
 
 
-def measure_traffic(args):
+def measure_traffic(args, block_threads=None):
     """roofline.traffic, measured by THIS run: HBM bytes per launch of the dominant kernel from the L2's fabric counters,
     collected as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --kernel-trace --pmc`
     passes (never combined with other trace domains), per-dispatch averages, FETCH_SIZE doubled (gfx950 reports half the
@@ -233,7 +247,10 @@ def measure_traffic(args):
                    os.path.join(ROOT, "bench.py"), "--traffic-child", "--mode", args.mode, "--strategy", args.strategy,
                    "--out", args.out, "--offsets", args.offsets, "--queries-per-gpu", str(args.queries_per_gpu)]
             try:
-                r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+                env = dict(os.environ, TMPDIR="/tmp")
+                if block_threads:  # (the child's serial passes must run the kernel variant of the timed region)
+                    env["GFFX_HIP_WIN_THREADS"] = str(block_threads)
+                r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=240)
             except Exception as exc:
                 return {"error": repr(exc)[:200]}
             db = None
@@ -461,7 +478,10 @@ def main():
 
     result = None
     if rank == 0:
-        kern = run.kernel_us(max(5, min(args.steps, 30)))
+        # the kernel variant the timed region ran (the last pass of batch 0 in it): the serial passes measured for `roofline`
+        # and the PMC child are forced to the same block width
+        timed_threads = run.batches[0].block_threads or None
+        kern = run.kernel_us(max(5, min(args.steps, 30)), timed_threads)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -473,7 +493,7 @@ def main():
             except Exception:
                 traffic = None
         if world == 1 and not args.no_traffic and not args.quick:
-            live = measure_traffic(args)
+            live = measure_traffic(args, timed_threads)
             if live and "error" not in live:
                 traffic = live
             elif live and traffic is not None:
@@ -515,8 +535,9 @@ def main():
             "roofline": roofline_obj(kern, nq, pairs, out_b,
                                      "achieved = (12 B region + 4 B count + 4 B x pairs/region) x regions / summed HIP-event "
                                      "duration of a pass: serial launches back to back between one pair of HIP events on the engine's "
-                                     "stream (rank 0); kernels{} = the same with an event pair per launch", traffic,
-                                     run.pass_us_one_event_pair),
+                                     "stream (rank 0), forced to the block width of the timed region's launches (block_threads); "
+                                     "kernels{} = the same with an event pair per launch", traffic,
+                                     run.pass_us_one_event_pair, timed_threads),
         }
     if world == 1:
         # ---- strictly serial passes (one batch, one stream): what the committed rocprofv3 kernel stats show
@@ -524,8 +545,12 @@ def main():
         ser.size_and_warm(1)
         el = ser.timed(args.steps, barrier, torch)
         ser.check(pairs)
+        ks = ser.kernel_us(max(5, min(args.steps, 30)))  # (nothing forced: what the engine picks for a pass that runs alone)
         result["serial"] = {"ms_per_step": 1e3 * el / args.steps, "value": nq * args.steps / el, "unit": "queries/s",
-                            "batches_in_flight": 1}
+                            "batches_in_flight": 1,
+                            "roofline": roofline_obj(ks, nq, pairs, out_b, "one batch, passes strictly one after the other: the engine "
+                                                     "takes 1024-thread blocks (one per CU) for a 0.5-2.5 M-region pass that runs alone",
+                                                     None, ser.pass_us_one_event_pair, ser.block_threads)}
         ser.close()
     if world == 1 and not args.quick:
         # ---- the pass the CLI runs: root bitmap only (commands/intersect.rs:598-615 needs the unique roots, nothing else)
@@ -543,7 +568,7 @@ def main():
         pairs10 = p10.size_and_warm(1)
         k10 = p10.kernel_us(10)
         result["roofline_10m"] = roofline_obj(k10, len(reg10), pairs10, out_b, "10 M synthetic BED regions (seed 1002), same pass",
-                                              None, p10.pass_us_one_event_pair)
+                                              None, p10.pass_us_one_event_pair, p10.block_threads)
         p10.close()
         bm10 = Pass(engine, ix, cols10, len(reg10), 1, mode, engine.OUT_ROOT_BITMAP, strategy)
         bm10.size_and_warm(1)

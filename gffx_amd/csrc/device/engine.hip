@@ -9,6 +9,7 @@
 // plan: resident in every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and
 // the results out.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -237,6 +238,14 @@ static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, con
 
 using namespace gffx;
 
+// a counter that a copied index (gffx_hip_index_clone) does not inherit
+struct BusyCount {
+    std::atomic<int> v{0};
+    BusyCount() = default;
+    BusyCount(const BusyCount &) : v(0) {}
+    BusyCount &operator=(const BusyCount &) { return *this; }
+};
+
 struct gffx_hip_index {
     int device = 0;
     uint32_t n_chr = 0;
@@ -261,6 +270,7 @@ struct gffx_hip_index {
     uint4 *d_tile_desc = nullptr;  // per tile two uint4 (tile_join_kernels.hpp)
     uint32_t n_cells = 0, n_tiles = 0, cshift = 0;
     bool partition_ok = false;  // the tile plan exists (n_chr <= kMaxCells)
+    mutable BusyCount busy_batches;  // batches of this index with passes that nobody synchronised with yet
     std::vector<uint32_t> h_sorted_fids;
     std::vector<size_t> array_bytes;  // of arrays(), in order (gffx_hip_index_clone)
 
@@ -348,6 +358,9 @@ struct gffx_hip_batch {
     uint32_t n_blocks = 0;
     uint64_t chunk = 0;
     bool ran = false, waited = false;
+    uint32_t win_threads = 0;  // block width of the last windows pair pass (gffx_hip_batch_block_threads)
+    bool others_busy = false;  // at the last run: another batch of the index had passes in flight (co-resident kernels)
+    bool busy = false;  // counted in ix->busy_batches: a pass was enqueued since the last stream synchronisation
     uint64_t total = 0;
     // profiling
     bool profiling = false;
@@ -749,6 +762,7 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ix->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->busy) b->ix->busy_batches.v.fetch_sub(1, std::memory_order_relaxed);
     for (auto &p : b->pending) {
         (void)hipEventDestroy(p.a);
         (void)hipEventDestroy(p.b);
@@ -1337,33 +1351,47 @@ static int run_slots(gffx_hip_batch *b) {
 
 constexpr uint32_t kWinMaxLds = 80 * 1024;  // two blocks per CU share 160 KB
 
-template <int MODE, bool INV, bool AOS, bool ML, int OUT>
+template <int MODE, bool INV, bool AOS, bool ML, int OUT, int T>
 static void launch_win3(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, uint32_t stage_words, uint32_t fwords,
                         uint32_t lds) {
     static bool big_lds = false;  // beyond the default 64 KB of dynamic LDS a kernel has to opt in, once
     if (lds > 64 * 1024 && !big_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_win<MODE, INV, AOS, ML, OUT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinMaxLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_win<MODE, INV, AOS, ML, OUT, T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T == 1024 ? 2 * kWinMaxLds : kWinMaxLds));
         big_lds = true;
     }
-    hipLaunchKernelGGL((k_join_win<MODE, INV, AOS, ML, OUT>), dim3(grid), dim3(kWinThreads), lds, b->stream, b->ix->view(), b->q,
+    hipLaunchKernelGGL((k_join_win<MODE, INV, AOS, ML, OUT, T>), dim3(grid), dim3(T), lds, b->stream, b->ix->view(), b->q,
                        (unsigned long long)b->nq, o, vec_ok, stage_words, fwords);
 }
 
 template <int MODE, bool INV, bool AOS, bool ML>
-static void launch_win(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, int out_kind, uint32_t stage_words,
-                       uint32_t fwords, uint32_t lds) {
+static void launch_win(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, int out_kind, uint32_t threads,
+                       uint32_t stage_words, uint32_t fwords, uint32_t lds) {
     if (out_kind == 3)
-        launch_win3<MODE, INV, AOS, ML, 3>(b, grid, o, vec_ok, stage_words, fwords, lds);
+        launch_win3<MODE, INV, AOS, ML, 3, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
     else if (out_kind == 2)
-        launch_win3<MODE, INV, AOS, ML, 2>(b, grid, o, vec_ok, stage_words, fwords, lds);
+        launch_win3<MODE, INV, AOS, ML, 2, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
+    else if (threads == 1024)
+        launch_win3<MODE, INV, AOS, ML, 1, 1024>(b, grid, o, vec_ok, stage_words, fwords, lds);
     else
-        launch_win3<MODE, INV, AOS, ML, 1>(b, grid, o, vec_ok, stage_words, fwords, lds);
+        launch_win3<MODE, INV, AOS, ML, 1, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
 }
 
 // dynamic LDS of k_join_win: scratch + stage (root_fids or the LDS bitmap) + per-thread strips + coverage filter + seqid tables
-static uint32_t win_lds_bytes(const gffx_hip_index *ix, uint32_t stage_words, uint32_t fwords, bool ml) {
-    return 80 + 4 * stage_words + 4 * kWinStash * kWinThreads + 4 * fwords + (ml ? (ix->n_chr + 1) * 16 : 0);
+static uint32_t win_lds_bytes(const gffx_hip_index *ix, uint32_t stage_words, uint32_t fwords, bool ml, uint32_t threads = kWinThreads) {
+    return 80 + 4 * stage_words + 4 * kWinStash * threads + 4 * fwords + (ml ? (ix->n_chr + 1) * 16 : 0);
+}
+
+// Threads per block of a pair pass (OUT == 1).  1024 = one block per CU, rounds of 4096 regions: half the same-address
+// reservation atomics and barriers per region, but a single phase group per CU -- measured (kbench, us per pass, 512 / 1024
+// threads): 0.4 M regions 10.6 / 11.4, 0.6 M 13.6 / 12.2, 1 M 16.4 / 14.2, 2 M 28.0 / 26.5, 3 M 35.1 / 38.0, 10 M 91 / 105.
+// GFFX_HIP_WIN_THREADS forces one.
+// Two such kernels cannot share a CU (16 waves x 128 VGPRs fill it): with two batches in flight the 512-thread kernel gives
+// 9.35 us per 1 M-region step, the 1024-thread one 12.0 -- so the wide block is for a pass that runs ALONE on the device.
+static uint32_t win_pair_threads(const gffx_hip_batch *b) {
+    const long forced = env_long("GFFX_HIP_WIN_THREADS", 0, 0, 1024);
+    if (forced == 512 || forced == 1024) return (uint32_t)forced;
+    return (!b->others_busy && b->nq >= 500000 && b->nq <= 2500000) ? 1024u : (uint32_t)kWinThreads;
 }
 
 static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
@@ -1382,7 +1410,10 @@ static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
         b->fused_phase ^= 1;
     }
     const bool ml = meta_bytes(ix) <= kMetaLdsBytes;
-    const uint64_t rounds = (b->nq + kWinChunk - 1) / kWinChunk;
+    const uint32_t threads = out_kind == 1 ? win_pair_threads(b) : (uint32_t)kWinThreads;
+    if (out_kind == 1) b->win_threads = threads;
+    const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
+    const uint32_t max_lds = threads == 1024 ? 2 * kWinMaxLds : kWinMaxLds;  // (one block per CU may take the whole LDS)
     uint32_t grid, stage_words;
     if (out_kind == 3) {
         const uint32_t words = (ix->n_roots + 31) / 32;
@@ -1414,19 +1445,19 @@ static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
         if (o.triples) cap = std::min(cap, b->cap_triples);
         o.capacity = cap;
         grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", 1024, 1, 65535));
-        stage_words = out_kind == 1 ? kWinStage : 0;
+        stage_words = out_kind == 1 ? 8 * threads : 0;
     }
     // the coverage filter rides along when everything still fits half a CU's LDS
     uint32_t fwords = (ix->win_fwords + 3) / 4 * 4;
-    if (fwords < 4 || win_lds_bytes(ix, stage_words, fwords, ml) > kWinMaxLds) fwords = 0;
-    const uint32_t lds = win_lds_bytes(ix, stage_words, fwords, ml);
+    if (fwords < 4 || win_lds_bytes(ix, stage_words, fwords, ml, threads) > max_lds) fwords = 0;
+    const uint32_t lds = win_lds_bytes(ix, stage_words, fwords, ml, threads);
     const bool aos = b->q.aos != nullptr;
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int vec_ok = aos ? al(b->q.aos) : (al(b->q.chr) && al(b->q.start) && al(b->q.end));
     ProfEvent pe;
     prof_begin(b, GFFX_K_WINDOWS, &pe);
 #define GFFX_CASE2(M, I, A, L) \
-    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) launch_win<M, I, A, L>(b, grid, o, vec_ok, out_kind, stage_words, fwords, lds);
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) launch_win<M, I, A, L>(b, grid, o, vec_ok, out_kind, threads, stage_words, fwords, lds);
 #define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
     GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
     GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
@@ -1502,6 +1533,11 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     b->ran = true;
     b->waited = false;
     b->total = 0;
+    b->others_busy = b->ix->busy_batches.v.load(std::memory_order_relaxed) - (b->busy ? 1 : 0) > 0;
+    if (!b->busy) {
+        b->busy = true;
+        b->ix->busy_batches.v.fetch_add(1, std::memory_order_relaxed);
+    }
     const uint64_t nq = b->nq;
     int rc;
     if (b->flags & GFFX_OUT_OFFSETS) {
@@ -1564,6 +1600,10 @@ extern "C" int gffx_hip_batch_sync(gffx_hip_batch *b) {
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_sync: batch is NULL");
     GFFX_HIP_TRY(hipSetDevice(b->ix->device));
     GFFX_HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->busy) {
+        b->busy = false;
+        b->ix->busy_batches.v.fetch_sub(1, std::memory_order_relaxed);
+    }
     prof_resolve(b);
     return GFFX_OK;
 }
@@ -1772,6 +1812,8 @@ extern "C" int gffx_hip_batch_kernel_ms(gffx_hip_batch *b, int kernel_id, double
 }
 // n passes back to back on the batch's stream between ONE pair of HIP events: the average launch-to-launch duration without
 // the cost of an event pair per launch (which adds ~3 us to a ~18 us kernel)
+extern "C" uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *b) { return b ? b->win_threads : 0; }
+
 extern "C" int gffx_hip_batch_timed_runs(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags, int strategy, uint32_t n,
                                          double *total_ms) {
     if (!b || !total_ms || !n) return fail(GFFX_E_INVALID, "gffx_hip_batch_timed_runs: bad argument");

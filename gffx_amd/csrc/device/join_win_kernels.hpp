@@ -61,8 +61,7 @@
 namespace gffx {
 
 constexpr int kWinThreads = GFFX_WIN_THREADS;
-constexpr uint32_t kWinChunk = kWinThreads * 4;  // regions per round: one uint4 of every region column per thread
-constexpr uint32_t kWinStage = 2 * kWinChunk;    // root_fids of a round staged in LDS so that they leave as full lines
+// (regions per round = 4 x threads: one uint4 of every region column per thread; the LDS stage holds 8 x threads root_fids)
 constexpr uint32_t kWinLineBytes = 32;           // one index line: two 16-byte loads
 constexpr uint32_t kWinInline = 4;               // list entries inside the line when the whole list fits
 constexpr uint32_t kWinInlineTail = 3;           // ... when it does not: word 3 / word 7 mark and locate the tail
@@ -163,21 +162,24 @@ __device__ __forceinline__ void win_rest(const IndexView &ix, bool sweep, uint32
 
 // OUT: 1 = counts (+ offsets) and root_fids when out.fids is set (bench / depth), 2 = triples (+ root_fids),
 //      3 = root bitmap only (the CLI's pass)
+// T:   threads per block, 512 (two blocks per CU) or 1024 (one: rounds of 4096 regions, half the reservation atomics -- faster
+//      while the batch is one or two rounds per CU, i.e. around 1-3 M regions; the engine picks, OUT == 1 only)
 // Instruction diet (the pass is VALU-issue bound as much as memory bound: ~2 cycles per region and CU each): what is the
 // same for all lanes is kept scalar -- a round's base addresses (full rounds take a path without per-thread bounds checks),
 // the wave number, the round's pair segment; the filter test is an alignbit + bfe; the wave scan is 6 DPP adds; the next
 // round's regions are loaded into the registers of this round's as soon as the tests are done (the rare re-walks read
 // their region again from memory).
-template <int MODE, bool INVERT, bool AOS, bool META_LDS, int OUT>
-__global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(IndexView ix, QueryView q, unsigned long long nq,
+template <int MODE, bool INVERT, bool AOS, bool META_LDS, int OUT, int T>
+__global__ __launch_bounds__(T, T == 1024 ? 4 : GFFX_WIN_MIN_WAVES) void k_join_win(IndexView ix, QueryView q, unsigned long long nq,
                                                                                WinOut out, int vec_ok, uint32_t stage_words,
                                                                                uint32_t fwords) {
+    constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *s_scratch = reinterpret_cast<uint32_t *>(smem);                       // wave totals
     unsigned long long *s_base = reinterpret_cast<unsigned long long *>(smem + 64);  // 8 B
     uint32_t *s_fids = reinterpret_cast<uint32_t *>(smem + 80);                      // stage_words: root_fid stage / LDS bitmap
     uint32_t *s_stash = s_fids + stage_words + kWinStash * threadIdx.x;              // this thread's kWinStash words
-    uint32_t *s_filter = s_fids + stage_words + kWinStash * kWinThreads;             // fwords (a multiple of 4): coverage filter
+    uint32_t *s_filter = s_fids + stage_words + kWinStash * T;             // fwords (a multiple of 4): coverage filter
     uint4 *s_meta = reinterpret_cast<uint4 *>(s_filter + fwords);                    // n_chr + 1 (META_LDS)
     const bool bm_lds = OUT == 3 && out.bm_words != 0;
     const uint32_t tid = threadIdx.x, t4 = 4u * tid;
@@ -190,11 +192,11 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
     // the element-wise path afterwards (uniform branch).
     auto round_rsrc = [&](const uint32_t *col, unsigned long long first, uint32_t words) {
         const unsigned long long left = first < nq ? nq - first : 0ull;
-        const uint32_t rows = (uint32_t)min(left, (unsigned long long)kWinChunk);
+        const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(col + words * first), 0, rows * 4u * words, 0x00020000);
     };
     auto load_round = [&](unsigned long long r) {
-        const unsigned long long base = r * kWinChunk;  // (uniform)
+        const unsigned long long base = r * kChunk;  // (uniform)
 #ifndef GFFX_WIN_REGION_AUX
 #define GFFX_WIN_REGION_AUX 2  // nt: streamed once
 #endif
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
             qs[0] = s.x, qs[1] = s.y, qs[2] = s.z, qs[3] = s.w;
             qe[0] = e.x, qe[1] = e.y, qe[2] = e.z, qe[3] = e.w;
         }
-        if (base < nq && !(vec_ok && base + kWinChunk <= nq)) {
+        if (base < nq && !(vec_ok && base + kChunk <= nq)) {
             const unsigned long long i0 = base + t4;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -226,20 +228,20 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
             }
         }
     };
-    const unsigned long long n_rounds = (nq + kWinChunk - 1) / kWinChunk;
+    const unsigned long long n_rounds = (nq + kChunk - 1) / kChunk;
     if (blockIdx.x < n_rounds) load_round(blockIdx.x);  // in flight while the seqid table is staged
     // seqid -> {first window, windows, shift | wmax << 8, first filter bit}; entry n_chr is all zero ("no windows")
     const uint4 *cm;
     if (META_LDS) {
-        for (uint32_t i = tid; i <= ix.n_chr; i += kWinThreads) s_meta[i] = ix.win_meta[i];
+        for (uint32_t i = tid; i <= ix.n_chr; i += T) s_meta[i] = ix.win_meta[i];
         cm = s_meta;
     } else {
         cm = ix.win_meta;
     }
-    for (uint32_t x = tid; x < fwords / 4; x += kWinThreads)  // the coverage filter: 16 bytes per thread and trip
+    for (uint32_t x = tid; x < fwords / 4; x += T)  // the coverage filter: 16 bytes per thread and trip
         reinterpret_cast<uint4 *>(s_filter)[x] = reinterpret_cast<const uint4 *>(ix.win_filter)[x];
     if (bm_lds)
-        for (uint32_t x = tid; x < out.bm_words; x += kWinThreads) s_fids[x] = 0;
+        for (uint32_t x = tid; x < out.bm_words; x += T) s_fids[x] = 0;
     win_barrier();
     if (blockIdx.x == 0 && tid == 0) *out.pair_cursor_next = 0ull;
     // the index lines: buffer loads (32-bit offsets from one scalar base: no 64-bit address arithmetic per gather;
@@ -257,8 +259,8 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
     unsigned long long kept_total = 0;  // OUT == 3: this thread's kept pairs over all rounds
 
     for (unsigned long long r = blockIdx.x; r < n_rounds; r += gridDim.x) {
-        const unsigned long long base = r * kWinChunk;  // (uniform) first region of the round
-        const bool full = base + kWinChunk <= nq;       // (uniform) every thread has its 4 regions
+        const unsigned long long base = r * kChunk;  // (uniform) first region of the round
+        const bool full = base + kChunk <= nq;       // (uniform) every thread has its 4 regions
         const unsigned long long i0 = base + t4;        // this thread's 4 consecutive regions
         const uint32_t n_mine = full ? 4u : (i0 < nq ? (uint32_t)min(nq - i0, 4ull) : 0u);
         GFFX_WIN_STAMP(0);
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
         win_barrier();
         uint32_t wbase = 0, btotal = 0;
 #pragma unroll
-        for (int x = 0; x < kWinThreads / 64; ++x) {
+        for (int x = 0; x < T / 64; ++x) {
             const uint32_t v = s_scratch[x];
             if (x < wave) wbase += v;
             btotal += v;
@@ -462,9 +464,9 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
         if (staged) {  // the round's root_fids leave as full lines
             uint32_t *dst = out.fids + seg;  // (uniform)
             if (seg + btotal <= out.capacity) {
-                for (uint32_t x = tid; x < btotal; x += kWinThreads) GFFX_NT_STORE(s_fids[x], dst + x);
+                for (uint32_t x = tid; x < btotal; x += T) GFFX_NT_STORE(s_fids[x], dst + x);
             } else {
-                for (uint32_t x = tid; x < btotal; x += kWinThreads)
+                for (uint32_t x = tid; x < btotal; x += T)
                     if (seg + x < out.capacity) dst[x] = s_fids[x];
             }
         } else if (OUT == 2 || want_fids) {  // triples, or more root_fids than the stage holds: straight to global memory
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(kWinThreads, GFFX_WIN_MIN_WAVES) void k_join_win(In
         win_barrier();
         if (tid == 0 && s_base[0]) atomicAdd(out.pair_cursor, s_base[0]);
         if (bm_lds)
-            for (uint32_t x = tid; x < out.bm_words; x += kWinThreads) out.slabs[(size_t)blockIdx.x * out.bm_words + x] = s_fids[x];
+            for (uint32_t x = tid; x < out.bm_words; x += T) out.slabs[(size_t)blockIdx.x * out.bm_words + x] = s_fids[x];
     }
     // how many regions took the exact sweep (the host moves a batch that is mostly such regions to the sweep kernel)
 #pragma unroll

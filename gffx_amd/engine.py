@@ -155,6 +155,11 @@ class QueryBatch:
         check(lib().gffx_hip_batch_timed_runs(self._h, int(mode), int(bool(invert)), int(out_flags), int(strategy), int(n), C.byref(ms)))
         return 1e3 * ms.value / n
 
+    @property
+    def block_threads(self) -> int:
+        """threads per block of the last windows-strategy pair pass (512 or 1024; 0: none ran)"""
+        return int(lib().gffx_hip_batch_block_threads(self._h))
+
     def wait(self) -> None:
         check(lib().gffx_hip_batch_wait(self._h))
 

@@ -243,6 +243,11 @@ int gffx_hip_batch_reset_profile(gffx_hip_batch *);
  * launch-to-launch duration of a pass without an event pair per launch */
 int gffx_hip_batch_timed_runs(gffx_hip_batch *, int mode, int invert, uint32_t out_flags, int strategy, uint32_t n,
                               double *total_ms);
+/* Threads per block of the last windows-strategy pair pass of this batch (512 or 1024; 0: none ran).  The engine takes
+ * 1024-thread blocks (one per CU, rounds of 4096 regions) for a batch of 0.5-2.5 M regions while NO other batch of the
+ * index has passes in flight, 512-thread blocks (two per CU: kernels of two batches share the CUs) otherwise;
+ * GFFX_HIP_WIN_THREADS=512|1024 in the environment forces one. */
+uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *);
 
 /* One-shot drop-in for query_features (commands/intersect.rs:105-111): host regions in, host
  * triples out (malloc'd by the library, release with gffx_hip_free_host). */

@@ -67,6 +67,7 @@ extern "C" {
     pub fn gffx_hip_batch_run(b: *mut gffx_hip_batch, mode: c_int, invert: c_int, out_flags: u32, strategy: c_int) -> c_int;
     pub fn gffx_hip_batch_wait(b: *mut gffx_hip_batch) -> c_int;
     pub fn gffx_hip_batch_sync(b: *mut gffx_hip_batch) -> c_int;
+    pub fn gffx_hip_batch_block_threads(b: *const gffx_hip_batch) -> u32;
     // streaming BED ingestion through pinned staging buffers, several GPUs
     pub fn gffx_hip_regions_create(device: c_int, capacity_rows: u64, chunk_rows: u64, keep_all: c_int, out: *mut *mut gffx_hip_regions) -> c_int;
     pub fn gffx_hip_regions_destroy(r: *mut gffx_hip_regions);

@@ -598,3 +598,57 @@ def test_window_directory_is_coarsened_not_refused(monkeypatch):
     regions = synth.synth_bed(30_000, seed=32, edge_frac=0.02, roots=roots)
     for mode in OverlapMode:
         _check(roots, regions, mode, False, strategy=engine.STRATEGY_WINDOWS)
+
+
+def test_wide_block_variant(monkeypatch):
+    """k_join_win<..., T = 1024> (one block per CU, rounds of 4096 regions): forced through GFFX_HIP_WIN_THREADS on the small
+    and ragged cases, then the engine's own choice -- a 0.5-2.5 M-region pass that runs ALONE takes it, a pass launched while
+    another batch of the index is in flight takes 512-thread blocks -- with full parity of the 1 M-region pass either way."""
+    monkeypatch.setenv("GFFX_HIP_WIN_THREADS", "1024")
+    roots = synth.gencode_like_roots(300, seed=3, chroms=synth.SMALL2)
+    for n in (1, 3, 4095, 4096, 4097, 8200, 20000):
+        regions = synth.synth_bed(n, seed=11 + n, chroms=synth.SMALL2, width=(10, 200000), edge_frac=0.2, roots=roots)
+        for mode in OverlapMode:
+            for inv in (False, True):
+                _check(roots, regions, mode, inv, soa=bool(n & 1), strategy=engine.STRATEGY_WINDOWS)
+    big = synth.gencode_like_roots(63000, seed=42)
+    regions = synth.synth_bed(100_003, seed=1001, edge_frac=0.001, roots=big)
+    for mode in OverlapMode:
+        _check(big, regions, mode, False, strategy=engine.STRATEGY_WINDOWS)
+    monkeypatch.delenv("GFFX_HIP_WIN_THREADS")
+    # the engine's choice
+    co, s, e, f = big["chr_offsets"], big["start"], big["end"], big["fid"]
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    regions = synth.synth_bed(1_000_000, seed=1001)
+    want_t, want_c = oix.query_features(regions, 2, False)
+    flags = engine.OUT_FIDS | engine.OUT_OFFSETS32
+    a, other = engine.QueryBatch(ix, len(regions)), engine.QueryBatch(ix, len(regions))
+    for b in (a, other):
+        b.set_regions(regions)
+
+    def equal_to_oracle(b):
+        b.wait()
+        off, fids = b.offsets32().astype(np.int64), b.fids()
+        assert b.total_hits == len(want_t) and np.array_equal(b.counts(), want_c)
+        wc = want_c.astype(np.int64)
+        qid = np.repeat(np.arange(len(regions), dtype=np.int64), wc)
+        within = np.arange(len(qid), dtype=np.int64) - np.repeat(np.cumsum(wc) - wc, wc)
+        got = (qid << 32) | fids[off[qid] + within].astype(np.int64)
+        by_chr = np.argsort(regions[:, 0], kind="stable")
+        want = (np.repeat(by_chr, wc[by_chr]).astype(np.int64) << 32) | want_t[:, 0].astype(np.int64)
+        assert np.array_equal(np.sort(got), np.sort(want))
+
+    a.run(OverlapMode.Overlap, False, flags)  # alone
+    assert a.block_threads == 1024
+    equal_to_oracle(a)
+    other.run(OverlapMode.Overlap, False, flags)  # (not synchronised with: in flight as far as the engine knows)
+    a.run(OverlapMode.Overlap, False, flags)
+    assert a.block_threads == 512
+    equal_to_oracle(a)
+    equal_to_oracle(other)
+    a.run(OverlapMode.Overlap, False, flags)  # alone again
+    assert a.block_threads == 1024
+    a.wait()
+    a.close()
+    other.close()

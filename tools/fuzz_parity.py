@@ -75,6 +75,10 @@ for it in range(iters):
                 flag_sets = [engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS]
                 if strat == engine.STRATEGY_WINDOWS:  # u32 offsets next to the u64 ones; the CLI's bitmap-only pass
                     flag_sets += [engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_ROOT_BITMAP]
+                    if it % 3 == 0:  # the 1024-thread variant of the pair pass (the engine takes it for 0.5-2.5 M regions alone)
+                        os.environ["GFFX_HIP_WIN_THREADS"] = "1024"
+                    else:
+                        os.environ.pop("GFFX_HIP_WIN_THREADS", None)
                 for flags in flag_sets:
                     b.run(mode, inv, flags, strat)
                     b.wait()
