@@ -182,12 +182,16 @@ class Pass:
         the measured passes must use (the engine takes 1024-thread blocks for a 0.5-2.5 M-region pass that runs ALONE and
         512-thread blocks while another batch is in flight: serial passes measured for a timed region with two batches in
         flight have to be told which kernel that region ran)."""
+        before = os.environ.get("GFFX_HIP_WIN_THREADS")
         if block_threads:
             os.environ["GFFX_HIP_WIN_THREADS"] = str(block_threads)
         try:
             return self._kernel_us(n_prof)
         finally:
-            os.environ.pop("GFFX_HIP_WIN_THREADS", None)
+            if before is None:
+                os.environ.pop("GFFX_HIP_WIN_THREADS", None)
+            else:
+                os.environ["GFFX_HIP_WIN_THREADS"] = before
 
     def _kernel_us(self, n_prof):
         b0 = self.batches[0]
