@@ -417,7 +417,7 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
                 pos = z;
                 pc.last = pos >= text.size();
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return queue.size() < 16 || stop; });  // (up to 1 GB of text ahead while the devices come up)
+                cv.wait(lk, [&] { return queue.size() < 48 || stop; });  // (up to 3 GB of text = ~1.5 GB of parsed rows ahead while the devices come up: HIP start-up + index upload take ~0.25 s, in which 64 host threads parse ~1.3 GB)
                 if (stop) return;
                 queue.push_back(std::move(pc));
                 cv.notify_all();
@@ -453,6 +453,10 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
         for (size_t e = 0; e < d; ++e) distinct &= dev[d] != dev[e];
     if (D > 1 && !distinct)
         std::fprintf(stderr, "[WARN] --gpus %zu with %d visible device(s): logical devices share GPUs (no RCCL exchange)\n", D, visible);
+    if (verbose) {  // (only to tell the process's one-off HIP costs from the index's in the stage timers)
+        (void)gffx_hip_warmup(dev[0]);
+        sub.lap("  HIP runtime + context + code objects");
+    }
     index_data.ensure_device(dev[0]);
     std::vector<IndexClone> clones(D);
     std::vector<gffx_hip_index *> ix(D, index_data.device_index);

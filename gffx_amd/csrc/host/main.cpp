@@ -2,6 +2,7 @@
 // `gffx intersect` and `gffx depth` (BED source) (reference: main.rs:11-39, commands/depth.rs:34-72, commands/index.rs:11-23, commands/intersect.rs:32-70,
 // utils/common.rs:17-52).  Flag names, short flags, defaults and groups follow the reference's
 // clap derive; usage errors exit 2 like clap, run-time errors print `Error: <msg>` and exit 1.
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -308,5 +309,19 @@ int cli_main(int argc, char **argv) {
 }  // namespace gffx
 
 #ifndef GFFX_NO_MAIN
-int main(int argc, char **argv) { return gffx::cli_main(argc, argv); }
+// The command has closed (and checked) every output it wrote when cli_main returns.  What is left is teardown -- unmapping
+// a multi-GB BED file, freeing the region stores, shutting the HIP runtime down: ~0.1 s of a 0.9 s run on a 100 M-row BED --
+// which the kernel does faster when the process simply ends.  A preloaded tool (a profiler flushes its trace from an exit
+// handler) or GFFX_EXIT=normal keeps the ordinary exit.
+int main(int argc, char **argv) {
+    const int rc = gffx::cli_main(argc, argv);
+    const char *how = std::getenv("GFFX_EXIT");
+    const char *preload = std::getenv("LD_PRELOAD");
+    const bool tool = (preload && *preload) || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_ROOT") ||
+                      std::getenv("HSA_TOOLS_LIB");
+    if ((how && std::string(how) == "normal") || tool) return rc;
+    std::fflush(stdout);
+    std::fflush(stderr);
+    _exit(rc);
+}
 #endif
