@@ -1,0 +1,25 @@
+import os, subprocess, sys, time
+sys.path.insert(0, os.getcwd())
+from gffx_amd import synth
+roots = synth.gencode_like_roots(63000, seed=42)
+d = "/tmp/e2e_stream"; os.makedirs(d, exist_ok=True)
+gff = d + "/a.gff"
+print("GFF lines:", synth.write_gff3_fast(gff, roots), flush=True)
+G = "gffx_amd/bin/gffx"
+subprocess.run([G, "index", "-i", gff], check=True)
+n = 100_000_000
+bed = d + "/q.bed"
+synth.write_bed_fast(bed, synth.synth_bed(n, seed=1003), roots["names"])
+for flags in (["-e", "-t", "64"], ["-e", "-t", "128"], ["-t", "64"], ["-t", "128"], ["-e", "-t", "64", "-v"]):
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        r = subprocess.run([G, "intersect", "-i", gff, "-b", bed, "-o", d + "/out.gff"] + flags, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, r)
+    dt, r = best
+    print(" ".join(flags), "rc", r.returncode, "wall %.3f s = %.1f M regions/s" % (dt, n / dt / 1e6), flush=True)
+    print("\n".join("    " + l for l in r.stderr.split("\n") if "[TIMER]" in l), flush=True)
+env = dict(os.environ, GFFX_EXIT="normal")
+t0 = time.perf_counter(); subprocess.run([G, "intersect", "-i", gff, "-b", bed, "-o", d + "/out.gff", "-e", "-t", "64"], env=env); print("normal exit: wall %.3f" % (time.perf_counter() - t0))
