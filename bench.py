@@ -17,7 +17,8 @@ The JSON line carries, next to the contract's fields:
   roofline_10m          the same for a 10 M-region batch (seed 1002)
   cli_pass              the pass the CLI runs (root bitmap only) at 1 M and 10 M regions, next to the root_fid pass
   t_xfer                host regions in (pinned), counts + root_fids back on the host: two batches double-buffered
-  t_e2e                 the `gffx` CLI on a 3.5 M-line synthetic GFF3 x the 1 M-row BED: wall clock + its stage timers
+  t_e2e                 the `gffx` CLI on a 3.5 M-line synthetic GFF3 x the 1 M-row BED: wall clock + its stage timers; and x a
+                        100 M-row BED (2.4 GB of text) with 64 host threads
   join_b                Join B (k_lines_exists over a 3.4 M-line table) with the device-built region tables
   depth                 `gffx depth`'s kernel (k_depth_regions) on the same regions against a 3.4 M-line table
   cpu_baseline          the oracle's Join A on 1 thread (the reference is serial there), + all cores, + Join B on all cores
@@ -37,6 +38,7 @@ import argparse
 import ctypes
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
@@ -355,6 +357,36 @@ def e2e_leg(synth, roots, regions, tmp):
                 stages = [ln.strip() for ln in r.stderr.splitlines() if "[TIMER]" in ln]
                 size = os.path.getsize(os.path.join(tmp, "out.gff"))
         out["runs"][name] = {"wall_s": best, "regions_per_s": len(regions) / best, "output_MB": size / 1e6, "stages": stages}
+    # BASELINE configs[3]'s size through the streaming CLI: 100 M rows (2.4 GB of BED text), --entire-group and per-line mode,
+    # 64 host threads (the reference's default of 12 is the first table column of DESIGN 5.2); best of 2, page cache warm
+    try:
+        big_n = 100_000_000
+        if shutil.disk_usage(tmp).free > (6 << 30):
+            big = os.path.join(tmp, "q100m.bed")
+            base_rows = synth.synth_bed(big_n // 10, seed=1003)  # (ten shifted copies of 10 M seeded rows: numpy needs ~1 min
+            shifted = []                                          #  for 100 M fresh ones, which would double the run)
+            for k in range(10):
+                part = base_rows.copy()
+                part[:, 1:] += np.uint32(13 * k)
+                shifted.append(part)
+            synth.write_bed_fast(big, np.concatenate(shifted), roots["names"])
+            del shifted, base_rows
+            for name, extra in (("intersect -e, 100 M rows, -t 64", ["-e", "-t", "64"]), ("intersect, 100 M rows, -t 64", ["-t", "64"])):
+                best = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([G, "intersect", "-i", gff, "-b", big, "-o", os.path.join(tmp, "out.gff")] + extra,
+                                       capture_output=True, text=True)
+                    dt = time.perf_counter() - t0
+                    if r.returncode != 0:
+                        raise RuntimeError(r.stderr[-300:])
+                    best = dt if best is None else min(best, dt)
+                out["runs"][name] = {"wall_s": best, "regions_per_s": big_n / best, "bed_rows": big_n,
+                                     "bed_GB": os.path.getsize(big) / 1e9,
+                                     "output_MB": os.path.getsize(os.path.join(tmp, "out.gff")) / 1e6}
+            os.remove(big)
+    except Exception as exc:  # (the small runs above stand on their own)
+        out["runs"]["100 M rows"] = {"error": repr(exc)[:300]}
     return out
 
 
