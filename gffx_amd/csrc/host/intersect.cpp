@@ -2,7 +2,6 @@
 // Join A (query_features) and Join B (the per-line predicate) run on the MI355X through
 // include/gffx_hip.h; everything else here is the reference's host logic: region/BED parsing,
 // root -> byte-block lookup, line splitting, type filter, ordered copy-out.
-#include <sys/mman.h>
 #include <algorithm>
 #include <exception>
 #include <chrono>
@@ -536,21 +535,6 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
     MappedFile f(bed_path);
     const std::string_view text = f.view();
     const SeqidTable seqids(index_data.seqid_to_num);
-    // A big file's pages are entered into the page table up front, by many threads at once (MADV_POPULATE_READ: the pages are
-    // in the page cache or read ahead): the parser's threads then take no faults on their input while the HIP runtime, which
-    // comes up at the same time, holds the address space's lock for its own mappings.
-    if (text.size() >= (256u << 20) && !std::getenv("GFFX_NO_POPULATE")) {
-        const size_t W = std::min<size_t>(std::max<size_t>(threads, 1), 32), page = 4096;
-        const char *base = text.data();
-        std::vector<std::thread> pop;
-        for (size_t w = 0; w < W; ++w)
-            pop.emplace_back([=] {
-                const size_t lo = text.size() / W * w / page * page, hi = w + 1 == W ? text.size() : text.size() / W * (w + 1) / page * page;
-                if (hi > lo) (void)::madvise(const_cast<char *>(base) + lo, hi - lo, 22 /* MADV_POPULATE_READ, Linux 5.14+ */);
-            });
-        for (auto &th : pop) th.join();
-        sub.lap("  populating the BED mapping");
-    }
     // The parser runs ahead on its own thread (each chunk on `threads` workers) while this thread brings the devices up
     // and then feeds them: a bounded queue of parsed chunks, in file order.
     struct Parsed {
