@@ -904,6 +904,7 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
         ranges.emplace_back(s, ee);
     }
     std::sort(ranges.begin(), ranges.end());
+    StageTimer sub{verbose};
 
     // line table of the hit blocks: (abs start, abs end incl. '\n', seqid number, raw start, raw end)
     struct Part {
@@ -970,6 +971,7 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
         ee.insert(ee.end(), P.e.begin(), P.e.end());
     }
 
+    sub.lap("  line table of the hit blocks (host threads)");
     // Join B on the device (commands/intersect.rs:500-521)
     std::vector<uint8_t> keep(std::max<size_t>(n_lines, 1), 0);
     if (n_lines) {
@@ -983,6 +985,7 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
         if (rc != GFFX_OK) hip_fail("gffx_hip_lines_test");
     }
 
+    sub.lap("  Join B on the device (region sort + tables + k_lines_exists + flags back)");
     std::vector<std::pair<uint64_t, uint64_t>> seg;
     for (size_t i = 0; i < n_lines;) {  // kept lines that touch in the file leave as one write
         if (!keep[i]) {
@@ -994,7 +997,9 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
         seg.emplace_back(ls[i], le[j - 1] - ls[i]);
         i = j;
     }
+    sub.lap("  runs of kept lines");
     write_segments(gff.data(), seg, output_path, threads);
+    sub.lap("  writing the kept lines");
     if (verbose) std::fprintf(stderr, "[INFO] match-only by coords completed; minput blocks %zu\n", blocks.size());
 }
 
