@@ -72,6 +72,16 @@ extern "C" int gffx_host_parse_bed_file(const char *gff, const char *bed, uint32
     });
 }
 
+extern "C" int gffx_host_parse_bed_file_chunked(const char *gff, const char *bed, uint32_t threads, uint64_t chunk_bytes,
+                                                uint32_t **regions, uint64_t *n_regions, char *err, size_t errlen) {
+    return guard(err, errlen, [&] {
+        const auto sqs = index_loader::load_sqs(gff);
+        const std::vector<uint32_t> flat = commands::intersect::parse_bed_file_chunked(bed, sqs.second, threads, chunk_bytes);
+        *regions = dup_vec(flat);
+        *n_regions = flat.size() / 3;
+    });
+}
+
 extern "C" int gffx_host_parse_region(const char *gff, const char *region, uint32_t out[3], char *err,
                                       size_t errlen) {
     return guard(err, errlen, [&] {

@@ -171,7 +171,10 @@ using Region = std::tuple<uint32_t, uint32_t, uint32_t>;  // (chr, start, end)
 Region parse_region(const std::string &region, const std::unordered_map<std::string, uint32_t> &seqid_map,
                     const CommonArgs &common);  // intersect.rs:172-198
 std::vector<Region> parse_bed_file(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
-                                   size_t threads = 1);  // :201-230
+                                   size_t threads = 1);
+// the same rows through the streaming CLI's chunked, pooled parser (flat words; no device)
+std::vector<uint32_t> parse_bed_file_chunked(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                                             size_t threads, size_t chunk_bytes);  // :201-230
 std::vector<size_t> line_chunks(std::string_view d, size_t parts);  // cut points at line starts (parallel parsers)
 
 // intersect.rs:105-169 on the device: one (root_fid, iv.start, iv.end) per kept pair.

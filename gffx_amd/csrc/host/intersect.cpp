@@ -409,6 +409,33 @@ std::vector<Region> parse_bed_file(const std::string &bed_path, const std::unord
     return regions;
 }
 
+// The rows of a BED file as the streaming CLI's parser thread produces them -- chunk by chunk (cut at line starts), every
+// chunk as four pieces per thread on workers that live as long as the file, row buffers reused from chunk to chunk -- without
+// a device: flat (chr, start, end) words in file order.  (Host-side check of that path: tests/test_host_cpu.py.)
+std::vector<uint32_t> parse_bed_file_chunked(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                                             size_t threads, size_t chunk_bytes) {
+    MappedFile f(bed_path);
+    const std::string_view text = f.view();
+    const SeqidTable seqids(seqid_map);
+    WorkerPool workers(std::min<size_t>(std::max<size_t>(threads, 1), 64) - 1);
+    std::vector<std::vector<uint32_t>> piece;  // (reused: keeps its capacity)
+    std::vector<uint32_t> rows;
+    chunk_bytes = std::max<size_t>(chunk_bytes, 1);
+    size_t pos = 0;
+    for (bool first = true; pos < text.size() || first; first = false) {
+        size_t z = std::min(text.size(), pos + chunk_bytes);
+        if (z < text.size()) {
+            const size_t nl = text.find('\n', z);
+            z = nl == std::string_view::npos ? text.size() : nl + 1;
+        }
+        parse_bed_pieces(text, pos, z, z == text.size(), seqids, threads, piece, &workers);
+        for (const auto &v : piece) rows.insert(rows.end(), v.begin(), v.end());
+        pos = z;
+        if (pos >= text.size()) break;
+    }
+    return rows;
+}
+
 std::vector<Region> query_features(TreeIndexData &index_data, const std::vector<Region> &regions, OverlapMode mode,
                                    bool invert, bool verbose, int device) {
     index_data.ensure_device(device);

@@ -23,6 +23,10 @@ int gffx_host_load_tree_index(const char *gff, uint32_t *n_chr, uint32_t **chr_o
 /* commands/intersect.rs:201-230 / :172-198 (the seqid map comes from <gff>.sqs) */
 int gffx_host_parse_bed_file(const char *gff, const char *bed, uint32_t **regions, uint64_t *n_regions,
                              char *err, size_t errlen);
+/* the same rows through the chunked parser of the streaming CLI (chunks of chunk_bytes cut at line starts, four pieces per
+ * thread on persistent workers, recycled row buffers): host/intersect.cpp::stream_unique_roots' producer, without a device */
+int gffx_host_parse_bed_file_chunked(const char *gff, const char *bed, uint32_t threads, uint64_t chunk_bytes, uint32_t **regions,
+                                     uint64_t *n_regions, char *err, size_t errlen);
 int gffx_host_parse_region(const char *gff, const char *region, uint32_t out[3], char *err, size_t errlen);
 /* index_loader/gof.rs:54-128: offsets[2*i], offsets[2*i+1] = block of roots[i] (UINT64_MAX = missing) */
 int gffx_host_roots_to_offsets(const char *gff, const uint32_t *roots, uint64_t n, uint64_t *offsets,

@@ -410,3 +410,37 @@ def test_bed_parser_random_quirks_equal_the_oracle(host, tmp_path, monkeypatch):
             host.gffx_host_free(pr)
             assert np.array_equal(got, want), body
     assert 5 < n_err < 200
+
+
+def test_streaming_parser_chunks_pool_and_recycled_buffers(host, tmp_path, monkeypatch):
+    """The producer of the streaming CLI without a device (gffx_host_parse_bed_file_chunked): chunks cut at line starts, four
+    pieces per thread on persistent workers, the row buffers of one chunk reused by the next.  Rows and their order equal the
+    oracle's for several chunk sizes and thread counts; a bad row in a late chunk is reported as such."""
+    monkeypatch.setenv("GFFX_TREE_INDEX", "gof")
+    gff, roots = _make_gff(tmp_path, 6)
+    assert _build(host, gff)[0] == 0
+    oix = ob.OracleIndex.load(gff)
+    rng = np.random.default_rng(18)
+    rows = synth.synth_bed(260_000, seed=5, chroms=synth.SMALL2, width=(1, 50000), edge_frac=0.05, roots=roots)
+    junk = ["#c\n", "\n", "chrUn\t5\t9\n", "chr1 7\n", "chr2   10 \t 20  extra\n", "chr1\t+5\t9\r\n", " chr1\t9\t9\n", "chr1\t1\t2\t\xc3\xa9\n"]
+    bed = str(tmp_path / "stream.bed")
+    with open(bed, "w", encoding="utf-8") as f:
+        for i, (c, s, e) in enumerate(rows.tolist()):
+            if rng.random() < 0.01:
+                f.write(junk[int(rng.integers(len(junk)))])
+            f.write("%s\t%d\t%d\n" % (("chr1", "chr2")[c], s, e) if i % 3 else "%s\t%d\t%d\tn%d\t0\t+\n" % (("chr1", "chr2")[c], s, e, i))
+    assert os.path.getsize(bed) > (5 << 20)
+    want = oix.parse_bed_file(bed)
+    host.gffx_host_parse_bed_file_chunked.restype = C.c_int
+    host.gffx_host_parse_bed_file_chunked.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64, C.POINTER(u32p), u64p, C.c_char_p, C.c_size_t]
+    e = _err()
+    pr, nr = u32p(), C.c_uint64()
+    for threads, chunk in ((8, 3 << 19), (3, 1 << 20), (16, 1 << 22), (1, 1 << 21), (5, 1 << 30)):
+        assert host.gffx_host_parse_bed_file_chunked(gff.encode(), bed.encode(), threads, chunk, C.byref(pr), C.byref(nr), e, len(e)) == 0, e.value
+        got = np.ctypeslib.as_array(pr, shape=(max(nr.value, 1), 3))[: nr.value].copy()
+        host.gffx_host_free(pr)
+        assert np.array_equal(got, want), (threads, chunk)
+    with open(bed, "a") as f:
+        f.write("chr1\t12x\t50\n")
+    assert host.gffx_host_parse_bed_file_chunked(gff.encode(), bed.encode(), 8, 1 << 20, C.byref(pr), C.byref(nr), e, len(e)) == -1
+    assert b"12x" in e.value
