@@ -52,6 +52,7 @@ SIGNATURES = {
     "gffx_hip_batch_copy_counts": (C.c_int, [vp, u32p]),
     "gffx_hip_batch_copy_offsets": (C.c_int, [vp, u64p]),
     "gffx_hip_batch_copy_offsets32": (C.c_int, [vp, u32p]),
+    "gffx_hip_batch_copy_segbase": (C.c_int, [vp, u64p]),
     "gffx_hip_batch_copy_query_records": (C.c_int, [vp, u32p, u32p, u64p]),
     "gffx_hip_batch_copy_fids": (C.c_int, [vp, u32p]),
     "gffx_hip_batch_copy_triples": (C.c_int, [vp, u32p]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "gffx_hip_batch_device_regions": (vp, [vp]),
     "gffx_hip_batch_device_offsets": (vp, [vp]),
     "gffx_hip_batch_device_offsets32": (vp, [vp]),
+    "gffx_hip_batch_device_segbase": (vp, [vp]),
     "gffx_hip_batch_reserve_hits": (C.c_int, [vp, C.c_uint64]),
     "gffx_hip_batch_set_profiling": (C.c_int, [vp, C.c_int]),
     "gffx_hip_batch_kernel_ms": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), u64p]),

@@ -14,7 +14,9 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <memory>
+#include <mutex>
 #include <numeric>
+#include <utility>
 
 #include "depth_kernels.hpp"
 #include "gffx_device.hpp"
@@ -22,6 +24,7 @@
 #include "join_fused_kernels.hpp"
 #include "join_slot_kernels.hpp"
 #include "join_win_kernels.hpp"
+#include "join_wave_kernels.hpp"
 #include "partition_kernels.hpp"
 #include "regions_store.hpp"
 #include "tile_join_kernels.hpp"
@@ -335,6 +338,7 @@ struct gffx_hip_batch {
     uint32_t *d_fids = nullptr, *d_triples = nullptr, *d_bitmap = nullptr;
     unsigned long long *d_offsets = nullptr;
     uint32_t *d_offsets32 = nullptr;            // GFFX_OUT_OFFSETS32
+    unsigned long long *d_segbase = nullptr;    // GFFX_OUT_SEGBASE: ceil(max_q / 256)
     uint32_t *d_slabs = nullptr;                // windows strategy, root-bitmap passes: one LDS bitmap image per block
     uint32_t slab_blocks = 0;
     uint64_t cap_fids = 0, cap_triples = 0;
@@ -777,6 +781,7 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     (void)hipFree(b->d_bitmap);
     (void)hipFree(b->d_offsets);
     (void)hipFree(b->d_offsets32);
+    (void)hipFree(b->d_segbase);
     (void)hipFree(b->d_slabs);
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_cursor);
@@ -1351,30 +1356,39 @@ static int run_slots(gffx_hip_batch *b) {
 
 constexpr uint32_t kWinMaxLds = 80 * 1024;  // two blocks per CU share 160 KB
 
+// Beyond the default 64 KB of dynamic LDS a kernel has to opt in (hipFuncSetAttribute) -- per FUNCTION and per DEVICE: a
+// clone of the index on another GPU (gffx_hip_index_clone) needs its own call, and host threads of several devices launch
+// concurrently (gffx depth --gpus N).  One table for all kernels: {function, device} pairs that have opted in.
+static int lds_opt_in(const void *func, int device, uint32_t lds, uint32_t max_lds) {
+    if (lds <= 64 * 1024) return GFFX_OK;
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto &d : done)
+        if (d.first == func && d.second == device) return GFFX_OK;
+    GFFX_HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+    done.emplace_back(func, device);
+    return GFFX_OK;
+}
+
 template <int MODE, bool INV, bool AOS, bool ML, int OUT, int T>
-static void launch_win3(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, uint32_t stage_words, uint32_t fwords,
-                        uint32_t lds) {
-    static bool big_lds = false;  // beyond the default 64 KB of dynamic LDS a kernel has to opt in, once
-    if (lds > 64 * 1024 && !big_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_join_win<MODE, INV, AOS, ML, OUT, T>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T == 1024 ? 2 * kWinMaxLds : kWinMaxLds));
-        big_lds = true;
-    }
+static int launch_win3(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, uint32_t stage_words, uint32_t fwords,
+                       uint32_t lds) {
+    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_win<MODE, INV, AOS, ML, OUT, T>), b->ix->device, lds,
+                              T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
+    if (rc) return rc;
     hipLaunchKernelGGL((k_join_win<MODE, INV, AOS, ML, OUT, T>), dim3(grid), dim3(T), lds, b->stream, b->ix->view(), b->q,
                        (unsigned long long)b->nq, o, vec_ok, stage_words, fwords);
+    return GFFX_OK;
 }
 
 template <int MODE, bool INV, bool AOS, bool ML>
-static void launch_win(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, int out_kind, uint32_t threads,
-                       uint32_t stage_words, uint32_t fwords, uint32_t lds) {
-    if (out_kind == 3)
-        launch_win3<MODE, INV, AOS, ML, 3, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
-    else if (out_kind == 2)
-        launch_win3<MODE, INV, AOS, ML, 2, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
-    else if (threads == 1024)
-        launch_win3<MODE, INV, AOS, ML, 1, 1024>(b, grid, o, vec_ok, stage_words, fwords, lds);
-    else
-        launch_win3<MODE, INV, AOS, ML, 1, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
+static int launch_win(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, int out_kind, uint32_t threads,
+                      uint32_t stage_words, uint32_t fwords, uint32_t lds) {
+    if (out_kind == 3) return launch_win3<MODE, INV, AOS, ML, 3, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
+    if (out_kind == 2) return launch_win3<MODE, INV, AOS, ML, 2, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
+    if (threads == 1024) return launch_win3<MODE, INV, AOS, ML, 1, 1024>(b, grid, o, vec_ok, stage_words, fwords, lds);
+    return launch_win3<MODE, INV, AOS, ML, 1, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
 }
 
 // dynamic LDS of k_join_win: scratch + stage (root_fids or the LDS bitmap) + per-thread strips + coverage filter + seqid tables
@@ -1394,7 +1408,99 @@ static uint32_t win_pair_threads(const gffx_hip_batch *b) {
     return (!b->others_busy && b->nq >= 500000 && b->nq <= 2500000) ? 1024u : (uint32_t)kWinThreads;
 }
 
+
+// ---- pair passes of the windows strategy: k_join_wave (join_wave_kernels.hpp)
+
+template <int MODE, bool INV, bool AOS, bool ML, int T>
+static int launch_wave2(gffx_hip_batch *b, uint32_t grid, const WaveOut &o, int vec_ok, uint32_t fwords, uint32_t keep_words,
+                        uint32_t lds) {
+    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_wave<MODE, INV, AOS, ML, T>), b->ix->device, lds,
+                              T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_join_wave<MODE, INV, AOS, ML, T>), dim3(grid), dim3(T), lds, b->stream, b->ix->view(), b->q,
+                       (unsigned long long)b->nq, o, vec_ok, fwords, keep_words);
+    return GFFX_OK;
+}
+
+template <int MODE, bool INV, bool AOS, bool ML>
+static int launch_wave(gffx_hip_batch *b, uint32_t grid, const WaveOut &o, int vec_ok, uint32_t threads, uint32_t fwords,
+                       uint32_t keep_words, uint32_t lds) {
+    if (threads == 1024) return launch_wave2<MODE, INV, AOS, ML, 1024>(b, grid, o, vec_ok, fwords, keep_words, lds);
+    return launch_wave2<MODE, INV, AOS, ML, 512>(b, grid, o, vec_ok, fwords, keep_words, lds);
+}
+
+// dynamic LDS of k_join_wave: header + two strips per wave + parked offsets + per-thread strips + coverage filter + seqid table
+static uint32_t wave_lds_bytes(const gffx_hip_index *ix, uint32_t threads, uint32_t keep_words, uint32_t fwords, bool ml) {
+    return kWaveHdrBytes + 4 * (threads / 64) * 2 * kWaveStage + 4 * threads * 2 * keep_words + 4 * kWinStash * threads + 4 * fwords +
+           (ml ? (ix->n_chr + 1) * 16 : 0);
+}
+
+// Threads per block of a pair pass.  The waves of k_join_wave are independent, so the block width only sets how many regions
+// share one reservation atomic (2048 or 4096) and whether two kernels can share a CU: 1024-thread blocks (one per CU) for a
+// pass that runs alone, 512 (two per CU) while another batch of the index has passes in flight.  GFFX_HIP_WIN_THREADS forces one.
+static uint32_t wave_pair_threads(const gffx_hip_batch *b) {
+    const long forced = env_long("GFFX_HIP_WIN_THREADS", 0, 0, 1024);
+    if (forced == 512 || forced == 1024) return (uint32_t)forced;
+    return (!b->others_busy && b->nq >= 500000) ? 1024u : 512u;
+}
+
+static int run_wave_pass(gffx_hip_batch *b) {
+    const gffx_hip_index *ix = b->ix;
+    WaveOut o{};
+    o.counts = b->d_counts;
+    o.err = reinterpret_cast<uint32_t *>(b->d_status);
+    o.slow = b->d_status + 4;
+    b->fused_word = 2 + b->fused_phase;
+    o.pair_cursor = b->d_status + b->fused_word;
+    o.pair_cursor_next = b->d_status + 2 + (b->fused_phase ^ 1);
+    b->fused_phase ^= 1;
+    o.segbase = (b->flags & GFFX_OUT_SEGBASE) ? b->d_segbase : nullptr;
+    o.offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr;
+    o.offsets32 = (b->flags & GFFX_OUT_OFFSETS32) ? b->d_offsets32 : nullptr;
+    o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
+    o.capacity = o.fids ? b->cap_fids : UINT64_MAX;
+    const bool ml = meta_bytes(ix) <= kMetaLdsBytes;
+    uint32_t threads = wave_pair_threads(b);
+    const uint32_t keep_words = (o.offsets || o.offsets32) ? 2u : 0u;
+    uint32_t fwords = (ix->win_fwords + 3) / 4 * 4;
+    auto max_lds = [](uint32_t t) { return t == 1024 ? 2 * kWinMaxLds : kWinMaxLds; };
+    if (fwords < 4 || wave_lds_bytes(ix, threads, keep_words, fwords, ml) > max_lds(threads)) {
+        if (fwords >= 4 && threads == 512 && wave_lds_bytes(ix, 1024, keep_words, fwords, ml) <= max_lds(1024))
+            threads = 1024;  // (the filter is worth more than the second block per CU)
+        else
+            fwords = 0;
+    }
+    b->win_threads = threads;
+    const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", threads == 1024 ? 256 : 512, 1, 65535));
+    const uint32_t lds = wave_lds_bytes(ix, threads, keep_words, fwords, ml);
+    const bool aos = b->q.aos != nullptr;
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int vec_ok = aos ? al(b->q.aos) : (al(b->q.chr) && al(b->q.start) && al(b->q.end));
+    ProfEvent pe;
+    int lrc = GFFX_OK;
+    prof_begin(b, GFFX_K_WAVE, &pe);
+#define GFFX_CASE2(M, I, A, L) \
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) lrc = launch_wave<M, I, A, L>(b, grid, o, vec_ok, threads, fwords, keep_words, lds);
+#define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
+    GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
+    GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
+    GFFX_CASE(2, false, false) GFFX_CASE(2, false, true) GFFX_CASE(2, true, false) GFFX_CASE(2, true, true)
+#undef GFFX_CASE
+#undef GFFX_CASE2
+    prof_end(b, &pe);
+    if (lrc) return lrc;
+    GFFX_HIP_TRY(hipGetLastError());
+    return GFFX_OK;
+}
+
 static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
+    // pair passes (counts / offsets / root_fids): the wave kernel; GFFX_HIP_PAIR_KERNEL=win keeps the block-synchronous one
+    if (out_kind == 1 && !second) {
+        const char *pk = getenv("GFFX_HIP_PAIR_KERNEL");
+        if (!(pk && !strcmp(pk, "win"))) return run_wave_pass(b);
+        if (b->flags & GFFX_OUT_SEGBASE) return fail(GFFX_E_INVALID, "GFFX_OUT_SEGBASE needs the wave kernel (GFFX_HIP_PAIR_KERNEL=win is set)");
+    }
     const gffx_hip_index *ix = b->ix;
     WinOut o{};
     o.counts = b->d_counts;
@@ -1455,9 +1561,10 @@ static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int vec_ok = aos ? al(b->q.aos) : (al(b->q.chr) && al(b->q.start) && al(b->q.end));
     ProfEvent pe;
+    int lrc = GFFX_OK;
     prof_begin(b, GFFX_K_WINDOWS, &pe);
 #define GFFX_CASE2(M, I, A, L) \
-    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) launch_win<M, I, A, L>(b, grid, o, vec_ok, out_kind, threads, stage_words, fwords, lds);
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) lrc = launch_win<M, I, A, L>(b, grid, o, vec_ok, out_kind, threads, stage_words, fwords, lds);
 #define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
     GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
     GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
@@ -1465,6 +1572,7 @@ static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
 #undef GFFX_CASE
 #undef GFFX_CASE2
     prof_end(b, &pe);
+    if (lrc) return lrc;
     GFFX_HIP_TRY(hipGetLastError());
     if (out_kind == 3 && o.slabs) {
         const uint32_t words = o.bm_words;
@@ -1480,7 +1588,7 @@ static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
 // own over the position copy of the window table (the CLI asks for the bitmap alone: one pass).
 static int run_windows(gffx_hip_batch *b) {
     const bool want_bitmap = b->flags & GFFX_OUT_ROOT_BITMAP;
-    const bool want_pairs = b->flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32);
+    const bool want_pairs = b->flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32 | GFFX_OUT_SEGBASE);
     if (want_bitmap && !(b->flags & GFFX_OUT_BITMAP_KEEP))
         GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
     b->slots_passes++;
@@ -1525,9 +1633,11 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     b->invert = invert ? 1 : 0;
     b->flags = out_flags | GFFX_OUT_COUNTS;
     b->strategy = pick_strategy(b, strategy);
-    if ((out_flags & (GFFX_OUT_OFFSETS32 | GFFX_OUT_BITMAP_KEEP)) && b->strategy != GFFX_STRATEGY_WINDOWS) {
+    if ((out_flags & GFFX_OUT_SEGBASE) && (out_flags & GFFX_OUT_TRIPLES))
+        return fail(GFFX_E_INVALID, "gffx_hip_batch_run: GFFX_OUT_SEGBASE is an output of the root_fid passes, not of GFFX_OUT_TRIPLES");
+    if ((out_flags & (GFFX_OUT_OFFSETS32 | GFFX_OUT_BITMAP_KEEP | GFFX_OUT_SEGBASE)) && b->strategy != GFFX_STRATEGY_WINDOWS) {
         if (strategy != GFFX_STRATEGY_AUTO)
-            return fail(GFFX_E_INVALID, "gffx_hip_batch_run: GFFX_OUT_OFFSETS32 / GFFX_OUT_BITMAP_KEEP need the windows strategy (or AUTO)");
+            return fail(GFFX_E_INVALID, "gffx_hip_batch_run: GFFX_OUT_OFFSETS32 / GFFX_OUT_BITMAP_KEEP / GFFX_OUT_SEGBASE need the windows strategy (or AUTO)");
         b->strategy = GFFX_STRATEGY_WINDOWS;  // (AUTO's sweep-kernel choice is a speed matter only)
     }
     b->ran = true;
@@ -1545,6 +1655,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         if (nq == 0) GFFX_HIP_TRY(hipMemsetAsync(b->d_offsets, 0, sizeof(unsigned long long), b->stream));
     }
     if ((b->flags & GFFX_OUT_OFFSETS32) && !b->d_offsets32 && (rc = dev_alloc(&b->d_offsets32, b->max_q + 4))) return rc;
+    if ((b->flags & GFFX_OUT_SEGBASE) && !b->d_segbase && (rc = dev_alloc(&b->d_segbase, b->max_q / kWaveGroup + 2))) return rc;
     if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !b->d_bitmap) {
         if ((rc = dev_alloc(&b->d_bitmap, ((size_t)b->ix->n_roots + 31) / 32 + 1))) return rc;
         GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));  // (GFFX_OUT_BITMAP_KEEP on a first pass)
@@ -1732,6 +1843,13 @@ extern "C" int gffx_hip_batch_copy_offsets32(gffx_hip_batch *b, uint32_t *host) 
     if (b->nq) GFFX_HIP_TRY(hipMemcpy(host, b->d_offsets32, b->nq * 4, hipMemcpyDeviceToHost));
     return GFFX_OK;
 }
+extern "C" int gffx_hip_batch_copy_segbase(gffx_hip_batch *b, uint64_t *host) {
+    int rc = need_waited(b, "gffx_hip_batch_copy_segbase", GFFX_OUT_SEGBASE);
+    if (rc) return rc;
+    if (b->nq) GFFX_HIP_TRY(hipMemcpy(host, b->d_segbase, (b->nq + kWaveGroup - 1) / kWaveGroup * 8, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+
 extern "C" int gffx_hip_batch_copy_query_records(gffx_hip_batch *b, uint32_t *rows, uint32_t *counts,
                                                  uint64_t *offsets) {
     int rc = need_waited(b, "gffx_hip_batch_copy_query_records",
@@ -1786,6 +1904,9 @@ extern "C" const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *b)
 extern "C" const uint32_t *gffx_hip_batch_device_regions(const gffx_hip_batch *b) { return (b && b->have_regions) ? b->q.aos : nullptr; }
 extern "C" const uint32_t *gffx_hip_batch_device_offsets32(const gffx_hip_batch *b) {
     return (b && (b->flags & GFFX_OUT_OFFSETS32)) ? b->d_offsets32 : nullptr;
+}
+extern "C" const uint64_t *gffx_hip_batch_device_segbase(const gffx_hip_batch *b) {
+    return (b && (b->flags & GFFX_OUT_SEGBASE)) ? reinterpret_cast<const uint64_t *>(b->d_segbase) : nullptr;
 }
 extern "C" const uint64_t *gffx_hip_batch_device_offsets(const gffx_hip_batch *b) {
     return (b && (b->flags & GFFX_OUT_OFFSETS)) ? reinterpret_cast<const uint64_t *>(b->d_offsets) : nullptr;

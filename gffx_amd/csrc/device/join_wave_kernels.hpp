@@ -1,0 +1,423 @@
+// join_wave_kernels.hpp -- Join A over the window index, pair passes (counts + root_fids): the kernel AUTO runs since
+// round 3.  Same index, same per-region work and the same result set as k_join_win (join_win_kernels.hpp; utils/tree.rs:110
+// + intersect.rs:145-161); what changed is how the waves of a block work together.
+//
+// k_join_win ran a block as ONE phase group: three block barriers per 2048-region round (scan totals, reservation, stage),
+// so every wave waited for the slowest one three times per round -- and 99.8 % of the waves hold at least one region whose
+// list tail costs a dependent L2 round trip -- and then for the round trip of the reservation atomic.  Measured there: the
+// skeleton streams at 4 TB/s, the gathers add their full time on top, nothing overlaps.  Here
+//   * a WAVE is the unit: its 256 regions of a round (64 lanes x 4 consecutive regions) are loaded, looked up, tested,
+//     scanned (6 DPP adds) and their kept root_fids parked in a wave-private LDS strip without any block barrier;
+//   * the block still reserves ONE pair segment per round (same-address device atomics serialise at ~90 per us across the
+//     chip: one per round, not per wave), but by ARRIVAL: every wave adds {1, its total} to an LDS word and gets its
+//     offset inside the round's segment back; the wave that arrives last issues the global atomicAdd;
+//   * the answer is not waited for: the wave goes on with the NEXT round (region loads, line gathers, tests) and only then
+//     collects the segment base of the previous one -- posted in LDS by the wave that issued the atomic -- and writes its
+//     strip out as full lines.  Atomic latency, the slowest wave and the list tails of other waves are hidden behind a
+//     round of useful work; waves of a block drift up to one round apart, so the vector memory path (gathers) and the VALU
+//     (tests, scans) of a CU are busy at the same time.  There is no s_barrier in the round loop.
+// Output: counts[nq] (input order), fids (pair segments), and per GROUP of 256 consecutive regions (a wave's share of a
+// round) the start of the group's run of pairs (GFFX_OUT_SEGBASE, 8 bytes per 256 regions): the segments of a group's
+// regions follow each other in input order, so a region's segment starts at segbase[i / 256] + the counts of the group's
+// regions before it.  Per-region offsets (GFFX_OUT_OFFSETS / _OFFSETS32) are still written when asked for.
+// A wave whose round keeps more pairs than its strip holds (kWaveStage) takes a synchronous path for that round: it waits
+// for the segment base and writes its pairs straight from a second, generic walk of its regions.
+// Roofline bound: HBM.  Algorithmic bytes per region: 12 in + 4 + 4*h out.
+#pragma once
+#include "join_win_kernels.hpp"
+
+namespace gffx {
+
+constexpr uint32_t kWaveGroup = 256;   // regions of one wave and round = one run of pairs (GFFX_OUT_SEGBASE granule)
+constexpr uint32_t kWaveStage = 512;   // root_fids a wave parks in LDS per round (two rounds in flight)
+constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequence numbers
+
+struct WaveOut {
+    uint32_t *counts;               // nq, input order
+    unsigned long long *segbase;    // ceil(nq / 256): start of every group's run of pairs (or nullptr)
+    unsigned long long *offsets;    // nq, input order: start of the region's pair segment (or nullptr)
+    uint32_t *offsets32;            // the same as u32 (or nullptr)
+    uint32_t *fids;                 // pair segments (or nullptr: counts only)
+    uint32_t *err;                  // bit0 = chr out of range
+    unsigned long long *slow;       // regions that took the exact sweep (AUTO's heuristic)
+    unsigned long long *pair_cursor;       // kept pairs of this pass (zero on entry)
+    unsigned long long *pair_cursor_next;  // the other cursor word: zeroed here for the next pass
+    unsigned long long capacity;
+};
+
+// every kept pair of ONE region, generic walk (the synchronous path and nothing else): f(root_fid)
+template <int MODE, bool INVERT, typename F>
+__device__ __forceinline__ void wave_walk_region(const IndexView &ix, const uint4 *cm, uint32_t chr, uint32_t qs, uint32_t qe,
+                                                 F &&f) {
+    if (chr >= ix.n_chr) return;
+    if (MODE == GFFX_MODE_OVERLAP && INVERT) return;
+    const uint4 m = cm[chr];
+    const uint32_t shift = m.z & 31u, wmax = m.z >> 8;
+    if (m.y == 0) return;
+    const bool fits = qe > qs && qe - qs <= wmax;
+    const uint32_t b = (qe - 1) >> shift;
+    bool sweep = !fits;
+    if (fits) {
+        if (b >= m.y) return;  // beyond the last window nothing reaches the region
+        const uint32_t *l = reinterpret_cast<const uint32_t *>(ix.win + 2ull * (m.x + b));
+        const uint32_t rel = wmax - (b << shift), rqs = qs + rel, rqe = qe + rel;
+        const bool tail = l[3] == kWinTailMark;
+        const uint32_t hdr = tail ? l[7] : 0u;
+        if ((hdr & 255u) == 255u) {
+            sweep = true;
+        } else {
+            for (uint32_t j = 0; j < (tail ? kWinInlineTail : kWinInline); ++j) {
+                const uint32_t w = l[j];
+                if (win_test<MODE, INVERT>(w & 0xFFFFu, w >> 16, rqs, rqe)) f(l[4 + j]);
+            }
+            if (tail) {
+                const uint4 *sp = ix.win_spill + (hdr >> 8);
+                for (uint32_t j = kWinInlineTail; j < (hdr & 255u); ++j) {
+                    const uint4 x = sp[j - kWinInlineTail];
+                    if (win_test<MODE, INVERT>(x.x, x.y, qs, qe)) f(x.z);
+                }
+            }
+        }
+    }
+    if (sweep)
+        for_each_kept<MODE, INVERT>(ix, ix.chr_meta[chr], qs, qe, [&](uint32_t, uint32_t, const uint4 &a) {
+            f(a.w);
+            return true;
+        });
+}
+
+// T: threads per block (512: two blocks per CU; 1024: one, half the reservation atomics)
+// keep_words: 2 when per-region offsets are written (each lane parks its place inside the round's segment), else 0
+template <int MODE, bool INVERT, bool AOS, bool META_LDS, int T>
+__global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, unsigned long long nq, WaveOut out, int vec_ok,
+                                                    uint32_t fwords, uint32_t keep_words) {
+    constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
+    constexpr uint32_t kWaves = T / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *s_arrive = reinterpret_cast<unsigned long long *>(smem);          // [2] arrivals << 56 | pairs so far
+    unsigned long long *s_post_base = reinterpret_cast<unsigned long long *>(smem + 16);  // [2] the round's segment base
+    uint32_t *s_post_seq = reinterpret_cast<uint32_t *>(smem + 32);                       // [2] block round + 1 it belongs to
+    uint32_t *s_stage_all = reinterpret_cast<uint32_t *>(smem + kWaveHdrBytes);           // waves x 2 x kWaveStage
+    uint32_t *s_keep_all = s_stage_all + kWaves * 2 * kWaveStage;                         // T x 2 x keep_words
+    uint32_t *s_stash = s_keep_all + (size_t)T * 2 * keep_words + kWinStash * threadIdx.x;  // this thread's kWinStash words
+    uint32_t *s_filter = s_keep_all + (size_t)T * 2 * keep_words + kWinStash * T;         // fwords (a multiple of 4)
+    uint4 *s_meta = reinterpret_cast<uint4 *>(s_filter + fwords);                          // n_chr + 1 (META_LDS)
+    const uint32_t tid = threadIdx.x, t4 = 4u * tid;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t *s_stage = s_stage_all + (size_t)wave * 2 * kWaveStage;  // this wave's two strips
+
+    uint32_t qc[4], qs[4], qe[4];  // the round's 4 consecutive regions of the thread
+    auto round_rsrc = [&](const uint32_t *col, unsigned long long first, uint32_t words) {
+        const unsigned long long left = first < nq ? nq - first : 0ull;
+        const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(col + words * first), 0, rows * 4u * words, 0x00020000);
+    };
+    auto load_round = [&](unsigned long long r) {
+        const unsigned long long base = r * kChunk;  // (uniform)
+        constexpr int kNt = GFFX_WIN_REGION_AUX;
+        if (AOS) {
+            const __amdgpu_buffer_rsrc_t ra = round_rsrc(q.aos, base, 3);
+            const gffx_v4u a = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4, 0, kNt),
+                           b = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 16, 0, kNt),
+                           c = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 32, 0, kNt);
+            qc[0] = a.x, qs[0] = a.y, qe[0] = a.z;
+            qc[1] = a.w, qs[1] = b.x, qe[1] = b.y;
+            qc[2] = b.z, qs[2] = b.w, qe[2] = c.x;
+            qc[3] = c.y, qs[3] = c.z, qe[3] = c.w;
+        } else {
+            const gffx_v4u c = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.chr, base, 1), 4u * t4, 0, kNt),
+                           s = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.start, base, 1), 4u * t4, 0, kNt),
+                           e = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.end, base, 1), 4u * t4, 0, kNt);
+            qc[0] = c.x, qc[1] = c.y, qc[2] = c.z, qc[3] = c.w;
+            qs[0] = s.x, qs[1] = s.y, qs[2] = s.z, qs[3] = s.w;
+            qe[0] = e.x, qe[1] = e.y, qe[2] = e.z, qe[3] = e.w;
+        }
+        if (base < nq && !(vec_ok && base + kChunk <= nq)) {
+            const unsigned long long i0 = base + t4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                qc[k] = 0xFFFFFFFFu;  // "no region"
+                qs[k] = qe[k] = 0;
+                if (i0 + k < nq) load_query<AOS>(q, i0 + k, qc[k], qs[k], qe[k]);
+            }
+        }
+    };
+    const unsigned long long n_rounds = (nq + kChunk - 1) / kChunk;
+    if (blockIdx.x < n_rounds) load_round(blockIdx.x);  // in flight while the tables are staged
+    const uint4 *cm;
+    if (META_LDS) {
+        for (uint32_t i = tid; i <= ix.n_chr; i += T) s_meta[i] = ix.win_meta[i];
+        cm = s_meta;
+    } else {
+        cm = ix.win_meta;
+    }
+    for (uint32_t x = tid; x < fwords / 4; x += T)
+        reinterpret_cast<uint4 *>(s_filter)[x] = reinterpret_cast<const uint4 *>(ix.win_filter)[x];
+    if (tid < 2) {
+        s_arrive[tid] = 0ull;
+        s_post_seq[tid] = 0u;
+    }
+    win_barrier();  // the ONLY block barrier: tables staged, arrival words zero
+    if (blockIdx.x == 0 && tid == 0) *out.pair_cursor_next = 0ull;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(ix.win), 0,
+                                                                        (uint32_t)(ix.n_win * kWinLineBytes), 0x00020000);
+    uint32_t bad = 0, n_slow = 0;
+
+    // ---- what is left to do for the wave's PREVIOUS round once its segment base is known (all wave-uniform)
+    bool p_valid = false, p_poster = false;
+    uint32_t p_total = 0, p_seq = 0;
+    unsigned long long p_off = 0, p_round = 0;
+    unsigned long long p_got = 0;  // lane 0 of the poster: what the reservation atomic returned
+
+    auto post = [&](uint32_t par, uint32_t seq, unsigned long long got) {  // the wave that issued the round's atomic
+        if (lane == 0) {
+            s_post_base[par] = got;
+            __hip_atomic_store(&s_post_seq[par], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto await_base = [&](uint32_t par, uint32_t seq) -> unsigned long long {
+        while ((uint32_t)__builtin_amdgcn_readfirstlane(
+                   (int)__hip_atomic_load(&s_post_seq[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq)
+            __builtin_amdgcn_s_sleep(1);
+        const unsigned long long b = s_post_base[par];
+        return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    };
+    // per-region offsets of a round from the parked {place inside the wave's run, counts}
+    auto put_offsets = [&](unsigned long long round, unsigned long long seg, uint32_t lp0, uint32_t c0, uint32_t c1, uint32_t c2) {
+        const unsigned long long base = round * kChunk, i0 = base + t4, pos = seg + lp0;
+        if (base + kChunk <= nq) {
+            if (out.offsets) {
+                win_nt_store2(out.offsets + i0, pos, pos + c0);
+                win_nt_store2(out.offsets + i0 + 2, pos + c0 + c1, pos + c0 + c1 + c2);
+            }
+            if (out.offsets32) {
+                const uint32_t p32 = (uint32_t)pos;
+                win_nt_store4(out.offsets32 + i0, p32, p32 + c0, p32 + c0 + c1, p32 + c0 + c1 + c2);
+            }
+        } else {
+            const uint32_t c[3] = {c0, c1, c2};
+            unsigned long long o = pos;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k < nq) {
+                    if (out.offsets) out.offsets[i0 + k] = o;
+                    if (out.offsets32) out.offsets32[i0 + k] = (uint32_t)o;
+                }
+                if (k < 3) o += c[k];
+            }
+        }
+    };
+    auto group_base = [&](unsigned long long round, unsigned long long seg) {  // GFFX_OUT_SEGBASE: one word per wave and round
+        const unsigned long long g = round * kWaves + (uint32_t)wave;
+        if (out.segbase && lane == 0 && g * kWaveGroup < nq) out.segbase[g] = seg;
+    };
+    auto finish_prev = [&]() {
+        if (!p_valid) return;
+        const uint32_t par = (p_seq - 1) & 1u;
+        if (p_poster) post(par, p_seq, p_got);
+        const unsigned long long seg = await_base(par, p_seq) + p_off;
+        group_base(p_round, seg);
+        if (out.fids) {
+            const uint32_t *st = s_stage + par * kWaveStage;
+            uint32_t *dst = out.fids + seg;  // (uniform)
+            if (seg + p_total <= out.capacity) {
+                for (uint32_t x = lane; x < p_total; x += 64) GFFX_NT_STORE(st[x], dst + x);
+            } else {
+                for (uint32_t x = lane; x < p_total; x += 64)
+                    if (seg + x < out.capacity) dst[x] = st[x];
+            }
+        }
+        if (keep_words) {
+            const uint32_t *kp = s_keep_all + ((size_t)par * T + tid) * 2;
+            const uint32_t a = kp[0], b = kp[1];
+            put_offsets(p_round, seg, a & 0xFFFFu, a >> 16, b & 0xFFFFu, b >> 16);
+        }
+        p_valid = false;
+    };
+
+    uint32_t k_round = 0;  // the block's rounds, counted
+    for (unsigned long long r = blockIdx.x; r < n_rounds; r += gridDim.x, ++k_round) {
+        const unsigned long long base = r * kChunk;  // (uniform) first region of the round
+        const bool full = base + kChunk <= nq;       // (uniform) every thread has its 4 regions
+        const unsigned long long i0 = base + t4;     // this thread's 4 consecutive regions
+        const uint32_t n_mine = full ? 4u : (i0 < nq ? (uint32_t)min(nq - i0, 4ull) : 0u);
+        GFFX_WIN_STAMP(0);
+        // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
+        uint32_t sweep = 0;  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
+        uint32_t off[4], rel[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool inb = qc[k] < ix.n_chr;
+            bad |= (!inb && (uint32_t)k < n_mine) ? 1u : 0u;
+            const uint4 m = cm[min(qc[k], ix.n_chr)];
+            const uint32_t shift = m.z & 31u, wmax = m.z >> 8;
+            const bool live = m.y != 0 && !(MODE == GFFX_MODE_OVERLAP && INVERT);
+            const bool fits = qe[k] > qs[k] && qe[k] - qs[k] <= wmax;
+            const uint32_t b = (qe[k] - 1) >> shift;
+            bool cov = true;
+            if (fwords) {
+                const uint32_t a2 = qs[k] >> ix.win_fshift, d = min(((qe[k] - 1) >> ix.win_fshift) - a2, 30u);
+                const uint32_t bit = m.w + a2, w = min(bit >> 5, fwords - 2);
+                const uint32_t v = __builtin_amdgcn_alignbit(s_filter[w + 1], s_filter[w], bit);
+                cov = __builtin_amdgcn_ubfe(v, 0, d + 1) != 0;
+            }
+            off[k] = (live && fits && b < m.y && cov) ? (m.x + b) * kWinLineBytes : kWinNoLine;
+            rel[k] = wmax - (b << shift);
+            sweep |= (live && !fits) ? 1u << k : 0u;
+        }
+        gffx_v4u wc[4], wf[4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        GFFX_WIN_STAMP(1);
+        // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept root_fids wait in
+        // the thread's LDS strip)
+        uint32_t hdr[4], tc[4] = {0, 0, 0, 0};
+        uint32_t deferred = sweep, n_rest = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool tail = wc[k].w == kWinTailMark;
+            hdr[k] = tail ? wf[k].w : 0u;
+            deferred |= tail ? 1u << k : 0u;
+            sweep |= (hdr[k] & 255u) == 255u ? 1u << k : 0u;
+        }
+        if (deferred) {
+            n_slow += __popc(sweep);
+            uint32_t d = deferred;
+            while (d) {
+                const int k = __ffs(d) - 1;
+                d &= d - 1;
+                uint32_t c = 0;
+                win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
+                                              [&](uint32_t, uint32_t, uint32_t fid, uint32_t) {
+                                                  if (n_rest < kWinStash) s_stash[n_rest] = fid;
+                                                  ++n_rest;
+                                                  ++c;
+                                              });
+                tc[0] += k == 0 ? c : 0u;
+                tc[1] += k == 1 ? c : 0u;
+                tc[2] += k == 2 ? c : 0u;
+                tc[3] += k == 3 ? c : 0u;
+            }
+        }
+        // ---- four exact tests per region, in the line's relative coordinates
+        uint32_t cnt[4], mask[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t rqs = qs[k] + rel[k], rqe = qe[k] + rel[k];
+            uint32_t mk = 0;
+            mk |= win_test<MODE, INVERT>(wc[k].x & 0xFFFFu, wc[k].x >> 16, rqs, rqe) ? 1u : 0u;
+            mk |= win_test<MODE, INVERT>(wc[k].y & 0xFFFFu, wc[k].y >> 16, rqs, rqe) ? 2u : 0u;
+            mk |= win_test<MODE, INVERT>(wc[k].z & 0xFFFFu, wc[k].z >> 16, rqs, rqe) ? 4u : 0u;
+            mk |= win_test<MODE, INVERT>(wc[k].w & 0xFFFFu, wc[k].w >> 16, rqs, rqe) ? 8u : 0u;
+            mask[k] = mk;
+            cnt[k] = __popc(mk) + tc[k];
+        }
+        // the regions are done with: the next round's take their registers
+        load_round(r + gridDim.x);
+        GFFX_WIN_STAMP(2);
+        const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        const uint32_t inc = win_wave_scan(mine);
+        const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);  // (uniform) the wave's kept pairs
+        const uint32_t lp0 = inc - mine;  // this thread's first pair inside the wave's run
+        if (full) {
+            win_nt_store4(out.counts + base + t4, cnt[0], cnt[1], cnt[2], cnt[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((uint32_t)k < n_mine) out.counts[i0 + k] = cnt[k];
+        }
+        // ---- park the round's root_fids in this wave's strip (by final position inside the wave's run)
+        const uint32_t par = k_round & 1u;
+        const bool staged = wtotal <= kWaveStage;  // (uniform)
+        if (staged) {
+            if (out.fids) {
+                uint32_t *st = s_stage + par * kWaveStage;
+                const uint32_t lpk[4] = {lp0, lp0 + cnt[0], lp0 + cnt[0] + cnt[1], lp0 + cnt[0] + cnt[1] + cnt[2]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t m = mask[k], lp = lpk[k];
+                    if (m & 1u) st[lp] = wf[k].x;
+                    if (m & 2u) st[lp + (m & 1u)] = wf[k].y;
+                    if (m & 4u) st[lp + __popc(m & 3u)] = wf[k].z;
+                    if (m & 8u) st[lp + __popc(m & 7u)] = wf[k].w;
+                }
+                uint32_t d = deferred, taken = 0;
+                while (d) {  // list tails / sweeps: from the strip, or (rare) walked again
+                    const int k = __ffs(d) - 1;
+                    d &= d - 1;
+                    uint32_t e = win_sel(lpk, k) + __popc(win_sel(mask, k));
+                    if (n_rest <= kWinStash) {
+                        for (uint32_t t = win_sel(tc, k); t; --t) st[e++] = s_stash[taken++];
+                    } else {
+                        uint32_t c_, s_, e_;
+                        load_query<AOS>(q, i0 + k, c_, s_, e_);
+                        win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, c_, s_, e_, win_sel(hdr, k),
+                                                      [&](uint32_t, uint32_t, uint32_t fid, uint32_t) { st[e++] = fid; });
+                    }
+                }
+            }
+            if (keep_words) {
+                uint32_t *kp = s_keep_all + ((size_t)par * T + tid) * 2;
+                kp[0] = lp0 | cnt[0] << 16;
+                kp[1] = cnt[1] | cnt[2] << 16;
+            }
+        }
+        // ---- arrive: this wave's share of the round's segment; the last wave to arrive reserves the segment
+        unsigned long long old = 0;
+        if (lane == 0) old = atomicAdd(&s_arrive[par], (1ull << 56) | (unsigned long long)wtotal);
+        old = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(old >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)old);
+        const unsigned long long my_off = old & ((1ull << 56) - 1);
+        const bool last = (uint32_t)(old >> 56) == kWaves - 1;  // (uniform)
+        unsigned long long got = 0;
+        if (last) {
+            const unsigned long long btotal = my_off + wtotal;
+            if (lane == 0) {
+                __hip_atomic_store(&s_arrive[par], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (btotal) got = atomicAdd(out.pair_cursor, btotal);
+            }
+        }
+        GFFX_WIN_STAMP(3);
+        // ---- the previous round: its segment base has had a whole round to arrive
+        finish_prev();
+        if (staged) {
+            p_valid = true;
+            p_poster = last;
+            p_got = got;
+            p_total = wtotal;
+            p_off = my_off;
+            p_round = r;
+            p_seq = k_round + 1;
+        } else {
+            // more pairs than the strip holds: wait for the base now and write them from a second walk of the regions
+            if (last) post(par, k_round + 1, got);
+            const unsigned long long seg = await_base(par, k_round + 1) + my_off;
+            group_base(r, seg);
+            if (out.offsets || out.offsets32) put_offsets(r, seg, lp0, cnt[0], cnt[1], cnt[2]);
+            if (out.fids) {
+                unsigned long long o = seg + lp0;
+                for (uint32_t k = 0; k < n_mine; ++k) {
+                    uint32_t c_, s_, e_;
+                    load_query<AOS>(q, i0 + k, c_, s_, e_);
+                    wave_walk_region<MODE, INVERT>(ix, cm, c_, s_, e_, [&](uint32_t fid) {
+                        if (o < out.capacity) out.fids[o] = fid;
+                        ++o;
+                    });
+                }
+            }
+        }
+        GFFX_WIN_STAMP(4);
+    }
+    finish_prev();
+    if (bad) atomicOr(out.err, 1u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64);
+    if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow);
+}
+
+}  // namespace gffx

@@ -30,14 +30,15 @@ class OverlapMode(enum.IntEnum):
 
 
 OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS, OUT_EMIT_ORDER = 1, 2, 4, 8, 16, 32
-OUT_OFFSETS32, OUT_BITMAP_KEEP = 64, 128
+OUT_OFFSETS32, OUT_BITMAP_KEEP, OUT_SEGBASE = 64, 128, 256
+SEG_GROUP = 256  # regions per OUT_SEGBASE entry
 STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED, STRATEGY_FUSED, STRATEGY_SLOTS, STRATEGY_WINDOWS = 0, 1, 2, 3, 4, 5
 K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE, K_FUSED_DIRECT, K_DEPTH, K_SLOTS = 0, 1, 2, 3, 4, 5, 6, 7, 8
-K_WINDOWS, K_BITMAP_OR = 9, 10
+K_WINDOWS, K_BITMAP_OR, K_WAVE = 9, 10, 11
 KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_partition",
                 K_LINES: "k_lines_exists", K_FUSED: "k_tile_join", K_UNPERMUTE: "k_unpermute",
                 K_FUSED_DIRECT: "k_join_fused", K_DEPTH: "k_depth_regions", K_SLOTS: "k_join_slots",
-                K_WINDOWS: "k_join_win", K_BITMAP_OR: "k_bitmap_or"}
+                K_WINDOWS: "k_join_win", K_BITMAP_OR: "k_bitmap_or", K_WAVE: "k_join_wave"}
 
 
 def device_count() -> int:
@@ -201,6 +202,24 @@ class QueryBatch:
         out = np.empty(max(self.n_queries, 1), dtype=np.uint32)
         check(lib().gffx_hip_batch_copy_offsets32(self._h, _p(out)))
         return out[: self.n_queries]
+
+    def segbase(self) -> np.ndarray:
+        """OUT_SEGBASE: start of the run of pairs of every group of SEG_GROUP consecutive regions (u64)."""
+        n = (self.n_queries + SEG_GROUP - 1) // SEG_GROUP
+        out = np.empty(max(n, 1), dtype=np.uint64)
+        check(lib().gffx_hip_batch_copy_segbase(self._h, out.ctypes.data_as(u64p)))
+        return out[:n]
+
+    def offsets_from_segbase(self, counts: np.ndarray | None = None) -> np.ndarray:
+        """Per-region segment starts derived the way a consumer of OUT_SEGBASE does: group base + counts before the region."""
+        c = (self.counts() if counts is None else counts).astype(np.uint64)
+        n = len(c)
+        if n == 0:
+            return np.zeros(0, dtype=np.uint64)
+        ex = np.cumsum(c) - c
+        g0 = np.arange(0, n, SEG_GROUP)
+        within = ex - np.repeat(ex[g0], np.minimum(SEG_GROUP, n - g0))
+        return np.repeat(self.segbase(), np.minimum(SEG_GROUP, n - g0)) + within
 
     def query_records(self, with_offsets: bool = True):
         """(rows, counts, offsets) in emission order: rows[i] = input row of the i-th served query."""

@@ -85,6 +85,12 @@ enum gffx_out {
     GFFX_OUT_BITMAP_KEEP = 128, /* with GFFX_OUT_ROOT_BITMAP: do not clear the batch's bitmap first -- a caller that streams a
                                  BED file chunk by chunk through one batch accumulates the unique roots of all chunks
                                  (commands/intersect.rs:598-615 dedups over the whole file) */
+    GFFX_OUT_SEGBASE = 256,   /* windows strategy (AUTO picks it): per GROUP of 256 consecutive regions (regions 256 g .. 256 g + 255,
+                                 a wave's share of a round) the u64 start of the group's run of pairs -- ceil(nq / 256)
+                                 entries, 8 bytes per 256 regions.  The segments of a group's regions follow each other in
+                                 input order, so region i's segment starts at segbase[i / 256] + the counts of the group's
+                                 regions before i: a consumer that reads the counts anyway needs no per-region offsets
+                                 (they are not part of the algorithmic bytes).  The runs tile [0, pairs) exactly. */
     GFFX_OUT_EMIT_ORDER = 32  /* partitioned strategy: leave the per-query results in emission order
                                  ({input row, count, offset} records: gffx_hip_batch_copy_query_records) and
                                  skip the scatter into input-order arrays; _copy_counts / _copy_offsets then
@@ -123,7 +129,8 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
     GFFX_K_SLOTS = 8,
     GFFX_K_WINDOWS = 9,
     GFFX_K_BITMAP_OR = 10,
-    GFFX_K__COUNT = 11
+    GFFX_K_WAVE = 11, /* k_join_wave: the windows strategy's pair passes (counts + root_fids) */
+    GFFX_K__COUNT = 12
 };
 
 typedef struct gffx_hip_index gffx_hip_index;
@@ -215,6 +222,7 @@ uint64_t gffx_hip_batch_total_hits(const gffx_hip_batch *);
 int gffx_hip_batch_copy_counts(gffx_hip_batch *, uint32_t *host /* nq */);
 int gffx_hip_batch_copy_offsets(gffx_hip_batch *, uint64_t *host /* nq+1 */);
 int gffx_hip_batch_copy_offsets32(gffx_hip_batch *, uint32_t *host /* nq */); /* GFFX_OUT_OFFSETS32 */
+int gffx_hip_batch_copy_segbase(gffx_hip_batch *, uint64_t *host /* ceil(nq / 256) */); /* GFFX_OUT_SEGBASE */
 /* per-query records in emission order: rows[i] = input row, counts[i] = kept pairs, offsets[i] = start of
  * its segment in fids / triples (needs GFFX_OUT_OFFSETS); any pointer may be NULL; nq entries each */
 int gffx_hip_batch_copy_query_records(gffx_hip_batch *, uint32_t *rows, uint32_t *counts, uint64_t *offsets);
@@ -227,6 +235,7 @@ const uint32_t *gffx_hip_batch_device_counts(const gffx_hip_batch *);
 const uint32_t *gffx_hip_batch_device_fids(const gffx_hip_batch *);
 const uint64_t *gffx_hip_batch_device_offsets(const gffx_hip_batch *);
 const uint32_t *gffx_hip_batch_device_offsets32(const gffx_hip_batch *);
+const uint64_t *gffx_hip_batch_device_segbase(const gffx_hip_batch *);
 const uint32_t *gffx_hip_batch_device_triples(const gffx_hip_batch *);
 /* the batch's own device copy of the regions as AoS triples (after _set_regions_host; NULL for SoA / borrowed regions) */
 const uint32_t *gffx_hip_batch_device_regions(const gffx_hip_batch *);

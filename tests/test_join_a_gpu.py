@@ -70,6 +70,21 @@ def _check(roots, regions, mode, invert, soa=False, strategy=engine.STRATEGY_AUT
     want_pairs = np.stack([np.repeat(by_chr, wc[by_chr]), want_t[:, 0].astype(np.int64)], axis=1)
     order = lambda a: a[np.lexsort((a[:, 1], a[:, 0]))]  # noqa: E731
     assert np.array_equal(order(got_pairs), order(want_pairs))
+    if strategy in (engine.STRATEGY_AUTO, engine.STRATEGY_WINDOWS):
+        # the pass bench.py times: counts + root_fids + ONE segment base per group of 256 regions (no per-region offsets);
+        # a consumer derives a region's segment from the group's base and the counts before it
+        b.run(mode, invert, engine.OUT_FIDS | engine.OUT_SEGBASE, strategy)
+        b.wait()
+        c3, f3, sb = b.counts(), b.fids(), b.segbase()
+        assert np.array_equal(c3, want_c) and len(f3) == len(want_t) and len(sb) == (len(regions) + 255) // 256
+        off3 = b.offsets_from_segbase(c3).astype(np.int64)
+        got3 = np.stack([qid, f3[off3[qid] + within].astype(np.int64)], axis=1)
+        assert np.array_equal(order(got3), order(want_pairs))
+        gtot = np.add.reduceat(wc, np.arange(0, len(wc), 256)) if len(wc) else np.zeros(0, np.int64)
+        nzg = gtot > 0  # the groups' runs tile [0, pairs)
+        lo, hi = sb.astype(np.int64)[nzg], sb.astype(np.int64)[nzg] + gtot[nzg]
+        o3 = np.argsort(lo)
+        assert len(lo) == 0 or (lo[o3][0] == 0 and hi[o3][-1] == len(want_t) and np.array_equal(hi[o3][:-1], lo[o3][1:]))
     b.run(mode, invert, FLAGS, strategy)  # (back to the full pass for the records below; segment order is per pass)
     b.wait()
     off = b.offsets()
@@ -425,7 +440,7 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
     wide = synth.synth_bed(5000, seed=1, chroms=synth.SMALL2, width=(200_000, 900_000))
     narrow = synth.synth_bed(5000, seed=2, chroms=synth.SMALL2, width=(100, 5000))
     b = engine.QueryBatch(ix, 5000)
-    for regions, want_second in ((wide, "k_join_fused"), (narrow, "k_join_win")):
+    for regions, want_second in ((wide, "k_join_fused"), (narrow, "k_join_wave")):
         b.set_regions(regions)
         _, want_c = oix.query_features(regions, 2, False)
         used = []
@@ -437,7 +452,7 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
             b.set_profiling(False)
             used.append([name for kid, name in engine.KERNEL_NAMES.items() if b.kernel_ms(kid)[1]])
             assert np.array_equal(b.counts(), want_c)
-        assert used[0] == ["k_join_win"] and used[1] == [want_second]
+        assert used[0] == ["k_join_wave"] and used[1] == [want_second]
 
 
 def test_offsets32_and_bitmap_accumulation():

@@ -123,8 +123,8 @@ int main(int argc, char **argv) {
         gffx_hip_batch_sync(b);
     }
     gffx_hip_batch_set_profiling(b, 0);
-    const char *names[] = {"join_count", "join_emit", "partition", "lines", "tile_join", "unpermute", "join_fused", "depth", "join_slots", "join_win", "bitmap_or"};
-    for (int k = 0; k < 11; k++) {
+    const char *names[] = {"join_count", "join_emit", "partition", "lines", "tile_join", "unpermute", "join_fused", "depth", "join_slots", "join_win", "bitmap_or", "join_wave"};
+    for (int k = 0; k < 12; k++) {
         double t;
         uint64_t n;
         gffx_hip_batch_kernel_ms(b, k, &t, &n);
