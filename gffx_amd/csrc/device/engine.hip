@@ -191,6 +191,62 @@ static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const
     return fail(GFFX_E_INVALID, "index too large for the window directory (%u seqids need more than 2^25 lines)", n_chr);
 }
 
+// Tail lines of the window index (gffx_device.hpp, join_wave_kernels.hpp): for every window whose list has 5..7 entries a
+// second line with entries 3..6 in the line's own format, plus the LDS tables that locate it (bitmap + u16 ranks per 32
+// windows).  Derived from the finished lines and spill records; `meta` still holds {first window, windows, shift, wmax}.
+// Nothing is built when the tables exceed GFFX_HIP_WIN_TAIL_KB (default 19 KB of LDS) or 65535 tail lines.
+static void build_window_tails(uint32_t n_chr, const std::vector<uint32_t> &h_start, const std::vector<uint4> &h_aux,
+                               const std::vector<uint4> &meta, const std::vector<uint4> &win, const std::vector<uint4> &spill,
+                               std::vector<uint4> &tail_lines, std::vector<uint32_t> &tab, uint32_t &twords) {
+    tail_lines.clear(), tab.clear();
+    twords = 0;
+    const size_t n_win = win.size() / 2;
+    const size_t nw = (n_win + 31) / 32;
+    const size_t tab_words = (nw + (nw + 1) / 2 + 3) / 4 * 4;
+    const uint64_t budget = (uint64_t)env_long("GFFX_HIP_WIN_TAIL_KB", 19, 0, 64) * 1024;
+    if (!n_win || tab_words * 4 > budget) return;
+    std::vector<uint32_t> bits(nw, 0);
+    const uint32_t *ww = reinterpret_cast<const uint32_t *>(win.data());
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint4 m = meta[c];
+        if (m.z > kWinMaxShift || m.w == 0) continue;  // no windows on this seqid
+        const uint64_t W = 1ull << m.z, wmax = m.w;
+        for (uint64_t b = 0; b < m.y; b++) {
+            const size_t w = (size_t)m.x + b;
+            const uint32_t *l = ww + 8 * w;
+            if (l[3] != kWinTailMark) continue;
+            const uint32_t n = l[7] & 255u;
+            if (n <= kWinInline || n > kWinInlineTail + 4) continue;  // (dense: n = 255)
+            bits[w >> 5] |= 1u << (w & 31);
+            uint32_t t[8] = {kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent, 0, 0, 0, 0};
+            const int64_t org = (int64_t)(b * W) - (int64_t)wmax;
+            for (uint32_t j = kWinInlineTail; j < n; j++) {
+                const uint4 r = spill[(l[7] >> 8) + j - kWinInlineTail];  // {start, end, root_fid, position}
+                const int64_t rs = std::max<int64_t>((int64_t)r.x - org, 0);
+                const int64_t re = std::min<int64_t>((int64_t)r.y - org, (int64_t)(W + wmax + 1));
+                t[j - kWinInlineTail] = (uint32_t)rs | ((uint32_t)re << 16);
+                t[4 + j - kWinInlineTail] = r.z;
+            }
+            tail_lines.push_back(make_uint4(t[0], t[1], t[2], t[3]));
+            tail_lines.push_back(make_uint4(t[4], t[5], t[6], t[7]));
+        }
+    }
+    if (tail_lines.size() / 2 > 65535 || tail_lines.empty()) {
+        tail_lines.clear();
+        return;
+    }
+    (void)h_start, (void)h_aux;
+    tab.assign(tab_words, 0u);
+    uint16_t *rank = reinterpret_cast<uint16_t *>(tab.data() + nw);
+    uint32_t acc = 0;
+    for (size_t x = 0; x < nw; x++) {
+        tab[x] = bits[x];
+        rank[x] = (uint16_t)acc;
+        acc += (uint32_t)__builtin_popcount(bits[x]);
+    }
+    twords = (uint32_t)nw;
+}
+
 // Coverage filter of the window index (gffx_device.hpp): the smallest cell size whose bitmap fits GFFX_HIP_WIN_FILTER_KB
 // (default 24 KB of LDS per block; 48 KB measured 1.5 % faster at 10 M regions, 1.5 % slower at 1 M), but never so small that a region the lines answer (width <= wmax) spans more than 32 cells.
 static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
@@ -264,6 +320,9 @@ struct gffx_hip_index {
     uint32_t n_win = 0;
     uint32_t *d_win_filter = nullptr;
     uint32_t win_fwords = 0, win_fshift = 0;
+    uint4 *d_win_tail = nullptr;          // tail lines (k_join_wave)
+    uint32_t *d_win_tailtab = nullptr;
+    uint32_t n_tail = 0, win_twords = 0;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
     uint32_t *d_cell_base = nullptr;
     uint16_t *d_cell_tile = nullptr;
@@ -281,7 +340,8 @@ struct gffx_hip_index {
     std::vector<void **> arrays() {
         return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_slot_meta,
                 (void **)&d_slots,     (void **)&d_spill,     (void **)&d_slot_pos,   (void **)&d_win_meta,   (void **)&d_win,
-                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_cell_base,
+                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_win_tail,   (void **)&d_win_tailtab,
+                (void **)&d_cell_base,
                 (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
     }
 
@@ -303,6 +363,10 @@ struct gffx_hip_index {
         v.win_filter = d_win_filter;
         v.win_fwords = win_fwords;
         v.win_fshift = win_fshift;
+        v.win_tail = d_win_tail;
+        v.win_tailtab = d_win_tailtab;
+        v.n_tail = n_tail;
+        v.win_twords = win_twords;
         v.n_chr = n_chr;
         v.n_roots = n_roots;
         return v;
@@ -555,6 +619,10 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     std::vector<uint4> win_meta, win, win_pos, win_spill;
     if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill)) return wrc;
     ix->n_win = (uint32_t)(win.size() / 2);
+    std::vector<uint4> win_tail;
+    std::vector<uint32_t> win_tailtab;
+    build_window_tails(n_chr, h_start, h_aux, win_meta, win, win_spill, win_tail, win_tailtab, ix->win_twords);
+    ix->n_tail = (uint32_t)(win_tail.size() / 2);
     std::vector<uint32_t> win_filter;
     std::vector<uint2> win_fmeta;
     build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);
@@ -657,7 +725,8 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         (rc = dev_upload(&ix->d_spill, spill)) || (rc = dev_upload(&ix->d_slot_pos, slot_pos)) ||
         (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = dev_upload(&ix->d_win, win)) ||
         (rc = dev_upload(&ix->d_win_pos, win_pos)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
-        (rc = dev_upload(&ix->d_win_filter, win_filter)) ||
+        (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_tail, win_tail)) ||
+        (rc = dev_upload(&ix->d_win_tailtab, win_tailtab)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -667,6 +736,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
     ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),      bytes(slot_meta), bytes(slots),     bytes(spill),
                        bytes(slot_pos),  bytes(win_meta),  bytes(win),        bytes(win_pos),   bytes(win_spill), bytes(win_filter),
+                       bytes(win_tail),  bytes(win_tailtab),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
     GFFX_HIP_TRY(hipDeviceSynchronize());
@@ -715,6 +785,8 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_win_pos);
     (void)hipFree(ix->d_win_spill);
     (void)hipFree(ix->d_win_filter);
+    (void)hipFree(ix->d_win_tail);
+    (void)hipFree(ix->d_win_tailtab);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);
     (void)hipFree(ix->d_tile_meta);
@@ -1413,26 +1485,28 @@ static uint32_t win_pair_threads(const gffx_hip_batch *b) {
 
 template <int MODE, bool INV, bool AOS, bool ML, int T>
 static int launch_wave2(gffx_hip_batch *b, uint32_t grid, const WaveOut &o, int vec_ok, uint32_t fwords, uint32_t keep_words,
-                        uint32_t lds) {
+                        uint32_t twords, uint32_t lds) {
     const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_wave<MODE, INV, AOS, ML, T>), b->ix->device, lds,
                               T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
     if (rc) return rc;
     hipLaunchKernelGGL((k_join_wave<MODE, INV, AOS, ML, T>), dim3(grid), dim3(T), lds, b->stream, b->ix->view(), b->q,
-                       (unsigned long long)b->nq, o, vec_ok, fwords, keep_words);
+                       (unsigned long long)b->nq, o, vec_ok, fwords, keep_words, twords);
     return GFFX_OK;
 }
 
 template <int MODE, bool INV, bool AOS, bool ML>
 static int launch_wave(gffx_hip_batch *b, uint32_t grid, const WaveOut &o, int vec_ok, uint32_t threads, uint32_t fwords,
-                       uint32_t keep_words, uint32_t lds) {
-    if (threads == 1024) return launch_wave2<MODE, INV, AOS, ML, 1024>(b, grid, o, vec_ok, fwords, keep_words, lds);
-    return launch_wave2<MODE, INV, AOS, ML, 512>(b, grid, o, vec_ok, fwords, keep_words, lds);
+                       uint32_t keep_words, uint32_t twords, uint32_t lds) {
+    if (threads == 1024) return launch_wave2<MODE, INV, AOS, ML, 1024>(b, grid, o, vec_ok, fwords, keep_words, twords, lds);
+    return launch_wave2<MODE, INV, AOS, ML, 512>(b, grid, o, vec_ok, fwords, keep_words, twords, lds);
 }
 
 // dynamic LDS of k_join_wave: header + two strips per wave + parked offsets + per-thread strips + coverage filter + seqid table
-static uint32_t wave_lds_bytes(const gffx_hip_index *ix, uint32_t threads, uint32_t keep_words, uint32_t fwords, bool ml) {
-    return kWaveHdrBytes + 4 * (threads / 64) * 2 * kWaveStage + 4 * threads * 2 * keep_words + 4 * kWinStash * threads + 4 * fwords +
-           (ml ? (ix->n_chr + 1) * 16 : 0);
+static uint32_t wave_lds_bytes(const gffx_hip_index *ix, uint32_t threads, uint32_t keep_words, uint32_t fwords, uint32_t twords,
+                               bool ml) {
+    const uint32_t tab_words = twords ? (twords + (twords + 1) / 2 + 3) / 4 * 4 : 0;
+    return kWaveHdrBytes + 4 * (threads / 64) * kWaveDepth * kWaveStage + 4 * threads * kWaveDepth * keep_words + 4 * kWaveStash * threads + 4 * fwords +
+           4 * tab_words + (ml ? (ix->n_chr + 1) * 16 : 0);
 }
 
 // Threads per block of a pair pass.  The waves of k_join_wave are independent, so the block width only sets how many regions
@@ -1462,18 +1536,16 @@ static int run_wave_pass(gffx_hip_batch *b) {
     const bool ml = meta_bytes(ix) <= kMetaLdsBytes;
     uint32_t threads = wave_pair_threads(b);
     const uint32_t keep_words = (o.offsets || o.offsets32) ? 2u : 0u;
-    uint32_t fwords = (ix->win_fwords + 3) / 4 * 4;
+    uint32_t fwords = (ix->win_fwords + 3) / 4 * 4, twords = ix->win_twords;
+    if (fwords < 4) fwords = 0;
     auto max_lds = [](uint32_t t) { return t == 1024 ? 2 * kWinMaxLds : kWinMaxLds; };
-    if (fwords < 4 || wave_lds_bytes(ix, threads, keep_words, fwords, ml) > max_lds(threads)) {
-        if (fwords >= 4 && threads == 512 && wave_lds_bytes(ix, 1024, keep_words, fwords, ml) <= max_lds(1024))
-            threads = 1024;  // (the filter is worth more than the second block per CU)
-        else
-            fwords = 0;
-    }
+    // what does not fit the block's LDS goes in this order: the tail tables, then the coverage filter
+    if (wave_lds_bytes(ix, threads, keep_words, fwords, twords, ml) > max_lds(threads)) twords = 0;
+    if (wave_lds_bytes(ix, threads, keep_words, fwords, twords, ml) > max_lds(threads)) fwords = 0;
     b->win_threads = threads;
     const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", threads == 1024 ? 256 : 512, 1, 65535));
-    const uint32_t lds = wave_lds_bytes(ix, threads, keep_words, fwords, ml);
+    const uint32_t lds = wave_lds_bytes(ix, threads, keep_words, fwords, twords, ml);
     const bool aos = b->q.aos != nullptr;
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int vec_ok = aos ? al(b->q.aos) : (al(b->q.chr) && al(b->q.start) && al(b->q.end));
@@ -1481,7 +1553,7 @@ static int run_wave_pass(gffx_hip_batch *b) {
     int lrc = GFFX_OK;
     prof_begin(b, GFFX_K_WAVE, &pe);
 #define GFFX_CASE2(M, I, A, L) \
-    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) lrc = launch_wave<M, I, A, L>(b, grid, o, vec_ok, threads, fwords, keep_words, lds);
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) lrc = launch_wave<M, I, A, L>(b, grid, o, vec_ok, threads, fwords, keep_words, twords, lds);
 #define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
     GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
     GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)

@@ -96,6 +96,16 @@ struct IndexView {
     const uint32_t *win_filter;
     uint32_t win_fwords;  // 0 = no filter
     uint32_t win_fshift;
+    // Tail lines (k_join_wave): a window whose list has 5..7 entries keeps entries 0..2 in its line (word 3 = 0xFFFFFFFF) and
+    // entries 3..6 in a second 32-byte line of the same format (window-relative 16-bit coordinates + root_fids) in win_tail,
+    // one per such window, in window order.  win_tailtab (staged in LDS) = win_twords bitmap words, one bit per window
+    // ("has a tail line"), followed by win_twords u16 ranks (tail lines before the word's first window): a region knows
+    // BEFORE its line arrives whether and where a tail line exists, so both loads are in flight together.
+    // win_twords = 0: no tail lines (the tables would not fit LDS); such lists are walked from win_spill.
+    const uint4 *win_tail;
+    const uint32_t *win_tailtab;
+    uint32_t n_tail;      // tail lines
+    uint32_t win_twords;  // bitmap words (= ceil(n_win / 32)), 0 = none
     uint32_t n_chr;
     uint32_t n_roots;
 };

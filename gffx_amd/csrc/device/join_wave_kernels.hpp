@@ -26,11 +26,33 @@
 #pragma once
 #include "join_win_kernels.hpp"
 
+#ifndef GFFX_WAVE_FINISH_EARLY
+#define GFFX_WAVE_FINISH_EARLY 1
+#endif
+#ifndef GFFX_WAVE_DEPTH
+#define GFFX_WAVE_DEPTH 3  // rounds a wave may be ahead of the segment base it still waits for (2 or 3)
+#endif
+#ifndef GFFX_WAVE_STORE_AUX
+#define GFFX_WAVE_STORE_AUX 2  // cache policy bits of the result stores (counts, root_fids): 1 = sc0, 2 = nt, 16 = sc1
+#endif
+#ifndef GFFX_WAVE_LOAD_AUX
+#define GFFX_WAVE_LOAD_AUX GFFX_WIN_REGION_AUX  // ... of the region loads
+#endif
+#ifndef GFFX_WAVE_EXEC_LOADS
+#define GFFX_WAVE_EXEC_LOADS 0  // index lines are only requested by the lanes that have one (0: every lane, out-of-range offsets)
+#endif
+#ifndef GFFX_WAVE_STAGGER
+#define GFFX_WAVE_STAGGER 0
+#endif
+
 namespace gffx {
 
 constexpr uint32_t kWaveGroup = 256;   // regions of one wave and round = one run of pairs (GFFX_OUT_SEGBASE granule)
 constexpr uint32_t kWaveStage = 512;   // root_fids a wave parks in LDS per round (two rounds in flight)
-constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequence numbers
+constexpr uint32_t kWaveDepth = GFFX_WAVE_DEPTH;  // strips per wave: a round's root_fids wait kWaveDepth - 1 rounds for their place
+constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequence numbers (kWaveDepth <= 3 of each)
+static_assert(kWaveDepth == 2 || kWaveDepth == 3, "header layout");
+constexpr uint32_t kWaveStash = 2;     // per thread: kept root_fids of deferred regions wait here (LDS) for the staging
 
 struct WaveOut {
     uint32_t *counts;               // nq, input order
@@ -90,21 +112,26 @@ __device__ __forceinline__ void wave_walk_region(const IndexView &ix, const uint
 // keep_words: 2 when per-region offsets are written (each lane parks its place inside the round's segment), else 0
 template <int MODE, bool INVERT, bool AOS, bool META_LDS, int T>
 __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, unsigned long long nq, WaveOut out, int vec_ok,
-                                                    uint32_t fwords, uint32_t keep_words) {
+                                                    uint32_t fwords, uint32_t keep_words, uint32_t twords) {
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     constexpr uint32_t kWaves = T / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *s_arrive = reinterpret_cast<unsigned long long *>(smem);          // [2] arrivals << 56 | pairs so far
-    unsigned long long *s_post_base = reinterpret_cast<unsigned long long *>(smem + 16);  // [2] the round's segment base
-    uint32_t *s_post_seq = reinterpret_cast<uint32_t *>(smem + 32);                       // [2] block round + 1 it belongs to
-    uint32_t *s_stage_all = reinterpret_cast<uint32_t *>(smem + kWaveHdrBytes);           // waves x 2 x kWaveStage
-    uint32_t *s_keep_all = s_stage_all + kWaves * 2 * kWaveStage;                         // T x 2 x keep_words
-    uint32_t *s_stash = s_keep_all + (size_t)T * 2 * keep_words + kWinStash * threadIdx.x;  // this thread's kWinStash words
-    uint32_t *s_filter = s_keep_all + (size_t)T * 2 * keep_words + kWinStash * T;         // fwords (a multiple of 4)
-    uint4 *s_meta = reinterpret_cast<uint4 *>(s_filter + fwords);                          // n_chr + 1 (META_LDS)
+    constexpr uint32_t D = kWaveDepth;
+    unsigned long long *s_arrive = reinterpret_cast<unsigned long long *>(smem);              // [D] arrivals << 56 | pairs so far
+    unsigned long long *s_post_base = reinterpret_cast<unsigned long long *>(smem + 8 * D);   // [D] the round's segment base
+    uint32_t *s_post_seq = reinterpret_cast<uint32_t *>(smem + 16 * D);                       // [D] block round + 1 it belongs to
+    uint32_t *s_stage_all = reinterpret_cast<uint32_t *>(smem + kWaveHdrBytes);               // waves x D x kWaveStage
+    uint32_t *s_keep_all = s_stage_all + kWaves * D * kWaveStage;                             // T x D x keep_words
+    uint32_t *s_stash = s_keep_all + (size_t)T * D * keep_words + kWaveStash * threadIdx.x;   // this thread's kWaveStash words
+    uint32_t *s_filter = s_keep_all + (size_t)T * D * keep_words + kWaveStash * T;            // fwords (a multiple of 4)
+    // tail tables (gffx_device.hpp): twords bitmap words + twords u16 ranks, padded to a multiple of 4 words
+    const uint32_t tab_words = twords ? (twords + (twords + 1) / 2 + 3) / 4 * 4 : 0;
+    uint32_t *s_tbits = s_filter + fwords;
+    const uint16_t *s_trank = reinterpret_cast<const uint16_t *>(s_tbits + twords);
+    uint4 *s_meta = reinterpret_cast<uint4 *>(s_tbits + tab_words);                        // n_chr + 1 (META_LDS)
     const uint32_t tid = threadIdx.x, t4 = 4u * tid;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint32_t *s_stage = s_stage_all + (size_t)wave * 2 * kWaveStage;  // this wave's two strips
+    uint32_t *s_stage = s_stage_all + (size_t)wave * D * kWaveStage;  // this wave's strips
 
     uint32_t qc[4], qs[4], qe[4];  // the round's 4 consecutive regions of the thread
     auto round_rsrc = [&](const uint32_t *col, unsigned long long first, uint32_t words) {
@@ -114,7 +141,20 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
     };
     auto load_round = [&](unsigned long long r) {
         const unsigned long long base = r * kChunk;  // (uniform)
-        constexpr int kNt = GFFX_WIN_REGION_AUX;
+#if defined(GFFX_WIN_ABL_NOSTREAM)  // (tools/kbench.hip: no region loads at all -- pseudo-random regions from the row number)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t h = (uint32_t)(base + t4 + k) * 2654435761u;
+                h ^= h >> 15, h *= 2246822519u, h ^= h >> 13;
+                qc[k] = (h >> 8) % 24u;
+                qs[k] = (h * 3266489917u) % 40000000u;
+                qe[k] = qs[k] + 100u + (h & 8191u);
+            }
+            return;
+        }
+#endif
+        constexpr int kNt = GFFX_WAVE_LOAD_AUX;
         if (AOS) {
             const __amdgpu_buffer_rsrc_t ra = round_rsrc(q.aos, base, 3);
             const gffx_v4u a = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4, 0, kNt),
@@ -153,7 +193,9 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
     }
     for (uint32_t x = tid; x < fwords / 4; x += T)
         reinterpret_cast<uint4 *>(s_filter)[x] = reinterpret_cast<const uint4 *>(ix.win_filter)[x];
-    if (tid < 2) {
+    for (uint32_t x = tid; x < tab_words / 4; x += T)
+        reinterpret_cast<uint4 *>(s_tbits)[x] = reinterpret_cast<const uint4 *>(ix.win_tailtab)[x];
+    if (tid < D) {
         s_arrive[tid] = 0ull;
         s_post_seq[tid] = 0u;
     }
@@ -161,13 +203,22 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
     if (blockIdx.x == 0 && tid == 0) *out.pair_cursor_next = 0ull;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(ix.win), 0,
                                                                         (uint32_t)(ix.n_win * kWinLineBytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_tail = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(ix.win_tail), 0, (uint32_t)(twords ? ix.n_tail * kWinLineBytes : 0u), 0x00020000);
     uint32_t bad = 0, n_slow = 0;
 
-    // ---- what is left to do for the wave's PREVIOUS round once its segment base is known (all wave-uniform)
-    bool p_valid = false, p_poster = false;
-    uint32_t p_total = 0, p_seq = 0;
-    unsigned long long p_off = 0, p_round = 0;
-    unsigned long long p_got = 0;  // lane 0 of the poster: what the reservation atomic returned
+    // ---- what is left to do for the wave's previous D - 1 rounds once their segment bases are known (all wave-uniform;
+    // entry 0 = the latest round)
+    constexpr int P = (int)D - 1;
+    bool p_valid[P], p_poster[P];
+    uint32_t p_total[P], p_seq[P], p_slot[P];
+    unsigned long long p_off[P], p_round[P];
+    // lane 0 of the wave that issued the LATEST round's reservation atomic: what it returned.  (One register pair, never
+    // copied while the atomic is in flight: a copy would be a wait for it.  The base is posted during the next round, before
+    // the entries shift.)
+    unsigned long long p_got = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) p_valid[i] = p_poster[i] = false, p_total[i] = p_seq[i] = p_slot[i] = 0, p_off[i] = p_round[i] = 0;
 
     auto post = [&](uint32_t par, uint32_t seq, unsigned long long got) {  // the wave that issued the round's atomic
         if (lane == 0) {
@@ -212,31 +263,62 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
         const unsigned long long g = round * kWaves + (uint32_t)wave;
         if (out.segbase && lane == 0 && g * kWaveGroup < nq) out.segbase[g] = seg;
     };
-    auto finish_prev = [&]() {
-        if (!p_valid) return;
-        const uint32_t par = (p_seq - 1) & 1u;
-        if (p_poster) post(par, p_seq, p_got);
-        const unsigned long long seg = await_base(par, p_seq) + p_off;
-        group_base(p_round, seg);
+    // a round's segment base is posted by the wave that issued its atomic: as soon as that wave has its next round's
+    // gathers in flight (the atomic's answer is there by then) -- a full round before anybody has to have it (D = 3)
+    auto post_pending = [&]() {  // (only the latest round can still be unposted)
+        if (p_valid[0] && p_poster[0]) {
+            post(p_slot[0], p_seq[0], p_got);
+            p_poster[0] = false;
+        }
+    };
+    auto finish = [&](int i) {  // (i: compile-time after unrolling)
+        if (!p_valid[i]) return;
+        const uint32_t slot = p_slot[i];
+#if defined(GFFX_WIN_ABL_NOSYNC)  // (tools/kbench.hip: no reservation at all -- every wave's run at a fixed place)
+        const unsigned long long seg = (p_round[i] * kWaves + (uint32_t)wave) * kWaveStage;
+#else
+        const unsigned long long seg = await_base(slot, p_seq[i]) + p_off[i];
+#endif
+        group_base(p_round[i], seg);
         if (out.fids) {
-            const uint32_t *st = s_stage + par * kWaveStage;
+            const uint32_t *st = s_stage + slot * kWaveStage;
             uint32_t *dst = out.fids + seg;  // (uniform)
-            if (seg + p_total <= out.capacity) {
-                for (uint32_t x = lane; x < p_total; x += 64) GFFX_NT_STORE(st[x], dst + x);
+            if (seg + p_total[i] <= out.capacity) {
+                // (a buffer store from the run's own base: no 64-bit address arithmetic per lane, and the cache policy bits)
+                const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(dst, 0, p_total[i] * 4u, 0x00020000);
+                for (uint32_t x = lane; x < p_total[i]; x += 64)
+                    __builtin_amdgcn_raw_buffer_store_b32(st[x], rf, x * 4u, 0, GFFX_WAVE_STORE_AUX);
             } else {
-                for (uint32_t x = lane; x < p_total; x += 64)
+                for (uint32_t x = lane; x < p_total[i]; x += 64)
                     if (seg + x < out.capacity) dst[x] = st[x];
             }
         }
         if (keep_words) {
-            const uint32_t *kp = s_keep_all + ((size_t)par * T + tid) * 2;
+            const uint32_t *kp = s_keep_all + ((size_t)slot * T + tid) * 2;
             const uint32_t a = kp[0], b = kp[1];
-            put_offsets(p_round, seg, a & 0xFFFFu, a >> 16, b & 0xFFFFu, b >> 16);
+            put_offsets(p_round[i], seg, a & 0xFFFFu, a >> 16, b & 0xFFFFu, b >> 16);
         }
-        p_valid = false;
+        p_valid[i] = false;
+    };
+    auto finish_prev = [&]() {
+        // Every path is past the latest reservation atomic here (it was issued before this round's gathers); saying so makes
+        // p_got an ordinary register again: the next round may overwrite it without a wait for "whatever may still be in flight".
+        asm volatile("" : "+v"(p_got));
+        post_pending();
+        finish(P - 1);  // the oldest round in flight
     };
 
-    uint32_t k_round = 0;  // the block's rounds, counted
+    uint32_t k_round = 0, slot_now = 0;  // the block's rounds, counted; k_round % D
+    // The first round's regions are waited for HERE, once: pending at the loop's entry (with possibly nothing issued after them)
+    // they would turn the wait at the top of EVERY round into s_waitcnt vmcnt(0) -- a drain of the previous round's stores
+    // and of its reservation atomic -- because the compiler merges the entry's state with the back edge's.
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(qc[k]), "+v"(qs[k]), "+v"(qe[k]));
+#if GFFX_WAVE_STAGGER
+    // (experiment: the waves of a SIMD start 0, 1, 2, 3 x GFFX_WAVE_STAGGER x 64 x 16 clocks late, so that a CU's waves are not
+    //  all in the same phase; wave w runs on SIMD w % 4)
+    for (int z = 0; z < (int)((wave >> 2) & 3) * GFFX_WAVE_STAGGER; ++z) __builtin_amdgcn_s_sleep(16);
+#endif
     for (unsigned long long r = blockIdx.x; r < n_rounds; r += gridDim.x, ++k_round) {
         const unsigned long long base = r * kChunk;  // (uniform) first region of the round
         const bool full = base + kChunk <= nq;       // (uniform) every thread has its 4 regions
@@ -262,29 +344,87 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                 const uint32_t v = __builtin_amdgcn_alignbit(s_filter[w + 1], s_filter[w], bit);
                 cov = __builtin_amdgcn_ubfe(v, 0, d + 1) != 0;
             }
+#if defined(GFFX_WIN_ABL_NOGATHER)
+            off[k] = (live && fits && b < m.y && cov && qs[k] == 0xFFFFFFF0u) ? (m.x + b) * kWinLineBytes : kWinNoLine;
+#else
             off[k] = (live && fits && b < m.y && cov) ? (m.x + b) * kWinLineBytes : kWinNoLine;
+#endif
             rel[k] = wmax - (b << shift);
             sweep |= (live && !fits) ? 1u << k : 0u;
         }
-        gffx_v4u wc[4], wf[4];
+        // ---- the FIRST of the thread's regions whose window has a tail line (list of 5..7 entries: the LDS bitmap knows)
+        // reads that line together with its own: no dependent second gather.  (A second such region of the thread, longer
+        // lists, dense windows and sweeps are deferred below.)
+        uint32_t tsel = 4, toff = kWinNoLine, t_qs = 0, t_qe = 0;
+        if (twords) {  // kernel-uniform
+            uint32_t t_w = 0, t_bits = 0;
+#pragma unroll
+            for (int k = 3; k >= 0; --k) {
+                const uint32_t w = off[k] >> 5;  // the window's number (a region without a line: beyond the table)
+                const uint32_t tb = s_tbits[min(w >> 5, twords - 1)];
+                const bool ht = (int)off[k] >= 0 && __builtin_amdgcn_ubfe(tb, w & 31u, 1) != 0;
+                tsel = ht ? (uint32_t)k : tsel;
+                t_w = ht ? w : t_w;
+                t_bits = ht ? tb : t_bits;
+                t_qs = ht ? qs[k] + rel[k] : t_qs;
+                t_qe = ht ? qe[k] + rel[k] : t_qe;
+            }
+            const uint32_t rank = s_trank[min(t_w >> 5, twords - 1)] + __popc(t_bits & ((1u << (t_w & 31u)) - 1u));
+            toff = tsel < 4 ? rank * kWinLineBytes : kWinNoLine;
+        }
+        gffx_v4u wc[4], wf[4], wtc, wtf;
         __builtin_amdgcn_sched_barrier(0);
+#if GFFX_WAVE_EXEC_LOADS
+        // Only the lanes that have a line ask for it: the vector memory path spends time on EVERY lane of a load instruction
+        // that is switched on, in range or not (~1 cycle per out-of-range lane against ~2.9 per line fetched), and 37 % of the
+        // bench's regions stop at the coverage filter.  The other lanes' registers are left as they are (the empty asm says
+        // "written": no zero fill) and every result taken from them is masked with `has` below.
+        uint32_t has = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            asm volatile("" : "=v"(wc[k]), "=v"(wf[k]));
+            if ((int)off[k] >= 0) {
+                wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+                wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+            }
+            has |= (int)off[k] >= 0 ? 1u << k : 0u;
+        }
+        asm volatile("" : "=v"(wtc), "=v"(wtf));
+        if (tsel < 4) {
+            wtc = __builtin_amdgcn_raw_buffer_load_b128(rs_tail, toff, 0, 0);
+            wtf = __builtin_amdgcn_raw_buffer_load_b128(rs_tail, toff + 16, 0, 0);
+        }
+#else
+        const uint32_t has = 15u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+        wtc = __builtin_amdgcn_raw_buffer_load_b128(rs_tail, toff, 0, 0);
+        wtf = __builtin_amdgcn_raw_buffer_load_b128(rs_tail, toff + 16, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         GFFX_WIN_STAMP(1);
+#if GFFX_WAVE_FINISH_EARLY
+        // ---- the previous round, while this round's lines are on their way: its segment base has had the whole region /
+        // index arithmetic above to arrive (the wave that issued the atomic posts it here)
+        finish_prev();
+#endif
+        GFFX_WIN_STAMP(2);
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept root_fids wait in
         // the thread's LDS strip)
         uint32_t hdr[4], tc[4] = {0, 0, 0, 0};
         uint32_t deferred = sweep, n_rest = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const bool tail = wc[k].w == kWinTailMark;
+            const bool tail = wc[k].w == kWinTailMark && (has >> k & 1u) && (uint32_t)k != tsel;  // (region tsel has its tail line at hand)
             hdr[k] = tail ? wf[k].w : 0u;
             deferred |= tail ? 1u << k : 0u;
             sweep |= (hdr[k] & 255u) == 255u ? 1u << k : 0u;
         }
+#if defined(GFFX_WIN_ABL_NODEFER)
+        deferred = 0;
+#endif
         if (deferred) {
             n_slow += __popc(sweep);
             uint32_t d = deferred;
@@ -294,7 +434,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                 uint32_t c = 0;
                 win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
                                               [&](uint32_t, uint32_t, uint32_t fid, uint32_t) {
-                                                  if (n_rest < kWinStash) s_stash[n_rest] = fid;
+                                                  if (n_rest < kWaveStash) s_stash[n_rest] = fid;
                                                   ++n_rest;
                                                   ++c;
                                               });
@@ -304,6 +444,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                 tc[3] += k == 3 ? c : 0u;
             }
         }
+        GFFX_WIN_STAMP(3);
         // ---- four exact tests per region, in the line's relative coordinates
         uint32_t cnt[4], mask[4];
 #pragma unroll
@@ -314,25 +455,43 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
             mk |= win_test<MODE, INVERT>(wc[k].y & 0xFFFFu, wc[k].y >> 16, rqs, rqe) ? 2u : 0u;
             mk |= win_test<MODE, INVERT>(wc[k].z & 0xFFFFu, wc[k].z >> 16, rqs, rqe) ? 4u : 0u;
             mk |= win_test<MODE, INVERT>(wc[k].w & 0xFFFFu, wc[k].w >> 16, rqs, rqe) ? 8u : 0u;
+            mk = (has >> k & 1u) ? mk : 0u;
             mask[k] = mk;
             cnt[k] = __popc(mk) + tc[k];
         }
+        // ... and the tail line's entries 3..6 of region tsel (a thread without one read zeros: nothing passes)
+        uint32_t mask_t = 0;
+        mask_t |= win_test<MODE, INVERT>(wtc.x & 0xFFFFu, wtc.x >> 16, t_qs, t_qe) ? 1u : 0u;
+        mask_t |= win_test<MODE, INVERT>(wtc.y & 0xFFFFu, wtc.y >> 16, t_qs, t_qe) ? 2u : 0u;
+        mask_t |= win_test<MODE, INVERT>(wtc.z & 0xFFFFu, wtc.z >> 16, t_qs, t_qe) ? 4u : 0u;
+        mask_t |= win_test<MODE, INVERT>(wtc.w & 0xFFFFu, wtc.w >> 16, t_qs, t_qe) ? 8u : 0u;
+        mask_t = tsel < 4 ? mask_t : 0u;
+        {
+            const uint32_t ct = __popc(mask_t);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cnt[k] += (uint32_t)k == tsel ? ct : 0u;
+        }
         // the regions are done with: the next round's take their registers
         load_round(r + gridDim.x);
-        GFFX_WIN_STAMP(2);
+        GFFX_WIN_STAMP(4);
         const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         const uint32_t inc = win_wave_scan(mine);
         const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);  // (uniform) the wave's kept pairs
         const uint32_t lp0 = inc - mine;  // this thread's first pair inside the wave's run
-        if (full) {
-            win_nt_store4(out.counts + base + t4, cnt[0], cnt[1], cnt[2], cnt[3]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((uint32_t)k < n_mine) out.counts[i0 + k] = cnt[k];
+        {
+            // counts: ONE 16-byte buffer store per thread on every path (rows beyond the batch fall outside the descriptor and
+            // are dropped by the range check).  A conditional store here would make "no memory operation was issued after the
+            // region prefetch" a possible path, and the wait for the prefetched regions at the top of the next round would
+            // become s_waitcnt vmcnt(0): a full drain of this round's stores and of the reservation atomic, every round.
+            const unsigned long long left = nq - base;  // (base < nq inside the loop)
+            const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
+            gffx_v4u cv;
+            cv.x = cnt[0], cv.y = cnt[1], cv.z = cnt[2], cv.w = cnt[3];
+            __builtin_amdgcn_raw_buffer_store_b128(cv, __builtin_amdgcn_make_buffer_rsrc(out.counts + base, 0, rows * 4u, 0x00020000),
+                                                   4u * t4, 0, GFFX_WAVE_STORE_AUX);
         }
         // ---- park the round's root_fids in this wave's strip (by final position inside the wave's run)
-        const uint32_t par = k_round & 1u;
+        const uint32_t par = slot_now;
         const bool staged = wtotal <= kWaveStage;  // (uniform)
         if (staged) {
             if (out.fids) {
@@ -346,18 +505,29 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                     if (m & 4u) st[lp + __popc(m & 3u)] = wf[k].z;
                     if (m & 8u) st[lp + __popc(m & 7u)] = wf[k].w;
                 }
+                if (mask_t) {  // the tail line's kept entries follow the region's inline ones
+                    uint32_t e = win_sel(lpk, (int)tsel) + __popc(win_sel(mask, (int)tsel));
+                    if (mask_t & 1u) st[e++] = wtf.x;
+                    if (mask_t & 2u) st[e++] = wtf.y;
+                    if (mask_t & 4u) st[e++] = wtf.z;
+                    if (mask_t & 8u) st[e++] = wtf.w;
+                }
                 uint32_t d = deferred, taken = 0;
                 while (d) {  // list tails / sweeps: from the strip, or (rare) walked again
                     const int k = __ffs(d) - 1;
                     d &= d - 1;
                     uint32_t e = win_sel(lpk, k) + __popc(win_sel(mask, k));
-                    if (n_rest <= kWinStash) {
+                    if (n_rest <= kWaveStash) {
                         for (uint32_t t = win_sel(tc, k); t; --t) st[e++] = s_stash[taken++];
                     } else {
                         uint32_t c_, s_, e_;
                         load_query<AOS>(q, i0 + k, c_, s_, e_);
                         win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, c_, s_, e_, win_sel(hdr, k),
                                                       [&](uint32_t, uint32_t, uint32_t fid, uint32_t) { st[e++] = fid; });
+                        // (rare path, late in the round: leave no load of it in flight -- registers the compiler must treat as
+                        //  "maybe still being loaded" at the top of the next round would turn the wait there into vmcnt(0) for
+                        //  EVERY round, a drain of the counts store and of the reservation atomic)
+                        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                     }
                 }
             }
@@ -367,35 +537,47 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                 kp[1] = cnt[1] | cnt[2] << 16;
             }
         }
+        GFFX_WIN_STAMP(5);
         // ---- arrive: this wave's share of the round's segment; the last wave to arrive reserves the segment
         unsigned long long old = 0;
+#if !defined(GFFX_WIN_ABL_NOSYNC)
         if (lane == 0) old = atomicAdd(&s_arrive[par], (1ull << 56) | (unsigned long long)wtotal);
+#endif
         old = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(old >> 32)) << 32) |
               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)old);
         const unsigned long long my_off = old & ((1ull << 56) - 1);
         const bool last = (uint32_t)(old >> 56) == kWaves - 1;  // (uniform)
-        unsigned long long got = 0;
+        p_got = 0;  // (the previous round's answer was posted above, after this round's gathers were issued)
         if (last) {
             const unsigned long long btotal = my_off + wtotal;
             if (lane == 0) {
                 __hip_atomic_store(&s_arrive[par], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (btotal) got = atomicAdd(out.pair_cursor, btotal);
+                if (btotal) p_got = atomicAdd(out.pair_cursor, btotal);
             }
         }
-        GFFX_WIN_STAMP(3);
+        GFFX_WIN_STAMP(6);
+#if !GFFX_WAVE_FINISH_EARLY
         // ---- the previous round: its segment base has had a whole round to arrive
         finish_prev();
+#endif
+#pragma unroll
+        for (int i = P - 1; i > 0; --i) {  // (entry P - 1 was finished above)
+            p_valid[i] = p_valid[i - 1], p_poster[i] = p_poster[i - 1], p_total[i] = p_total[i - 1];
+            p_off[i] = p_off[i - 1], p_round[i] = p_round[i - 1], p_seq[i] = p_seq[i - 1], p_slot[i] = p_slot[i - 1];
+        }
+        p_valid[0] = false;
         if (staged) {
-            p_valid = true;
-            p_poster = last;
-            p_got = got;
-            p_total = wtotal;
-            p_off = my_off;
-            p_round = r;
-            p_seq = k_round + 1;
+            p_valid[0] = true;
+            p_poster[0] = last;
+            p_total[0] = wtotal;
+            p_off[0] = my_off;
+            p_round[0] = r;
+            p_seq[0] = k_round + 1;
+            p_slot[0] = par;
         } else {
             // more pairs than the strip holds: wait for the base now and write them from a second walk of the regions
-            if (last) post(par, k_round + 1, got);
+            // (the rounds before were posted above, right after this round's gathers: nobody waits for THIS wave while it waits)
+            if (last) post(par, k_round + 1, p_got);
             const unsigned long long seg = await_base(par, k_round + 1) + my_off;
             group_base(r, seg);
             if (out.offsets || out.offsets32) put_offsets(r, seg, lp0, cnt[0], cnt[1], cnt[2]);
@@ -410,10 +592,14 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                     });
                 }
             }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): as above (rare path at the end of a round)
         }
-        GFFX_WIN_STAMP(4);
+        slot_now = slot_now + 1 == D ? 0u : slot_now + 1;
+        GFFX_WIN_STAMP(7);
     }
-    finish_prev();
+    post_pending();
+#pragma unroll
+    for (int i = P - 1; i >= 0; --i) finish(i);
     if (bad) atomicOr(out.err, 1u);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64);
