@@ -94,8 +94,28 @@ void write_segments(const uint8_t *base, const std::vector<std::pair<uint64_t, u
         out.close();
         return;
     }
-    const int fd = ::open(output_path->c_str(), O_RDWR | O_CREAT | O_TRUNC, 0666);  // (O_RDWR: a shared writable mapping needs it)
+    // A target that is not a regular file (FIFO, /dev/stdout, a process substitution, a tty) cannot be written at offsets:
+    // it gets the segments in order through write(), opened the way the reference's File::create opens it (write-only).
+    struct stat st {};
+    const bool special = ::stat(output_path->c_str(), &st) == 0 && !S_ISREG(st.st_mode);
+    const int fd = ::open(output_path->c_str(), (special ? O_WRONLY : O_RDWR) | O_CREAT | O_TRUNC, 0666);  // (O_RDWR: a shared writable mapping needs it)
     if (fd < 0) throw Error("cannot create output file \"" + *output_path + "\"");
+    if (special || ::fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        bool bad = false;
+        for (const auto &[off, len] : seg) {
+            const uint8_t *p = base + off;
+            uint64_t left = len;
+            while (left && !bad) {
+                const ssize_t w = ::write(fd, p, static_cast<size_t>(std::min<uint64_t>(left, 1u << 30)));
+                if (w < 0 && errno == EINTR) continue;
+                if (w <= 0) bad = true;
+                else p += w, left -= static_cast<uint64_t>(w);
+            }
+            if (bad) break;
+        }
+        if (::close(fd) != 0 || bad) throw Error("write failed");
+        return;
+    }
     std::vector<uint64_t> dst(seg.size() + 1, 0);
     for (size_t i = 0; i < seg.size(); ++i) dst[i + 1] = dst[i] + seg[i].second;
     const uint64_t total = dst.back();

@@ -42,38 +42,6 @@ std::vector<uint32_t> flatten(const std::vector<Region> &regions) {
     return flat;
 }
 
-struct OutFile {
-    FILE *f = nullptr;
-    bool owned = false;
-    explicit OutFile(const std::optional<std::string> &path) {
-        if (path) {
-            f = std::fopen(path->c_str(), "wb");
-            if (!f) throw Error("cannot create output file \"" + *path + "\"");
-            owned = true;
-            std::setvbuf(f, nullptr, _IOFBF, 32 << 20);  // WRITE_BUF_SIZE, intersect.rs:23
-        } else {
-            f = stdout;
-        }
-    }
-    // The reference propagates `writer.flush()?` (intersect.rs:405,425; common.rs:270): with a large stdio buffer most of
-    // the output is written here, so ENOSPC / EIO / a closed pipe must fail the run, not truncate the file silently.
-    void close() {
-        FILE *g = f;
-        f = nullptr;
-        if (!g) return;
-        const bool bad = std::fflush(g) != 0 || std::ferror(g);
-        if (owned && std::fclose(g) != 0) throw Error("write failed (closing the output)");
-        if (bad) throw Error("write failed (flushing the output)");
-    }
-    ~OutFile() {  // best effort only: the writers call close()
-        if (!f) return;
-        if (owned)
-            std::fclose(f);
-        else
-            std::fflush(f);
-    }
-};
-
 }  // namespace
 
 // intersect.rs:172-198
@@ -631,6 +599,10 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
     if (visible <= 0) throw Error(std::string("no HIP device visible (the engine has no CPU fallback)"));
     const size_t D = static_cast<size_t>(std::max(1, n_gpus));
     std::vector<int> dev(D);
+    // --device names a real device (out of range is an error, as in the engine); only the ADDITIONAL logical devices of
+    // --gpus N wrap around the visible ones
+    if (device < 0 || device >= visible)
+        throw Error("device " + std::to_string(device) + " out of range (" + std::to_string(visible) + " visible)");
     for (size_t d = 0; d < D; ++d) dev[d] = (device + static_cast<int>(d)) % visible;
     bool distinct = true;
     for (size_t d = 1; d < D; ++d)
@@ -710,21 +682,34 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
                 for (uint32_t c = 0; c < n_seq; ++c) res.has_regions[c] |= seen[w][c];
             n_dev[0] = off[T];
         } else {
-            // bucket sizes of the chunk, the plan, then every parser thread scatters its rows to their device's staging
-            std::vector<std::vector<uint64_t>> cnt(T, std::vector<uint64_t>(n_seq, 0));
+            // bucket sizes of the chunk, the plan, then the rows are scattered to their device's staging buffer.  W <= 16
+            // workers take CONTIGUOUS runs of the parser's pieces (file order), so a row's rank inside its seqid's bucket is
+            // (rows of the seqid in earlier workers) + (rows seen so far by this worker): one exclusive prefix over the
+            // workers, O(n_seq x W) work and memory per chunk whatever the number of pieces (a draft assembly has 10^5 seqids).
+            const size_t W = std::min<size_t>(T, 16);
+            auto first_piece = [&](size_t w) { return T * w / W; };
+            std::vector<std::vector<uint64_t>> cnt(W, std::vector<uint64_t>(n_seq, 0));
             {
-                auto work = [&](size_t t) {
-                    for (size_t i = 0; i < piece[t].size(); i += 3) cnt[t][piece[t][i]]++;
+                auto work = [&](size_t w) {
+                    for (size_t t = first_piece(w); t < first_piece(w + 1); ++t)
+                        for (size_t i = 0; i < piece[t].size(); i += 3) cnt[w][piece[t][i]]++;
                 };
                 std::vector<std::thread> pool;
-                for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+                for (size_t w = 1; w < W; ++w) pool.emplace_back(work, w);
                 work(0);
                 for (auto &th : pool) th.join();
             }
             std::vector<uint64_t> size(n_seq, 0);
-            for (size_t t = 0; t < T; ++t)
-                for (uint32_t c = 0; c < n_seq; ++c) size[c] += cnt[t][c];
-            for (uint32_t c = 0; c < n_seq; ++c) res.has_regions[c] |= size[c] != 0;
+            for (uint32_t c = 0; c < n_seq; ++c) {
+                uint64_t acc = 0;
+                for (size_t w = 0; w < W; ++w) {  // cnt[w][c] becomes the rank of worker w's first row of seqid c
+                    const uint64_t n = cnt[w][c];
+                    cnt[w][c] = acc;
+                    acc += n;
+                }
+                size[c] = acc;
+                res.has_regions[c] |= acc != 0;
+            }
             const auto plan = plan_shards(size, D);
             // per seqid: its slices as (lo, hi, device, offset inside the device's share)
             struct Dest {
@@ -743,24 +728,23 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
             for (size_t d = 0; d < D; ++d) all_base[d + 1] = all_base[d] + n_dev[d];
             std::vector<uint32_t *> stage(D);
             for (size_t d = 0; d < D; ++d) stage[d] = gffx_hip_regions_staging(store[d].h, k);
-            auto work = [&](size_t t) {
-                std::vector<uint64_t> rank(n_seq, 0);  // bucket rank of this thread's next row of the seqid (file order)
-                for (uint32_t c = 0; c < n_seq; ++c)
-                    for (size_t u = 0; u < t; ++u) rank[c] += cnt[u][c];
-                for (size_t i = 0; i < piece[t].size(); i += 3) {
-                    const uint32_t c = piece[t][i];
-                    const uint64_t p = rank[c]++;
-                    const std::vector<Dest> &v = dest[c];
-                    size_t j = 0;
-                    while (j + 1 < v.size() && p >= v[j].hi) ++j;
-                    const uint64_t at = v[j].off + (p - v[j].lo);
-                    const uint32_t d = v[j].d;
-                    if (d != 0 || !keep_store) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[d] + 3 * at);
-                    if (keep_store) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[0] + 3 * (all_base[d] + at));
-                }
+            auto work = [&](size_t w) {
+                std::vector<uint64_t> &rank = cnt[w];  // bucket rank of this worker's next row of the seqid (file order)
+                for (size_t t = first_piece(w); t < first_piece(w + 1); ++t)
+                    for (size_t i = 0; i < piece[t].size(); i += 3) {
+                        const uint32_t c = piece[t][i];
+                        const uint64_t p = rank[c]++;
+                        const std::vector<Dest> &v = dest[c];
+                        size_t j = 0;
+                        while (j + 1 < v.size() && p >= v[j].hi) ++j;
+                        const uint64_t at = v[j].off + (p - v[j].lo);
+                        const uint32_t d = v[j].d;
+                        if (d != 0 || !keep_store) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[d] + 3 * at);
+                        if (keep_store) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[0] + 3 * (all_base[d] + at));
+                    }
             };
             std::vector<std::thread> pool;
-            for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+            for (size_t w = 1; w < W; ++w) pool.emplace_back(work, w);
             work(0);
             for (auto &th : pool) th.join();
         }
@@ -808,16 +792,22 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
         // not materialised by a bitmap pass} -- the per-device region counts and bitmap population
         for (size_t d = 0; d < D; ++d) counts[2 * d + 1] = 0;
         std::vector<uint64_t> gathered(2 * D * D, 0);
+        // (every result of the run already sits on the host: the exchange is the job's reported hit-count step, and a node
+        //  without a usable librccl must not lose a finished run to it -- a failure is a warning)
+        bool exchanged = false;
         if (distinct) {
-            if (gffx_hip_allgather_counts(static_cast<int>(D), dev.data(), counts.data(), gathered.data()) != GFFX_OK)
-                hip_fail("gffx_hip_allgather_counts");
-            for (size_t d = 0; d < D; ++d)
-                if (gathered[2 * d] != counts[2 * d]) throw Error("the RCCL all-gather returned different region counts");
+            if (gffx_hip_allgather_counts(static_cast<int>(D), dev.data(), counts.data(), gathered.data()) != GFFX_OK) {
+                std::fprintf(stderr, "[WARN] hit-count all-gather over RCCL failed: %s\n", gffx_hip_last_error());
+            } else {
+                exchanged = true;
+                for (size_t d = 0; d < D; ++d)
+                    if (gathered[2 * d] != counts[2 * d]) throw Error("the RCCL all-gather returned different region counts");
+            }
         }
         if (verbose)
             for (size_t d = 0; d < D; ++d)
                 std::fprintf(stderr, "[INFO] device %d: %llu regions%s\n", dev[d], (unsigned long long)dev_rows[d],
-                             distinct ? " (all-gathered over RCCL)" : "");
+                             exchanged ? " (all-gathered over RCCL)" : "");
         sub.lap("  hit-count exchange");
     }
     const uint32_t *fids = gffx_hip_index_sorted_fids(index_data.device_index);

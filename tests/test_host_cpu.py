@@ -227,6 +227,18 @@ def test_load_tree_index_parse_bed_and_offsets_equal_the_oracle(host, tmp_path, 
     rc, msg = ob.intersect_run(gff, want, bed=bed, mode=2, entire_group=True)
     assert rc == 0, msg
     assert open(outp, "rb").read() == open(want, "rb").read()
+    # -o to something that cannot be written at offsets (FIFO, /dev/stdout, a process substitution): the reference's
+    # File::create + sequential writes work there, so must this writer (same bytes, in order)
+    import threading
+    fifo = str(tmp_path / "out.fifo")
+    os.mkfifo(fifo)
+    got = {}
+    reader = threading.Thread(target=lambda: got.setdefault("bytes", open(fifo, "rb").read()))
+    reader.start()
+    rc = host.gffx_host_write_gff_output(gff.encode(), blocks.ctypes.data_as(u64p), len(blocks), fifo.encode(), e, len(e))
+    reader.join(timeout=30)
+    assert rc == 0, e.value.decode()
+    assert got.get("bytes") == open(want, "rb").read()
 
 
 def test_line_helpers_match_the_python_restatement(host):
