@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- BED overlap queries/sec against a GRCh38-scale GFF index on N MI355X.
 
-One "step" = one pass of the intersect hot path (Join A: regions x root intervals -> per-region kept counts and u32
-segment offsets in input order, and the root_fids of every kept pair) over one batch of synthetic BED regions that is
-already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: 1 M synthetic BED regions (seed 1001, chr ~ length,
+One PASS of the intersect hot path = Join A: regions x root intervals -> per-region kept counts (input order), the root_fids
+of every kept pair, and one segment base per group of 256 regions (GFFX_OUT_SEGBASE: a region's segment starts at its group's
+base + the counts before it) over one batch of synthetic BED regions that is already resident in HBM.  One "step" =
+--passes-per-step (default 100) such passes over the SAME resident batch, so that the timed region of K steps lasts tens of
+milliseconds whatever K the driver passes (a 1 M-region pass is ~10 us: 20 single passes would be a 0.2 ms measurement).  Workload at N=1 = BASELINE.json configs[1]: 1 M synthetic BED regions (seed 1001, chr ~ length,
 width U[100,10000], unsorted) x a GENCODE/GRCh38-shaped index (25 seqids, ~63 k root genes of a ~3.4 M-line annotation,
 seed 42), --overlap mode.
 
 The JSON line carries, next to the contract's fields:
-  value / ms_per_step   K steps issued round-robin to --inflight (default 2) QueryBatch objects (own HIP stream and result
-                        buffers each, the same resident regions): the launch ramp / drain of one pass overlaps the next.
-                        The pipeline is warmed (2 x inflight passes, synced) immediately before the timed region.
+  value / ms_per_step   K steps = K x passes-per-step passes issued round-robin to --inflight (default 2) QueryBatch objects (own HIP
+                        stream and result buffers each, the same resident regions) by ONE call into the C-ABI
+                        (gffx_hip_batches_run_n: the launch loop runs in C): the launch ramp / drain of one pass overlaps the next.
+                        The pipeline is warmed (2 x inflight passes, synced) immediately before the timed region.  The timed
+                        region is repeated --repeats times (default 5), each bracketed by barrier + synchronize; `value` is the
+                        MEDIAN repeat, `repeats` lists them all.
   serial                the same K steps with ONE batch: strictly serial passes (what profiles/*kernel_stats* shows); the engine
                         takes 1024-thread blocks for such a pass (roofline inside), 512-thread blocks while two batches are in flight
   roofline              dominant kernel, HIP-event durations of serial back-to-back launches on the engine's stream
-  roofline_10m          the same for a 10 M-region batch (seed 1002)
+  roofline_10m          the same for a 10 M-region batch (seed 1002); roofline_10m_contained: --contained (configs[2]'s mode);
+                        wide_regions: 1 M regions of width U[100, 200000] (AUTO moves the batch to the sweep kernel);
+                        sorted_bed: the 1 M batch sorted by (seqid, start) as BED files usually are
   cli_pass              the pass the CLI runs (root bitmap only) at 1 M and 10 M regions, next to the root_fid pass
   t_xfer                host regions in (pinned), counts + root_fids back on the host: two batches double-buffered
   t_e2e                 the `gffx` CLI on a 3.5 M-line synthetic GFF3 x the 1 M-row BED: wall clock + its stage timers; and x a
@@ -56,7 +63,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--passes-per-step", type=int, default=100,
+                    help="a step = this many passes over the resident batch (the timed region then lasts tens of ms)")
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is measured this many times; value = median")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--queries-per-gpu", type=int, default=1_000_000)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -66,8 +76,9 @@ def parse_args():
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
     ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused", "slots", "windows"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
-    ap.add_argument("--offsets", default="u32", choices=["u32", "u64", "none"],
-                    help="per-region segment offsets written by the pass (u32 needs the windows strategy / auto)")
+    ap.add_argument("--offsets", default="seg", choices=["seg", "u32", "u64", "none"],
+                    help="where the pairs of a region are: seg = one u64 base per group of 256 regions (GFFX_OUT_SEGBASE, windows "
+                         "strategy / auto); u32 / u64 = a segment start per region")
     ap.add_argument("--presort", default="none", choices=["none", "chr_end"],
                     help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
     ap.add_argument("--exchange", default=None, choices=["final", "final-timed", "per-step"])
@@ -93,6 +104,23 @@ def host_info():
     return {"cpu": model, "nproc": os.cpu_count()}
 
 
+def reference_toolchain():
+    """the harness probes for a Rust toolchain; with one (and the reference's crates vendored) the real `gffx`
+    could be built and timed -- tools/pin_against_reference.py does that.  Here it only records what it found."""
+    cargo = shutil.which("cargo")
+    out = {"cargo": None, "reference_binary_timed": False,
+           "note": "no Rust toolchain on this box: the baseline below is the C restatement (oracle/), not the Rust binary"}
+    if cargo:
+        try:
+            v = subprocess.run([cargo, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
+        except Exception as exc:  # noqa: BLE001
+            v = "cargo found but not runnable: %r" % (exc,)
+        out["cargo"] = v
+        out["note"] = ("cargo is present; the real binary is built and compared by tools/pin_against_reference.py --cargo (it needs "
+                       "the reference tree and its crates, which are not on the GPU box): the baseline below is still the C restatement")
+    return out
+
+
 def cpu_baseline(roots, regions, mode, budget_s):
     """Oracle (C restatement of the reference's serial tree walk, intersect.rs:124-166) timed on this host: 1 thread,
     like the reference.  Bounded sample of the same workload."""
@@ -110,6 +138,7 @@ def cpu_baseline(roots, regions, mode, budget_s):
         hits = len(t)
         reps += 1
     return {"value": done / t_used, "unit": "queries/s", "cores": 1, "kind": "port", "host": host_info(),
+            "reference_toolchain": reference_toolchain(),
             "sample": "%d x the full %d-region batch of this workload, Join A only (pointer-based centered interval tree, "
                       "serial, as commands/intersect.rs:124-166); C restatement, not the Rust binary" % (reps, n),
             "pairs_per_batch": hits}
@@ -140,6 +169,12 @@ class Pass:
         self.batches[self.issued % len(self.batches)].run(self.mode, False, self.flags, self.strategy)
         self.issued += 1
 
+    def run_n(self, n_passes):
+        """n passes round-robin over the batches, issued by ONE call into the C-ABI (the launch loop runs in C)."""
+        arr = (ctypes.c_void_p * len(self.batches))(*[bb._h for bb in self.batches])
+        self.engine.check(self.engine.lib().gffx_hip_batches_run_n(arr, len(self.batches), self.mode, 0, self.flags, self.strategy,
+                                                                   n_passes))
+
     def sync(self):
         for bb in self.batches:
             bb.sync()
@@ -159,16 +194,14 @@ class Pass:
         self.sync()
         return pairs
 
-    def timed(self, steps, barrier, torch):
+    def timed(self, n_passes, barrier, torch):
+        """One timed region: exactly n_passes passes between barrier + synchronize on both sides."""
         # warm the pipeline immediately before the timed region: >= 2 x inflight passes, drained
-        for _ in range(2 * len(self.batches)):
-            self.step()
+        self.run_n(2 * len(self.batches))
         self.sync()
-        self.issued = 0
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step()
+        self.run_n(n_passes)
         self.sync()
         torch.cuda.synchronize()
         return time.perf_counter() - t0
@@ -298,7 +331,7 @@ def xfer_leg(engine, torch, ix, regions, mode, pairs, reps=8):
     pin_fids = [torch.empty(cap, dtype=torch.int32).pin_memory() for _ in range(2)]
     u32p = ctypes.POINTER(ctypes.c_uint32)
     bs = [engine.QueryBatch(ix, nq) for _ in range(2)]
-    flags = engine.OUT_FIDS | engine.OUT_OFFSETS32
+    flags = engine.OUT_FIDS | engine.OUT_SEGBASE
 
     def one(k):
         b = bs[k]
@@ -396,10 +429,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus),
-                  file=sys.stderr)
-            sys.exit(2)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # invoked like the 1-GPU run: start the ranks as fresh child processes (this process has not touched the GPU and
+            # never will -- nothing is exec'ed or forked from a process that initialised HIP) and pass their output through
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            sys.exit(subprocess.call(cmd, env=env))
         args.gpus = world
     if args.exchange is None:
         args.exchange = "final-timed" if (args.scaling == "strong" and world > 1) else "final"
@@ -430,7 +470,8 @@ def main():
     strategy = {"auto": 0, "direct": 1, "sorted": 2, "fused": 3, "slots": 4, "windows": 5}[args.strategy]
     out_flags = {"counts": engine.OUT_COUNTS, "fids": engine.OUT_FIDS, "triples": engine.OUT_TRIPLES}[args.out]
     if args.strategy != "direct" and args.out != "counts":
-        out_flags |= {"u32": engine.OUT_OFFSETS32, "u64": engine.OUT_OFFSETS, "none": 0}[args.offsets]
+        offs = args.offsets if args.strategy in ("auto", "windows") or args.offsets != "seg" else "u64"
+        out_flags |= {"seg": engine.OUT_SEGBASE, "u32": engine.OUT_OFFSETS32, "u64": engine.OUT_OFFSETS, "none": 0}[offs]
     if args.strategy == "sorted":
         out_flags |= engine.OUT_EMIT_ORDER
     out_b = {"counts": 0.0, "fids": 4.0, "triples": 12.0}[args.out]
@@ -476,27 +517,39 @@ def main():
     if world > 1:  # the collective's first call sets up its channels: not part of the job's steady state
         shard.allgather_hit_counts(nq, pairs, device=coll_dev)
 
-    # ---- the timed region: exactly K steps between barrier + synchronize, MAX over ranks
-    if world > 1 and args.exchange != "final":
-        for _ in range(2 * len(run.batches)):
-            run.step()
-        run.sync()
-        run.issued = 0
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run.step()
+    # ---- the timed region: exactly K steps (= K x passes-per-step passes) between barrier + synchronize, MAX over ranks;
+    # measured --repeats times, the MEDIAN repeat is the line's value
+    n_passes = args.steps * args.passes_per_step
+
+    def timed_once():
+        if world > 1 and args.exchange != "final":
+            run.run_n(2 * len(run.batches))
+            run.sync()
+            barrier()
+            t0 = time.perf_counter()
             if args.exchange == "per-step":
-                run.batches[(run.issued - 1) % len(run.batches)].wait()
-                shard.allgather_hit_counts(nq, pairs, device=coll_dev)
-        run.sync()
-        if args.exchange == "final-timed":  # the job's one exchange step, inside the timed region
-            run.batches[0].wait()
-            shard.allgather_hit_counts(nq, run.batches[0].total_hits, device=coll_dev)
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-    else:
-        elapsed = run.timed(args.steps, barrier, torch)
+                for _ in range(args.steps):
+                    run.run_n(args.passes_per_step)
+                    run.batches[0].wait()
+                    shard.allgather_hit_counts(nq, pairs, device=coll_dev)
+            else:
+                run.run_n(n_passes)
+            run.sync()
+            if args.exchange == "final-timed":  # the job's one exchange step, inside the timed region
+                run.batches[0].wait()
+                shard.allgather_hit_counts(nq, run.batches[0].total_hits, device=coll_dev)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        else:
+            el = run.timed(n_passes, barrier, torch)
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    all_elapsed = [timed_once() for _ in range(max(1, args.repeats))]
+    elapsed = float(np.median(all_elapsed))
     barrier()
     run.check(pairs)
     exchange_ms = None
@@ -505,9 +558,6 @@ def main():
         counts = shard.allgather_hit_counts(nq, pairs, device=coll_dev)
         torch.cuda.synchronize()
         exchange_ms = 1e3 * (time.perf_counter() - tx)
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         nq_total, pairs_total = int(counts[:, 0].sum()), int(counts[:, 1].sum())
     else:
         nq_total, pairs_total = nq, pairs
@@ -536,12 +586,17 @@ def main():
                 traffic["live_measurement_error"] = live["error"]
         result = {
             "metric": "BED overlap queries/sec vs GRCh38-scale GFF index at 1/2/4/8 MI355X",  # BASELINE.json
-            "value": nq_total * args.steps / elapsed,
+            "value": nq_total * n_passes / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "passes_per_step": args.passes_per_step,
+            "us_per_pass": 1e6 * elapsed / n_passes,
+            "repeats": {"n": len(all_elapsed), "timed_region_ms": [1e3 * x for x in all_elapsed],
+                        "value_min": nq_total * n_passes / max(all_elapsed), "value_max": nq_total * n_passes / min(all_elapsed),
+                        "note": "every repeat = exactly K steps between barrier + synchronize; value is the median repeat"},
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -549,14 +604,16 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE %s: %d synthetic BED regions %s (seed %d) x GENCODE/GRCh38-shaped index (25 seqids, %d root "
-                            "genes, seed 42), --%s, regions resident in HBM as u32 SoA"
+                            "genes, seed 42), --%s, regions resident in HBM as u32 SoA; one step = %d passes over the resident batch "
+                            "(one kernel launch per pass)"
                             % (cfg, nq_global if strong else args.queries_per_gpu, "in total" if strong else "per GPU", seed,
-                               ix.n_roots, args.mode),
+                               ix.n_roots, args.mode, args.passes_per_step),
                 "regions_total": nq_total,
                 "kept_pairs_total": pairs_total,
                 "pairs_per_region": pairs_total / max(nq_total, 1),
                 "outputs": "per-region counts%s (input order) + %s, segments in round order"
-                           % ({"u32": " and u32 segment offsets", "u64": " and u64 segment offsets", "none": ""}[args.offsets]
+                           % ({"seg": " and one u64 segment base per group of 256 regions", "u32": " and u32 segment offsets",
+                               "u64": " and u64 segment offsets", "none": ""}[args.offsets]
                               if args.out != "counts" else "", args.out),
                 "strategy": args.strategy,
                 "presort": args.presort,
@@ -572,17 +629,19 @@ def main():
                                      "achieved = (12 B region + 4 B count + 4 B x pairs/region) x regions / summed HIP-event "
                                      "duration of a pass: serial launches back to back between one pair of HIP events on the engine's "
                                      "stream (rank 0), forced to the block width of the timed region's launches (block_threads); "
-                                     "kernels{} = the same with an event pair per launch", traffic,
+                                     "kernels{} = the same with an event pair per launch.  The resident batch is re-read by every "
+                                     "pass: at 1 M regions (12 MB) the input stream is served by the 256 MB Infinity Cache, not by HBM "
+                                     "(immaterial at this fraction of the roofline, but it is not a cold-HBM figure)", traffic,
                                      run.pass_us_one_event_pair, timed_threads),
         }
     if world == 1:
         # ---- strictly serial passes (one batch, one stream): what the committed rocprofv3 kernel stats show
         ser = Pass(engine, ix, cols, nq, 1, mode, out_flags, strategy)
         ser.size_and_warm(1)
-        el = ser.timed(args.steps, barrier, torch)
+        el = ser.timed(n_passes, barrier, torch)
         ser.check(pairs)
         ks = ser.kernel_us(max(5, min(args.steps, 30)))  # (nothing forced: what the engine picks for a pass that runs alone)
-        result["serial"] = {"ms_per_step": 1e3 * el / args.steps, "value": nq * args.steps / el, "unit": "queries/s",
+        result["serial"] = {"ms_per_step": 1e3 * el / args.steps, "us_per_pass": 1e6 * el / n_passes, "value": nq * n_passes / el, "unit": "queries/s",
                             "batches_in_flight": 1,
                             "roofline": roofline_obj(ks, nq, pairs, out_b, "one batch, passes strictly one after the other: the engine "
                                                      "takes 1024-thread blocks (one per CU) for a 0.5-2.5 M-region pass that runs alone",
@@ -606,6 +665,13 @@ def main():
         result["roofline_10m"] = roofline_obj(k10, len(reg10), pairs10, out_b, "10 M synthetic BED regions (seed 1002), same pass",
                                               None, p10.pass_us_one_event_pair, p10.block_threads)
         p10.close()
+        # ... and in --contained mode (BASELINE configs[2]'s mode)
+        p10c = Pass(engine, ix, cols10, len(reg10), 1, 0, out_flags, strategy)
+        pairs10c = p10c.size_and_warm(1)
+        k10c = p10c.kernel_us(10)
+        result["roofline_10m_contained"] = roofline_obj(k10c, len(reg10), pairs10c, out_b, "the same 10 M regions, --contained "
+                                                        "(BASELINE configs[2]'s mode)", None, p10c.pass_us_one_event_pair, p10c.block_threads)
+        p10c.close()
         bm10 = Pass(engine, ix, cols10, len(reg10), 1, mode, engine.OUT_ROOT_BITMAP, strategy)
         bm10.size_and_warm(1)
         kb10 = bm10.kernel_us(5)
@@ -614,6 +680,27 @@ def main():
         bm10.close()
         result["cli_pass"] = cli
         del cols10, reg10
+        # ---- regions the window lines cannot answer (wider than wmax = 16 Ki): AUTO moves the batch to the sweep kernel
+        regw = synth.synth_bed(nq, seed=1004, width=(100, 200000))
+        colsw = to_dev(torch, regw, dev)
+        pw = Pass(engine, ix, colsw, nq, 1, mode, out_flags & ~engine.OUT_SEGBASE | engine.OUT_OFFSETS, 0)
+        pairsw = pw.size_and_warm(2)  # (the second waited pass is the one AUTO re-routes)
+        kw = pw.kernel_us(10)
+        result["wide_regions"] = roofline_obj(kw, nq, pairsw, out_b, "%d regions of width U[100, 200000] (seed 1004), AUTO, u64 offsets: "
+                                              "most regions are wider than the window lines serve, the batch's passes run on the "
+                                              "sweep kernel" % nq, None, pw.pass_us_one_event_pair, pw.block_threads)
+        pw.close()
+        del colsw, regw
+        # ---- a BED file sorted by (seqid, start), as most are
+        regs = np.ascontiguousarray(regions[np.lexsort((regions[:, 1], regions[:, 0]))])
+        colss = to_dev(torch, regs, dev)
+        ps = Pass(engine, ix, colss, nq, 1, mode, out_flags, strategy)
+        pairss = ps.size_and_warm(1)
+        ks_ = ps.kernel_us(10)
+        result["sorted_bed"] = roofline_obj(ks_, nq, pairss, out_b, "the headline's regions sorted by (seqid, start)", None,
+                                            ps.pass_us_one_event_pair, ps.block_threads)
+        ps.close()
+        del colss, regs
         # ---- transfers included, and the product CLI end to end
         result["t_xfer"] = xfer_leg(engine, torch, ix, regions, mode, pairs)
         try:

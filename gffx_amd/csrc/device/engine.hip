@@ -2029,6 +2029,16 @@ extern "C" int gffx_hip_batch_timed_runs(gffx_hip_batch *b, int mode, int invert
     return rc;
 }
 
+extern "C" int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
+                                      int strategy, uint64_t n_passes) {
+    if (!batches || !n_batches) return fail(GFFX_E_INVALID, "gffx_hip_batches_run_n: no batches");
+    for (uint64_t i = 0; i < n_passes; ++i) {
+        const int rc = gffx_hip_batch_run(batches[i % n_batches], mode, invert, out_flags, strategy);
+        if (rc) return rc;
+    }
+    return GFFX_OK;
+}
+
 extern "C" int gffx_hip_batch_reset_profile(gffx_hip_batch *b) {
     if (!b) return fail(GFFX_E_INVALID, "reset_profile: batch is NULL");
     for (int i = 0; i < GFFX_K__COUNT; i++) {

@@ -252,6 +252,10 @@ int gffx_hip_batch_reset_profile(gffx_hip_batch *);
  * launch-to-launch duration of a pass without an event pair per launch */
 int gffx_hip_batch_timed_runs(gffx_hip_batch *, int mode, int invert, uint32_t out_flags, int strategy, uint32_t n,
                               double *total_ms);
+/* n_passes passes enqueued round-robin over n_batches batches (batch i % n_batches takes pass i) in one call: a host that
+ * keeps several batches in flight pays one FFI crossing for the lot (bench.py's timed region: the launch loop runs in C). */
+int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
+                           int strategy, uint64_t n_passes);
 /* Threads per block of the last windows-strategy pair pass of this batch (512 or 1024; 0: none ran).  The engine takes
  * 1024-thread blocks (one per CU, rounds of 4096 regions) for a batch of 0.5-2.5 M regions while NO other batch of the
  * index has passes in flight, 512-thread blocks (two per CU: kernels of two batches share the CUs) otherwise;
