@@ -159,6 +159,54 @@ def test_load_region_index_reads_rit_rix_and_falls_back_to_gof(host, tmp_path, m
         shutil.move(gff + ".rix.bak", gff + ".rix")
 
 
+def _hex_image(path):
+    out = bytearray()
+    for ln in open(path):
+        out += bytes.fromhex(ln.split("#", 1)[0])
+    return bytes(out)
+
+
+def test_hand_encoded_rit_image_is_what_both_writers_write_and_both_readers_read(host, tmp_path, golden_dir, monkeypatch):
+    """tests/golden/rit_fixture.rit.hex is a .rit image of two trees written BY HAND from the bincode 1.x rules (not by
+    index_builder.cpp, not by the oracle).  Both builders must write exactly those bytes for rit_fixture.gff, and both
+    readers must turn the hand-written bytes into the hand-derived intervals (utils/tree_io.rs:37-63, tree_index.rs:36-82)."""
+    want = _hex_image(os.path.join(golden_dir, "rit_fixture.rit.hex"))
+    assert len(want) == 65 + 53
+    expect = [[(100, 200, 0), (150, 400, 1), (500, 600, 2)], [(0, 50, 3), (60, 80, 4)]]
+
+    def per_chr(t):
+        co, s, e, f = t
+        return [sorted(zip(s[co[c]:co[c + 1]].tolist(), e[co[c]:co[c + 1]].tolist(), f[co[c]:co[c + 1]].tolist()))
+                for c in range(len(co) - 1)]
+
+    # writers: the host's builder and the oracle's
+    for who in ("host", "oracle"):
+        d = tmp_path / who
+        d.mkdir()
+        gff = str(d / "rit_fixture.gff")
+        shutil.copy(os.path.join(golden_dir, "rit_fixture.gff"), gff)
+        if who == "host":
+            assert _build(host, gff)[0] == 0
+        else:
+            ob.build_index(gff)
+        assert open(gff + ".rit", "rb").read() == want, who
+        assert json.load(open(gff + ".rix")) == [0, 65], who
+    # readers: over the hand-written bytes (put in place of the builder's)
+    gff = str(tmp_path / "host" / "rit_fixture.gff")
+    open(gff + ".rit", "wb").write(want)
+    open(gff + ".rix", "w").write("[0,65]")
+    monkeypatch.setenv("GFFX_TREE_INDEX", "rit")
+    rc, t = _host_tree_index(host, gff)
+    assert rc == 0 and per_chr(t) == expect
+    assert per_chr(ob.OracleIndex.load(gff, via_rit=True).export()) == expect
+    # a sequence length that runs past the tree's slice (tree 0 claims 200 intervals): the reference's message
+    broken = bytearray(want)
+    broken[5] = 200
+    open(gff + ".rit", "wb").write(bytes(broken))
+    rc, msg = _host_tree_index(host, gff)
+    assert rc == -1 and "bincode2 deserialize tree #" in msg, msg
+
+
 def test_load_tree_index_parse_bed_and_offsets_equal_the_oracle(host, tmp_path, monkeypatch):
     monkeypatch.setenv("GFFX_TREE_INDEX", "gof")  # builder order, array for array
     gff, roots = _make_gff(tmp_path, 5)
