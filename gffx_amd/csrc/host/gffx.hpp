@@ -190,6 +190,31 @@ bool gff_type_allowed(std::string_view line, const std::vector<std::string> &all
 // (intersect.rs:446-494).  Returns false where the reference's function returns false early.
 bool split_line_for_join_b(std::string_view line, std::string_view &seq, uint32_t &start, uint32_t &end);
 
+// The persistent all-line table `<gff>.lall` of the per-line mode (line_index.cpp has the layout): what
+// write_gff_match_only_by_coords parses out of every hit block on every run (intersect.rs:266-329), computed once by `gffx index`.
+struct AllLines {
+    std::vector<uint64_t> ls;                       // line start
+    std::vector<uint32_t> len, start, end, seq, type;  // bytes to the next line start; raw columns 4 / 5; name numbers
+    std::vector<uint8_t> flags;                     // bit 0: gff_line_overlaps_queries' split succeeded
+    std::vector<std::string> seq_names, type_names;
+};
+AllLines build_all_lines(std::string_view gff, size_t threads);
+void write_all_lines(const std::string &path, const AllLines &A, uint64_t gff_bytes, uint64_t key);
+class AllLinesView {  // the mapped image
+  public:
+    bool open(const std::string &path, uint64_t gff_bytes, uint64_t key, std::string &why);
+    bool block_lines(uint64_t s, uint64_t e, uint64_t &lo, uint64_t &hi) const;
+    uint64_t n_lines = 0;
+    const uint64_t *ls = nullptr;
+    const uint32_t *len = nullptr, *start = nullptr, *end = nullptr, *seq = nullptr, *type = nullptr;
+    const uint8_t *flags = nullptr;
+    std::vector<std::string_view> seq_names, type_names;
+
+  private:
+    MappedFile file_;
+    uint64_t gff_bytes_ = 0;
+};
+
 // intersect.rs:232-438: per hit block, per line: type filter, Join B on the device, copy out
 // the kept lines in file order.
 void write_gff_match_only_by_coords(const std::string &gff_path, const std::vector<Block> &blocks,

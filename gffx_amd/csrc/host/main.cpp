@@ -259,8 +259,13 @@ int run_index_cli(int argc, char **argv) {
         const auto t = commands::depth::build_block_table(gof, text.view(), std::min(hw ? hw : 1u, 12u));
         commands::depth::write_block_table(append_suffix(input, ".lsoa"), t, text.size(), commands::depth::line_table_key(input, gof));
         if (verbose) std::printf("Line table image: %zu lines in %zu blocks.\n", t.line_start.size(), t.block_line_off.size() - 1);
+        // ... and the all-line table `<gff>.lall` of intersect's per-line mode (line_index.cpp)
+        const auto all = commands::intersect::build_all_lines(text.view(), std::min(hw ? hw : 1u, 12u));
+        commands::intersect::write_all_lines(append_suffix(input, ".lall"), all, text.size(), commands::depth::line_table_key(input, gof));
+        if (verbose) std::printf("All-line table: %zu lines, %zu seqid names, %zu types.\n", all.ls.size(), all.seq_names.size(), all.type_names.size());
     } else {
         std::remove(append_suffix(input, ".lsoa").c_str());  // an image of an earlier index run would be stale
+        std::remove(append_suffix(input, ".lall").c_str());
     }
     if (verbose) std::printf("Index created successfully.\n");
     return 0;

@@ -74,6 +74,12 @@ class TreeIndexData:
             names = ["seq%d" % i for i in range(len(co) - 1)]
         return cls(h, names)
 
+    def clone(self, device: int) -> "TreeIndexData":
+        """The same index on another device of the node (gffx_hip_index_clone: device arrays copied GPU to GPU)."""
+        h = C.c_void_p()
+        check(lib().gffx_hip_index_clone(self._h, int(device), C.byref(h)))
+        return TreeIndexData(h, self.num_to_seqid)
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             lib().gffx_hip_index_destroy(self._h)

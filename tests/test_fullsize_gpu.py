@@ -172,3 +172,65 @@ def test_config4_depth_on_one_ranks_25m_share(big_annotation):
     got_rows = sorted(open(out, "rb").read().split(b"\n"))
     want_rows = sorted(open(want, "rb").read().split(b"\n"))
     assert len(got_rows) > 100_000 and got_rows == want_rows
+
+
+def test_config4_depth_200m_rows_over_8_logical_devices(big_annotation):
+    """configs[4] at its full size: `gffx depth --gpus 8` on 200 M read intervals (4.8 GB of BED text; the 8 logical devices
+    share the GPU of a 1-GPU box: rows go to the devices in 4 M-row batches, round robin, index and line table replicated,
+    per-group results merged by sum / min / max).  Checked: (1) the rows equal `--gpus 1`'s on the same 200 M rows;
+    (2) on the first two 25 M-row shards together (50 M rows), `--gpus 8` equals the ORACLE's rows of the two shards merged
+    per ID -- depth summed, min start, max end: how the reference merges its own batches (depth.rs:264-291)."""
+    import shutil
+    roots, gff, d = big_annotation
+    if shutil.disk_usage(str(d)).free < (9 << 30):
+        pytest.skip("needs ~7 GB of scratch space for the 200 M-row BED")
+    base = [synth.synth_bed(25_000_000, seed=1004), synth.synth_bed(25_000_000, seed=1005)]
+    shard = [str(d / ("reads_shard%d.bed" % k)) for k in range(2)]
+    big, two = str(d / "reads200m.bed"), str(d / "reads50m.bed")
+    tmp = str(d / "reads_part.bed")
+    with open(big, "wb") as fb:
+        for k in range(8):  # shards 2..7: the two seeded shards shifted by 13 k bp (numpy needs ~15 s per 25 M fresh rows)
+            rows = base[k % 2]
+            if k >= 2:
+                rows = rows.copy()
+                rows[:, 1:] += np.uint32(13 * k)
+            path = shard[k] if k < 2 else tmp
+            synth.write_bed_fast(path, rows, roots["names"])
+            with open(path, "rb") as fp:
+                shutil.copyfileobj(fp, fb, 1 << 24)
+    os.remove(tmp)
+    with open(two, "wb") as ft:
+        for k in range(2):
+            with open(shard[k], "rb") as fp:
+                shutil.copyfileobj(fp, ft, 1 << 24)
+    assert os.path.getsize(big) > 4_000_000_000
+
+    def depth(bed, gpus, out):
+        r = subprocess.run([GFFX, "depth", "-i", gff, "-s", bed, "-o", out, "-t", "64", "--gpus", str(gpus)], capture_output=True)
+        assert r.returncode == 0, r.stderr[-500:]
+        rows = open(out, "rb").read().split(b"\n")
+        return rows[0], sorted(x for x in rows[1:] if x)
+
+    h8, rows8 = depth(big, 8, str(d / "d200_8.tsv"))
+    h1, rows1 = depth(big, 1, str(d / "d200_1.tsv"))
+    assert h8 == h1 and len(rows8) > 100_000 and rows8 == rows1
+    os.remove(big)
+    # the oracle on the two seeded shards, merged per ID
+    merged = {}
+    for k in range(2):
+        want = str(d / ("depth_want%d.tsv" % k))
+        rc, msg = ob.depth_run(gff, shard[k], want)
+        assert rc == 0, msg
+        for ln in open(want, "rb").read().split(b"\n")[1:]:
+            if not ln:
+                continue
+            i, c, s, e, n = ln.split(b"\t")
+            if i in merged:
+                c0, s0, e0, n0 = merged[i]
+                assert c0 == c
+                merged[i] = (c, min(s0, int(s)), max(e0, int(e)), n0 + int(n))
+            else:
+                merged[i] = (c, int(s), int(e), int(n))
+    want_rows = sorted(b"\t".join([i, c, b"%d" % s, b"%d" % e, b"%d" % n]) for i, (c, s, e, n) in merged.items())
+    _, got_rows = depth(two, 8, str(d / "d50_8.tsv"))
+    assert got_rows == want_rows

@@ -3,6 +3,8 @@
 Compared per stage (SURVEY.md section 8a "hit set"): per-query kept counts, the multiset of
 (root_fid, start, end) triples, the CSR grouping of pairs per query, and the unique-root set.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -667,3 +669,62 @@ def test_wide_block_variant(monkeypatch):
     a.wait()
     a.close()
     other.close()
+
+
+def test_two_cloned_indexes_driven_from_two_threads():
+    """Multi-device bookkeeping before the first real 8-GPU run: two copies of the index made with gffx_hip_index_clone (on a
+    1-GPU box both land on device 0; on a node with more GPUs the second goes to device 1), each with its own batch, each
+    running 1 M-region pair passes with 1024-thread blocks (more than 64 KB of dynamic LDS: the per-(kernel, device) opt-in)
+    from its own host thread at the same time -- full parity of both against the oracle."""
+    import threading
+
+    big = synth.gencode_like_roots(63000, seed=42)
+    co, s, e, f = big["chr_offsets"], big["start"], big["end"], big["fid"]
+    ix0 = engine.TreeIndexData.from_roots(co, s, e, f)
+    ndev = engine.device_count()
+    clones = [ix0.clone(0), ix0.clone(1 % ndev)]
+    assert [c.device for c in clones] == [0, 1 % ndev] and all(c.n_roots == ix0.n_roots for c in clones)
+    ix0.close()  # (the clones own their device arrays)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    regions = [synth.synth_bed(1_000_000, seed=1001), synth.synth_bed(1_000_000, seed=77)]
+    want = [oix.query_features(r, 2, False) for r in regions]
+    flags = engine.OUT_FIDS | engine.OUT_SEGBASE
+    errors = []
+
+    def drive(k):
+        try:
+            b = engine.QueryBatch(clones[k], len(regions[k]))
+            b.set_regions(regions[k])
+            for _ in range(3):
+                b.run(OverlapMode.Overlap, False, flags)
+                b.wait()
+            want_t, want_c = want[k]
+            assert b.total_hits == len(want_t) and np.array_equal(b.counts(), want_c)
+            off, fids = b.offsets_from_segbase().astype(np.int64), b.fids()
+            wc = want_c.astype(np.int64)
+            qid = np.repeat(np.arange(len(wc), dtype=np.int64), wc)
+            within = np.arange(len(qid), dtype=np.int64) - np.repeat(np.cumsum(wc) - wc, wc)
+            got = (qid << 32) | fids[off[qid] + within].astype(np.int64)
+            by_chr = np.argsort(regions[k][:, 0], kind="stable")
+            exp = (np.repeat(by_chr, wc[by_chr]).astype(np.int64) << 32) | want_t[:, 0].astype(np.int64)
+            assert np.array_equal(np.sort(got), np.sort(exp))
+            b.close()
+        except Exception as exc:  # noqa: BLE001 (reported by the main thread)
+            errors.append((k, repr(exc)))
+
+    monkey = os.environ.get("GFFX_HIP_WIN_THREADS")
+    os.environ["GFFX_HIP_WIN_THREADS"] = "1024"
+    try:
+        threads = [threading.Thread(target=drive, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        if monkey is None:
+            os.environ.pop("GFFX_HIP_WIN_THREADS", None)
+        else:
+            os.environ["GFFX_HIP_WIN_THREADS"] = monkey
+    for c in clones:
+        c.close()
+    assert not errors, errors
