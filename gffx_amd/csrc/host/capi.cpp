@@ -214,6 +214,80 @@ extern "C" int gffx_host_line_table_check(const char *gff, uint32_t threads, cha
     return rc != 0 ? rc : usable;
 }
 
+extern "C" int gffx_host_all_lines_check(const char *gff, const char *types, uint32_t threads, uint64_t *n_lines, char *err, size_t errlen) {
+    int usable = 0;
+    const int rc = guard(err, errlen, [&] {
+        namespace ci = commands::intersect;
+        const index_loader::GofMap gof = index_loader::load_gof(gff);
+        const MappedFile text(gff);
+        const std::string_view data = text.view();
+        ci::AllLinesView view;
+        std::string why;
+        if (!view.open(append_suffix(gff, ".lall"), text.size(), commands::depth::line_table_key(gff, gof), why)) {
+            if (err && errlen) std::snprintf(err, errlen, "%s", why.c_str());
+            return;
+        }
+        // the image equals a fresh build on `threads` host threads ...
+        const ci::AllLines fresh = ci::build_all_lines(data, threads);
+        bool same = fresh.ls.size() == view.n_lines && fresh.seq_names.size() == view.seq_names.size() &&
+                    fresh.type_names.size() == view.type_names.size();
+        for (size_t i = 0; same && i < fresh.seq_names.size(); ++i) same = fresh.seq_names[i] == view.seq_names[i];
+        for (size_t i = 0; same && i < fresh.type_names.size(); ++i) same = fresh.type_names[i] == view.type_names[i];
+        for (size_t i = 0; same && i < fresh.ls.size(); ++i)
+            same = fresh.ls[i] == view.ls[i] && fresh.len[i] == view.len[i] && fresh.start[i] == view.start[i] && fresh.end[i] == view.end[i] &&
+                   fresh.seq[i] == view.seq[i] && fresh.type[i] == view.type[i] && fresh.flags[i] == view.flags[i];
+        if (!same) throw Error("the all-line image differs from a fresh build");
+        // ... and gives, for EVERY block of the index, exactly what the text walk of write_gff_match_only_by_coords finds
+        // (intersect.rs:284-321: split at '\n', skip empty / '#', -T on column 3, the 5-tab split with digits-only numbers)
+        std::vector<std::string> allow;
+        if (types) {
+            std::string_view tv(types);
+            size_t a = 0;
+            while (true) {
+                const size_t c = tv.find(',', a);
+                const std::string_view t = trim_unicode_ws(tv.substr(a, c == std::string_view::npos ? std::string_view::npos : c - a));
+                if (!t.empty()) allow.emplace_back(t);
+                if (c == std::string_view::npos) break;
+                a = c + 1;
+            }
+        }
+        uint64_t total = 0;
+        for (const auto &g : gof.entries) {
+            const uint64_t s = g.start_offset, e = std::min<uint64_t>(g.end_offset, data.size());
+            if (s >= e) continue;
+            uint64_t lo, hi;
+            if (!view.block_lines(s, e, lo, hi)) throw Error("a block of the index does not begin / end at line starts of the table");
+            size_t pos = s;
+            uint64_t i = lo;
+            while (pos < e) {
+                size_t nl = data.find('\n', pos);
+                nl = (nl == std::string_view::npos || nl >= e) ? e : nl + 1;
+                std::string_view line = data.substr(pos, nl - pos);
+                if (!line.empty() && line.back() == '\n') line.remove_suffix(1);
+                if (!line.empty() && line[0] != '#') {
+                    if (i >= hi || view.ls[i] != pos || view.ls[i] + view.len[i] != nl) throw Error("line boundaries differ");
+                    const bool t_ok = !types || ci::gff_type_allowed(line, allow);
+                    const bool t_tab = !types || (view.type[i] != 0xFFFFFFFFu &&
+                                                  std::find(allow.begin(), allow.end(), view.type_names[view.type[i]]) != allow.end());
+                    if (t_ok != t_tab) throw Error("the -T filter differs on a line");
+                    std::string_view seq;
+                    uint32_t a = 0, b = 0;
+                    const bool ok = ci::split_line_for_join_b(line, seq, a, b);
+                    if (ok != ((view.flags[i] & 1) != 0)) throw Error("the column split differs on a line");
+                    if (ok && (a != view.start[i] || b != view.end[i] || seq != view.seq_names[view.seq[i]])) throw Error("columns differ on a line");
+                    ++i;
+                    ++total;
+                }
+                pos = nl;
+            }
+            if (i != hi) throw Error("the table lists lines the text walk does not see");
+        }
+        if (n_lines) *n_lines = total;
+        usable = 1;
+    });
+    return rc != 0 ? rc : usable;
+}
+
 extern "C" int gffx_host_cli(int argc, char **argv) { return cli_main(argc, argv); }
 extern "C" void gffx_host_free(void *p) { std::free(p); }
 

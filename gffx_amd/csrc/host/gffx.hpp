@@ -221,13 +221,14 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
                                     const std::vector<Region> &regions, const std::vector<std::string> &num_to_seqid,
                                     const std::optional<std::string> &types_filter,
                                     const std::optional<std::string> &output_path, OverlapMode mode, bool verbose,
-                                    size_t threads, int device);
+                                    size_t threads, int device, const index_loader::GofMap *gof = nullptr);
 
 // The body of write_gff_match_only_by_coords with the regions on the host (flat triples) or in a device region store
 void write_matched_lines(const std::string &gff_path, const std::vector<Block> &blocks, const std::vector<char> &has_regions,
                          const uint32_t *flat, uint64_t n_regions, gffx_hip_regions *store,
                          const std::vector<std::string> &num_to_seqid, const std::optional<std::string> &types_filter,
-                         const std::optional<std::string> &output_path, OverlapMode mode, bool verbose, size_t threads, int device);
+                         const std::optional<std::string> &output_path, OverlapMode mode, bool verbose, size_t threads, int device,
+                         const index_loader::GofMap *gof = nullptr);  // (gof: for the key of the all-line table; loaded when null)
 
 // Chromosome-bucket sharding (the reference buckets by seqid first, intersect.rs:114-120): rows lo..hi of seqid chr's bucket
 struct ShardSlice {

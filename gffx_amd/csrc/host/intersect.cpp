@@ -863,13 +863,13 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
                                     const std::vector<Region> &regions, const std::vector<std::string> &num_to_seqid,
                                     const std::optional<std::string> &types_filter,
                                     const std::optional<std::string> &output_path, OverlapMode mode, bool verbose,
-                                    size_t threads, int device) {
+                                    size_t threads, int device, const index_loader::GofMap *gof) {
     std::vector<char> has(num_to_seqid.size(), 0);
     for (const auto &r : regions)
         if (std::get<0>(r) < has.size()) has[std::get<0>(r)] = 1;
     const std::vector<uint32_t> flat = flatten(regions);
     write_matched_lines(gff_path, blocks, has, flat.data(), regions.size(), nullptr, num_to_seqid, types_filter, output_path, mode,
-                        verbose, threads, device);
+                        verbose, threads, device, gof);
 }
 
 // The body of write_gff_match_only_by_coords with the regions either on the host (flat triples) or already in a device
@@ -877,7 +877,8 @@ void write_gff_match_only_by_coords(const std::string &gff_path, const std::vect
 void write_matched_lines(const std::string &gff_path, const std::vector<Block> &blocks, const std::vector<char> &has,
                          const uint32_t *flat, uint64_t n_regions, gffx_hip_regions *store,
                          const std::vector<std::string> &num_to_seqid, const std::optional<std::string> &types_filter,
-                         const std::optional<std::string> &output_path, OverlapMode mode, bool verbose, size_t threads, int device) {
+                         const std::optional<std::string> &output_path, OverlapMode mode, bool verbose, size_t threads, int device,
+                         const index_loader::GofMap *gof) {
     MappedFile gff;
     try {
         gff = MappedFile(gff_path);
@@ -923,6 +924,40 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
     std::sort(ranges.begin(), ranges.end());
     StageTimer sub{verbose};
 
+    // The all-line table `<gff>.lall` written by `gffx index` (line_index.cpp): with it no text is parsed here.  An index made
+    // by the reference's own `gffx index` has none, a stale or damaged one is not used, GFFX_LINE_TABLE=parse ignores it.
+    AllLinesView all;
+    bool use_all = false;
+    std::vector<char> type_ok;        // per type number: passes -T
+    std::vector<uint32_t> seq_target;  // per column-1 name number: the seqid number that owns regions, or UINT32_MAX
+    {
+        const char *lt = std::getenv("GFFX_LINE_TABLE");
+        std::string why = "disabled";
+        if (!(lt && std::string(lt) == "parse")) {
+            std::optional<index_loader::GofMap> own;
+            if (!gof) {
+                own = index_loader::load_gof(gff_path);
+                gof = &*own;
+            }
+            use_all = all.open(append_suffix(gff_path, ".lall"), file_len, depth::line_table_key(gff_path, *gof), why);
+        }
+        if (use_all) {
+            type_ok.assign(all.type_names.size(), 1);
+            if (types_filter)
+                for (size_t i = 0; i < all.type_names.size(); ++i)
+                    type_ok[i] = std::find(allow.begin(), allow.end(), all.type_names[i]) != allow.end();
+            seq_target.assign(all.seq_names.size(), UINT32_MAX);
+            for (size_t i = 0; i < all.seq_names.size(); ++i) {
+                const auto it = seq_with_regions.find(all.seq_names[i]);
+                if (it != seq_with_regions.end()) seq_target[i] = it->second;
+            }
+        }
+        if (verbose)
+            std::fprintf(stderr, use_all ? "[INFO] all-line table from %s.lall (%llu lines)\n" : "[INFO] all-line table not used (%s): parsing the hit blocks\n",
+                         use_all ? gff_path.c_str() : why.c_str(), (unsigned long long)all.n_lines);
+    }
+    std::atomic<bool> table_failed{false};
+
     // line table of the hit blocks: (abs start, abs end incl. '\n', seqid number, raw start, raw end)
     struct Part {
         std::vector<uint64_t> ls, le;
@@ -938,7 +973,37 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
             if (pi >= n_parts) return;
             Part &P = parts[pi];
             const size_t b0 = ranges.size() * pi / n_parts, b1 = ranges.size() * (pi + 1) / n_parts;
-            for (size_t b = b0; b < b1; ++b) {
+            for (size_t b = b0; b < b1 && use_all; ++b) {  // from the table: no text is read
+                uint64_t lo, hi;
+                if (table_failed.load(std::memory_order_relaxed)) return;
+                if (!all.block_lines(ranges[b].first, ranges[b].second, lo, hi)) {
+                    table_failed = true;
+                    return;
+                }
+                uint64_t at = ranges[b].first;
+                for (uint64_t i = lo; i < hi; ++i) {
+                    const uint64_t l0 = all.ls[i], l1 = l0 + all.len[i];
+                    if (l0 < at || l1 > ranges[b].second || all.len[i] == 0) {  // (damaged image: starts must ascend inside the block)
+                        table_failed = true;
+                        return;
+                    }
+                    at = l1;
+                    if (!(all.flags[i] & 1u)) continue;
+                    const uint32_t ty = all.type[i], sq = all.seq[i];
+                    if (types_filter && (ty >= type_ok.size() || !type_ok[ty])) continue;
+                    if (sq >= seq_target.size()) {
+                        table_failed = true;
+                        return;
+                    }
+                    if (seq_target[sq] == UINT32_MAX) continue;
+                    P.ls.push_back(l0);
+                    P.le.push_back(l1);
+                    P.seq.push_back(seq_target[sq]);
+                    P.s.push_back(all.start[i]);
+                    P.e.push_back(all.end[i]);
+                }
+            }
+            for (size_t b = b0; b < b1 && !use_all; ++b) {
                 size_t pos = ranges[b].first;
                 const size_t stop = ranges[b].second;
                 while (pos < stop) {  // intersect.rs:284-321
@@ -965,11 +1030,19 @@ void write_matched_lines(const std::string &gff_path, const std::vector<Block> &
             }
         }
     };
-    {
+    auto run_parts = [&]() {
         std::vector<std::thread> pool;
         for (size_t t = 1; t < n_threads && t < n_parts; ++t) pool.emplace_back(work);
         work();
         for (auto &t : pool) t.join();
+    };
+    run_parts();
+    if (use_all && table_failed) {  // the image does not describe these blocks (offsets that are not line starts, damage)
+        std::fprintf(stderr, "[WARN] %s.lall does not match the index's blocks; parsing the GFF text instead\n", gff_path.c_str());
+        use_all = false;
+        for (Part &P : parts) P = Part{};
+        next = 0;
+        run_parts();
     }
     size_t n_lines = 0;
     for (const Part &P : parts) n_lines += P.ls.size();
@@ -1064,10 +1137,10 @@ void run(const IntersectArgs &args) {
     if (per_line && args.bed)
         write_matched_lines(args.common.input, blocks, sr.has_regions, nullptr, sr.n_regions, kept.h, index_data.num_to_seqid,
                             args.common.types, args.common.output, mode, verbose, args.common.effective_threads(),
-                            gffx_hip_index_device(index_data.device_index));
+                            gffx_hip_index_device(index_data.device_index), &gof);
     else if (per_line)
         write_gff_match_only_by_coords(args.common.input, blocks, regions, index_data.num_to_seqid, args.common.types,
-                                       args.common.output, mode, verbose, args.common.effective_threads(), args.device);
+                                       args.common.output, mode, verbose, args.common.effective_threads(), args.device, &gof);
     else
         write_gff_output(args.common.input, blocks, args.common.output, verbose);
     timer.lap(!args.common.entire_group || args.common.types ? "Join B + writing matched lines" : "Writing blocks");

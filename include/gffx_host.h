@@ -51,6 +51,11 @@ int gffx_host_depth_block_table(const char *gff, uint32_t *n_blocks, uint64_t **
  * 1 = it loads and equals a fresh parse on `threads` host threads, 0 = not usable (absent / stale / does not
  * validate; the reason in err), < 0 = error or mismatch */
 int gffx_host_line_table_check(const char *gff, uint32_t threads, char *err, size_t errlen);
+/* the all-line table `<gff>.lall` written by `gffx index` for intersect's per-line mode (replaces the text
+ * walk of write_gff_match_only_by_coords, commands/intersect.rs:266-329): 1 = it loads, equals a fresh build on `threads`
+ * host threads, and gives for every block of the index the very lines, columns and -T decisions (types: comma list or NULL)
+ * the text walk gives; 0 = not usable (absent / stale; the reason in err); < 0 = error or mismatch.  *n_lines = lines checked. */
+int gffx_host_all_lines_check(const char *gff, const char *types, uint32_t threads, uint64_t *n_lines, char *err, size_t errlen);
 /* The chromosome-bucket plan of `gffx intersect --gpus N` (LPT with splitting over the per-seqid region counts of a BED
  * chunk; the reference buckets by seqid first, commands/intersect.rs:114-120).  slices = malloc'd (rank, chr, lo, hi) u64
  * quadruples, ranks ascending, a rank's slices sorted by (chr, lo). */

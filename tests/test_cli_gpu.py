@@ -20,7 +20,7 @@ MODES = {"contained": 0, "contains_region": 1, "overlap": 2}
 MODE_FLAG = {"contained": "-c", "contains_region": "-C", "overlap": "-O"}
 
 
-def _cli(gff, args, out=None):
+def _cli(gff, args, out=None, env=None):
     cmd = [GFFX, "intersect", "-i", gff]
     if "region" in args:
         cmd += ["-r", args["region"]]
@@ -36,7 +36,7 @@ def _cli(gff, args, out=None):
         cmd += ["-T", args["types"]]
     if out:
         cmd += ["-o", out]
-    return subprocess.run(cmd, capture_output=True)
+    return subprocess.run(cmd, capture_output=True, env=env)
 
 
 def test_appendix_e_known_answers_through_the_cli(tmp_path, golden_dir):
@@ -82,7 +82,13 @@ def test_all_flag_combinations_equal_the_oracle(tmp_path, seed, crlf):
                     want = open(want_p, "rb").read()
                     assert open(got_p, "rb").read() == want, (mode, invert, eg, types)
                     n_nonempty += bool(want)
+                    if not eg or types:  # the per-line mode a second time WITHOUT the all-line table (<gff>.lall): the text walk
+                        r = _cli(gff, dict(bed=bed, mode=mode, invert=invert, entire_group=eg, types=types), out=got_p,
+                                 env=dict(os.environ, GFFX_LINE_TABLE="parse"))
+                        assert r.returncode == 0 and open(got_p, "rb").read() == want, (mode, invert, eg, types, "parse")
     assert n_nonempty >= 12
+    r = subprocess.run([GFFX, "intersect", "-v", "-i", gff, "-b", bed, "-o", got_p], capture_output=True)
+    assert r.returncode == 0 and b"all-line table from" in r.stderr
     # stdout path and the single-region form
     rc, _ = ob.intersect_run(gff, want_p, region="chr1:100000-900000", mode=2)
     r = _cli(gff, dict(region="chr1:100000-900000"))
