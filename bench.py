@@ -74,7 +74,7 @@ def parse_args():
                          "sharded over the ranks, the hit-count all-gather inside the timed region")
     ap.add_argument("--strong-total", type=int, default=100_000_000)
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
-    ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused", "slots", "windows"])
+    ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused", "windows"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
     ap.add_argument("--offsets", default="seg", choices=["seg", "u32", "u64", "none"],
                     help="where the pairs of a region are: seg = one u64 base per group of 256 regions (GFFX_OUT_SEGBASE, windows "
@@ -467,7 +467,7 @@ def main():
     coll_dev = dev if backend == "nccl" else None  # gloo gathers CPU tensors
 
     mode = {"contained": 0, "contains_region": 1, "overlap": 2}[args.mode]
-    strategy = {"auto": 0, "direct": 1, "sorted": 2, "fused": 3, "slots": 4, "windows": 5}[args.strategy]
+    strategy = {"auto": 0, "direct": 1, "sorted": 2, "fused": 3, "windows": 5}[args.strategy]
     out_flags = {"counts": engine.OUT_COUNTS, "fids": engine.OUT_FIDS, "triples": engine.OUT_TRIPLES}[args.out]
     if args.strategy != "direct" and args.out != "counts":
         offs = args.offsets if args.strategy in ("auto", "windows") or args.offsets != "seg" else "u64"

@@ -3,7 +3,7 @@
 // HBM layout of an index (uploaded once, immutable; gffx_device.hpp has the field meanings):
 //   start[R] u32, aux[R] uint4 {end, pmax_prev, skip, root_fid} 20 B/root, seqid after seqid, by start
 //   chr_meta[n_chr] uint4, bins[...] uint4                      per-seqid bin directory (direct / fused strategies)
-//   slot_meta[n_chr] uint4, slots[...] 32 B, spill[...] 16 B    per-seqid candidate lists (slots strategy, the default)
+//   win_meta[n_chr + 1] uint4, win[...] 32 B lines, win_spill, win_tail + tables, win_filter    window index (windows strategy)
 //   cell_base / cell_tile / tile_meta / tile_aux / tile_bins    genome-window tile plan (partitioned strategy)
 // At GENCODE scale (63 k roots, 25 seqids) that is ~1.3 MB + ~2 MB of directory + ~0.2 MB of tile
 // plan: resident in every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and
@@ -22,7 +22,6 @@
 #include "gffx_device.hpp"
 #include "join_a_kernels.hpp"
 #include "join_fused_kernels.hpp"
-#include "join_slot_kernels.hpp"
 #include "join_win_kernels.hpp"
 #include "join_wave_kernels.hpp"
 #include "partition_kernels.hpp"
@@ -313,9 +312,6 @@ struct gffx_hip_index {
     uint4 *d_aux = nullptr;
     uint4 *d_chr_meta = nullptr;
     uint4 *d_bins = nullptr;
-    uint4 *d_slot_meta = nullptr, *d_slots = nullptr, *d_spill = nullptr;  // slot index (join_slot_kernels.hpp)
-    uint32_t *d_slot_pos = nullptr;
-    uint64_t n_slots = 0, n_spill = 0;
     uint4 *d_win_meta = nullptr, *d_win = nullptr, *d_win_pos = nullptr, *d_win_spill = nullptr;  // window index (join_win_kernels.hpp)
     uint32_t n_win = 0;
     uint32_t *d_win_filter = nullptr;
@@ -338,8 +334,7 @@ struct gffx_hip_index {
 
     // every device array of the index, in a fixed order
     std::vector<void **> arrays() {
-        return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_slot_meta,
-                (void **)&d_slots,     (void **)&d_spill,     (void **)&d_slot_pos,   (void **)&d_win_meta,   (void **)&d_win,
+        return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_win_meta,   (void **)&d_win,
                 (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_win_tail,   (void **)&d_win_tailtab,
                 (void **)&d_cell_base,
                 (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
@@ -351,10 +346,6 @@ struct gffx_hip_index {
         v.aux = d_aux;
         v.chr_meta = d_chr_meta;
         v.bins = d_bins;
-        v.slot_meta = d_slot_meta;
-        v.slots = d_slots;
-        v.spill = d_spill;
-        v.slot_pos = d_slot_pos;
         v.win_meta = d_win_meta;
         v.win = d_win;
         v.win_pos = d_win_pos;
@@ -417,8 +408,7 @@ struct gffx_hip_batch {
     int fused_phase = 0;            // which of d_status[2..3] the next fused pass uses as its pair cursor
     int fused_word = 2;             // ... and the one the last fused pass used
     uint64_t slow_seen_win = 0;     // windows strategy: the device's exact-sweep counter at the last wait
-    uint64_t slow_seen = 0;         // slots strategy: the device's slow-lane counter at the last wait
-    uint64_t slots_passes = 0;      // ... and the slot passes enqueued since
+    uint64_t win_passes = 0;        // ... and the windows passes enqueued since
     bool mostly_slow = false;       // ... > 1/4 of the regions took the slow lane: AUTO uses the sweep kernel
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
@@ -538,84 +528,6 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         bins.push_back(make_uint4(hi, pmax_incl(hi - 1), 0xFFFFFFFFu, 0xFFFFFFFFu));
     }
 
-    // Slot index (gffx_device.hpp): ~GFFX_HIP_SLOTS_PER_ENTRY windows per entry, widened until the lists total
-    // <= 8 per entry (a seqid of chromosome-long intervals ends with one window).
-    std::vector<uint4> slot_meta(n_chr, make_uint4(0, 0, 0, 0)), slots, spill;
-    std::vector<uint32_t> slot_pos;
-    {
-        const uint64_t per_entry = (uint64_t)env_long("GFFX_HIP_SLOTS_PER_ENTRY", 1, 1, 16);
-        const uint64_t wmax_min = (uint64_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
-        std::vector<uint32_t> len, fill;
-        // widest region the lists answer: 16 Ki, but between a quarter of the window and four windows (a dense
-        // seqid has narrow windows; every extra window of wmax lengthens every list by the entries it holds)
-        auto slot_wmax = [&](uint32_t shift) {
-            const uint64_t w = 1ull << shift;
-            return std::max<uint64_t>(w >> 2, std::min<uint64_t>(wmax_min, w << 2));
-        };
-        for (uint32_t c = 0; c < n_chr; c++) {
-            const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
-            if (hi == lo) continue;
-            const uint64_t max_end = std::max(h_aux[hi - 1].x, h_aux[hi - 1].y);
-            const uint64_t budget = std::max<uint64_t>(per_entry * (hi - lo), 16);
-            uint32_t shift = 0;
-            uint64_t wmax = 0, ns = 0;
-            for (;; shift++) {
-                wmax = slot_wmax(shift);
-                ns = ((max_end + wmax) >> shift) + 1;
-                if (ns > budget && shift < 40) continue;
-                uint64_t total = 0;  // list entries over all windows at this width
-                for (uint32_t i = lo; i < hi && total <= 8ull * (hi - lo) + 1024; i++) {
-                    const uint64_t fw = (uint64_t)h_start[i] >> shift;
-                    const uint64_t lw = std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift);
-                    if (lw >= fw) total += lw - fw + 1;  // (an interval with end < start lists itself nowhere)
-                }
-                if (total <= 8ull * (hi - lo) + 1024 || shift >= 40) break;
-            }
-            if (shift > 31) shift = 31, wmax = slot_wmax(31), ns = ((max_end + wmax) >> 31) + 1;
-            wmax = std::min<uint64_t>(wmax, 0xFFFFFFFFull);
-            if (slots.size() / 2 + ns >= 0xFFFFFFFFull) return fail(GFFX_E_INVALID, "index too large for the slot directory");
-            const uint32_t base = (uint32_t)(slots.size() / 2);
-            slot_meta[c] = make_uint4(base, (uint32_t)ns, shift, (uint32_t)wmax);
-            auto first_w = [&](uint32_t i) { return ((uint64_t)h_start[i] >> shift); };
-            auto last_w = [&](uint32_t i) { return std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift); };
-            len.assign(ns, 0);
-            for (uint32_t i = lo; i < hi; i++)
-                for (uint64_t b = first_w(i); b <= last_w(i); b++) len[b]++;
-            slots.resize(2 * ((size_t)base + ns), make_uint4(0, 0, 0xFFFFFFFFu, 0));
-            slot_pos.resize(2 * ((size_t)base + ns), 0);
-            fill.assign(ns, 0);
-            for (uint64_t b = 0; b < ns; b++) {
-                uint32_t n = len[b];
-                uint64_t off = 0;
-                if (n > kSlotMaxList || (n > 2 && spill.size() + (n - 2) >= (1ull << 24))) {
-                    n = 255;  // dense window (or the 24-bit spill offsets are used up): exact sweep
-                } else if (n > 2) {
-                    off = spill.size();
-                    spill.resize(spill.size() + (n - 2));
-                }
-                slots[2 * ((size_t)base + b)] = make_uint4(n | (uint32_t)(off << 8), 0, 0xFFFFFFFFu, 0);
-                slots[2 * ((size_t)base + b) + 1] = make_uint4(0, 0xFFFFFFFFu, 0, 0);
-            }
-            for (uint32_t i = lo; i < hi; i++) {  // ascending start: the lists come out sorted
-                for (uint64_t b = first_w(i); b <= last_w(i); b++) {
-                    uint4 &a = slots[2 * ((size_t)base + b)], &d = slots[2 * ((size_t)base + b) + 1];
-                    if ((a.x & 255u) == 255u) continue;
-                    const uint32_t j = fill[b]++;
-                    if (j == 0) {
-                        a.z = h_start[i], a.w = h_aux[i].x, d.x = h_aux[i].w;
-                        slot_pos[2 * ((size_t)base + b)] = i;
-                    } else if (j == 1) {
-                        d.y = h_start[i], d.z = h_aux[i].x, d.w = h_aux[i].w;
-                        slot_pos[2 * ((size_t)base + b) + 1] = i;
-                    } else {
-                        spill[(a.x >> 8) + j - 2] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
-                    }
-                }
-            }
-        }
-    }
-    ix->n_slots = slots.size() / 2;
-    ix->n_spill = spill.size();
     std::vector<uint4> win_meta, win, win_pos, win_spill;
     if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill)) return wrc;
     ix->n_win = (uint32_t)(win.size() / 2);
@@ -721,8 +633,6 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     int rc;
     if ((rc = dev_upload(&ix->d_start, h_start)) || (rc = dev_upload(&ix->d_aux, h_aux)) ||
         (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
-        (rc = dev_upload(&ix->d_slot_meta, slot_meta)) || (rc = dev_upload(&ix->d_slots, slots)) ||
-        (rc = dev_upload(&ix->d_spill, spill)) || (rc = dev_upload(&ix->d_slot_pos, slot_pos)) ||
         (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = dev_upload(&ix->d_win, win)) ||
         (rc = dev_upload(&ix->d_win_pos, win_pos)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
         (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_tail, win_tail)) ||
@@ -734,8 +644,8 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         return rc;
     }
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
-    ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),      bytes(slot_meta), bytes(slots),     bytes(spill),
-                       bytes(slot_pos),  bytes(win_meta),  bytes(win),        bytes(win_pos),   bytes(win_spill), bytes(win_filter),
+    ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),
+                       bytes(win_meta),  bytes(win),        bytes(win_pos),   bytes(win_spill), bytes(win_filter),
                        bytes(win_tail),  bytes(win_tailtab),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
@@ -776,10 +686,6 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_aux);
     (void)hipFree(ix->d_chr_meta);
     (void)hipFree(ix->d_bins);
-    (void)hipFree(ix->d_slot_meta);
-    (void)hipFree(ix->d_slots);
-    (void)hipFree(ix->d_spill);
-    (void)hipFree(ix->d_slot_pos);
     (void)hipFree(ix->d_win_meta);
     (void)hipFree(ix->d_win);
     (void)hipFree(ix->d_win_pos);
@@ -1363,67 +1269,6 @@ static int run_fused(gffx_hip_batch *b) {
     return GFFX_OK;
 }
 
-// ------------------------------------------------------------------------------------ slots strategy
-
-template <int MODE, bool INV, bool AOS, bool ML, int OUT>
-static void launch_slots3(gffx_hip_batch *b, uint32_t grid, const FusedOut &o, int vec_ok, uint32_t lds) {
-    hipLaunchKernelGGL((k_join_slots<MODE, INV, AOS, ML, OUT>), dim3(grid), dim3(kSlotThreads), lds, b->stream, b->ix->view(),
-                       b->q, (unsigned long long)b->nq, o, vec_ok);
-}
-
-template <int MODE, bool INV, bool AOS, bool ML>
-static void launch_slots(gffx_hip_batch *b, uint32_t grid, const FusedOut &o, int vec_ok) {
-    const uint32_t lds = 80 + 4 * kSlotStage + 4 * kSlotExtras * kSlotThreads + (ML ? meta_bytes(b->ix) : 0);
-    if (!o.fids && !o.triples && !o.bitmap)
-        launch_slots3<MODE, INV, AOS, ML, 0>(b, grid, o, vec_ok, lds);
-    else if (o.fids && !o.triples && !o.bitmap)
-        launch_slots3<MODE, INV, AOS, ML, 1>(b, grid, o, vec_ok, lds);
-    else
-        launch_slots3<MODE, INV, AOS, ML, 2>(b, grid, o, vec_ok, lds);
-}
-
-static int run_slots(gffx_hip_batch *b) {
-    if (b->flags & GFFX_OUT_ROOT_BITMAP)
-        GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
-    FusedOut o;
-    o.counts = b->d_counts;
-    o.offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr;
-    o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
-    o.triples = (b->flags & GFFX_OUT_TRIPLES) ? b->d_triples : nullptr;
-    o.bitmap = (b->flags & GFFX_OUT_ROOT_BITMAP) ? b->d_bitmap : nullptr;
-    o.err = reinterpret_cast<uint32_t *>(b->d_status);  // err[1] (the word's upper half) counts slow-lane queries
-    b->fused_word = 2 + b->fused_phase;
-    o.pair_cursor = b->d_status + b->fused_word;
-    o.pair_cursor_next = b->d_status + 2 + (b->fused_phase ^ 1);
-    b->fused_phase ^= 1;
-    uint64_t cap = UINT64_MAX;
-    if (o.fids) cap = std::min(cap, b->cap_fids);
-    if (o.triples) cap = std::min(cap, b->cap_triples);
-    o.capacity = cap;
-    b->slots_passes++;
-    const uint64_t rounds = (b->nq + kSlotChunk - 1) / kSlotChunk;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", 1024, 1, 65535));
-    const bool aos = b->q.aos != nullptr;
-    const bool ml = meta_bytes(b->ix) <= kMetaLdsBytes;
-    // 16-byte query loads need 16-byte aligned columns (a caller's device pointers may not be)
-    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    const int vec_ok = aos ? al(b->q.aos) : (al(b->q.chr) && al(b->q.start) && al(b->q.end));
-    ProfEvent pe;
-    prof_begin(b, GFFX_K_SLOTS, &pe);
-#define GFFX_CASE2(M, I, A, L) \
-    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) launch_slots<M, I, A, L>(b, grid, o, vec_ok);
-#define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
-    GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
-    GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
-    GFFX_CASE(2, false, false) GFFX_CASE(2, false, true) GFFX_CASE(2, true, false) GFFX_CASE(2, true, true)
-#undef GFFX_CASE
-#undef GFFX_CASE2
-    prof_end(b, &pe);
-    GFFX_HIP_TRY(hipGetLastError());
-    return GFFX_OK;
-}
-
-
 // ------------------------------------------------------------------------------------ windows strategy
 
 constexpr uint32_t kWinMaxLds = 80 * 1024;  // two blocks per CU share 160 KB
@@ -1457,29 +1302,15 @@ static int launch_win3(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int ve
 template <int MODE, bool INV, bool AOS, bool ML>
 static int launch_win(gffx_hip_batch *b, uint32_t grid, const WinOut &o, int vec_ok, int out_kind, uint32_t threads,
                       uint32_t stage_words, uint32_t fwords, uint32_t lds) {
+    (void)threads;  // (pair passes -- counts / offsets / root_fids -- are k_join_wave's: run_wave_pass)
     if (out_kind == 3) return launch_win3<MODE, INV, AOS, ML, 3, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
-    if (out_kind == 2) return launch_win3<MODE, INV, AOS, ML, 2, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
-    if (threads == 1024) return launch_win3<MODE, INV, AOS, ML, 1, 1024>(b, grid, o, vec_ok, stage_words, fwords, lds);
-    return launch_win3<MODE, INV, AOS, ML, 1, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
+    return launch_win3<MODE, INV, AOS, ML, 2, kWinThreads>(b, grid, o, vec_ok, stage_words, fwords, lds);
 }
 
 // dynamic LDS of k_join_win: scratch + stage (root_fids or the LDS bitmap) + per-thread strips + coverage filter + seqid tables
 static uint32_t win_lds_bytes(const gffx_hip_index *ix, uint32_t stage_words, uint32_t fwords, bool ml, uint32_t threads = kWinThreads) {
     return 80 + 4 * stage_words + 4 * kWinStash * threads + 4 * fwords + (ml ? (ix->n_chr + 1) * 16 : 0);
 }
-
-// Threads per block of a pair pass (OUT == 1).  1024 = one block per CU, rounds of 4096 regions: half the same-address
-// reservation atomics and barriers per region, but a single phase group per CU -- measured (kbench, us per pass, 512 / 1024
-// threads): 0.4 M regions 10.6 / 11.4, 0.6 M 13.6 / 12.2, 1 M 16.4 / 14.2, 2 M 28.0 / 26.5, 3 M 35.1 / 38.0, 10 M 91 / 105.
-// GFFX_HIP_WIN_THREADS forces one.
-// Two such kernels cannot share a CU (16 waves x 128 VGPRs fill it): with two batches in flight the 512-thread kernel gives
-// 9.35 us per 1 M-region step, the 1024-thread one 12.0 -- so the wide block is for a pass that runs ALONE on the device.
-static uint32_t win_pair_threads(const gffx_hip_batch *b) {
-    const long forced = env_long("GFFX_HIP_WIN_THREADS", 0, 0, 1024);
-    if (forced == 512 || forced == 1024) return (uint32_t)forced;
-    return (!b->others_busy && b->nq >= 500000 && b->nq <= 2500000) ? 1024u : (uint32_t)kWinThreads;
-}
-
 
 // ---- pair passes of the windows strategy: k_join_wave (join_wave_kernels.hpp)
 
@@ -1567,12 +1398,8 @@ static int run_wave_pass(gffx_hip_batch *b) {
 }
 
 static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
-    // pair passes (counts / offsets / root_fids): the wave kernel; GFFX_HIP_PAIR_KERNEL=win keeps the block-synchronous one
-    if (out_kind == 1 && !second) {
-        const char *pk = getenv("GFFX_HIP_PAIR_KERNEL");
-        if (!(pk && !strcmp(pk, "win"))) return run_wave_pass(b);
-        if (b->flags & GFFX_OUT_SEGBASE) return fail(GFFX_E_INVALID, "GFFX_OUT_SEGBASE needs the wave kernel (GFFX_HIP_PAIR_KERNEL=win is set)");
-    }
+    // pair passes (counts / offsets / root_fids) are the wave kernel's; k_join_win keeps the triples and root-bitmap passes
+    if (out_kind == 1 && !second) return run_wave_pass(b);
     const gffx_hip_index *ix = b->ix;
     WinOut o{};
     o.counts = b->d_counts;
@@ -1588,8 +1415,7 @@ static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
         b->fused_phase ^= 1;
     }
     const bool ml = meta_bytes(ix) <= kMetaLdsBytes;
-    const uint32_t threads = out_kind == 1 ? win_pair_threads(b) : (uint32_t)kWinThreads;
-    if (out_kind == 1) b->win_threads = threads;
+    const uint32_t threads = (uint32_t)kWinThreads;  // (triples and root-bitmap passes; pair passes are run_wave_pass's)
     const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
     const uint32_t max_lds = threads == 1024 ? 2 * kWinMaxLds : kWinMaxLds;  // (one block per CU may take the whole LDS)
     uint32_t grid, stage_words;
@@ -1663,7 +1489,7 @@ static int run_windows(gffx_hip_batch *b) {
     const bool want_pairs = b->flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32 | GFFX_OUT_SEGBASE);
     if (want_bitmap && !(b->flags & GFFX_OUT_BITMAP_KEEP))
         GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
-    b->slots_passes++;
+    b->win_passes++;
     int rc;
     if (want_pairs || !want_bitmap) {
         if ((rc = run_windows_pass(b, (b->flags & GFFX_OUT_TRIPLES) ? 2 : 1, false))) return rc;
@@ -1674,10 +1500,10 @@ static int run_windows(gffx_hip_batch *b) {
 }
 
 static bool one_kernel(int strategy) {
-    return strategy == GFFX_STRATEGY_FUSED || strategy == GFFX_STRATEGY_SLOTS || strategy == GFFX_STRATEGY_WINDOWS;
+    return strategy == GFFX_STRATEGY_FUSED || strategy == GFFX_STRATEGY_WINDOWS;
 }
 
-// AUTO: the slot kernel, unless the last waited pass over these regions sent most of them down its slow lane
+// AUTO: the window kernels, unless the last waited pass over these regions sent most of them down the exact sweep
 // (wide queries / dense windows): then the sweep kernel, which interleaves those chains, serves the batch.
 static int pick_strategy(const gffx_hip_batch *b, int strategy) {
     const bool part_ok = b->ix->partition_ok && b->max_q < (1ull << 32);
@@ -1695,7 +1521,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: batch is NULL");
     if (!b->have_regions) return fail(GFFX_E_STATE, "gffx_hip_batch_run: no regions set");
     if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad mode %d", mode);
-    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_WINDOWS)
+    if (strategy < GFFX_STRATEGY_AUTO || strategy > GFFX_STRATEGY_WINDOWS || strategy == 4 /* the retired slots strategy */)
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad strategy %d", strategy);
     if (strategy == GFFX_STRATEGY_SORTED && (!b->ix->partition_ok || b->max_q >= (1ull << 32)))
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: the partitioned strategy needs <= %u seqids / genome cells "
@@ -1744,7 +1570,6 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want && (rc = grow(&b->d_triples, &b->cap_triples, want, 3)))
             return rc;
         return b->strategy == GFFX_STRATEGY_SORTED    ? run_partitioned(b)
-               : b->strategy == GFFX_STRATEGY_SLOTS   ? run_slots(b)
                : b->strategy == GFFX_STRATEGY_WINDOWS ? run_windows(b)
                                                       : run_fused(b);
     }
@@ -1812,23 +1637,15 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         // the flag is sticky on the device (kernels only ever set it): clear it for the next pass
         GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
         GFFX_HIP_TRY(hipDeviceSynchronize());
-        b->slow_seen = 0;
         return fail(GFFX_E_CHR_RANGE, "a query's chr is >= the index's seqid count %u "
                                       "(the reference panics here: commands/intersect.rs:117)",
                     b->ix->n_chr);
     }
-    if (b->strategy == GFFX_STRATEGY_SLOTS) {  // slow-lane queries of the passes since the last wait
-        const uint64_t slow_now = b->h_status[0] >> 32;
-        const uint64_t passes = std::max<uint64_t>(b->slots_passes, 1);
-        b->mostly_slow = ((slow_now - b->slow_seen) & 0xFFFFFFFFull) / passes > b->nq / 4;
-        b->slow_seen = slow_now;
-        b->slots_passes = 0;
-    }
     if (b->strategy == GFFX_STRATEGY_WINDOWS) {  // regions the passes since the last wait sent to the exact sweep (own 64-bit word)
-        const uint64_t passes = std::max<uint64_t>(b->slots_passes, 1);
+        const uint64_t passes = std::max<uint64_t>(b->win_passes, 1);
         b->mostly_slow = (h_slow_win - b->slow_seen_win) / passes > b->nq / 4;
         b->slow_seen_win = h_slow_win;
-        b->slots_passes = 0;
+        b->win_passes = 0;
     }
     b->total = 0;
     if (part)
@@ -1857,19 +1674,14 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         // the partitioned strategy counts and emits in one kernel: the whole pass runs again
         const uint32_t keep_flags = b->flags;
         if (b->strategy == GFFX_STRATEGY_WINDOWS) b->flags |= GFFX_OUT_BITMAP_KEEP;  // (the first attempt already set every bit)
-        rc = part ? run_partitioned(b) : b->strategy == GFFX_STRATEGY_SLOTS ? run_slots(b) : b->strategy == GFFX_STRATEGY_WINDOWS ? run_windows(b) : fused ? run_fused(b) : enqueue_emit(b);
+        rc = part ? run_partitioned(b) : b->strategy == GFFX_STRATEGY_WINDOWS ? run_windows(b) : fused ? run_fused(b) : enqueue_emit(b);
         b->flags = keep_flags;
         if (rc) return rc;
         if ((rc = gffx_hip_batch_sync(b))) return rc;
-        if (b->strategy == GFFX_STRATEGY_SLOTS) {  // the replay counted its slow-lane queries again: not news
-            GFFX_HIP_TRY(hipMemcpy(b->h_status, b->d_status, sizeof(unsigned long long), hipMemcpyDeviceToHost));
-            b->slow_seen = b->h_status[0] >> 32;
-            b->slots_passes = 0;
-        }
         if (b->strategy == GFFX_STRATEGY_WINDOWS) {
             GFFX_HIP_TRY(hipMemcpy(b->h_status + 4, b->d_status + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost));
             b->slow_seen_win = b->h_status[4];
-            b->slots_passes = 0;
+            b->win_passes = 0;
         }
     }
     b->waited = true;

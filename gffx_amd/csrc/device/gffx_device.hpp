@@ -66,18 +66,6 @@ struct IndexView {
     // it still reach the query" -- queries in gene deserts end after this single access.
     // kPosMask limits an index to 2^27 roots.
     const uint4 *bins;
-    // Slot index (join_slot_kernels.hpp): a seqid is cut into windows of 2^shift bp; the slot of window b lists,
-    // by ascending start, every entry with start < (b+1) << shift and end + wmax > b << shift -- a superset of what
-    // a query of width <= wmax whose last base lies in the window can overlap.
-    //   slot_meta[seqid] = {first slot, n_slots, shift, wmax}      (n_slots = 0 for an empty seqid)
-    //   slots[2*s], slots[2*s+1] = {n | spill << 8, 0, e0.start, e0.end} {e0.fid, e1.start, e1.end, e1.fid}
-    //                              n = list length (<= kSlotMaxList), or 255: dense window, use the sweep
-    //   spill[spill + j - 2]     = {start, end, root_fid, position} of list entry j >= 2
-    //   slot_pos[2*s + j]        = position of slot entry j < 2 (root-bitmap passes)
-    const uint4 *slot_meta;
-    const uint4 *slots;
-    const uint4 *spill;
-    const uint32_t *slot_pos;
     // Window index (join_win_kernels.hpp): windows of 2^shift bp (shift <= 15), one 32-byte LINE per window holding up to
     // 4 entries as words {start_rel | end_rel << 16 x 4, root_fid x 4}, coordinates relative to (window start - wmax) and
     // clamped to 16 bits; win_pos is a copy with index positions in place of the root_fids (root-bitmap and triples
@@ -109,7 +97,6 @@ struct IndexView {
     uint32_t n_chr;
     uint32_t n_roots;
 };
-constexpr uint32_t kSlotMaxList = 16;
 constexpr uint32_t kPosBits = 27;
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1;
 constexpr uint32_t kCntSat = 31;

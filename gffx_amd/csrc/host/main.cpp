@@ -314,17 +314,18 @@ int cli_main(int argc, char **argv) {
 }  // namespace gffx
 
 #ifndef GFFX_NO_MAIN
-// The command has closed (and checked) every output it wrote when cli_main returns.  What is left is teardown -- unmapping
-// a multi-GB BED file, freeing the region stores, shutting the HIP runtime down: ~0.1 s of a 0.9 s run on a 100 M-row BED --
-// which the kernel does faster when the process simply ends.  A preloaded tool (a profiler flushes its trace from an exit
-// handler) or GFFX_EXIT=normal keeps the ordinary exit.
+// The process ends the ordinary way: destructors, atexit handlers, HIP runtime shutdown.  GFFX_EXIT=fast (opt-in, for
+// throughput runs on multi-GB inputs) skips that teardown once cli_main has closed and checked every output it wrote --
+// unmapping a 2.4 GB BED file, freeing the region stores and shutting HIP down cost ~0.1 s of a 0.9 s run there, and the
+// kernel reclaims all of it faster when the process simply ends.  Never under a preloaded tool (a profiler flushes its
+// trace from an exit handler).
 int main(int argc, char **argv) {
     const int rc = gffx::cli_main(argc, argv);
     const char *how = std::getenv("GFFX_EXIT");
+    if (!(how && std::string(how) == "fast")) return rc;
     const char *preload = std::getenv("LD_PRELOAD");
-    const bool tool = (preload && *preload) || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_ROOT") ||
-                      std::getenv("HSA_TOOLS_LIB");
-    if ((how && std::string(how) == "normal") || tool) return rc;
+    if ((preload && *preload) || std::getenv("ROCP_TOOL_LIBRARIES") || std::getenv("ROCPROFILER_REGISTER_ROOT") || std::getenv("HSA_TOOLS_LIB"))
+        return rc;
     std::fflush(stdout);
     std::fflush(stderr);
     _exit(rc);

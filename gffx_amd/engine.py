@@ -32,12 +32,12 @@ class OverlapMode(enum.IntEnum):
 OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS, OUT_EMIT_ORDER = 1, 2, 4, 8, 16, 32
 OUT_OFFSETS32, OUT_BITMAP_KEEP, OUT_SEGBASE = 64, 128, 256
 SEG_GROUP = 256  # regions per OUT_SEGBASE entry
-STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED, STRATEGY_FUSED, STRATEGY_SLOTS, STRATEGY_WINDOWS = 0, 1, 2, 3, 4, 5
+STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED, STRATEGY_FUSED, STRATEGY_WINDOWS = 0, 1, 2, 3, 5  # (4: the retired slots strategy)
 K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE, K_FUSED_DIRECT, K_DEPTH, K_SLOTS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 K_WINDOWS, K_BITMAP_OR, K_WAVE = 9, 10, 11
 KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_partition",
                 K_LINES: "k_lines_exists", K_FUSED: "k_tile_join", K_UNPERMUTE: "k_unpermute",
-                K_FUSED_DIRECT: "k_join_fused", K_DEPTH: "k_depth_regions", K_SLOTS: "k_join_slots",
+                K_FUSED_DIRECT: "k_join_fused", K_DEPTH: "k_depth_regions",
                 K_WINDOWS: "k_join_win", K_BITMAP_OR: "k_bitmap_or", K_WAVE: "k_join_wave"}
 
 

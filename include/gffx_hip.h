@@ -29,10 +29,11 @@
  * FxHashMap walk plus a tree DFS and is unspecified as well):
  *   DIRECT                 segments in INPUT order (CSR: offsets = exclusive prefix of the counts); inside a segment
  *                          descending position in the seqid's start-sorted list (ties in start: later builder order first)
- *   WINDOWS / SLOTS / FUSED  segments in the order in which 2048-region rounds reserve them (differs from run to run), the
- *                          regions of a round in input order; every query's segment start is given explicitly
- *                          (GFFX_OUT_OFFSETS / GFFX_OUT_OFFSETS32) and the segments tile [0, pairs) exactly.  Inside a segment:
- *                          WINDOWS and SLOTS ascending list order (start, ties in builder order) for regions answered from the
+ *   WINDOWS / FUSED        segments in the order in which rounds (2048 or 4096 regions) reserve them (differs from run to run);
+ *                          inside a round the runs of its groups of 256 regions in the order the waves arrive, the regions
+ *                          of a group in input order; every query's segment start is given explicitly (GFFX_OUT_OFFSETS /
+ *                          GFFX_OUT_OFFSETS32) or per group (GFFX_OUT_SEGBASE) and the segments tile [0, pairs) exactly.  Inside a segment:
+ *                          WINDOWS ascending list order (start, ties in builder order) for regions answered from the
  *                          window's candidate list, descending for regions that took the exact sweep; FUSED descending
  *   SORTED (partitioned)   segments in the order genome tiles were served, offsets explicit, inside a segment descending
  *
@@ -105,6 +106,7 @@ enum gffx_strategy {
     GFFX_STRATEGY_FUSED = 3,  /* queries in input order, ONE kernel: interleaved gathers from the L2-resident
                                  index, count + emit per block round; counts / offsets in input order, pair
                                  segments in the order rounds reserve them (offsets explicit) */
+    /* 4 was GFFX_STRATEGY_SLOTS (round 1's slot index, superseded by WINDOWS and removed in round 3: _run rejects it) */
     GFFX_STRATEGY_WINDOWS = 5, /* AUTO's choice.  One 32-byte index LINE per region: the line of the genome window
                                  (<= 2^15 bp) the region ends in lists up to 4 candidate roots {start, end as 16-bit
                                  window-relative coordinates, root_fid}; longer lists, dense windows, wide and
@@ -112,9 +114,6 @@ enum gffx_strategy {
                                  skip-link sweep).  Root-bitmap passes set bits in an LDS-private bitmap.  Output
                                  contract as FUSED.  Domain: end >= start for every root (an interval with end < start
                                  never leaves the reference's IntervalTree::build, utils/tree.rs:48-50). */
-    GFFX_STRATEGY_SLOTS = 4   /* as FUSED, but over the slot index: one 32-byte gather per region answers the
-                                 usual case (precomputed candidate list of the window the region ends in);
-                                 wide regions and dense windows take the exact sweep in their lane */
 };
 
 enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
@@ -126,7 +125,7 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
     GFFX_K_UNPERMUTE = 5,
     GFFX_K_FUSED_DIRECT = 6,
     GFFX_K_DEPTH = 7,
-    GFFX_K_SLOTS = 8,
+    GFFX_K_SLOTS = 8, /* (retired with the slots strategy; the number stays reserved) */
     GFFX_K_WINDOWS = 9,
     GFFX_K_BITMAP_OR = 10,
     GFFX_K_WAVE = 11, /* k_join_wave: the windows strategy's pair passes (counts + root_fids) */

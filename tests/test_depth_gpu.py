@@ -41,7 +41,7 @@ def _numpy_depth(roots, block_of_fid, block_off, ls, le, lg, n_groups, regions):
 
 
 @pytest.mark.parametrize("seed", range(4))
-@pytest.mark.parametrize("strategy", [engine.STRATEGY_SLOTS, engine.STRATEGY_FUSED, engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED])
+@pytest.mark.parametrize("strategy", [engine.STRATEGY_WINDOWS, engine.STRATEGY_FUSED, engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED])
 def test_depth_kernel_equals_the_definition(seed, strategy):
     rng = np.random.default_rng(seed)
     roots = synth.gencode_like_roots(400, seed=seed, chroms=synth.SMALL2, fid_stride=3)

@@ -15,8 +15,7 @@ from oracle import binding as ob
 pytestmark = pytest.mark.gpu
 
 FLAGS = engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS
-STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_SLOTS,
-              engine.STRATEGY_WINDOWS]
+STRATEGIES = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_WINDOWS]
 
 
 def _sorted_rows(t):
@@ -367,7 +366,7 @@ def test_capacity_replay_and_reuse():
 
 
 @pytest.mark.parametrize("nq,strategy", [(1_000_000, st) for st in STRATEGIES] +
-                         [(10_000_000, engine.STRATEGY_FUSED), (10_000_000, engine.STRATEGY_SLOTS), (12_500_000, engine.STRATEGY_SORTED)])
+                         [(10_000_000, engine.STRATEGY_FUSED), (10_000_000, engine.STRATEGY_WINDOWS), (12_500_000, engine.STRATEGY_SORTED)])
 def test_full_size_c2_properties(nq, strategy):
     """BASELINE config sizes (configs[1]: 1 M regions x 63 k roots; configs[2]: 10 M; configs[3]: one GPU's 12.5 M
     share of 100 M): sampled oracle parity + size-independent properties (sum of counts == pairs; invert
@@ -397,7 +396,7 @@ def test_full_size_c2_properties(nq, strategy):
         assert np.array_equal(res[(int(mode), False)][sel], want_c)
 
 
-@pytest.mark.parametrize("strategy", [engine.STRATEGY_SLOTS, engine.STRATEGY_WINDOWS])
+@pytest.mark.parametrize("strategy", [engine.STRATEGY_WINDOWS])
 @pytest.mark.parametrize("mode", list(OverlapMode))
 @pytest.mark.parametrize("invert", [False, True])
 def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert, strategy):
@@ -495,7 +494,7 @@ def test_offsets32_and_bitmap_accumulation():
 @pytest.mark.parametrize("shift", [0, 1, 3])
 def test_device_resident_regions_aligned_and_unaligned(shift):
     """The zero-copy path of bench.py: three device-resident u32 columns borrowed by pointer (allocated here with
-    hipMalloc through ctypes).  k_join_slots reads them
+    hipMalloc through ctypes).  the window kernels read them
     with 16-byte loads when it can; columns that start `shift` elements into an allocation are not 16-byte aligned and
     take the scalar loads."""
     import ctypes

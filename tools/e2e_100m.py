@@ -21,5 +21,5 @@ for flags in (["-e", "-t", "64"], ["-e", "-t", "128"], ["-t", "64"], ["-t", "128
     dt, r = best
     print(" ".join(flags), "rc", r.returncode, "wall %.3f s = %.1f M regions/s" % (dt, n / dt / 1e6), flush=True)
     print("\n".join("    " + l for l in r.stderr.split("\n") if "[TIMER]" in l), flush=True)
-env = dict(os.environ, GFFX_EXIT="normal")
-t0 = time.perf_counter(); subprocess.run([G, "intersect", "-i", gff, "-b", bed, "-o", d + "/out.gff", "-e", "-t", "64"], env=env); print("normal exit: wall %.3f" % (time.perf_counter() - t0))
+env = dict(os.environ, GFFX_EXIT="fast")  # (opt-in since round 3: the default is the ordinary exit)
+t0 = time.perf_counter(); subprocess.run([G, "intersect", "-i", gff, "-b", bed, "-o", d + "/out.gff", "-e", "-t", "64"], env=env); print("GFFX_EXIT=fast: wall %.3f" % (time.perf_counter() - t0))

@@ -10,7 +10,7 @@ from oracle import binding as ob
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-STRATS = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_SLOTS, engine.STRATEGY_WINDOWS]
+STRATS = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_WINDOWS]
 t0 = time.time()
 n_checks = 0
 for it in range(iters):

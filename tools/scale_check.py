@@ -19,7 +19,7 @@ sel = np.random.default_rng(1).choice(n, size=20000, replace=False)
 want_t, want_c = oix.query_features(regions[sel], 2, False)
 b = engine.QueryBatch(ix, n)
 b.set_regions(regions)
-for name, strat, flags in (("slots", engine.STRATEGY_SLOTS, engine.OUT_FIDS | engine.OUT_OFFSETS),
+for name, strat, flags in (("windows", engine.STRATEGY_WINDOWS, engine.OUT_FIDS | engine.OUT_OFFSETS),
                            ("fused", engine.STRATEGY_FUSED, engine.OUT_FIDS | engine.OUT_OFFSETS),
                            ("partitioned", engine.STRATEGY_SORTED, engine.OUT_FIDS | engine.OUT_OFFSETS)):
     t0 = time.perf_counter(); b.run(2, False, flags, strat); b.wait(); dt = time.perf_counter() - t0
