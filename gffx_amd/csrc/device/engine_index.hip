@@ -1,0 +1,526 @@
+// engine_index.hip -- the device index behind gffx_hip_index: built on the host once, uploaded once, immutable.
+//
+// HBM layout of an index (uploaded once, immutable; gffx_device.hpp has the field meanings):
+//   start[R] u32, aux[R] uint4 {end, pmax_prev, skip, root_fid} 20 B/root, seqid after seqid, by start
+//   chr_meta[n_chr] uint4, bins[...] uint4                      per-seqid bin directory (direct / fused strategies)
+//   win_meta[n_chr + 1] uint4, win[...] 32 B lines, win_spill, win_tail + tables, win_filter    window index (windows strategy)
+//   cell_base / cell_tile / tile_meta / tile_aux / tile_bins    genome-window tile plan (partitioned strategy)
+// At GENCODE scale (63 k roots, 25 seqids) that is ~1.3 MB + ~2 MB of directory + ~0.2 MB of tile
+// plan: resident in every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and
+// the results out.
+#include "engine_private.hpp"
+
+namespace gffx {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+// Window index (gffx_device.hpp, join_win_kernels.hpp): per seqid ~GFFX_HIP_WIN_PER_ENTRY windows per root (a power of
+// two wide, at most 2^15 bp: the lines hold 16-bit coordinates relative to the window); the line of window b lists, by
+// ascending start, the roots with start < (b+1) << shift and end + wmax > b << shift.  `start` / `aux` are the sorted
+// arrays of the index.  A seqid whose lists would be absurdly long at 2^15 bp (> 64 entries per root) gets NO windows but
+// meta {0, 1, 31, 0}: wmax = 0, so every region on it takes the exact sweep.
+// `coarsen` (k) halves the windows per root k times and, from k = 1 on, turns a seqid that would need windows wider than
+// 2^15 bp into a sweep-only one: the directory is addressed with 32-bit byte offsets below 2^31, at most 2^25 lines.
+// Returns 1 when the directory does not fit at this coarseness.
+static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
+                                 const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
+                                 std::vector<uint4> &win_pos, std::vector<uint4> &spill, uint32_t coarsen, uint64_t max_lines) {
+    meta.assign(n_chr + 1, make_uint4(0, 0, 0, 0));  // (+ one zero entry: a kernel may read one past the end)
+    win.clear(), win_pos.clear(), spill.clear();
+    const uint64_t per_entry = (uint64_t)env_long("GFFX_HIP_WIN_PER_ENTRY", 2, 1, 16);
+    const uint64_t wmax_min = (uint64_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
+    auto win_wmax = [&](uint32_t shift) {  // widest region the lines answer: 16 Ki, but between 1/4 and 4 windows,
+        const uint64_t w = 1ull << shift;  // and W + wmax + 1 <= 65535 (16-bit relative coordinates)
+        return std::min<uint64_t>(std::max<uint64_t>(w >> 2, std::min<uint64_t>(wmax_min, w << 2)), 65534 - w);
+    };
+    const uint4 sweep_only = make_uint4(0, 1, 31, 0);
+    std::vector<uint32_t> len, fill;
+    uint64_t total_win = 0;
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        if (hi == lo) continue;
+        const uint64_t max_end = std::max(h_aux[hi - 1].x, h_aux[hi - 1].y);
+        const uint64_t budget = std::max<uint64_t>((per_entry * (hi - lo)) >> coarsen, std::max<uint64_t>(16 >> coarsen, 1));
+        auto windows_at = [&](uint32_t sh) { return ((max_end + win_wmax(sh)) >> sh) + 1; };
+        auto entries_at = [&](uint32_t sh, uint64_t stop) {  // list entries over all windows at this width
+            const uint64_t wm = win_wmax(sh), ns = windows_at(sh);
+            uint64_t total = 0;
+            for (uint32_t i = lo; i < hi && total <= stop; i++) {
+                const uint64_t first = (uint64_t)h_start[i] >> sh;
+                const uint64_t last = std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wm - 1) >> sh);
+                if (last >= first) total += last - first + 1;  // (an interval with end < start lists itself nowhere)
+            }
+            return total;
+        };
+        uint32_t shift = 0;
+        while (shift < kWinMaxShift && windows_at(shift) > budget) shift++;
+        if (windows_at(shift) > budget && coarsen) {
+            meta[c] = sweep_only;
+            continue;
+        }
+        const uint64_t want = 8ull * (hi - lo) + 1024, most = 64ull * (hi - lo) + 1024;
+        while (shift < kWinMaxShift && entries_at(shift, want) > want) shift++;
+        if (entries_at(shift, most) > most) {
+            meta[c] = sweep_only;
+            continue;
+        }
+        const uint64_t wmax = win_wmax(shift), ns = windows_at(shift), W = 1ull << shift;
+        if (total_win + ns >= max_lines) return 1;
+        const uint32_t base = (uint32_t)total_win;
+        total_win += ns;
+        meta[c] = make_uint4(base, (uint32_t)ns, shift, (uint32_t)wmax);
+        auto first_w = [&](uint32_t i) { return ((uint64_t)h_start[i] >> shift); };
+        auto last_w = [&](uint32_t i) { return std::min<uint64_t>(ns - 1, ((uint64_t)h_aux[i].x + wmax - 1) >> shift); };
+        len.assign(ns, 0);
+        for (uint32_t i = lo; i < hi; i++)
+            for (uint64_t b = first_w(i); b <= last_w(i) && last_w(i) >= first_w(i); b++) len[b]++;
+        // a line = 8 words {coordinates x 4, root_fid (or position) x 4}, join_win_kernels.hpp
+        win.resize(2 * total_win, make_uint4(kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent));
+        win_pos.resize(2 * total_win, make_uint4(kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent));
+        uint32_t *ww = reinterpret_cast<uint32_t *>(win.data()), *wp = reinterpret_cast<uint32_t *>(win_pos.data());
+        for (uint64_t b = 0; b < ns; b++) {
+            uint32_t n = len[b];
+            uint64_t off = 0;
+            if (n > kWinMaxList || (n > kWinInline && spill.size() + (n - kWinInlineTail) >= (1ull << 24))) {
+                n = 255;  // dense window (or the 24-bit spill offsets are used up): exact sweep
+            } else if (n > kWinInline) {
+                off = spill.size();
+                spill.resize(spill.size() + (n - kWinInlineTail));
+            }
+            uint32_t *l = ww + 8 * ((size_t)base + b), *lp = wp + 8 * ((size_t)base + b);
+            for (int j = 0; j < 4; j++) l[j] = lp[j] = kWinAbsent, l[4 + j] = lp[4 + j] = 0;
+            if (n > kWinInline) l[3] = lp[3] = kWinTailMark, l[7] = lp[7] = n | (uint32_t)(off << 8);
+        }
+        fill.assign(ns, 0);
+        for (uint32_t i = lo; i < hi; i++) {  // ascending start: the lists come out sorted
+            if (last_w(i) < first_w(i)) continue;
+            for (uint64_t b = first_w(i); b <= last_w(i); b++) {
+                uint32_t *l = ww + 8 * ((size_t)base + b), *lp = wp + 8 * ((size_t)base + b);
+                const bool tail = l[3] == kWinTailMark;
+                if (tail && (l[7] & 255u) == 255u) continue;
+                const uint32_t j = fill[b]++;
+                if (j < (tail ? kWinInlineTail : kWinInline)) {
+                    // relative to b W - wmax; start clamped from below, end from above (outside every region the line serves)
+                    const int64_t org = (int64_t)(b * W) - (int64_t)wmax;
+                    const int64_t rs = std::max<int64_t>((int64_t)h_start[i] - org, 0);
+                    const int64_t re = std::min<int64_t>((int64_t)h_aux[i].x - org, (int64_t)(W + wmax + 1));
+                    l[j] = lp[j] = (uint32_t)rs | ((uint32_t)re << 16);
+                    l[4 + j] = h_aux[i].w;
+                    lp[4 + j] = i;
+                } else {
+                    spill[(l[7] >> 8) + j - kWinInlineTail] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
+                }
+            }
+        }
+    }
+    return GFFX_OK;
+}
+
+static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
+                              const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
+                              std::vector<uint4> &win_pos, std::vector<uint4> &spill) {
+    // (GFFX_HIP_WIN_MAX_LINES: tests shrink the limit to reach the coarsening path with small indexes)
+    const uint64_t max_lines = (uint64_t)env_long("GFFX_HIP_WIN_MAX_LINES", 1l << 25, 64, 1l << 25);
+    for (uint32_t coarsen = 0; coarsen < 40; ++coarsen) {
+        const int rc = build_window_index_at(n_chr, chr_offsets, h_start, h_aux, meta, win, win_pos, spill, coarsen, max_lines);
+        if (rc <= 0) return rc;
+    }
+    return fail(GFFX_E_INVALID, "index too large for the window directory (%u seqids need more than 2^25 lines)", n_chr);
+}
+
+// Tail lines of the window index (gffx_device.hpp, join_wave_kernels.hpp): for every window whose list has 5..7 entries a
+// second line with entries 3..6 in the line's own format, plus the LDS tables that locate it (bitmap + u16 ranks per 32
+// windows).  Derived from the finished lines and spill records; `meta` still holds {first window, windows, shift, wmax}.
+// Nothing is built when the tables exceed GFFX_HIP_WIN_TAIL_KB (default 19 KB of LDS) or 65535 tail lines.
+static void build_window_tails(uint32_t n_chr, const std::vector<uint32_t> &h_start, const std::vector<uint4> &h_aux,
+                               const std::vector<uint4> &meta, const std::vector<uint4> &win, const std::vector<uint4> &spill,
+                               std::vector<uint4> &tail_lines, std::vector<uint32_t> &tab, uint32_t &twords) {
+    tail_lines.clear(), tab.clear();
+    twords = 0;
+    const size_t n_win = win.size() / 2;
+    const size_t nw = (n_win + 31) / 32;
+    const size_t tab_words = (nw + (nw + 1) / 2 + 3) / 4 * 4;
+    const uint64_t budget = (uint64_t)env_long("GFFX_HIP_WIN_TAIL_KB", 19, 0, 64) * 1024;
+    if (!n_win || tab_words * 4 > budget) return;
+    std::vector<uint32_t> bits(nw, 0);
+    const uint32_t *ww = reinterpret_cast<const uint32_t *>(win.data());
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint4 m = meta[c];
+        if (m.z > kWinMaxShift || m.w == 0) continue;  // no windows on this seqid
+        const uint64_t W = 1ull << m.z, wmax = m.w;
+        for (uint64_t b = 0; b < m.y; b++) {
+            const size_t w = (size_t)m.x + b;
+            const uint32_t *l = ww + 8 * w;
+            if (l[3] != kWinTailMark) continue;
+            const uint32_t n = l[7] & 255u;
+            if (n <= kWinInline || n > kWinInlineTail + 4) continue;  // (dense: n = 255)
+            bits[w >> 5] |= 1u << (w & 31);
+            uint32_t t[8] = {kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent, 0, 0, 0, 0};
+            const int64_t org = (int64_t)(b * W) - (int64_t)wmax;
+            for (uint32_t j = kWinInlineTail; j < n; j++) {
+                const uint4 r = spill[(l[7] >> 8) + j - kWinInlineTail];  // {start, end, root_fid, position}
+                const int64_t rs = std::max<int64_t>((int64_t)r.x - org, 0);
+                const int64_t re = std::min<int64_t>((int64_t)r.y - org, (int64_t)(W + wmax + 1));
+                t[j - kWinInlineTail] = (uint32_t)rs | ((uint32_t)re << 16);
+                t[4 + j - kWinInlineTail] = r.z;
+            }
+            tail_lines.push_back(make_uint4(t[0], t[1], t[2], t[3]));
+            tail_lines.push_back(make_uint4(t[4], t[5], t[6], t[7]));
+        }
+    }
+    if (tail_lines.size() / 2 > 65535 || tail_lines.empty()) {
+        tail_lines.clear();
+        return;
+    }
+    (void)h_start, (void)h_aux;
+    tab.assign(tab_words, 0u);
+    uint16_t *rank = reinterpret_cast<uint16_t *>(tab.data() + nw);
+    uint32_t acc = 0;
+    for (size_t x = 0; x < nw; x++) {
+        tab[x] = bits[x];
+        rank[x] = (uint16_t)acc;
+        acc += (uint32_t)__builtin_popcount(bits[x]);
+    }
+    twords = (uint32_t)nw;
+}
+
+// Coverage filter of the window index (gffx_device.hpp): the smallest cell size whose bitmap fits GFFX_HIP_WIN_FILTER_KB
+// (default 24 KB of LDS per block; 48 KB measured 1.5 % faster at 10 M regions, 1.5 % slower at 1 M), but never so small that a region the lines answer (width <= wmax) spans more than 32 cells.
+static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
+                                const std::vector<uint4> &h_aux, const std::vector<uint4> &win_meta, std::vector<uint32_t> &bits,
+                                std::vector<uint2> &fmeta, uint32_t &fshift) {
+    fmeta.assign(n_chr + 1, make_uint2(0, 0));
+    bits.clear();
+    fshift = 0;
+    const uint64_t budget_bits = (uint64_t)env_long("GFFX_HIP_WIN_FILTER_KB", 24, 0, 120) * 1024 * 8;
+    if (!budget_bits) return;
+    auto cells_of = [&](uint32_t c, uint32_t sh) -> uint64_t {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        if (hi == lo) return 0;
+        const uint64_t max_pos = std::max<uint64_t>(std::max(h_aux[hi - 1].x, h_aux[hi - 1].y), h_start[hi - 1]);  // (starts ascend)
+        return (max_pos >> sh) + 1;
+    };
+    uint32_t wmax_all = 1;
+    for (uint32_t c = 0; c < n_chr; c++) wmax_all = std::max(wmax_all, win_meta[c].w);
+    uint32_t sh = 0;
+    while (sh < 31 && ((uint64_t)wmax_all >> sh) + 2 > 31) sh++;  // a region of width <= wmax touches <= (wmax >> sh) + 2 cells (the kernel tests 31)
+    for (; sh < 32; sh++) {
+        uint64_t tot = 0;
+        for (uint32_t c = 0; c < n_chr; c++) tot += (cells_of(c, sh) + 31) / 32 * 32;
+        if (tot <= budget_bits) break;
+    }
+    if (sh >= 32) return;
+    fshift = sh;
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        const uint64_t nc = cells_of(c, sh);
+        if (!nc) continue;
+        const uint32_t base = (uint32_t)bits.size() * 32u;
+        fmeta[c] = make_uint2(base, (uint32_t)nc);
+        bits.resize(bits.size() + (nc + 31) / 32, 0u);
+        for (uint32_t i = lo; i < hi; i++) {
+            // a region keeps the root only if start < qe && end > qs: it then holds a base of [start, end) -- or, for an EMPTY
+            // interval (end == start: the reference keeps it when qs < start < qe), the base `start`.  (end < start is outside
+            // the domain: the reference's IntervalTree::build never terminates on one, tree.rs:48-50.)
+            const uint64_t a = (uint64_t)h_start[i] >> sh, b = h_aux[i].x > h_start[i] ? ((uint64_t)h_aux[i].x - 1) >> sh : a;
+            for (uint64_t x = a; x <= b && x < nc; x++) bits[(base + x) >> 5] |= 1u << ((base + x) & 31);
+        }
+    }
+    bits.push_back(0u);                           // (the kernel reads word pairs)
+    while (bits.size() & 3u) bits.push_back(0u);  // (... and stages the bitmap 16 bytes at a time)
+}
+
+}  // namespace gffx
+
+// ------------------------------------------------------------------------------------ misc
+
+extern "C" int gffx_hip_abi_version(void) { return GFFX_HIP_ABI_VERSION; }
+extern "C" int gffx_hip_device_count(void) { return device_count_quiet(); }
+extern "C" const char *gffx_hip_last_error(void) { return g_last_error.c_str(); }
+
+__global__ void k_warm(uint32_t *p) {
+    if (p) *p = 1;
+}
+// Pay the process's one-off HIP costs (runtime + context creation, code-object load) now, e.g. on a host thread
+// while the BED file is still being parsed.  Errors are reported but nothing depends on the call.
+extern "C" int gffx_hip_warmup(int device) {
+    const int ndev = device_count_quiet();
+    if (ndev <= 0) return fail(GFFX_E_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
+    GFFX_HIP_TRY(hipSetDevice(device));
+    GFFX_HIP_TRY(hipFree(nullptr));
+    hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, 0, (uint32_t *)nullptr);
+    GFFX_HIP_TRY(hipGetLastError());
+    GFFX_HIP_TRY(hipDeviceSynchronize());
+    return GFFX_OK;
+}
+extern "C" void gffx_hip_free_host(void *p) { free(p); }
+
+// ------------------------------------------------------------------------------------ index
+
+extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets,
+                                     const uint32_t *start, const uint32_t *end,
+                                     const uint32_t *root_fid, int device, gffx_hip_index **out) {
+    if (!out) return fail(GFFX_E_INVALID, "gffx_hip_index_create: out is NULL");
+    *out = nullptr;
+    if (!chr_offsets) return fail(GFFX_E_INVALID, "gffx_hip_index_create: chr_offsets is NULL");
+    for (uint32_t c = 0; c < n_chr; c++)
+        if (chr_offsets[c] > chr_offsets[c + 1])
+            return fail(GFFX_E_INVALID, "gffx_hip_index_create: chr_offsets not ascending at %u", c);
+    if (chr_offsets[0] != 0)
+        return fail(GFFX_E_INVALID, "gffx_hip_index_create: chr_offsets[0] must be 0");
+    const uint32_t R = chr_offsets[n_chr];
+    if (R > kPosMask)
+        return fail(GFFX_E_INVALID, "gffx_hip_index_create: %u roots exceed the engine's limit of %u", R, kPosMask);
+    if (R && (!start || !end || !root_fid))
+        return fail(GFFX_E_INVALID, "gffx_hip_index_create: NULL interval arrays");
+    const int ndev = device_count_quiet();
+    if (ndev <= 0) return fail(GFFX_E_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
+    GFFX_HIP_TRY(hipSetDevice(device));
+
+    // Per seqid: stable sort by start (the tree does the same: utils/tree.rs:40), running max of
+    // `end`, skip links (nearest earlier entry with a strictly greater end: monotonic stack), and
+    // the bin directory of the direct / fused strategies (~2 bins per entry, >= 64).
+    std::vector<uint32_t> h_start(R);
+    std::vector<uint4> h_aux(R);
+    std::vector<uint4> chr_meta(n_chr);
+    std::vector<uint4> bins;
+    std::vector<uint32_t> order, stack;
+    std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
+    ix->h_sorted_fids.resize(R);
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        order.resize(hi - lo);
+        std::iota(order.begin(), order.end(), lo);
+        std::stable_sort(order.begin(), order.end(),
+                         [&](uint32_t a, uint32_t b) { return start[a] < start[b]; });
+        stack.clear();
+        uint32_t pm = 0;  // running max of `end` over the entries before i
+        for (uint32_t k = 0; k < hi - lo; k++) {
+            const uint32_t j = order[k], i = lo + k;
+            while (!stack.empty() && h_aux[stack.back()].x <= end[j]) stack.pop_back();
+            const uint32_t skip = stack.empty() ? lo : stack.back() + 1;
+            stack.push_back(i);
+            h_start[i] = start[j];
+            h_aux[i] = make_uint4(end[j], pm, skip, root_fid[j]);
+            ix->h_sorted_fids[i] = root_fid[j];
+            pm = std::max(pm, end[j]);
+        }
+        auto pmax_incl = [&](uint32_t i) { return std::max(h_aux[i].x, h_aux[i].y); };
+        if (hi == lo) {
+            chr_meta[c] = make_uint4(lo, lo, (uint32_t)bins.size(), 0u);
+            continue;
+        }
+        const uint32_t max_start = h_start[hi - 1];
+        const uint64_t budget = std::max<uint64_t>((uint64_t)env_long("GFFX_HIP_BINS_PER_ENTRY", 2, 1, 64) * (hi - lo), 64);
+        uint32_t shift = 0;
+        while ((((uint64_t)max_start >> shift) + 1) > budget) shift++;
+        const uint32_t nb = (max_start >> shift) + 1;
+        if (nb >= (1u << kPosBits)) return fail(GFFX_E_INVALID, "index too large for the bin directory");
+        chr_meta[c] = make_uint4(lo, hi, (uint32_t)bins.size(), (shift << kPosBits) | nb);
+        uint32_t p = lo;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint64_t edge = (uint64_t)b << shift, next_edge = (uint64_t)(b + 1) << shift;
+            while (p < hi && h_start[p] < edge) p++;
+            uint32_t q = p;
+            while (q < hi && h_start[q] < next_edge) q++;
+            bins.push_back(make_uint4(p | (std::min(q - p, kCntSat) << kPosBits), p > lo ? pmax_incl(p - 1) : 0u,
+                                      q > p ? h_start[p] : 0xFFFFFFFFu, q > p + 1 ? h_start[p + 1] : 0xFFFFFFFFu));
+        }
+        // sentinel: nothing starts at or after nb << shift
+        bins.push_back(make_uint4(hi, pmax_incl(hi - 1), 0xFFFFFFFFu, 0xFFFFFFFFu));
+    }
+
+    std::vector<uint4> win_meta, win, win_pos, win_spill;
+    if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill)) return wrc;
+    ix->n_win = (uint32_t)(win.size() / 2);
+    std::vector<uint4> win_tail;
+    std::vector<uint32_t> win_tailtab;
+    build_window_tails(n_chr, h_start, h_aux, win_meta, win, win_spill, win_tail, win_tailtab, ix->win_twords);
+    ix->n_tail = (uint32_t)(win_tail.size() / 2);
+    std::vector<uint32_t> win_filter;
+    std::vector<uint2> win_fmeta;
+    build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);
+    // the kernel's seqid record: {first window, windows, shift | wmax << 8, first filter bit}
+    for (uint32_t c = 0; c <= n_chr; c++) win_meta[c] = make_uint4(win_meta[c].x, win_meta[c].y, win_meta[c].z | (win_meta[c].w << 8), win_fmeta[c].x);
+    ix->win_fwords = (uint32_t)win_filter.size();
+
+    // Partitioned strategy: cells of 2^cshift bp (<= kMaxCells in total, >= 1 per seqid) merged into
+    // tiles of <= kTileEntries entries; per tile a 1024-bin u16 directory over start (gffx_device.hpp).
+    std::vector<uint32_t> cell_base(n_chr + 1, 0);
+    std::vector<uint16_t> cell_tile;
+    std::vector<uint4> tile_meta;
+    std::vector<uint2> tile_aux;
+    std::vector<uint16_t> tile_bins;
+    uint32_t cshift = 0;
+    const bool plan = n_chr >= 1 && n_chr <= kMaxCells;
+    if (plan) {
+        auto cells_of = [&](uint32_t c, uint32_t sh) -> uint64_t {
+            const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+            return hi > lo ? ((uint64_t)h_start[hi - 1] >> sh) + 1 : 1;
+        };
+        for (;; cshift++) {
+            uint64_t tot = 0;
+            for (uint32_t c = 0; c < n_chr; c++) tot += cells_of(c, cshift);
+            if (tot <= kMaxCells || cshift == 31) break;
+        }
+        for (uint32_t c = 0; c < n_chr; c++) cell_base[c + 1] = cell_base[c] + (uint32_t)cells_of(c, cshift);
+    }
+    const bool plan_ok = plan && cell_base[n_chr] <= kMaxCells;
+    if (plan_ok) {
+        cell_tile.resize(cell_base[n_chr]);
+        for (uint32_t c = 0; c < n_chr; c++) {
+            const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+            const uint32_t nc = cell_base[c + 1] - cell_base[c];
+            uint32_t p = lo;          // first entry of the current cell
+            uint32_t t_first = lo;    // first entry of the open tile
+            uint32_t t_cell = 0;      // first cell of the open tile
+            auto close_tile = [&](uint32_t cell_end, uint32_t ent_end, bool last) {
+                const uint32_t tid = (uint32_t)tile_meta.size();
+                for (uint32_t x = t_cell; x < cell_end; x++) cell_tile[cell_base[c] + x] = (uint16_t)tid;
+                const uint64_t w0 = (uint64_t)t_cell << cshift;
+                const uint64_t w1 = last ? (hi > lo ? (uint64_t)h_start[hi - 1] + 1 : w0 + 1) : (uint64_t)cell_end << cshift;
+                const uint64_t span = std::max<uint64_t>(w1 > w0 ? w1 - w0 : 1, 1);
+                uint32_t bs = 0;
+                while (((span - 1) >> bs) >= kTileBins) bs++;
+                const uint32_t n_ent = ent_end - t_first;
+                tile_meta.push_back(make_uint4(t_first, ent_end, (uint32_t)w0, lo));
+                tile_aux.push_back(make_uint2(bs, n_ent <= kTileEntries ? 1u : 0u));
+                const size_t base = tile_bins.size();
+                tile_bins.resize(base + kTileBinStride, 0);
+                if (n_ent <= kTileEntries) {
+                    uint32_t k = 0;
+                    for (uint32_t b = 0; b <= kTileBins; b++) {
+                        const uint64_t edge = w0 + ((uint64_t)b << bs);
+                        while (k < n_ent && (uint64_t)h_start[t_first + k] < edge) k++;
+                        tile_bins[base + b] = (uint16_t)k;
+                    }
+                }
+                t_first = ent_end;
+                t_cell = cell_end;
+            };
+            for (uint32_t x = 0; x < nc; x++) {
+                uint32_t q = p;
+                if (x + 1 == nc) {
+                    q = hi;
+                } else {
+                    const uint64_t edge = (uint64_t)(x + 1) << cshift;
+                    while (q < hi && (uint64_t)h_start[q] < edge) q++;
+                }
+                // adding cell x would overflow the open tile: close it before x
+                if (x > t_cell && (q - t_first) > kTileEntries) close_tile(x, p, false);
+                p = q;
+            }
+            close_tile(nc, hi, true);
+        }
+    }
+
+    // what k_tile_join needs per tile, in one 32-byte record
+    std::vector<uint4> tile_desc;
+    if (plan_ok) {
+        for (size_t t = 0; t < tile_meta.size(); t++) {
+            const uint4 m = tile_meta[t];
+            tile_desc.push_back(make_uint4(m.x, (m.y - m.x) | (tile_aux[t].y ? 0x80000000u : 0u), m.z, m.w));
+            tile_desc.push_back(make_uint4(tile_aux[t].x, 0u, 0u, 0u));
+        }
+        if (cell_tile.size() & 1) cell_tile.push_back(0);  // k_partition copies the table as 4-byte words
+    }
+
+    ix->device = device;
+    ix->n_chr = n_chr;
+    ix->n_roots = R;
+    ix->n_cells = plan_ok ? cell_base[n_chr] : 0;
+    ix->n_tiles = (uint32_t)tile_meta.size();
+    ix->cshift = cshift;
+    ix->partition_ok = plan_ok && ix->n_tiles >= 1 && ix->n_tiles <= kMaxTiles;
+    int rc;
+    if ((rc = dev_upload(&ix->d_start, h_start)) || (rc = dev_upload(&ix->d_aux, h_aux)) ||
+        (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
+        (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = dev_upload(&ix->d_win, win)) ||
+        (rc = dev_upload(&ix->d_win_pos, win_pos)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
+        (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_tail, win_tail)) ||
+        (rc = dev_upload(&ix->d_win_tailtab, win_tailtab)) ||
+        (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
+        (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
+        (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
+        gffx_hip_index_destroy(ix.release());
+        return rc;
+    }
+    auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
+    ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),
+                       bytes(win_meta),  bytes(win),        bytes(win_pos),   bytes(win_spill), bytes(win_filter),
+                       bytes(win_tail),  bytes(win_tailtab),
+                       bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
+    // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
+    GFFX_HIP_TRY(hipDeviceSynchronize());
+    *out = ix.release();
+    return GFFX_OK;
+}
+
+extern "C" int gffx_hip_index_clone(const gffx_hip_index *src, int device, gffx_hip_index **out) {
+    if (!out) return fail(GFFX_E_INVALID, "gffx_hip_index_clone: out is NULL");
+    *out = nullptr;
+    if (!src) return fail(GFFX_E_INVALID, "gffx_hip_index_clone: index is NULL");
+    const int ndev = device_count_quiet();
+    if (device < 0 || device >= ndev) return fail(GFFX_E_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
+    std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index(*src));  // scalars and host vectors; the pointers are replaced below
+    ix->device = device;
+    std::vector<void **> dst = ix->arrays();
+    std::vector<void **> from = const_cast<gffx_hip_index *>(src)->arrays();
+    for (void **p : dst) *p = nullptr;
+    GFFX_HIP_TRY(hipSetDevice(device));
+    for (size_t i = 0; i < dst.size(); ++i) {
+        hipError_t e = hipMalloc(dst[i], src->array_bytes[i]);
+        if (e == hipSuccess) e = hipMemcpy(*dst[i], *from[i], src->array_bytes[i], hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            gffx_hip_index_destroy(ix.release());
+            return fail(e == hipErrorOutOfMemory ? GFFX_E_OOM : GFFX_E_HIP, "gffx_hip_index_clone: %s", hipGetErrorString(e));
+        }
+    }
+    GFFX_HIP_TRY(hipDeviceSynchronize());
+    *out = ix.release();
+    return GFFX_OK;
+}
+
+extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipFree(ix->d_start);
+    (void)hipFree(ix->d_aux);
+    (void)hipFree(ix->d_chr_meta);
+    (void)hipFree(ix->d_bins);
+    (void)hipFree(ix->d_win_meta);
+    (void)hipFree(ix->d_win);
+    (void)hipFree(ix->d_win_pos);
+    (void)hipFree(ix->d_win_spill);
+    (void)hipFree(ix->d_win_filter);
+    (void)hipFree(ix->d_win_tail);
+    (void)hipFree(ix->d_win_tailtab);
+    (void)hipFree(ix->d_cell_base);
+    (void)hipFree(ix->d_cell_tile);
+    (void)hipFree(ix->d_tile_meta);
+    (void)hipFree(ix->d_tile_aux);
+    (void)hipFree(ix->d_tile_bins);
+    (void)hipFree(ix->d_tile_desc);
+    delete ix;
+}
+
+extern "C" uint32_t gffx_hip_index_n_chr(const gffx_hip_index *ix) { return ix ? ix->n_chr : 0; }
+extern "C" uint64_t gffx_hip_index_n_roots(const gffx_hip_index *ix) { return ix ? ix->n_roots : 0; }
+extern "C" int gffx_hip_index_device(const gffx_hip_index *ix) { return ix ? ix->device : -1; }
+extern "C" const uint32_t *gffx_hip_index_sorted_fids(const gffx_hip_index *ix) {
+    return ix ? ix->h_sorted_fids.data() : nullptr;
+}
+

@@ -1,0 +1,220 @@
+// engine_private.hpp -- what the translation units of the engine share: host helpers, the index / batch objects behind the
+// opaque handles of include/gffx_hip.h, and the few functions that cross a file boundary.
+//   engine_index.hip    index builders (window lines, tail lines, coverage filter, bin directory, tile plan), create / clone / destroy
+//   engine_batch.hip    batches: regions in, run / wait / results out, profiling; the direct, fused and partitioned strategies
+//   engine_windows.hip  the windows strategy: k_join_wave (pair passes) and k_join_win (triples, root bitmap)
+//   engine_regions.hip  region stores (streaming BED ingestion) and the RCCL hit-count exchange
+//   engine_depth.hip    `gffx depth`
+// (join_b.hip and coverage.hip were separate translation units already; engine.hip includes all five for the tools that
+//  build the engine into one binary: tools/kbench.hip, tools/win_index_check.hip)
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <utility>
+
+#include "gffx_device.hpp"
+
+namespace gffx {
+
+inline int device_count_quiet() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+inline long env_long(const char *name, long dflt, long lo, long hi) {
+    const char *e = getenv(name);
+    if (e && *e) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= lo && v <= hi) return v;
+    }
+    return dflt;
+}
+
+template <typename T>
+inline int dev_alloc(T **p, size_t n) {
+    *p = nullptr;
+    GFFX_HIP_TRY(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return GFFX_OK;
+}
+
+template <typename T>
+inline int dev_upload(T **p, const std::vector<T> &v) {
+    int rc = dev_alloc(p, v.size());
+    if (rc) return rc;
+    if (!v.empty()) GFFX_HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GFFX_OK;
+}
+
+
+
+}  // namespace gffx
+
+using namespace gffx;
+
+// a counter that a copied index (gffx_hip_index_clone) does not inherit
+struct BusyCount {
+    std::atomic<int> v{0};
+    BusyCount() = default;
+    BusyCount(const BusyCount &) : v(0) {}
+    BusyCount &operator=(const BusyCount &) { return *this; }
+};
+
+struct gffx_hip_index {
+    int device = 0;
+    uint32_t n_chr = 0;
+    uint32_t n_roots = 0;
+    uint32_t *d_start = nullptr;
+    uint4 *d_aux = nullptr;
+    uint4 *d_chr_meta = nullptr;
+    uint4 *d_bins = nullptr;
+    uint4 *d_win_meta = nullptr, *d_win = nullptr, *d_win_pos = nullptr, *d_win_spill = nullptr;  // window index (join_win_kernels.hpp)
+    uint32_t n_win = 0;
+    uint32_t *d_win_filter = nullptr;
+    uint32_t win_fwords = 0, win_fshift = 0;
+    uint4 *d_win_tail = nullptr;          // tail lines (k_join_wave)
+    uint32_t *d_win_tailtab = nullptr;
+    uint32_t n_tail = 0, win_twords = 0;
+    // partitioned strategy: genome-window tiles (gffx_device.hpp)
+    uint32_t *d_cell_base = nullptr;
+    uint16_t *d_cell_tile = nullptr;
+    uint4 *d_tile_meta = nullptr;
+    uint2 *d_tile_aux = nullptr;
+    uint16_t *d_tile_bins = nullptr;
+    uint4 *d_tile_desc = nullptr;  // per tile two uint4 (tile_join_kernels.hpp)
+    uint32_t n_cells = 0, n_tiles = 0, cshift = 0;
+    bool partition_ok = false;  // the tile plan exists (n_chr <= kMaxCells)
+    mutable BusyCount busy_batches;  // batches of this index with passes that nobody synchronised with yet
+    std::vector<uint32_t> h_sorted_fids;
+    std::vector<size_t> array_bytes;  // of arrays(), in order (gffx_hip_index_clone)
+
+    // every device array of the index, in a fixed order
+    std::vector<void **> arrays() {
+        return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_win_meta,   (void **)&d_win,
+                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_win_tail,   (void **)&d_win_tailtab,
+                (void **)&d_cell_base,
+                (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
+    }
+
+    IndexView view() const {
+        IndexView v;
+        v.start = d_start;
+        v.aux = d_aux;
+        v.chr_meta = d_chr_meta;
+        v.bins = d_bins;
+        v.win_meta = d_win_meta;
+        v.win = d_win;
+        v.win_pos = d_win_pos;
+        v.win_spill = d_win_spill;
+        v.n_win = n_win;
+        v.win_filter = d_win_filter;
+        v.win_fwords = win_fwords;
+        v.win_fshift = win_fshift;
+        v.win_tail = d_win_tail;
+        v.win_tailtab = d_win_tailtab;
+        v.n_tail = n_tail;
+        v.win_twords = win_twords;
+        v.n_chr = n_chr;
+        v.n_roots = n_roots;
+        return v;
+    }
+    TilePlanView plan_view() const {
+        return TilePlanView{d_cell_base, d_cell_tile, d_tile_meta, d_tile_aux, d_tile_bins, n_chr, n_cells, n_tiles, cshift};
+    }
+};
+
+struct ProfEvent {
+    int kernel;
+    hipEvent_t a, b;
+};
+
+struct gffx_hip_batch {
+    const gffx_hip_index *ix = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t max_q = 0, nq = 0;
+    // inputs
+    uint32_t *d_regions = nullptr;  // owned AoS upload buffer (3*max_q)
+    uint32_t *d_soa = nullptr;      // owned SoA upload buffer (3*max_q), lazily allocated
+    QueryView q{};
+    bool have_regions = false;
+    // outputs / workspace
+    uint32_t *d_counts = nullptr;
+    unsigned long long *d_block_sums = nullptr;
+    unsigned long long *d_status = nullptr;     // [0] error bits; partitioned strategy: [1] kept pairs; [2], [3] the alternating
+                                                // pair cursors of the one-kernel strategies; [4] regions that took the exact
+                                                // sweep (windows strategy); [5], [6] scratch cursors of a second (bitmap) pass
+    static constexpr int kStatusWords = 8;
+    unsigned long long *h_status = nullptr;     // pinned: [0] error bits, [1] pair cursor / [1..] block sums
+    static constexpr uint32_t kMaxBlocks = 8192;
+    uint32_t *d_fids = nullptr, *d_triples = nullptr, *d_bitmap = nullptr;
+    unsigned long long *d_offsets = nullptr;
+    uint32_t *d_offsets32 = nullptr;            // GFFX_OUT_OFFSETS32
+    unsigned long long *d_segbase = nullptr;    // GFFX_OUT_SEGBASE: ceil(max_q / 256)
+    uint32_t *d_slabs = nullptr;                // windows strategy, root-bitmap passes: one LDS bitmap image per block
+    uint32_t slab_blocks = 0;
+    uint64_t cap_fids = 0, cap_triples = 0;
+    uint64_t reserve = 0;
+    // partitioned strategy workspace (allocated on first use)
+    uint4 *d_rec = nullptr;         // n_tiles regions of sub_cap 16-byte records
+    uint32_t *d_cursor = nullptr;   // 2 sets of n_tiles cursors (alternating; the join zeroes the other set)
+    uint4 *d_q_rec = nullptr;       // per-query results in emission order: {row, count, offset lo, offset hi}
+    bool unpermuted = false;        // d_counts / d_offsets hold the input-order view of the last pass
+    uint32_t sub_cap = 0;           // queries per sub-batch == records per tile region
+    int cursor_phase = 0;
+    int fused_phase = 0;            // which of d_status[2..3] the next fused pass uses as its pair cursor
+    int fused_word = 2;             // ... and the one the last fused pass used
+    uint64_t slow_seen_win = 0;     // windows strategy: the device's exact-sweep counter at the last wait
+    uint64_t win_passes = 0;        // ... and the windows passes enqueued since
+    bool mostly_slow = false;       // ... > 1/4 of the regions took the slow lane: AUTO uses the sweep kernel
+    // last run
+    int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
+    uint32_t flags = 0;
+    uint32_t n_blocks = 0;
+    uint64_t chunk = 0;
+    bool ran = false, waited = false;
+    uint32_t win_threads = 0;  // block width of the last windows pair pass (gffx_hip_batch_block_threads)
+    bool others_busy = false;  // at the last run: another batch of the index had passes in flight (co-resident kernels)
+    bool busy = false;  // counted in ix->busy_batches: a pass was enqueued since the last stream synchronisation
+    uint64_t total = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfEvent> pending;
+    double k_ms[GFFX_K__COUNT] = {0};
+    uint64_t k_n[GFFX_K__COUNT] = {0};
+};
+
+
+namespace gffx {
+
+// ---- what crosses a file boundary
+constexpr uint32_t kWinMaxLds = 80 * 1024;  // two blocks per CU share 160 KB
+void prof_begin(gffx_hip_batch *b, int kernel, ProfEvent *pe);  // engine_batch.hip
+void prof_end(gffx_hip_batch *b, ProfEvent *pe);
+void prof_resolve(gffx_hip_batch *b);
+uint32_t meta_bytes(const gffx_hip_index *ix);
+int run_windows(gffx_hip_batch *b);  // engine_windows.hip
+int batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who);  // engine_batch.hip
+int need_input_order(gffx_hip_batch *b);
+
+template <typename T>
+inline int grow(T **p, uint64_t *cap, uint64_t want, size_t elems_per) {
+    if (*cap >= want && *p) return GFFX_OK;
+    if (*p) GFFX_HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    int rc = dev_alloc(p, want * elems_per);
+    if (rc) return rc;
+    *cap = want;
+    return GFFX_OK;
+}
+
+}  // namespace gffx

@@ -97,6 +97,15 @@ struct IndexView {
     uint32_t n_chr;
     uint32_t n_roots;
 };
+// format of a window-index line (join_win_kernels.hpp has the description)
+constexpr uint32_t kWinLineBytes = 32;           // one index line: two 16-byte loads
+constexpr uint32_t kWinInline = 4;               // list entries inside the line when the whole list fits
+constexpr uint32_t kWinInlineTail = 3;           // ... when it does not: word 3 / word 7 mark and locate the tail
+constexpr uint32_t kWinMaxShift = 15;            // widest window: W + wmax + 1 must fit 16 bits
+constexpr uint32_t kWinTailMark = 0xFFFFFFFFu;   // word 3 of a line whose list continues in win_spill
+constexpr uint32_t kWinAbsent = 0x0000FFFFu;     // coordinate word of an absent entry
+constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (n = 255)
+constexpr uint32_t kWaveGroup = 256;             // regions per GFFX_OUT_SEGBASE entry: 64 lanes x 4 regions, one wave's share of a round
 constexpr uint32_t kPosBits = 27;
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1;
 constexpr uint32_t kCntSat = 31;

@@ -47,7 +47,7 @@
 
 namespace gffx {
 
-constexpr uint32_t kWaveGroup = 256;   // regions of one wave and round = one run of pairs (GFFX_OUT_SEGBASE granule)
+// (kWaveGroup = 256, the GFFX_OUT_SEGBASE granule = a wave's regions per round, is in gffx_device.hpp)
 constexpr uint32_t kWaveStage = 512;   // root_fids a wave parks in LDS per round (two rounds in flight)
 constexpr uint32_t kWaveDepth = GFFX_WAVE_DEPTH;  // strips per wave: a round's root_fids wait kWaveDepth - 1 rounds for their place
 constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequence numbers (kWaveDepth <= 3 of each)

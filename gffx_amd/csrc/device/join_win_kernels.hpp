@@ -62,13 +62,7 @@ namespace gffx {
 
 constexpr int kWinThreads = GFFX_WIN_THREADS;
 // (regions per round = 4 x threads: one uint4 of every region column per thread; the LDS stage holds 8 x threads root_fids)
-constexpr uint32_t kWinLineBytes = 32;           // one index line: two 16-byte loads
-constexpr uint32_t kWinInline = 4;               // list entries inside the line when the whole list fits
-constexpr uint32_t kWinInlineTail = 3;           // ... when it does not: word 3 / word 7 mark and locate the tail
-constexpr uint32_t kWinMaxShift = 15;            // widest window: W + wmax + 1 must fit 16 bits
-constexpr uint32_t kWinTailMark = 0xFFFFFFFFu;   // word 3 of a line whose list continues in win_spill
-constexpr uint32_t kWinAbsent = 0x0000FFFFu;     // coordinate word of an absent entry
-constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (n = 255)
+// (the line format's constants -- kWinLineBytes, kWinInline, kWinTailMark, ... -- are in gffx_device.hpp: the index builder shares them)
 constexpr uint32_t kWinStash = 4;                // per thread: kept root_fids of list tails / sweeps wait here (LDS) for the emit
 
 typedef uint32_t gffx_v4u __attribute__((ext_vector_type(4)));

@@ -85,7 +85,7 @@ for it in range(iters):
     table = engine.DepthTable(g, block_off, ls, le, lg, block_of_fid)
     bt = engine.QueryBatch(ix, nq)
     bt.set_regions(reg)
-    bt.run(2, False, engine.OUT_FIDS | engine.OUT_OFFSETS, int(rng.choice([0, 1, 2, 3, 4])))
+    bt.run(2, False, engine.OUT_FIDS | engine.OUT_OFFSETS, int(rng.choice([0, 1, 2, 3, 5])))
     bt.wait()
     table.accumulate(bt)
     want = _numpy_depth(roots, block_of_fid, block_off, ls, le, lg, g, reg)
