@@ -211,14 +211,15 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
     // entry 0 = the latest round)
     constexpr int P = (int)D - 1;
     bool p_valid[P], p_poster[P];
-    uint32_t p_total[P], p_seq[P], p_slot[P];
+    uint32_t p_total[P], p_seq[P], p_slot[P], p_strip[P];  // (p_slot: the round's arrival / post slot; p_strip: where its root_fids wait)
     unsigned long long p_off[P], p_round[P];
     // lane 0 of the wave that issued the LATEST round's reservation atomic: what it returned.  (One register pair, never
     // copied while the atomic is in flight: a copy would be a wait for it.  The base is posted during the next round, before
     // the entries shift.)
     unsigned long long p_got = 0;
+    bool p_big = false;  // the latest round took ALL of the wave's strips (see `big` below): it is flushed before anything is parked again
 #pragma unroll
-    for (int i = 0; i < P; ++i) p_valid[i] = p_poster[i] = false, p_total[i] = p_seq[i] = p_slot[i] = 0, p_off[i] = p_round[i] = 0;
+    for (int i = 0; i < P; ++i) p_valid[i] = p_poster[i] = false, p_total[i] = p_seq[i] = p_slot[i] = p_strip[i] = 0, p_off[i] = p_round[i] = 0;
 
     auto post = [&](uint32_t par, uint32_t seq, unsigned long long got) {  // the wave that issued the round's atomic
         if (lane == 0) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
 #endif
         group_base(p_round[i], seg);
         if (out.fids) {
-            const uint32_t *st = s_stage + slot * kWaveStage;
+            const uint32_t *st = s_stage + p_strip[i] * kWaveStage;
             uint32_t *dst = out.fids + seg;  // (uniform)
             if (seg + p_total[i] <= out.capacity) {
                 // (a buffer store from the run's own base: no 64-bit address arithmetic per lane, and the cache policy bits)
@@ -491,11 +492,23 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                                                    4u * t4, 0, GFFX_WAVE_STORE_AUX);
         }
         // ---- park the round's root_fids in this wave's strip (by final position inside the wave's run)
-        const uint32_t par = slot_now;
-        const bool staged = wtotal <= kWaveStage;  // (uniform)
+        // A wave whose round keeps more pairs than one strip holds (gene-dense stretches of a SORTED BED file do that to whole
+        // blocks) takes all D strips for it -- they are contiguous -- after flushing what they still hold, and flushes the
+        // round before it parks anything again: such rounds run one round deep instead of D - 1, through the same code.
+        // Only a round beyond D strips (> 1536 pairs of 256 regions) is written synchronously from a second walk.
+        const bool big = wtotal > kWaveStage && wtotal <= D * kWaveStage;  // (uniform)
+        if (p_big || big) {
+            post_pending();
+#pragma unroll
+            for (int i = P - 1; i >= 0; --i) finish(i);
+            p_big = false;
+        }
+        const uint32_t par = slot_now;  // the round's slot: arrival word, posted base (the same for every wave of the block)
+        const uint32_t strip = big ? 0u : slot_now;
+        const bool staged = wtotal <= D * kWaveStage;  // (uniform)
         if (staged) {
             if (out.fids) {
-                uint32_t *st = s_stage + par * kWaveStage;
+                uint32_t *st = s_stage + strip * kWaveStage;
                 const uint32_t lpk[4] = {lp0, lp0 + cnt[0], lp0 + cnt[0] + cnt[1], lp0 + cnt[0] + cnt[1] + cnt[2]};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -564,6 +577,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
         for (int i = P - 1; i > 0; --i) {  // (entry P - 1 was finished above)
             p_valid[i] = p_valid[i - 1], p_poster[i] = p_poster[i - 1], p_total[i] = p_total[i - 1];
             p_off[i] = p_off[i - 1], p_round[i] = p_round[i - 1], p_seq[i] = p_seq[i - 1], p_slot[i] = p_slot[i - 1];
+            p_strip[i] = p_strip[i - 1];
         }
         p_valid[0] = false;
         if (staged) {
@@ -574,6 +588,8 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
             p_round[0] = r;
             p_seq[0] = k_round + 1;
             p_slot[0] = par;
+            p_strip[0] = strip;
+            p_big = big;
         } else {
             // more pairs than the strip holds: wait for the base now and write them from a second walk of the regions
             // (the rounds before were posted above, right after this round's gathers: nobody waits for THIS wave while it waits)

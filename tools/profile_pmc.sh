@@ -6,7 +6,7 @@
 # the box for the whole gpurun limit.  Counter passes are separate runs with --kernel-trace only (never combined with other traces).
 set -u
 TAG=$1; shift
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline --quick --inflight 1 $*"  # serial passes: per-kernel durations without overlap
+ARGS="--steps 20 --warmup 3 --passes-per-step 1 --repeats 1 --no-cpu-baseline --quick --inflight 1 $*"  # serial passes: per-kernel durations without overlap
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG
