@@ -286,7 +286,11 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
             uint32_t *dst = out.fids + seg;  // (uniform)
             if (seg + p_total[i] <= out.capacity) {
                 // (a buffer store from the run's own base: no 64-bit address arithmetic per lane, and the cache policy bits)
+#if defined(GFFX_WIN_ABL_NOSTORE)
+                const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0u, 0x00020000);
+#else
                 const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(dst, 0, p_total[i] * 4u, 0x00020000);
+#endif
                 for (uint32_t x = lane; x < p_total[i]; x += 64)
                     __builtin_amdgcn_raw_buffer_store_b32(st[x], rf, x * 4u, 0, GFFX_WAVE_STORE_AUX);
             } else {
@@ -488,8 +492,13 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
             const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
             gffx_v4u cv;
             cv.x = cnt[0], cv.y = cnt[1], cv.z = cnt[2], cv.w = cnt[3];
+#if defined(GFFX_WIN_ABL_NOSTORE)  // (tools/kbench.hip: no result leaves the kernel; the store below is out of range)
+            __builtin_amdgcn_raw_buffer_store_b128(cv, __builtin_amdgcn_make_buffer_rsrc(out.counts + base, 0, 0u, 0x00020000),
+                                                   4u * t4, 0, GFFX_WAVE_STORE_AUX);
+#else
             __builtin_amdgcn_raw_buffer_store_b128(cv, __builtin_amdgcn_make_buffer_rsrc(out.counts + base, 0, rows * 4u, 0x00020000),
                                                    4u * t4, 0, GFFX_WAVE_STORE_AUX);
+#endif
         }
         // ---- park the round's root_fids in this wave's strip (by final position inside the wave's run)
         // A wave whose round keeps more pairs than one strip holds (gene-dense stretches of a SORTED BED file do that to whole
@@ -507,7 +516,11 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
         const uint32_t strip = big ? 0u : slot_now;
         const bool staged = wtotal <= D * kWaveStage;  // (uniform)
         if (staged) {
+#if defined(GFFX_WIN_ABL_NOSTAGE)
+            if (out.fids && qs[0] == 0xFFFFFFF1u) {
+#else
             if (out.fids) {
+#endif
                 uint32_t *st = s_stage + strip * kWaveStage;
                 const uint32_t lpk[4] = {lp0, lp0 + cnt[0], lp0 + cnt[0] + cnt[1], lp0 + cnt[0] + cnt[1] + cnt[2]};
 #pragma unroll
