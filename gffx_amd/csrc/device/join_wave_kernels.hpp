@@ -41,6 +41,12 @@
 #ifndef GFFX_WAVE_EXEC_LOADS
 #define GFFX_WAVE_EXEC_LOADS 0  // index lines are only requested by the lanes that have one (0: every lane, out-of-range offsets)
 #endif
+#ifndef GFFX_WAVE_RARE_IX_KERNARG
+#define GFFX_WAVE_RARE_IX_KERNARG 1
+#endif
+#ifndef GFFX_WAVE_PIN_BAD
+#define GFFX_WAVE_PIN_BAD 0
+#endif
 #ifndef GFFX_WAVE_STAGGER
 #define GFFX_WAVE_STAGGER 0
 #endif
@@ -115,6 +121,20 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                                                     uint32_t fwords, uint32_t keep_words, uint32_t twords) {
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     constexpr uint32_t kWaves = T / 64;
+#if GFFX_WAVE_RARE_IX_KERNARG
+    // The rare paths (list tails in win_spill, exact sweeps) read the index view where it already lies -- it is this kernel's
+    // first argument, i.e. the first bytes of the kernarg segment -- through a pointer that is "made" inside the rare block:
+    // the view's twenty-odd pointers then are not live across the round loop (as by-value arguments used inside the loop they
+    // are loaded once and kept in SGPRs, most of them spilled to VGPR lanes: v_writelane / v_readlane are VALU instructions).
+    auto rare_ix = [&]() -> const IndexView & {
+        typedef const IndexView __attribute__((address_space(4))) * KernargView;
+        KernargView p = (KernargView)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return *(const IndexView *)p;
+    };
+#else
+    auto rare_ix = [&]() -> const IndexView & { return ix; };
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t D = kWaveDepth;
     unsigned long long *s_arrive = reinterpret_cast<unsigned long long *>(smem);              // [D] arrivals << 56 | pairs so far
@@ -357,6 +377,10 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
             rel[k] = wmax - (b << shift);
             sweep |= (live && !fits) ? 1u << k : 0u;
         }
+#if GFFX_WAVE_PIN_BAD
+        asm volatile("" : "+v"(bad));  // (computed HERE: sunk to the end of the round it would keep this round's seqid registers alive
+                                        //  past the prefetch of the next round's regions -- eight register copies per round)
+#endif
         // ---- the FIRST of the thread's regions whose window has a tail line (list of 5..7 entries: the LDS bitmap knows)
         // reads that line together with its own: no dependent second gather.  (A second such region of the thread, longer
         // lists, dense windows and sweeps are deferred below.)
@@ -437,7 +461,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                 const int k = __ffs(d) - 1;
                 d &= d - 1;
                 uint32_t c = 0;
-                win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
+                win_rest<MODE, INVERT, false>(rare_ix(), sweep >> k & 1u, win_sel(qc, k), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k),
                                               [&](uint32_t, uint32_t, uint32_t fid, uint32_t) {
                                                   if (n_rest < kWaveStash) s_stash[n_rest] = fid;
                                                   ++n_rest;
@@ -548,7 +572,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                     } else {
                         uint32_t c_, s_, e_;
                         load_query<AOS>(q, i0 + k, c_, s_, e_);
-                        win_rest<MODE, INVERT, false>(ix, sweep >> k & 1u, c_, s_, e_, win_sel(hdr, k),
+                        win_rest<MODE, INVERT, false>(rare_ix(), sweep >> k & 1u, c_, s_, e_, win_sel(hdr, k),
                                                       [&](uint32_t, uint32_t, uint32_t fid, uint32_t) { st[e++] = fid; });
                         // (rare path, late in the round: leave no load of it in flight -- registers the compiler must treat as
                         //  "maybe still being loaded" at the top of the next round would turn the wait there into vmcnt(0) for
@@ -615,7 +639,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
                 for (uint32_t k = 0; k < n_mine; ++k) {
                     uint32_t c_, s_, e_;
                     load_query<AOS>(q, i0 + k, c_, s_, e_);
-                    wave_walk_region<MODE, INVERT>(ix, cm, c_, s_, e_, [&](uint32_t fid) {
+                    wave_walk_region<MODE, INVERT>(rare_ix(), cm, c_, s_, e_, [&](uint32_t fid) {
                         if (o < out.capacity) out.fids[o] = fid;
                         ++o;
                     });
