@@ -74,7 +74,8 @@ for it in range(iters):
                     continue
                 flag_sets = [engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS]
                 if strat == engine.STRATEGY_WINDOWS:  # u32 offsets next to the u64 ones; the CLI's bitmap-only pass
-                    flag_sets += [engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_ROOT_BITMAP]
+                    flag_sets += [engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_ROOT_BITMAP,
+                                  engine.OUT_FIDS | engine.OUT_SEGBASE]  # (the pass bench.py times: one base per 256 regions)
                     if it % 3 == 0:  # the 1024-thread variant of the pair pass (the engine takes it for 0.5-2.5 M regions alone)
                         os.environ["GFFX_HIP_WIN_THREADS"] = "1024"
                     else:
@@ -89,7 +90,10 @@ for it in range(iters):
                         n_checks += 1
                         if ok:
                             continue
-                    off = b.offsets() if ok or flags != engine.OUT_ROOT_BITMAP else None
+                    if flags & engine.OUT_SEGBASE:
+                        off = np.concatenate([b.offsets_from_segbase(c), [np.uint64(b.total_hits)]]).astype(np.uint64) if ok else None
+                    else:
+                        off = b.offsets() if ok or flags != engine.OUT_ROOT_BITMAP else None
                     if ok and flags & engine.OUT_OFFSETS32:
                         ok = np.array_equal(off[:-1], b.offsets32().astype(np.uint64))
                     if ok and flags & engine.OUT_FIDS:
