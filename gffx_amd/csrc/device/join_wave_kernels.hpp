@@ -47,6 +47,11 @@
 #ifndef GFFX_WAVE_PIN_BAD
 #define GFFX_WAVE_PIN_BAD 0
 #endif
+#ifndef GFFX_CLK  // tools/kbench.hip -DGFFX_CLKCHECK: shader clock against wall clock over a block's life
+#define GFFX_CLK(which) \
+    do {                \
+    } while (0)
+#endif
 #ifndef GFFX_WAVE_STAGGER
 #define GFFX_WAVE_STAGGER 0
 #endif
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
             }
         }
     };
+    GFFX_CLK(0);  // (tools/kbench.hip -DGFFX_CLKCHECK: effective shader clock over the block's life)
     const unsigned long long n_rounds = (nq + kChunk - 1) / kChunk;
     if (blockIdx.x < n_rounds) load_round(blockIdx.x);  // in flight while the tables are staged
     const uint4 *cm;
@@ -657,6 +663,7 @@ __global__ __launch_bounds__(T, 4) void k_join_wave(IndexView ix, QueryView q, u
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64);
     if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow);
+    GFFX_CLK(1);
 }
 
 }  // namespace gffx

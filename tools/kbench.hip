@@ -20,6 +20,17 @@ __device__ int g_stamp_sel;
     } while (0)
 #endif
 
+#if GFFX_CLKCHECK  // shader clocks (clock64) against the 100 MHz wall clock over a block's life: the CU's effective frequency
+__device__ unsigned long long g_clk[8192 * 4];
+#define GFFX_CLK(which)                                                          \
+    do {                                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) {                             \
+            g_clk[blockIdx.x * 4 + 2 * (which)] = clock64();                     \
+            g_clk[blockIdx.x * 4 + 2 * (which) + 1] = wall_clock64();            \
+        }                                                                        \
+    } while (0)
+#endif
+
 #include "../gffx_amd/csrc/device/engine.hip"
 
 static const struct { const char *name; uint32_t len; } kChroms[] = {
@@ -159,6 +170,20 @@ int main(int argc, char **argv) {
         for (int k = 1; k < 16; k++)
             if (sum[k] > 0) printf(" [%d]%.2f", k, sum[k] / nb);
         printf("\n");
+    }
+#endif
+#if GFFX_CLKCHECK
+    {
+        std::vector<unsigned long long> z(8192 * 4, 0);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z.data(), z.size() * 8);
+        gffx_hip_batch_run(b, GFFX_MODE_OVERLAP, 0, flags, strategy);
+        gffx_hip_batch_sync(b);
+        hipMemcpyFromSymbol(z.data(), HIP_SYMBOL(g_clk), z.size() * 8);
+        double sc = 0, sw = 0;
+        int nb = 0;
+        for (int blk = 0; blk < 8192; ++blk)
+            if (z[blk * 4 + 3] > z[blk * 4 + 1]) sc += (double)(z[blk * 4 + 2] - z[blk * 4]), sw += (double)(z[blk * 4 + 3] - z[blk * 4 + 1]), nb++;
+        printf("clock check: %d blocks, mean life %.2f us, shader clock over it %.0f MHz\n", nb, sw / nb * 0.01, 100.0 * sc / sw);
     }
 #endif
     gffx_hip_batch_destroy(b);
