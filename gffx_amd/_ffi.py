@@ -80,7 +80,8 @@ SIGNATURES = {
     "gffx_hip_lines_last_kernel_ms": (C.c_double, [vp]),
     "gffx_hip_lines_last_prep_ms": (C.c_double, [vp]),
     "gffx_hip_lines_copy_tables": (C.c_int, [vp, u64p, u32p, u32p, u32p, u32p]),
-    "gffx_hip_lines_copy_dirs": (C.c_int, [vp, u64p, u32p, u32p, u32p]),
+    "gffx_hip_lines_copy_dirs": (C.c_int, [vp, u64p, u32p, u32p]),
+    "gffx_hip_lines_copy_degenerate": (C.c_int, [vp, u64p, u64p, u32p]),
     "gffx_hip_segments_covered": (C.c_int, [C.c_int, C.c_uint64, u32p, u32p, u32p, u32p, C.c_uint64, C.c_uint32, u32p]),
     "gffx_hip_depth_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, u64p, u32p, u32p, u32p, C.c_uint32, u32p,
                                         C.POINTER(vp)]),

@@ -3,25 +3,31 @@
 // gff_line_overlaps_queries; called for every non-comment line of every hit block, :284-321).
 //
 // The reference scans all regions of the seqid linearly per line: O(lines x regions_of_seqid),
-// its dominant cost.  Here the regions are radix-sorted ON THE DEVICE by (seqid, start, end) once per run (radix_sort.hpp) and three
-// monotone helper arrays make each mode a couple of binary searches.  With (s, e) the RAW
-// column-4/5 integers of the line (1-based closed, no swap: intersect.rs:475-489) and the regions'
-// raw (qs, qe) (no s<e check: intersect.rs:223-225):
+// its dominant cost.  Here the regions are radix-sorted ON THE DEVICE by (seqid, start) once per run (radix_sort.hpp,
+// stable: ties keep the BED order) and two monotone helper columns make each mode one or two directory lookups.  With
+// (s, e) the RAW column-4/5 integers of the line (1-based closed, no swap: intersect.rs:475-489) and the regions' raw
+// (qs, qe) (no s<e check: intersect.rs:223-225):
 //   Contained       exists q: s >= qs && e <= qe   <=>  PM(s) >= e      PM(x) = max{qe : qs <= x}
 //   ContainsRegion  exists q: s <= qs && e >= qe   <=>  SM(s) <= e      SM(x) = min{qe : qs >= x}
 //   Overlap  (qs<=s<=qe) || (qs<=e<=qe) || (s<=qs<=e) || (s<=qe<=e)     (intersect.rs:512-515)
-//                                                  <=>  PM(s) >= s || PM(e) >= e
-//                                                       || some qs in [s,e] || some qe in [s,e]
-// Each clause is a conjunction of two comparisons on one region, so the rewrite is exact for every
-// input, including degenerate regions (qs > qe) and lines (s > e); tests check it against the
-// oracle's literal scan.  Every search first narrows to one bin of a per-seqid directory over the
-// sorted array (built with the sort, ~2 bins per region), so it touches ~3 words instead of ~17.  No invert here: intersect.rs:232-240 has no such parameter.
+//     a line with s <= e:  for a region with qs <= qe the four clauses are exactly  qs <= e && qe >= s, so over those
+//                          regions the answer is  PM(e) >= s  -- ONE lookup.  A DEGENERATE region (qs > qe; a zero-length
+//                          BED row is one) can only match clauses 3 and 4, i.e. when one of its two ends lies in [s, e];
+//                          if it passes the PM test (qs <= e && qe >= s) both ends do, so PM over ALL regions gives no
+//                          false positive, and the degenerate ones are completed by
+//                              CD(first qs > e) - CD(first qs >= s) > 0      CD(i) = degenerate regions before position i
+//                              || some degenerate qe in [s, e]               DE = their ends, sorted per seqid
+//                          (both skipped when the run has no degenerate region: the usual case).
+//     a line with s > e:   clauses 3 and 4 are empty, the rest is  PM(s) >= s || PM(e) >= e.
+// Each clause is a conjunction of two comparisons on one region, so the rewrite is exact for every input; tests check it
+// against the oracle's literal scan.  Every lookup first narrows to one bin of a per-seqid directory over the sorted
+// starts (~2 bins per region), so it touches the directory pair and one or two 16-byte records instead of a 17-step
+// binary search.  No invert here: intersect.rs:232-240 has no such parameter.
 //
-// HBM layout: line table SoA {seq, start, end} u32 x n_lines, file order (neighbouring lanes =
-// neighbouring lines = nearby coordinates -> the searches of a wave walk the same cache lines);
-// per run: q_off[n_seq+1], QS (sorted starts), PM (prefix max of ends), SM (suffix min of ends),
-// QE (sorted ends), each u32 x n_regions.  One thread per line, one byte out.
-// Roofline bound: HBM; algorithmic bytes per line: 12 in + 1 out.
+// HBM layout: line table SoA {seq, start, end} u32 x n_lines, file order (neighbouring lanes = neighbouring lines =
+// nearby coordinates -> the lookups of a wave walk the same cache lines); per run: T[i] = {qs, PM, SM, CD} (16 B, one
+// load) for the regions in (seqid, start) order + the sentinel T[n], dir (u32 per bin), SeqMeta (32 B per seqid, staged
+// in LDS), DE.  One thread per line, one byte out.  Roofline bound: HBM; algorithmic bytes per line: 12 in + 1 out.
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -39,52 +45,28 @@ struct LinesView {
     const uint32_t *seq, *start, *end;
     unsigned long long n;
 };
-struct RegionsView {
-    const unsigned long long *q_off;  // n_seq + 1
-    const uint32_t *qs, *pm, *sm, *qe;
-    // Directories over the sorted starts and the sorted ends of every seqid: dir[d_off[c] + b] = first position
-    // whose value >= b << shift(c), for b = 0..nb(c) (the last one = the seqid's end).  A search for x only has
-    // to look inside [dir[b], dir[b+1]) with b = x >> shift -- usually zero or one element instead of a 17-step
-    // binary search over all regions of the seqid.  nullptr: no directory (plain binary search).
-    const uint32_t *dir_qs, *dir_qe;
-    const unsigned long long *d_off;  // n_seq + 1
-    const uint2 *d_meta;              // per seqid {shift, nb}
-    uint32_t n_seq;
+// per seqid: its regions are T[q_lo, q_hi); its directory is dir[d_base .. d_base + nb]: dir[d_base + b] = first
+// position whose start >= b << shift (entry nb = q_hi); its degenerate ends are DE[dq_lo, dq_hi)
+struct SeqMeta {
+    uint32_t q_lo, q_hi, shift, nb;
+    uint32_t d_base, dq_lo, dq_hi, pad;
 };
+struct RegionsView {
+    const uint4 *T;        // n + 1 records {qs, pm, sm, cd}
+    const uint32_t *dir;
+    const SeqMeta *meta;   // n_seq
+    const uint32_t *de;    // sorted {seqid, qe} pairs of the degenerate regions (word 2 p + 1 = the end)
+    uint32_t n_seq, n_deg;
+};
+constexpr uint32_t kMetaLds = 256;  // seqids whose SeqMeta a block stages in LDS (more: read through the caches)
 
-// narrow [lo, hi) to the directory bin of x
-__device__ __forceinline__ void dir_narrow(const uint32_t *dir, const RegionsView &R, uint32_t seq, uint32_t x,
-                                           unsigned long long &lo, unsigned long long &hi) {
-    if (!dir) return;
-    const uint2 m = R.d_meta[seq];
-    const uint32_t b = x >> m.x;
-    if (b >= m.y) {
-        lo = hi;  // beyond the largest value of the seqid
-        return;
-    }
-    const uint32_t *d = dir + R.d_off[seq] + b;
-    lo = d[0];
-    hi = d[1];
-}
-
-// first index in [lo, hi) with a[i] >= x
-__device__ __forceinline__ unsigned long long lower_bound_u32(const uint32_t *a, unsigned long long lo,
-                                                              unsigned long long hi, uint32_t x) {
+// first position in [lo, hi) whose start is > x (UPPER) / >= x
+template <bool UPPER>
+__device__ __forceinline__ uint32_t bound_qs(const uint4 *T, uint32_t lo, uint32_t hi, uint32_t x) {
     while (lo < hi) {
-        const unsigned long long mid = (lo + hi) >> 1;
-        if (a[mid] < x)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-// first index in [lo, hi) with a[i] > x
-__device__ __forceinline__ unsigned long long upper_bound_u32(const uint32_t *a, unsigned long long lo,
-                                                              unsigned long long hi, uint32_t x) {
-    while (lo < hi) {
-        const unsigned long long mid = (lo + hi) >> 1;
-        if (a[mid] <= x)
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t v = T[mid].x;
+        if (UPPER ? v <= x : v < x)
             lo = mid + 1;
         else
             hi = mid;
@@ -92,58 +74,106 @@ __device__ __forceinline__ unsigned long long upper_bound_u32(const uint32_t *a,
     return lo;
 }
 
-template <int MODE>
+// PM(x) = max{qe : qs <= x} over the seqid's regions; false: no region starts at or before x.  *pos = first position with
+// start > x.  The directory pair gives the bin [a, c); T[a - 1] and T[a] are loaded together, which settles bins of 0 or
+// 1 regions (most of them, at 2 bins per region) without a further step.
+__device__ __forceinline__ bool pm_at(const RegionsView &R, const SeqMeta &m, uint32_t x, uint32_t &pm, uint32_t *pos = nullptr) {
+    const uint32_t b = x >> m.shift;
+    uint32_t u;
+    if (b >= m.nb) {
+        u = m.q_hi;  // beyond the largest start of the seqid
+    } else {
+        const uint32_t a = R.dir[m.d_base + b], c = R.dir[m.d_base + b + 1];
+        const uint4 t0 = R.T[a], tm = R.T[a > m.q_lo ? a - 1 : a];
+        if (c == a || t0.x > x) {
+            if (pos) *pos = a;
+            pm = tm.y;
+            return a > m.q_lo;
+        }
+        if (c == a + 1) {
+            if (pos) *pos = c;
+            pm = t0.y;
+            return true;
+        }
+        u = bound_qs<true>(R.T, a + 1, c, x);
+    }
+    if (pos) *pos = u;
+    if (u == m.q_lo) return false;
+    pm = R.T[u - 1].y;
+    return true;
+}
+
+// first position of the seqid whose start is >= x (q_hi: none); *t = its record when there is one
+__device__ __forceinline__ uint32_t lower_qs(const RegionsView &R, const SeqMeta &m, uint32_t x, uint4 *t = nullptr) {
+    const uint32_t b = x >> m.shift;
+    if (b >= m.nb) return m.q_hi;
+    const uint32_t a = R.dir[m.d_base + b], c = R.dir[m.d_base + b + 1];
+    const uint4 t0 = R.T[a], t1 = R.T[a + 1];  // (T has n + 1 records)
+    uint32_t l;
+    if (c == a || t0.x >= x) {
+        if (t) *t = t0;
+        return a;  // (an empty bin below the seqid's last one: a < q_hi)
+    }
+    if (c == a + 1) {
+        if (t) *t = t1;
+        return c;
+    }
+    l = bound_qs<false>(R.T, a + 1, c, x);
+    if (t && l < m.q_hi) *t = R.T[l];
+    return l;
+}
+
+template <int MODE, bool META_LDS>
 __global__ __launch_bounds__(256) void k_lines_exists(LinesView L, RegionsView R, uint8_t *keep) {
+    __shared__ uint4 s_meta[META_LDS ? 2 * kMetaLds : 2];
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.n) return;
-    const uint32_t seq = L.seq[i];
+    const bool live = i < L.n;
+    const uint32_t seq = live ? L.seq[i] : 0xFFFFFFFFu;
+    const uint32_t s = live ? L.start[i] : 0u, e = live ? L.end[i] : 0u;
+    if (META_LDS) {
+        for (uint32_t t = threadIdx.x; t < 2 * R.n_seq; t += 256) s_meta[t] = reinterpret_cast<const uint4 *>(R.meta)[t];
+        __syncthreads();
+    }
+    if (!live) return;
     uint8_t k = 0;
     if (seq < R.n_seq) {
-        const unsigned long long lo = R.q_off[seq], hi = R.q_off[seq + 1];
-        if (hi > lo) {  // a seqid without regions has no map entry (intersect.rs:495-498)
-            const uint32_t s = L.start[i], e = L.end[i];
-            auto ub_qs = [&](uint32_t x) {
-                unsigned long long a = lo, b = hi;
-                dir_narrow(R.dir_qs, R, seq, x, a, b);
-                return upper_bound_u32(R.qs, a, b, x);
-            };
-            auto lb_qs = [&](uint32_t x) {
-                unsigned long long a = lo, b = hi;
-                dir_narrow(R.dir_qs, R, seq, x, a, b);
-                return lower_bound_u32(R.qs, a, b, x);
-            };
-            auto lb_qe = [&](uint32_t x) {
-                unsigned long long a = lo, b = hi;
-                dir_narrow(R.dir_qe, R, seq, x, a, b);
-                return lower_bound_u32(R.qe, a, b, x);
-            };
-            auto ub_qe = [&](uint32_t x) {
-                unsigned long long a = lo, b = hi;
-                dir_narrow(R.dir_qe, R, seq, x, a, b);
-                return upper_bound_u32(R.qe, a, b, x);
-            };
+        SeqMeta m;
+        if (META_LDS) {
+            const uint4 m0 = s_meta[2 * seq], m1 = s_meta[2 * seq + 1];
+            m = SeqMeta{m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        } else {
+            m = R.meta[seq];
+        }
+        if (m.q_hi > m.q_lo) {  // a seqid without regions has no map entry (intersect.rs:495-498)
+            uint32_t pm = 0;
             if (MODE == GFFX_MODE_CONTAINED) {
-                const unsigned long long u = ub_qs(s);  // regions with qs <= s
-                k = (u > lo && R.pm[u - 1] >= e) ? 1 : 0;
+                k = (pm_at(R, m, s, pm) && pm >= e) ? 1 : 0;
             } else if (MODE == GFFX_MODE_CONTAINS_REGION) {
-                const unsigned long long l = lb_qs(s);  // regions with qs >= s
-                k = (l < hi && R.sm[l] <= e) ? 1 : 0;
-            } else {
-                const unsigned long long us = ub_qs(s);
-                bool any = us > lo && R.pm[us - 1] >= s;  // qs <= s <= qe
-                if (!any) {
-                    const unsigned long long ue = ub_qs(e);
-                    any = ue > lo && R.pm[ue - 1] >= e;  // qs <= e <= qe
-                    if (!any && s <= e) {
-                        const unsigned long long ls = lb_qs(s);
-                        any = ls < ue;  // some qs in [s, e]
-                        if (!any) {
-                            const unsigned long long a = lb_qe(s);
-                            const unsigned long long b = ub_qe(e);
-                            any = a < b;  // some qe in [s, e]
+                uint4 t = make_uint4(0, 0, 0, 0);
+                const uint32_t l = lower_qs(R, m, s, &t);
+                k = (l < m.q_hi && t.z <= e) ? 1 : 0;
+            } else if (s <= e) {
+                uint32_t u = 0;
+                bool any = pm_at(R, m, e, pm, &u) && pm >= s;
+                if (!any && R.n_deg) {  // the degenerate regions (qs > qe): one of their two ends in [s, e]
+                    const uint32_t l = lower_qs(R, m, s);
+                    any = R.T[u].w != R.T[l].w;
+                    if (!any && m.dq_hi > m.dq_lo) {
+                        uint32_t lo = m.dq_lo, hi = m.dq_hi;
+                        while (lo < hi) {  // first degenerate end >= s
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (R.de[2 * mid + 1] < s)
+                                lo = mid + 1;
+                            else
+                                hi = mid;
                         }
+                        any = lo < m.dq_hi && R.de[2 * lo + 1] <= e;
                     }
                 }
+                k = any ? 1 : 0;
+            } else {
+                bool any = pm_at(R, m, s, pm) && pm >= s;  // qs <= s <= qe
+                if (!any) any = pm_at(R, m, e, pm) && pm >= e;  // qs <= e <= qe
                 k = any ? 1 : 0;
             }
         }
@@ -151,158 +181,235 @@ __global__ __launch_bounds__(256) void k_lines_exists(LinesView L, RegionsView R
     keep[i] = k;
 }
 
-
 // ---- region tables on the device (what the reference builds per run as `query_ivmap`, intersect.rs:621-633) --------------
-// The records {seqid, qs, qe} are radix-sorted by (seqid, qs, qe) (radix_sort.hpp); q_off, QS, PM, SM come from that order,
-// QE from a second sort by (seqid, qe); the two bin directories are filled from the sorted arrays.  All kernels below are
-// one thread per region.
-
-// q_off[c] = first sorted position of seqid c (n_seq + 1 entries): every boundary thread fills the seqids it skips over
-__global__ __launch_bounds__(256) void k_b_offsets(const uint32_t *rec, unsigned long long n, uint32_t n_seq, unsigned long long *q_off) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t s = min(rec[3 * i], n_seq);  // (a seqid out of range is reported by the sort's histogram kernel)
-    const long long prev = i ? (long long)min(rec[3 * (i - 1)], n_seq) : -1;
-    for (long long c = prev + 1; c <= (long long)s; ++c) q_off[c] = i;
-    if (i + 1 == n)
-        for (uint32_t c = s + 1; c <= n_seq; ++c) q_off[c] = n;
-}
-
-// column w of the sorted records; head[i] = 1 where a seqid's run starts (forward) / ends (backward scans)
-__global__ __launch_bounds__(256) void k_b_columns(const uint32_t *rec, unsigned long long n, uint32_t *qs, uint32_t *qe_by_qs,
-                                                   uint8_t *head_fwd, uint8_t *head_bwd) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t s = rec[3 * i];
-    qs[i] = rec[3 * i + 1];
-    qe_by_qs[i] = rec[3 * i + 2];
-    head_fwd[i] = (i == 0 || rec[3 * (i - 1)] != s) ? 1 : 0;
-    head_bwd[i] = (i + 1 == n || rec[3 * (i + 1)] != s) ? 1 : 0;
-}
-__global__ __launch_bounds__(256) void k_b_column2(const uint32_t *rec, unsigned long long n, uint32_t *out) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = rec[3 * i + 2];
-}
-
-// Segmented inclusive scan, one level: MAXOP ? running max : running min; BACKWARD scans from the end (element x of the
-// scan is array element n-1-x).  head[x'] = 1 starts a new segment.  Blocks of 1024 elements; the block's last value and
-// "has a head" flag go to agg / agg_head (the next level scans those), k_b_scan_apply folds the carries back in.
+// The records {seqid, qs, qe} are radix-sorted by (seqid, qs) (radix_sort.hpp).  Three kernels turn the sorted records into
+// the tables: k_b_local (per 1024-region block: the T records with block-local running max / min / degenerate count, the
+// per-seqid offsets, the block's carries), k_b_carry (ONE block: scans the carries of all blocks, lays out the directories),
+// k_b_finish (folds the carries in, fills the directory, writes the degenerate regions' {seqid, qe} out in order).
 constexpr int kScanBlock = 1024;
+constexpr int kScanWaves = kScanBlock / 64;
+
+struct BlockCarry {          // per 1024-region block, arrays of n_blocks (+ 1) entries
+    uint32_t *max_out, *min_out;    // k_b_local: running max at the block's last region / running min at its first
+    uint32_t *head_any;             // bit0: a seqid starts inside the block, bit1: a seqid ends inside it
+    uint32_t *first_head, *last_tail;  // thread index of the first region that starts a seqid (1024: none) / the last that ends one (-1)
+    uint32_t *deg;                  // degenerate regions in the block
+    uint32_t *max_in, *min_in, *deg_in;  // k_b_carry: what the block's open seqid brings in from the left / right; degenerate regions before it
+};
+
 template <bool MAXOP>
 __device__ __forceinline__ uint32_t scan_op(uint32_t a, uint32_t b) {
     return MAXOP ? max(a, b) : min(a, b);
 }
+// segmented inclusive scan over the 1024 threads of a block, in thread order (BACKWARD: from thread 1023 down); f = 1 starts
+// a segment.  Returns the scanned value; f becomes "a segment start at or before me inside the block".  s_v / s_f: 16 words each.
 template <bool MAXOP, bool BACKWARD>
-__global__ __launch_bounds__(kScanBlock) void k_b_scan_local(const uint32_t *val, const uint8_t *head, unsigned long long n, uint32_t *out,
-                                                             uint32_t *agg, uint8_t *agg_head) {
-    __shared__ uint32_t s_v[kScanBlock / 64];
-    __shared__ uint32_t s_f[kScanBlock / 64];
-    const unsigned long long x = (unsigned long long)blockIdx.x * kScanBlock + threadIdx.x;
-    const bool live = x < n;
-    const unsigned long long i = BACKWARD ? n - 1 - (live ? x : 0) : x;
-    uint32_t v = live ? val[i] : (MAXOP ? 0u : 0xFFFFFFFFu);
-    uint32_t f = live ? head[i] : 1u;
+__device__ __forceinline__ uint32_t block_seg_scan(uint32_t v, uint32_t &f, uint32_t *s_v, uint32_t *s_f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t pv = __shfl_up(v, o, 64), pf = __shfl_up(f, o, 64);
-        if (lane >= o) {
+        const uint32_t pv = BACKWARD ? __shfl_down(v, o, 64) : __shfl_up(v, o, 64);
+        const uint32_t pf = BACKWARD ? __shfl_down(f, o, 64) : __shfl_up(f, o, 64);
+        if (BACKWARD ? lane + o < 64 : lane >= o) {
             if (!f) v = scan_op<MAXOP>(pv, v);
             f |= pf;
         }
     }
-    if (lane == 63) s_v[wave] = v, s_f[wave] = f;
+    if (lane == (BACKWARD ? 0 : 63)) s_v[wave] = v, s_f[wave] = f;
     __syncthreads();
-    // carry of the preceding waves of the block: the value of the segment still open where this wave starts
-    // (serial over <= 15 wave totals; a wave that holds a head restarts it)
+    // carry of the waves before me (in scan order): the value of the segment still open where this wave starts
     uint32_t cv = 0, cf = 0;
-    for (int w = 0; w < wave; ++w) {
-        cv = (w == 0 || s_f[w]) ? s_v[w] : scan_op<MAXOP>(cv, s_v[w]);
-        cf |= s_f[w];
+    if (BACKWARD) {
+        for (int w = kScanWaves - 1; w > wave; --w) {
+            cv = (w == kScanWaves - 1 || s_f[w]) ? s_v[w] : scan_op<MAXOP>(cv, s_v[w]);
+            cf |= s_f[w];
+        }
+        if (wave < kScanWaves - 1 && !f) v = scan_op<MAXOP>(cv, v);
+    } else {
+        for (int w = 0; w < wave; ++w) {
+            cv = (w == 0 || s_f[w]) ? s_v[w] : scan_op<MAXOP>(cv, s_v[w]);
+            cf |= s_f[w];
+        }
+        if (wave > 0 && !f) v = scan_op<MAXOP>(cv, v);
     }
-    if (wave > 0 && !f) v = scan_op<MAXOP>(cv, v);
     f |= cf;
-    if (live) out[i] = v;
-    if (threadIdx.x == kScanBlock - 1 || x + 1 == n) {
-        if (live) agg[blockIdx.x] = v, agg_head[blockIdx.x] = (uint8_t)(f ? 1 : 0);
-    }
+    __syncthreads();  // (s_v / s_f are reused by the next scan)
+    return v;
 }
-// fold the scanned block carries in: an element before the first head of its block continues the previous blocks' segment
-template <bool MAXOP, bool BACKWARD>
-__global__ __launch_bounds__(kScanBlock) void k_b_scan_apply(const uint8_t *head, unsigned long long n, uint32_t *out, const uint32_t *agg_scanned) {
-    __shared__ uint32_t s_any[kScanBlock / 64];
-    if (blockIdx.x == 0) return;
-    const unsigned long long x = (unsigned long long)blockIdx.x * kScanBlock + threadIdx.x;
-    const bool live = x < n;
-    const unsigned long long i = BACKWARD ? n - 1 - (live ? x : 0) : x;
-    const uint32_t f = live ? head[i] : 1u;
-    // "a head at or before me inside the block": inclusive OR-scan
+// exclusive sum over the 1024 threads; *total = the block's sum
+__device__ __forceinline__ uint32_t block_sum_scan(uint32_t v, uint32_t *s_v, uint32_t *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long m = __ballot(f != 0);
-    const bool before_in_wave = (m & ((2ull << lane) - 1ull)) != 0;
-    if (lane == 0) s_any[wave] = m != 0;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_v[wave] = inc;
     __syncthreads();
-    bool seen = before_in_wave;
-    for (int w = 0; w < wave; ++w) seen |= s_any[w] != 0;
-    if (live && !seen) out[i] = scan_op<MAXOP>(agg_scanned[blockIdx.x - 1], out[i]);
+    uint32_t base = 0, all = 0;
+    for (int w = 0; w < kScanWaves; ++w) {
+        base += w < wave ? s_v[w] : 0u;
+        all += s_v[w];
+    }
+    *total = all;
+    __syncthreads();
+    return base + inc - v;
 }
 
-// per seqid: the directory geometry {shift, nb} over max(largest start, largest end) and the directory's place d_off
-__global__ __launch_bounds__(256) void k_b_dir_meta(const unsigned long long *q_off, const uint32_t *qs, const uint32_t *qe, uint32_t n_seq,
-                                                    uint2 *d_meta, unsigned long long *d_off) {
-    __shared__ unsigned long long s_run;
-    if (threadIdx.x == 0) s_run = 0;
+__global__ __launch_bounds__(kScanBlock) void k_b_local(const uint32_t *rec, unsigned long long n, uint32_t n_seq, uint4 *T, uint32_t *q_off,
+                                                        BlockCarry C) {
+    __shared__ uint32_t s_v[kScanWaves], s_f[kScanWaves];
+    __shared__ uint32_t s_first, s_last;
+    if (threadIdx.x == 0) s_first = kScanBlock, s_last = 0xFFFFFFFFu;
+    const unsigned long long i = (unsigned long long)blockIdx.x * kScanBlock + threadIdx.x;
+    const bool live = i < n;
+    uint32_t seq = 0xFFFFFFFFu, qs = 0, qe = 0;
+    bool head = true, tail = true;  // (a thread past the end is its own segment)
+    if (live) {
+        seq = rec[3 * i], qs = rec[3 * i + 1], qe = rec[3 * i + 2];
+        head = i == 0 || rec[3 * (i - 1)] != seq;
+        tail = i + 1 == n || rec[3 * (i + 1)] != seq;
+        if (head) {  // q_off[c] = first sorted position of seqid c: every boundary fills the seqids it skips over
+            const uint32_t c1 = min(seq, n_seq);  // (a seqid out of range is reported by the sort's histogram kernel)
+            const long long c0 = i ? (long long)min(rec[3 * (i - 1)], n_seq) : -1;
+            for (long long c = c0 + 1; c <= (long long)c1; ++c) q_off[c] = (uint32_t)i;
+        }
+        if (i + 1 == n)
+            for (uint32_t c = min(seq, n_seq) + 1; c <= n_seq; ++c) q_off[c] = (uint32_t)n;
+    }
     __syncthreads();
-    // seqids in chunks of 256: sizes, then a serial prefix by thread 0 (n_seq is small)
-    for (uint32_t c0 = 0; c0 < n_seq; c0 += 256) {
+    if (live && head) atomicMin(&s_first, threadIdx.x);
+    if (live && tail) atomicMax((int *)&s_last, (int)threadIdx.x);
+    uint32_t ff = head ? 1u : 0u, fb = tail ? 1u : 0u;
+    const uint32_t pm = block_seg_scan<true, false>(live ? qe : 0u, ff, s_v, s_f);
+    const uint32_t sm = block_seg_scan<false, true>(live ? qe : 0xFFFFFFFFu, fb, s_v, s_f);
+    uint32_t n_deg = 0;
+    const uint32_t cd = block_sum_scan((live && qs > qe) ? 1u : 0u, s_v, &n_deg);
+    if (live) T[i] = make_uint4(qs, pm, sm, cd);
+    if (live && (threadIdx.x == kScanBlock - 1 || i + 1 == n)) C.max_out[blockIdx.x] = pm;
+    if (threadIdx.x == 0) {
+        C.min_out[blockIdx.x] = sm;
+        C.deg[blockIdx.x] = n_deg;
+        C.first_head[blockIdx.x] = s_first;
+        C.last_tail[blockIdx.x] = s_last;
+        C.head_any[blockIdx.x] = (s_first < kScanBlock ? 1u : 0u) | (s_last != 0xFFFFFFFFu ? 2u : 0u);
+    }
+}
+
+// ONE block.  (1) the carries of all region blocks: max_in[b] = running max of the seqid open at the end of block b - 1,
+// min_in[b] = running min of the seqid open at the start of block b + 1, deg_in[b] = degenerate regions before block b;
+// (2) per seqid the directory geometry {shift, nb} over its largest start (~2 bins per region, >= 16) and its place d_base.
+// cnt[0] = degenerate regions in total, cnt[1] = directory words in total.
+__global__ __launch_bounds__(kScanBlock) void k_b_carry(uint32_t n_blocks, BlockCarry C, const uint32_t *q_off, const uint4 *T, uint32_t n_seq,
+                                                        SeqMeta *meta, uint32_t *cnt) {
+    __shared__ uint32_t s_v[kScanWaves], s_f[kScanWaves];
+    __shared__ uint32_t s_run, s_runf;
+    // forward: running max
+    if (threadIdx.x == 0) s_run = 0, s_runf = 1;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += kScanBlock) {
+        const uint32_t b = b0 + threadIdx.x;
+        const bool live = b < n_blocks;
+        uint32_t f = live ? (C.head_any[b] & 1u) : 1u;
+        uint32_t v = block_seg_scan<true, false>(live ? C.max_out[b] : 0u, f, s_v, s_f);
+        if (!f) v = max(v, s_run);  // the chunks before this one
+        if (live) C.max_in[b + 1] = v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1) s_run = v;
+        __syncthreads();
+    }
+    // backward: running min (thread x of a chunk = block n_blocks - 1 - x0 - x)
+    if (threadIdx.x == 0) s_run = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t x0 = 0; x0 < n_blocks; x0 += kScanBlock) {
+        const uint32_t x = x0 + threadIdx.x;
+        const bool live = x < n_blocks;
+        const uint32_t b = live ? n_blocks - 1 - x : 0;
+        uint32_t f = live ? ((C.head_any[b] >> 1) & 1u) : 1u;
+        uint32_t v = block_seg_scan<false, false>(live ? C.min_out[b] : 0xFFFFFFFFu, f, s_v, s_f);
+        if (!f) v = min(v, s_run);
+        if (live && b > 0) C.min_in[b - 1] = v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1) s_run = v;
+        __syncthreads();
+    }
+    // degenerate regions before every block
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += kScanBlock) {
+        const uint32_t b = b0 + threadIdx.x;
+        uint32_t total = 0;
+        const uint32_t ex = block_sum_scan(b < n_blocks ? C.deg[b] : 0u, s_v, &total);
+        if (b < n_blocks) C.deg_in[b] = run + ex;
+        run += total;
+    }
+    if (threadIdx.x == 0) cnt[0] = run;
+    // directories
+    run = 0;
+    for (uint32_t c0 = 0; c0 < n_seq; c0 += kScanBlock) {
         const uint32_t c = c0 + threadIdx.x;
+        SeqMeta m{0, 0, 0, 0, 0, 0, 0, 0};
         uint32_t size = 0;
         if (c < n_seq) {
-            const unsigned long long lo = q_off[c], hi = q_off[c + 1];
-            uint2 m = make_uint2(0, 0);
-            if (hi > lo) {
-                const uint32_t vmax = max(qs[hi - 1], qe[hi - 1]);
-                const unsigned long long budget = max(2ull * (hi - lo), 16ull);
+            m.q_lo = q_off[c], m.q_hi = q_off[c + 1];
+            if (m.q_hi > m.q_lo) {
+                const uint32_t vmax = T[m.q_hi - 1].x;
+                const unsigned long long budget = max(2ull * (m.q_hi - m.q_lo), 16ull);
                 uint32_t shift = 0;
                 while ((((unsigned long long)vmax >> shift) + 1) > budget) shift++;
-                m = make_uint2(shift, (vmax >> shift) + 1);
-                size = m.y + 1;
+                m.shift = shift, m.nb = (vmax >> shift) + 1;
+                size = m.nb + 1;
             }
-            d_meta[c] = m;
         }
-        __shared__ uint32_t s_size[256];
-        s_size[threadIdx.x] = size;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long run = s_run;
-            for (uint32_t k = 0; k < 256 && c0 + k < n_seq; ++k) {
-                d_off[c0 + k] = run;
-                run += s_size[k];
-            }
-            s_run = run;
-            if (c0 + 256 >= n_seq) d_off[n_seq] = run;
+        uint32_t total = 0;
+        const uint32_t ex = block_sum_scan(size, s_v, &total);
+        if (c < n_seq) {
+            m.d_base = run + ex;
+            meta[c] = m;
         }
-        __syncthreads();
+        run += total;
     }
-    if (n_seq == 0 && threadIdx.x == 0) d_off[0] = 0;
+    if (threadIdx.x == 0) cnt[1] = run;
 }
 
-// dir[d_off[c] + b] = first sorted position of seqid c whose value >= b << shift, b = 0..nb (nb: the seqid's end)
-__global__ __launch_bounds__(256) void k_b_dir_fill(const uint32_t *val, const uint32_t *rec /* seqid of element i */, unsigned long long n,
-                                                    uint32_t n_seq, const unsigned long long *q_off, const unsigned long long *d_off, const uint2 *d_meta,
-                                                    uint32_t *dir) {
+// Folds the carries into T, fills the directory, writes the sentinel T[n] and the degenerate regions' {seqid, qe} (in
+// (seqid, start) order, position = CD) for the sort by (seqid, qe).
+__global__ __launch_bounds__(256) void k_b_finish(const uint32_t *rec, unsigned long long n, uint32_t n_seq, uint4 *T, BlockCarry C,
+                                                  const SeqMeta *meta, uint32_t *dir, uint32_t *deg_out, const uint32_t *cnt) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c = rec[3 * i];
+    const uint32_t blk = (uint32_t)(i / kScanBlock), tid = (uint32_t)(i % kScanBlock);
+    uint4 t = T[i];
+    const uint32_t c = rec[3 * i], qe = rec[3 * i + 2];
+    if (tid < C.first_head[blk]) t.y = max(t.y, C.max_in[blk]);  // (block 0 starts with a head)
+    if ((int)tid > (int)C.last_tail[blk]) t.z = min(t.z, C.min_in[blk]);
+    t.w += C.deg_in[blk];
+    T[i] = t;
+    if (t.x > qe) deg_out[2 * (size_t)t.w] = c, deg_out[2 * (size_t)t.w + 1] = qe;
+    if (i + 1 == n) T[n] = make_uint4(0u, 0u, 0u, cnt[0]);
     if (c >= n_seq) return;  // (reported by the sort's histogram kernel)
-    const unsigned long long lo = q_off[c], hi = q_off[c + 1];
-    const uint2 m = d_meta[c];
-    uint32_t *d = dir + d_off[c];
-    const uint32_t b = val[i] >> m.x;
-    const long long bprev = i > lo ? (long long)(val[i - 1] >> m.x) : -1;
+    const SeqMeta m = meta[c];
+    uint32_t *d = dir + m.d_base;
+    const uint32_t b = t.x >> m.shift;
+    const long long bprev = i > m.q_lo ? (long long)(T[i - 1].x >> m.shift) : -1;
     for (long long x = bprev + 1; x <= (long long)b; ++x) d[x] = (uint32_t)i;
-    if (i + 1 == hi)
-        for (uint32_t x = b + 1; x <= m.y; ++x) d[x] = (uint32_t)hi;
+    if (i + 1 == m.q_hi)
+        for (uint32_t x = b + 1; x <= m.nb; ++x) d[x] = m.q_hi;
+}
+
+// the sorted {seqid, qe} pairs of the degenerate regions -> every seqid's range [dq_lo, dq_hi) in SeqMeta
+__global__ __launch_bounds__(256) void k_b_deg_ranges(const uint32_t *pairs, uint32_t n, uint32_t n_seq, SeqMeta *meta) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c1 = min(pairs[2 * i], n_seq);
+    const long long c0 = i ? (long long)min(pairs[2 * (i - 1)], n_seq) : -1;
+    // seqids (c0, c1] start at i; seqids [c0, c1) end at i
+    for (long long c = c0 + 1; c <= (long long)c1 && c < (long long)n_seq; ++c) meta[c].dq_lo = i;
+    for (long long c = max(c0, 0ll); c < (long long)c1; ++c) meta[c].dq_hi = i;
+    if (i + 1 == n) {
+        if (c1 < n_seq) meta[c1].dq_hi = n;
+        for (uint32_t c = c1 + 1; c < n_seq; ++c) meta[c].dq_lo = meta[c].dq_hi = n;
+    }
 }
 
 }  // namespace gffx
@@ -319,20 +426,21 @@ struct gffx_hip_lines {
     hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // ... and the device preparation of the region tables
     double last_kernel_ms = 0.0, last_prep_ms = 0.0;
     // region tables of the last _test (grow-only device buffers)
-    uint64_t cap_q = 0, cap_seq = 0, cap_work = 0, cap_dir = 0;
-    uint32_t *d_rec_a = nullptr, *d_rec_b = nullptr, *d_rec_c = nullptr;  // 3 u32 per region: input / sort ping-pong / kept (seqid, qs, qe) order
-    uint32_t *d_tab = nullptr;       // QS, PM, SM, QE, E (qe in qs order): 5 x cap_q
-    uint8_t *d_head = nullptr;       // 2 x cap_q
-    uint32_t *d_scan = nullptr;      // carries of the scan levels
-    uint8_t *d_scan_head = nullptr;
+    uint64_t cap_q = 0, cap_seq = 0, cap_work = 0, cap_dir = 0, cap_blocks = 0;
+    uint32_t *d_rec_a = nullptr, *d_rec_b = nullptr;  // 3 u32 per region: input / sort ping-pong; later the degenerate pairs
+    uint4 *d_T = nullptr;            // cap_q + 1
+    uint32_t *d_carry = nullptr;     // BlockCarry: 9 arrays of cap_blocks + 1
     uint32_t *d_work = nullptr;      // sort work space
-    unsigned long long *d_qoff = nullptr, *d_doff = nullptr;  // cap_seq + 1
-    uint2 *d_dmeta = nullptr;
-    uint32_t *d_dir = nullptr;       // 2 x cap_dir
-    uint32_t *d_err = nullptr;
+    uint32_t *d_qoff = nullptr;      // cap_seq + 1
+    SeqMeta *d_meta = nullptr;       // cap_seq
+    uint32_t *d_dir = nullptr;       // cap_dir
+    uint32_t *d_err = nullptr;       // 4 words
+    uint32_t *d_cnt = nullptr;       // {degenerate regions, directory words}
+    uint32_t *h_cnt = nullptr;       // pinned copy
+    const uint32_t *d_de = nullptr;  // the sorted degenerate pairs of the last Overlap _test (inside d_rec_a / d_rec_b)
     uint64_t last_nq = 0;
-    uint32_t last_n_seq = 0;
-    bool last_dir = false;
+    uint32_t last_n_seq = 0, last_n_deg = 0;
+    bool last_deg_known = false;
 };
 
 template <typename T>
@@ -351,23 +459,11 @@ extern "C" void gffx_hip_lines_destroy(gffx_hip_lines *L) {
     if (!L) return;
     (void)hipSetDevice(L->device);
     if (L->stream) (void)hipStreamSynchronize(L->stream);
-    (void)hipFree(L->d_seq);
-    (void)hipFree(L->d_start);
-    (void)hipFree(L->d_end);
-    (void)hipFree(L->d_keep);
-    (void)hipFree(L->d_rec_a);
-    (void)hipFree(L->d_rec_b);
-    (void)hipFree(L->d_rec_c);
-    (void)hipFree(L->d_tab);
-    (void)hipFree(L->d_head);
-    (void)hipFree(L->d_scan);
-    (void)hipFree(L->d_scan_head);
-    (void)hipFree(L->d_work);
-    (void)hipFree(L->d_qoff);
-    (void)hipFree(L->d_doff);
-    (void)hipFree(L->d_dmeta);
-    (void)hipFree(L->d_dir);
-    (void)hipFree(L->d_err);
+    for (void *p : {(void *)L->d_seq, (void *)L->d_start, (void *)L->d_end, (void *)L->d_keep, (void *)L->d_rec_a, (void *)L->d_rec_b,
+                    (void *)L->d_T, (void *)L->d_carry, (void *)L->d_work, (void *)L->d_qoff, (void *)L->d_meta, (void *)L->d_dir,
+                    (void *)L->d_err, (void *)L->d_cnt})
+        (void)hipFree(p);
+    if (L->h_cnt) (void)hipHostFree(L->h_cnt);
     for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_p0, L->ev_p1})
         if (e) (void)hipEventDestroy(e);
     if (L->stream) (void)hipStreamDestroy(L->stream);
@@ -393,8 +489,10 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
     L->n = n_lines;
     int rc;
     if ((rc = dalloc(&L->d_seq, n_lines)) || (rc = dalloc(&L->d_start, n_lines)) ||
-        (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)) || (rc = dalloc(&L->d_err, 4)))
+        (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)) || (rc = dalloc(&L->d_err, 4)) ||
+        (rc = dalloc(&L->d_cnt, 4)))
         return rc;
+    GFFX_HIP_TRY(hipHostMalloc((void **)&L->h_cnt, 16, hipHostMallocDefault));
     GFFX_HIP_TRY(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&L->ev_a, &L->ev_b, &L->ev_p0, &L->ev_p1}) GFFX_HIP_TRY(hipEventCreate(e));
     if (n_lines) {
@@ -407,29 +505,32 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
     return GFFX_OK;
 }
 
-static int lines_reserve(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int sort_passes) {
+constexpr int kSortPassesMax = 4 + 4;  // the coordinate's four bytes + up to four of the seqid
+
+static int lines_reserve(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq) {
     int rc;
     if (nq > L->cap_q) {
         const uint64_t cap = nq + nq / 8 + 1024;
         const size_t blocks = (size_t)((cap + kScanBlock - 1) / kScanBlock) + 2;
-        if ((rc = regrow(&L->d_rec_a, 3 * cap)) || (rc = regrow(&L->d_rec_b, 3 * cap)) || (rc = regrow(&L->d_rec_c, 3 * cap)) ||
-            (rc = regrow(&L->d_tab, 5 * cap)) || (rc = regrow(&L->d_head, 2 * cap)) || (rc = regrow(&L->d_scan, 4 * blocks)) ||
-            (rc = regrow(&L->d_scan_head, 2 * blocks)))
+        if ((rc = regrow(&L->d_rec_a, 3 * cap)) || (rc = regrow(&L->d_rec_b, 3 * cap)) || (rc = regrow(&L->d_T, cap + 1)) ||
+            (rc = regrow(&L->d_carry, 9 * (blocks + 1))))
             return rc;
         L->cap_q = cap;
+        L->cap_blocks = blocks;
         L->cap_dir = 0;
     }
+    // <= 2 bins per region (>= 16 per seqid, + 1 closing word) and the power-of-two rounding of the bin width never adds
     const uint64_t want_dir = 2 * L->cap_q + 17ull * (n_seq + 1) + 64;
     if (want_dir > L->cap_dir) {
-        if ((rc = regrow(&L->d_dir, 2 * want_dir))) return rc;
+        if ((rc = regrow(&L->d_dir, want_dir))) return rc;
         L->cap_dir = want_dir;
     }
     if (n_seq + 1 > L->cap_seq) {
         const uint64_t cap = n_seq + 1 + 64;
-        if ((rc = regrow(&L->d_qoff, cap + 1)) || (rc = regrow(&L->d_doff, cap + 1)) || (rc = regrow(&L->d_dmeta, cap))) return rc;
+        if ((rc = regrow(&L->d_qoff, cap + 1)) || (rc = regrow(&L->d_meta, cap))) return rc;
         L->cap_seq = cap;
     }
-    const uint64_t want_work = DeviceSort::work_words(L->cap_q, sort_passes);
+    const uint64_t want_work = DeviceSort::work_words(L->cap_q, kSortPassesMax);
     if (want_work > L->cap_work) {
         if ((rc = regrow(&L->d_work, want_work))) return rc;
         L->cap_work = want_work;
@@ -437,79 +538,73 @@ static int lines_reserve(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int sor
     return GFFX_OK;
 }
 
-// one direction of the segmented scans: local blocks, the carries (recursively), fold back
-template <bool MAXOP, bool BACKWARD>
-static int seg_scan(gffx_hip_lines *L, const uint32_t *val, const uint8_t *head, uint64_t n, uint32_t *out) {
-    // level 0 over the elements; level 1 over the block carries (forward from here on: the carries already are in scan order)
-    const uint32_t b0 = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
-    uint32_t *agg0 = L->d_scan, *agg0s = L->d_scan + b0 + 1;
-    uint8_t *h0 = L->d_scan_head;
-    hipLaunchKernelGGL((k_b_scan_local<MAXOP, BACKWARD>), dim3(b0), dim3(kScanBlock), 0, L->stream, val, head, (unsigned long long)n, out, agg0, h0);
-    if (b0 > 1) {
-        const uint32_t b1 = (b0 + kScanBlock - 1) / kScanBlock;
-        uint32_t *agg1 = agg0s + b0 + 1, *agg1s = agg1 + b1 + 1;
-        uint8_t *h1 = h0 + b0 + 1;
-        hipLaunchKernelGGL((k_b_scan_local<MAXOP, false>), dim3(b1), dim3(kScanBlock), 0, L->stream, agg0, h0, (unsigned long long)b0, agg0s, agg1, h1);
-        if (b1 > 1) {  // > 1 M blocks = > 10^9 regions never happens (the sort refuses 2^30), two carry levels are enough up to 2^30
-            hipLaunchKernelGGL((k_b_scan_local<MAXOP, false>), dim3(1), dim3(kScanBlock), 0, L->stream, agg1, h1, (unsigned long long)b1, agg1s,
-                               agg1s + b1 + 1, h1 + b1 + 1);
-            hipLaunchKernelGGL((k_b_scan_apply<MAXOP, false>), dim3(b1), dim3(kScanBlock), 0, L->stream, h0, (unsigned long long)b0, agg0s, agg1s);
-        }
-        hipLaunchKernelGGL((k_b_scan_apply<MAXOP, BACKWARD>), dim3(b0), dim3(kScanBlock), 0, L->stream, head, (unsigned long long)n, out, agg0s);
-    }
-    GFFX_HIP_TRY(hipGetLastError());
-    return GFFX_OK;
+template <int MODE>
+static void launch_lines(gffx_hip_lines *L, const RegionsView &rv) {
+    const LinesView lv{L->d_seq, L->d_start, L->d_end, (unsigned long long)L->n};
+    const unsigned blocks = (unsigned)((L->n + 255) / 256);
+    if (rv.n_seq <= kMetaLds)
+        hipLaunchKernelGGL((k_lines_exists<MODE, true>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+    else
+        hipLaunchKernelGGL((k_lines_exists<MODE, false>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
 }
 
 // Region tables from the records in d_rec_a (AoS {seqid, qs, qe}, any order), then k_lines_exists.
 static int lines_run(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int mode, uint8_t *keep_host) {
     const unsigned long long n = nq;
-    const uint32_t g256 = (uint32_t)((n + 255) / 256);
     int seq_bytes = 1;
     while (seq_bytes < 4 && (n_seq > (1u << (8 * seq_bytes)))) seq_bytes++;
-    SortPlan p1{}, p2{};
-    for (int b = 0; b < 4; ++b) p1.word[p1.n_passes] = 2, p1.shift[p1.n_passes++] = (uint8_t)(8 * b);
+    SortPlan p1{}, p2{};  // (seqid, start) for the records; (seqid, end) for the degenerate pairs {seqid, end}
     for (int b = 0; b < 4; ++b) p1.word[p1.n_passes] = 1, p1.shift[p1.n_passes++] = (uint8_t)(8 * b);
     for (int b = 0; b < seq_bytes; ++b) p1.word[p1.n_passes] = 0, p1.shift[p1.n_passes++] = (uint8_t)(8 * b);
-    for (int b = 0; b < 4; ++b) p2.word[p2.n_passes] = 2, p2.shift[p2.n_passes++] = (uint8_t)(8 * b);
-    for (int b = 0; b < seq_bytes; ++b) p2.word[p2.n_passes] = 0, p2.shift[p2.n_passes++] = (uint8_t)(8 * b);
-    uint32_t *qs = L->d_tab, *pm = qs + L->cap_q, *sm = pm + L->cap_q, *qe = sm + L->cap_q, *eq = qe + L->cap_q;
-    const bool use_dir = nq > 0;
+    p2 = p1;
     GFFX_HIP_TRY(hipEventRecord(L->ev_p0, L->stream));
     GFFX_HIP_TRY(hipMemsetAsync(L->d_err, 0, 16, L->stream));
-    GFFX_HIP_TRY(hipMemsetAsync(L->d_qoff, 0, (n_seq + 1) * 8, L->stream));
-    GFFX_HIP_TRY(hipMemsetAsync(L->d_doff, 0, (n_seq + 1) * 8, L->stream));
+    GFFX_HIP_TRY(hipMemsetAsync(L->d_cnt, 0, 16, L->stream));
+    L->d_de = nullptr;
+    L->last_n_deg = 0;
+    L->last_deg_known = false;
     if (nq) {
-        uint32_t *s1 = nullptr, *s2 = nullptr;
-        int rc = DeviceSort::run(L->stream, L->d_rec_a, L->d_rec_b, n, p1, n_seq, L->d_work, L->d_err, &s1);
+        const uint32_t n_blocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock), g256 = (uint32_t)((n + 255) / 256);
+        const size_t stride = L->cap_blocks + 1;
+        uint32_t *c = L->d_carry;
+        const BlockCarry C{c, c + stride, c + 2 * stride, c + 3 * stride, c + 4 * stride, c + 5 * stride, c + 6 * stride, c + 7 * stride, c + 8 * stride};
+        uint32_t *s1 = nullptr;
+        int rc = DeviceSort::run<3>(L->stream, L->d_rec_a, L->d_rec_b, n, p1, n_seq, L->d_work, L->d_err, &s1);
         if (rc) return rc;
-        // keep the (seqid, qs, qe) order: the second sort needs both ping-pong buffers
-        GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_c, s1, n * 12, hipMemcpyDeviceToDevice, L->stream));
-        hipLaunchKernelGGL(k_b_offsets, dim3(g256), dim3(256), 0, L->stream, L->d_rec_c, n, n_seq, L->d_qoff);
-        hipLaunchKernelGGL(k_b_columns, dim3(g256), dim3(256), 0, L->stream, L->d_rec_c, n, qs, eq, L->d_head, L->d_head + L->cap_q);
-        if ((rc = seg_scan<true, false>(L, eq, L->d_head, nq, pm))) return rc;               // PM: running max of the ends
-        if ((rc = seg_scan<false, true>(L, eq, L->d_head + L->cap_q, nq, sm))) return rc;     // SM: running min from the right
-        if (s1 != L->d_rec_a) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, s1, n * 12, hipMemcpyDeviceToDevice, L->stream));
-        if ((rc = DeviceSort::run(L->stream, L->d_rec_a, L->d_rec_b, n, p2, n_seq, L->d_work, L->d_err, &s2))) return rc;
-        hipLaunchKernelGGL(k_b_column2, dim3(g256), dim3(256), 0, L->stream, s2, n, qe);
-        hipLaunchKernelGGL(k_b_dir_meta, dim3(1), dim3(256), 0, L->stream, L->d_qoff, qs, qe, n_seq, L->d_dmeta, L->d_doff);
-        hipLaunchKernelGGL(k_b_dir_fill, dim3(g256), dim3(256), 0, L->stream, qs, L->d_rec_c, n, n_seq, L->d_qoff, L->d_doff, L->d_dmeta, L->d_dir);
-        hipLaunchKernelGGL(k_b_dir_fill, dim3(g256), dim3(256), 0, L->stream, qe, s2, n, n_seq, L->d_qoff, L->d_doff, L->d_dmeta, L->d_dir + L->cap_dir);
+        uint32_t *other = s1 == L->d_rec_a ? L->d_rec_b : L->d_rec_a;
+        hipLaunchKernelGGL(k_b_local, dim3(n_blocks), dim3(kScanBlock), 0, L->stream, s1, n, n_seq, L->d_T, L->d_qoff, C);
+        hipLaunchKernelGGL(k_b_carry, dim3(1), dim3(kScanBlock), 0, L->stream, n_blocks, C, L->d_qoff, L->d_T, n_seq, L->d_meta, L->d_cnt);
+        hipLaunchKernelGGL(k_b_finish, dim3(g256), dim3(256), 0, L->stream, s1, n, n_seq, L->d_T, C, L->d_meta, L->d_dir, other, L->d_cnt);
         GFFX_HIP_TRY(hipGetLastError());
+        if (mode == GFFX_MODE_OVERLAP) {
+            // only Overlap looks at the degenerate regions' ends; how many there are decides what is launched next
+            GFFX_HIP_TRY(hipMemcpyAsync(L->h_cnt, L->d_cnt, 16, hipMemcpyDeviceToHost, L->stream));
+            GFFX_HIP_TRY(hipStreamSynchronize(L->stream));
+            const uint32_t n_deg = L->h_cnt[0];
+            L->last_n_deg = n_deg;
+            L->last_deg_known = true;
+            if (n_deg) {
+                uint32_t *sd = nullptr;
+                if ((rc = DeviceSort::run<2>(L->stream, other, s1, n_deg, p2, n_seq, L->d_work, L->d_err, &sd))) return rc;
+                hipLaunchKernelGGL(k_b_deg_ranges, dim3((n_deg + 255) / 256), dim3(256), 0, L->stream, sd, n_deg, n_seq, L->d_meta);
+                GFFX_HIP_TRY(hipGetLastError());
+                L->d_de = sd;
+            }
+        }
+    } else {
+        GFFX_HIP_TRY(hipMemsetAsync(L->d_meta, 0, (size_t)std::max<uint32_t>(n_seq, 1) * sizeof(SeqMeta), L->stream));
+        GFFX_HIP_TRY(hipMemsetAsync(L->d_qoff, 0, ((size_t)n_seq + 1) * 4, L->stream));
     }
     GFFX_HIP_TRY(hipEventRecord(L->ev_p1, L->stream));
     if (L->n) {
-        LinesView lv{L->d_seq, L->d_start, L->d_end, (unsigned long long)L->n};
-        RegionsView rv{L->d_qoff, qs, pm, sm, qe, use_dir ? L->d_dir : nullptr, use_dir ? L->d_dir + L->cap_dir : nullptr,
-                       L->d_doff, L->d_dmeta, n_seq};
-        const unsigned blocks = (unsigned)((L->n + 255) / 256);
+        const RegionsView rv{L->d_T, L->d_dir, L->d_meta, L->d_de, n_seq, L->last_n_deg};
         GFFX_HIP_TRY(hipEventRecord(L->ev_a, L->stream));
         if (mode == GFFX_MODE_CONTAINED)
-            hipLaunchKernelGGL((k_lines_exists<GFFX_MODE_CONTAINED>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+            launch_lines<GFFX_MODE_CONTAINED>(L, rv);
         else if (mode == GFFX_MODE_CONTAINS_REGION)
-            hipLaunchKernelGGL((k_lines_exists<GFFX_MODE_CONTAINS_REGION>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+            launch_lines<GFFX_MODE_CONTAINS_REGION>(L, rv);
         else
-            hipLaunchKernelGGL((k_lines_exists<GFFX_MODE_OVERLAP>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+            launch_lines<GFFX_MODE_OVERLAP>(L, rv);
         GFFX_HIP_TRY(hipGetLastError());
         GFFX_HIP_TRY(hipEventRecord(L->ev_b, L->stream));
         GFFX_HIP_TRY(hipMemcpyAsync(keep_host, L->d_keep, L->n, hipMemcpyDeviceToHost, L->stream));
@@ -522,7 +617,6 @@ static int lines_run(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int mode, u
     if (hipEventElapsedTime(&ms, L->ev_p0, L->ev_p1) == hipSuccess) L->last_prep_ms = ms;
     L->last_nq = nq;
     L->last_n_seq = n_seq;
-    L->last_dir = use_dir;
     if (h_err[0] & 2u)
         return fail(GFFX_E_CHR_RANGE, "gffx_hip_lines_test: a region has chr >= %u", n_seq);
     if (h_err[0] & 4u) return fail(GFFX_E_HIP, "gffx_hip_lines_test: the device sort timed out waiting for an earlier tile");
@@ -542,7 +636,7 @@ extern "C" int gffx_hip_lines_test(gffx_hip_lines *L, const uint32_t *regions, u
     int rc = lines_check(L, regions, nq, mode, keep_host, "gffx_hip_lines_test");
     if (rc) return rc;
     GFFX_HIP_TRY(hipSetDevice(L->device));
-    if ((rc = lines_reserve(L, nq, n_seq, 9 + 3))) return rc;
+    if ((rc = lines_reserve(L, nq, n_seq))) return rc;
     if (nq) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, regions, nq * 12, hipMemcpyHostToDevice, L->stream));
     return lines_run(L, nq, n_seq, mode, keep_host);
 }
@@ -553,7 +647,7 @@ extern "C" int gffx_hip_lines_test_device(gffx_hip_lines *L, const uint32_t *d_r
     int rc = lines_check(L, d_regions, nq, mode, keep_host, "gffx_hip_lines_test_device");
     if (rc) return rc;
     GFFX_HIP_TRY(hipSetDevice(L->device));
-    if ((rc = lines_reserve(L, nq, n_seq, 9 + 3))) return rc;
+    if ((rc = lines_reserve(L, nq, n_seq))) return rc;
     if (nq) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, d_regions, nq * 12, hipMemcpyDeviceToDevice, L->stream));
     return lines_run(L, nq, n_seq, mode, keep_host);
 }
@@ -565,36 +659,74 @@ extern "C" int gffx_hip_lines_test_store(gffx_hip_lines *L, const gffx_hip_regio
     if (rc) return rc;
     if (R->device != L->device) return fail(GFFX_E_INVALID, "gffx_hip_lines_test_store: store and line table on different devices");
     GFFX_HIP_TRY(hipSetDevice(L->device));
-    if ((rc = lines_reserve(L, nq, n_seq, 9 + 3))) return rc;
+    if ((rc = lines_reserve(L, nq, n_seq))) return rc;
     for (int k = 0; k < 2; ++k)  // every append has to have landed
         if (R->pending[k]) GFFX_HIP_TRY(hipStreamWaitEvent(L->stream, R->copied[k], 0));
     if (nq) GFFX_HIP_TRY(hipMemcpyAsync(L->d_rec_a, R->d, nq * 12, hipMemcpyDeviceToDevice, L->stream));
     return lines_run(L, nq, n_seq, mode, keep_host);
 }
 
-// The region tables of the last _test, for parity tests: q_off (n_seq + 1), then QS, PM, SM, QE (nq each).
-extern "C" int gffx_hip_lines_copy_tables(gffx_hip_lines *L, uint64_t *q_off, uint32_t *qs, uint32_t *pm, uint32_t *sm, uint32_t *qe) {
+// The region tables of the last _test, for parity tests: q_off (n_seq + 1), then QS, PM, SM, CD (nq each).
+extern "C" int gffx_hip_lines_copy_tables(gffx_hip_lines *L, uint64_t *q_off, uint32_t *qs, uint32_t *pm, uint32_t *sm, uint32_t *cd) {
     if (!L) return fail(GFFX_E_INVALID, "gffx_hip_lines_copy_tables: lines is NULL");
     GFFX_HIP_TRY(hipSetDevice(L->device));
     const uint64_t nq = L->last_nq;
-    if (q_off) GFFX_HIP_TRY(hipMemcpy(q_off, L->d_qoff, (L->last_n_seq + 1) * 8, hipMemcpyDeviceToHost));
-    uint32_t *host[4] = {qs, pm, sm, qe};
-    for (int t = 0; t < 4; ++t)
-        if (host[t] && nq) GFFX_HIP_TRY(hipMemcpy(host[t], L->d_tab + (size_t)t * L->cap_q, nq * 4, hipMemcpyDeviceToHost));
+    if (q_off) {
+        std::vector<uint32_t> off(L->last_n_seq + 1, 0);
+        GFFX_HIP_TRY(hipMemcpy(off.data(), L->d_qoff, off.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < off.size(); i++) q_off[i] = off[i];
+    }
+    if (nq && (qs || pm || sm || cd)) {
+        std::vector<uint4> t(nq);
+        GFFX_HIP_TRY(hipMemcpy(t.data(), L->d_T, nq * sizeof(uint4), hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < nq; i++) {
+            if (qs) qs[i] = t[i].x;
+            if (pm) pm[i] = t[i].y;
+            if (sm) sm[i] = t[i].z;
+            if (cd) cd[i] = t[i].w;
+        }
+    }
     return GFFX_OK;
 }
-// ... and the two bin directories: d_off (n_seq + 1), shift_nb (2 per seqid), dir_qs / dir_qe (d_off[n_seq] each)
-extern "C" int gffx_hip_lines_copy_dirs(gffx_hip_lines *L, uint64_t *d_off, uint32_t *shift_nb, uint32_t *dir_qs, uint32_t *dir_qe) {
+// ... the bin directory over QS: d_off (n_seq + 1), shift_nb (2 per seqid), dir_qs (d_off[n_seq] words) ...
+extern "C" int gffx_hip_lines_copy_dirs(gffx_hip_lines *L, uint64_t *d_off, uint32_t *shift_nb, uint32_t *dir_qs) {
     if (!L) return fail(GFFX_E_INVALID, "gffx_hip_lines_copy_dirs: lines is NULL");
     GFFX_HIP_TRY(hipSetDevice(L->device));
-    std::vector<unsigned long long> off(L->last_n_seq + 1, 0);
-    GFFX_HIP_TRY(hipMemcpy(off.data(), L->d_doff, off.size() * 8, hipMemcpyDeviceToHost));
-    if (d_off)
-        for (size_t i = 0; i < off.size(); i++) d_off[i] = off[i];
-    if (shift_nb && L->last_n_seq) GFFX_HIP_TRY(hipMemcpy(shift_nb, L->d_dmeta, (size_t)L->last_n_seq * 8, hipMemcpyDeviceToHost));
-    const uint64_t total = off.back();
+    std::vector<SeqMeta> meta(L->last_n_seq);
+    if (L->last_n_seq) GFFX_HIP_TRY(hipMemcpy(meta.data(), L->d_meta, meta.size() * sizeof(SeqMeta), hipMemcpyDeviceToHost));
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < L->last_n_seq; c++) {
+        if (d_off) d_off[c] = meta[c].d_base;
+        if (shift_nb) shift_nb[2 * c] = meta[c].shift, shift_nb[2 * c + 1] = meta[c].nb;
+        total = meta[c].d_base + (meta[c].q_hi > meta[c].q_lo ? meta[c].nb + 1 : 0);
+    }
+    if (!L->last_nq) total = 0;
+    if (d_off) d_off[L->last_n_seq] = total;
     if (dir_qs && total) GFFX_HIP_TRY(hipMemcpy(dir_qs, L->d_dir, total * 4, hipMemcpyDeviceToHost));
-    if (dir_qe && total) GFFX_HIP_TRY(hipMemcpy(dir_qe, L->d_dir + L->cap_dir, total * 4, hipMemcpyDeviceToHost));
+    return GFFX_OK;
+}
+// ... and, after an Overlap-mode _test, the degenerate regions (start > end): *n_deg of them, dq_off (n_seq + 1) and their
+// ends sorted per seqid (de: *n_deg words; call once with de = NULL to learn the size)
+extern "C" int gffx_hip_lines_copy_degenerate(gffx_hip_lines *L, uint64_t *n_deg, uint64_t *dq_off, uint32_t *de) {
+    if (!L) return fail(GFFX_E_INVALID, "gffx_hip_lines_copy_degenerate: lines is NULL");
+    if (!L->last_deg_known && L->last_nq) return fail(GFFX_E_INVALID, "gffx_hip_lines_copy_degenerate: the last _test was not in Overlap mode");
+    GFFX_HIP_TRY(hipSetDevice(L->device));
+    if (n_deg) *n_deg = L->last_n_deg;
+    if (dq_off) {
+        std::vector<SeqMeta> meta(L->last_n_seq);
+        if (L->last_n_seq && L->last_nq) GFFX_HIP_TRY(hipMemcpy(meta.data(), L->d_meta, meta.size() * sizeof(SeqMeta), hipMemcpyDeviceToHost));
+        uint64_t run = 0;
+        for (uint32_t c = 0; c < L->last_n_seq; c++) {
+            dq_off[c] = run;
+            if (L->last_n_deg && L->last_nq) run += meta[c].dq_hi - meta[c].dq_lo;
+        }
+        dq_off[L->last_n_seq] = run;
+    }
+    if (de && L->last_n_deg) {
+        std::vector<uint32_t> pairs(2 * (size_t)L->last_n_deg);
+        GFFX_HIP_TRY(hipMemcpy(pairs.data(), L->d_de, pairs.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < L->last_n_deg; i++) de[i] = pairs[2 * (size_t)i + 1];
+    }
     return GFFX_OK;
 }
 extern "C" double gffx_hip_lines_last_prep_ms(const gffx_hip_lines *L) { return L ? L->last_prep_ms : 0.0; }

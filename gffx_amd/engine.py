@@ -326,19 +326,27 @@ class LineTable:
         return lib().gffx_hip_lines_last_prep_ms(self._h)
 
     def tables(self, nq: int, n_seq: int):
-        """Region tables of the last ``test``: dict(q_off, qs, pm, sm, qe, d_off, shift_nb, dir_qs, dir_qe)."""
+        """Region tables of the last ``test``: dict(q_off, qs, pm, sm, cd, d_off, shift_nb, dir_qs) and, after an
+        Overlap-mode test, dq_off / de (the regions with start > end: their ends sorted per seqid)."""
         u64p = _ffi.u64p
         q_off = np.zeros(n_seq + 1, dtype=np.uint64)
         tabs = [np.zeros(max(nq, 1), dtype=np.uint32) for _ in range(4)]
         check(lib().gffx_hip_lines_copy_tables(self._h, q_off.ctypes.data_as(u64p), *[_p(t) for t in tabs]))
         d_off = np.zeros(n_seq + 1, dtype=np.uint64)
         shift_nb = np.zeros((max(n_seq, 1), 2), dtype=np.uint32)
-        check(lib().gffx_hip_lines_copy_dirs(self._h, d_off.ctypes.data_as(u64p), _p(shift_nb), None, None))
+        check(lib().gffx_hip_lines_copy_dirs(self._h, d_off.ctypes.data_as(u64p), _p(shift_nb), None))
         total = int(d_off[-1])
-        dq, de = np.zeros(max(total, 1), dtype=np.uint32), np.zeros(max(total, 1), dtype=np.uint32)
-        check(lib().gffx_hip_lines_copy_dirs(self._h, None, None, _p(dq), _p(de)))
-        return dict(q_off=q_off, qs=tabs[0][:nq], pm=tabs[1][:nq], sm=tabs[2][:nq], qe=tabs[3][:nq], d_off=d_off,
-                    shift_nb=shift_nb[:n_seq], dir_qs=dq[:total], dir_qe=de[:total])
+        dq = np.zeros(max(total, 1), dtype=np.uint32)
+        check(lib().gffx_hip_lines_copy_dirs(self._h, None, None, _p(dq)))
+        out = dict(q_off=q_off, qs=tabs[0][:nq], pm=tabs[1][:nq], sm=tabs[2][:nq], cd=tabs[3][:nq], d_off=d_off,
+                   shift_nb=shift_nb[:n_seq], dir_qs=dq[:total])
+        n_deg = C.c_uint64(0)
+        if lib().gffx_hip_lines_copy_degenerate(self._h, C.byref(n_deg), None, None) == 0:
+            dq_off = np.zeros(n_seq + 1, dtype=np.uint64)
+            de = np.zeros(max(n_deg.value, 1), dtype=np.uint32)
+            check(lib().gffx_hip_lines_copy_degenerate(self._h, None, dq_off.ctypes.data_as(u64p), _p(de)))
+            out.update(dq_off=dq_off, de=de[: n_deg.value])
+        return out
 
 
 class DepthTable:

@@ -287,16 +287,21 @@ int gffx_hip_lines_test_device(gffx_hip_lines *, const uint32_t *d_regions, uint
 int gffx_hip_lines_test_store(gffx_hip_lines *, const gffx_hip_regions *, uint32_t n_seq, int mode, uint8_t *keep_host);
 /* HIP-event duration (ms) of k_lines_exists in the last _test call, on the table's own stream */
 double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *);
-/* ... and of the device preparation of the region tables before it: radix sort by (seqid, start, end) and by (seqid, end),
- * running max / min of the ends, bin directories (the reference builds `query_ivmap` on the CPU: intersect.rs:621-633) */
+/* ... and of the device preparation of the region tables before it: radix sort by (seqid, start), running max / min of the
+ * ends, the bin directory and -- Overlap mode, when the run has regions with start > end -- the sort of those regions' ends
+ * (the reference builds `query_ivmap` on the CPU: intersect.rs:621-633) */
 double gffx_hip_lines_last_prep_ms(const gffx_hip_lines *);
-/* The region tables of the last _test, for parity checks: q_off (n_seq + 1 entries), then per region in (seqid, start,
- * end) order: QS = start, PM = running max of `end` inside the seqid, SM = running min of `end` from the seqid's last
- * region backwards, and QE = the ends sorted per seqid.  Any pointer may be NULL. */
-int gffx_hip_lines_copy_tables(gffx_hip_lines *, uint64_t *q_off, uint32_t *qs, uint32_t *pm, uint32_t *sm, uint32_t *qe);
-/* ... and the bin directories over QS and QE: d_off (n_seq + 1), shift_nb ({shift, bins} per seqid), dir_qs / dir_qe
- * (d_off[n_seq] entries each; dir[d_off[c] + b] = first position of seqid c whose value >= b << shift). */
-int gffx_hip_lines_copy_dirs(gffx_hip_lines *, uint64_t *d_off, uint32_t *shift_nb, uint32_t *dir_qs, uint32_t *dir_qe);
+/* The region tables of the last _test, for parity checks: q_off (n_seq + 1 entries), then per region in (seqid, start)
+ * order (stable: equal starts keep the order of `regions`): QS = start, PM = running max of `end` inside the seqid, SM =
+ * running min of `end` from the seqid's last region backwards, CD = regions with start > end before this position (all
+ * seqids).  Any pointer may be NULL. */
+int gffx_hip_lines_copy_tables(gffx_hip_lines *, uint64_t *q_off, uint32_t *qs, uint32_t *pm, uint32_t *sm, uint32_t *cd);
+/* ... the bin directory over QS: d_off (n_seq + 1), shift_nb ({shift, bins} per seqid), dir_qs (d_off[n_seq] entries;
+ * dir[d_off[c] + b] = first position of seqid c whose start >= b << shift, entry `bins` = the seqid's end) ... */
+int gffx_hip_lines_copy_dirs(gffx_hip_lines *, uint64_t *d_off, uint32_t *shift_nb, uint32_t *dir_qs);
+/* ... and, after an Overlap-mode _test, the regions with start > end: their number, dq_off (n_seq + 1) and their ends
+ * sorted per seqid (de: *n_deg entries; call with de = NULL first to learn the size). */
+int gffx_hip_lines_copy_degenerate(gffx_hip_lines *, uint64_t *n_deg, uint64_t *dq_off, uint32_t *de);
 
 /* ---- `gffx depth` with a BED source: compute_hit_depth / compute_root_depth (commands/depth.rs:121-293) --
  * The host parses every root BLOCK once (the byte range of a .gof record; for a root_fid with several

@@ -42,6 +42,41 @@ def test_random_small_coordinates_all_modes(seed):
     assert not lt.test(np.zeros((0, 3), np.uint32), n_seq, OverlapMode.Overlap).any()
 
 
+@pytest.mark.parametrize("kind", ["zero_length", "mixed", "clustered", "many_seqids"])
+def test_degenerate_and_clustered_regions_all_modes(kind):
+    """Regions with start > end (a zero-length BED row is one) only match through clauses 3 / 4 of intersect.rs:512-515;
+    clustered starts put hundreds of regions into one directory bin; > 256 seqids read SeqMeta from HBM instead of LDS."""
+    rng = np.random.default_rng({"zero_length": 1, "mixed": 2, "clustered": 3, "many_seqids": 4}[kind])
+    n_seq, nq, n_lines, span = 3, 400, 4000, 5000
+    if kind == "zero_length":
+        p = rng.integers(0, span, nq)
+        regions = np.stack([rng.integers(0, n_seq, nq), p + 1, p], axis=1)
+    elif kind == "mixed":
+        a, b = rng.integers(0, span, nq), rng.integers(0, span, nq)
+        regions = np.stack([rng.integers(0, n_seq, nq), a, b], axis=1)  # about half start > end
+        regions[::3, 2] = regions[::3, 1] + rng.integers(0, 50, len(regions[::3]))
+    elif kind == "clustered":
+        a = np.where(rng.random(nq) < 0.8, 1000 + rng.integers(0, 8, nq), rng.integers(0, 1 << 24, nq))
+        regions = np.stack([rng.integers(0, n_seq, nq), a, a + rng.integers(-3, 40, nq)], axis=1)
+    else:
+        n_seq, nq = 700, 3000
+        a = rng.integers(0, span, nq)
+        regions = np.stack([rng.integers(0, n_seq, nq), a, a + rng.integers(-20, 60, nq)], axis=1)
+    regions = np.maximum(regions, 0).astype(np.uint32)
+    seq = rng.integers(0, n_seq, n_lines).astype(np.uint32)
+    s = rng.integers(0, span + 50, n_lines).astype(np.uint32)
+    e = (s + rng.integers(-5, 80, n_lines)).clip(0).astype(np.uint32)
+    if kind == "clustered":
+        s[::2] = 990 + rng.integers(0, 30, len(s[::2]))
+        e[::2] = s[::2] + rng.integers(0, 12, len(s[::2]))
+    lt = engine.LineTable(seq, s, e)
+    for mode in OverlapMode:
+        got = lt.test(regions, n_seq, mode)
+        want = _oracle_keep(seq, s, e, regions, n_seq, mode)
+        assert np.array_equal(got, want), (kind, mode, np.flatnonzero(got != want)[:5])
+    lt.close()
+
+
 def test_u32_extremes_and_empty_table():
     seq = np.array([0, 0, 0, 0], np.uint32)
     s = np.array([0, 0xFFFFFFFF, 5, 0xFFFFFFFE], np.uint32)
@@ -82,25 +117,31 @@ def test_gencode_like_lines_against_sampled_oracle():
 
 
 def _host_tables(regions, n_seq):
-    """The region tables as the definition builds them (numpy): (seqid, start, end) order, running max / min of the
-    ends inside a seqid, the ends sorted per seqid, and the two bin directories (~2 bins per region, >= 16)."""
-    r = regions[np.lexsort((regions[:, 2], regions[:, 1], regions[:, 0]))]
+    """The region tables as the definition builds them (numpy): stable (seqid, start) order, running max / min of the
+    ends inside a seqid, the count of regions with start > end before every position, the bin directory over the starts
+    (~2 bins per region, >= 16), and the ends of the start > end regions sorted per seqid."""
+    r = regions[np.lexsort((regions[:, 1], regions[:, 0]))]  # (lexsort is stable: ties keep the BED order)
     n = len(r)
     q_off = np.concatenate([[0], np.cumsum(np.bincount(r[:, 0], minlength=n_seq))]).astype(np.uint64)
     qs, e = r[:, 1].copy(), r[:, 2].copy()
-    pm, sm, qe = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    pm, sm = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    deg = qs > e
+    cd = (np.cumsum(deg) - deg).astype(np.uint32)
     d_off = np.zeros(n_seq + 1, np.uint64)
+    dq_off = np.zeros(n_seq + 1, np.uint64)
     shift_nb = np.zeros((n_seq, 2), np.uint32)
     dq, de = [], []
     for c in range(n_seq):
         lo, hi = int(q_off[c]), int(q_off[c + 1])
         d_off[c + 1] = d_off[c]
+        dq_off[c + 1] = dq_off[c]
         if hi == lo:
             continue
         pm[lo:hi] = np.maximum.accumulate(e[lo:hi])
         sm[lo:hi] = np.minimum.accumulate(e[lo:hi][::-1])[::-1]
-        qe[lo:hi] = np.sort(e[lo:hi])
-        vmax = int(max(qs[hi - 1], qe[hi - 1]))
+        de.append(np.sort(e[lo:hi][deg[lo:hi]]))
+        dq_off[c + 1] = dq_off[c] + len(de[-1])
+        vmax = int(qs[hi - 1])
         budget = max(2 * (hi - lo), 16)
         shift = 0
         while (vmax >> shift) + 1 > budget:
@@ -109,17 +150,18 @@ def _host_tables(regions, n_seq):
         shift_nb[c] = (shift, nb)
         edges = np.arange(nb + 1, dtype=np.uint64) << np.uint64(shift)
         dq.append(lo + np.searchsorted(qs[lo:hi].astype(np.uint64), edges, "left"))
-        de.append(lo + np.searchsorted(qe[lo:hi].astype(np.uint64), edges, "left"))
-        dq[-1][-1] = de[-1][-1] = hi  # the last entry is the seqid's end
+        dq[-1][-1] = hi  # the last entry is the seqid's end
         d_off[c + 1] = d_off[c] + nb + 1
     cat = lambda x: np.concatenate(x).astype(np.uint32) if x else np.zeros(0, np.uint32)  # noqa: E731
-    return dict(q_off=q_off, qs=qs, pm=pm, sm=sm, qe=qe, d_off=d_off, shift_nb=shift_nb, dir_qs=cat(dq), dir_qe=cat(de))
+    return dict(q_off=q_off, qs=qs, pm=pm, sm=sm, cd=cd, d_off=d_off, shift_nb=shift_nb, dir_qs=cat(dq), dq_off=dq_off, de=cat(de))
 
 
-@pytest.mark.parametrize("case", ["tiny", "ties", "tile_edges", "many_seqids", "extremes", "bed_1m"])
+@pytest.mark.parametrize("case", ["tiny", "ties", "tile_edges", "many_seqids", "extremes", "one_seqid_small_coords", "all_degenerate",
+                                  "no_degenerate", "bed_1m"])
 def test_device_region_tables_equal_the_host_definition(case):
-    """The device preparation (radix sort by (seqid, start, end) and by (seqid, end), segmented running max / min, bin
-    directories: radix_sort.hpp, join_b.hip) gives bit-identical tables to the numpy definition."""
+    """The device preparation (stable radix sort by (seqid, start), segmented running max / min, degenerate counts, the bin
+    directory, the sorted ends of the start > end regions: radix_sort.hpp, join_b.hip) gives bit-identical tables to the
+    numpy definition."""
     rng = np.random.default_rng(hash(case) % 1000)
     if case == "tiny":
         n_seq, regions = 3, np.array([[2, 5, 9], [0, 7, 7], [2, 1, 3], [0, 7, 2], [2, 5, 1]], np.uint32)
@@ -137,8 +179,18 @@ def test_device_region_tables_equal_the_host_definition(case):
         n_seq, n = 2, 5000
         regions = np.stack([rng.integers(0, n_seq, n), rng.integers(0, 1 << 32, n), rng.integers(0, 1 << 32, n)], axis=1).astype(np.uint32)
         regions[:5] = [[0, 0xFFFFFFFF, 0xFFFFFFFF], [1, 0, 0], [0, 0xFFFFFFFF, 0], [1, 0, 0xFFFFFFFF], [0, 0x80000000, 0x7FFFFFFF]]
+    elif case == "one_seqid_small_coords":  # the seqid byte and the two high bytes of the starts are the same in every record
+        n_seq, n = 1, 30000
+        regions = np.stack([np.zeros(n), rng.integers(0, 1 << 16, n), rng.integers(0, 1 << 16, n)], axis=1).astype(np.uint32)
+    elif case == "all_degenerate":  # zero-length BED rows: start + 1 > end
+        n_seq, n = 6, 40000
+        p = rng.integers(0, 1 << 22, n)
+        regions = np.stack([rng.integers(0, n_seq, n), p + 1, p], axis=1).astype(np.uint32)
+    elif case == "no_degenerate":
+        n_seq, n = 6, 40000
+        p = rng.integers(0, 1 << 22, n)
+        regions = np.stack([rng.integers(0, n_seq, n), p, p + rng.integers(0, 1000, n)], axis=1).astype(np.uint32)
     else:
-        roots = synth.gencode_like_roots(63000, seed=42)
         n_seq, regions = 25, synth.synth_bed(1_000_000, seed=1001)
     lt = engine.LineTable(np.zeros(4, np.uint32), np.arange(4, dtype=np.uint32), np.arange(4, dtype=np.uint32) + 3)
     sizes = [2047, 2048, 2049, 4096, 6145] if case == "tile_edges" else [None]
