@@ -30,6 +30,7 @@
 // in LDS), DE.  One thread per line, one byte out.  Roofline bound: HBM; algorithmic bytes per line: 12 in + 1 out.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <memory>
 #include <numeric>
@@ -56,6 +57,7 @@ struct RegionsView {
     const uint32_t *dir;
     const SeqMeta *meta;   // n_seq
     const uint32_t *de;    // sorted {seqid, qe} pairs of the degenerate regions (word 2 p + 1 = the end)
+    const uint32_t *dird;  // their directory, same bins as `dir`: dird[d_base + b] = first pair of the seqid whose end >= b << shift
     uint32_t n_seq, n_deg;
 };
 constexpr uint32_t kMetaLds = 256;  // seqids whose SeqMeta a block stages in LDS (more: read through the caches)
@@ -123,7 +125,27 @@ __device__ __forceinline__ uint32_t lower_qs(const RegionsView &R, const SeqMeta
     return l;
 }
 
-template <int MODE, bool META_LDS>
+// some degenerate end in [s, e] (the seqid's bins: ends are below their starts, so below the largest start)
+__device__ __forceinline__ bool deg_end_in(const RegionsView &R, const SeqMeta &m, uint32_t s, uint32_t e) {
+    if (m.dq_hi == m.dq_lo) return false;
+    const uint32_t b = s >> m.shift;
+    if (b >= m.nb) return false;
+    uint32_t lo = R.dird[m.d_base + b], hi = R.dird[m.d_base + b + 1];
+    while (hi - lo > 2) {  // first end >= s inside the bin (a bin holds ~0.5 ends; clustered ones are halved down first)
+        const uint32_t mid = (lo + hi) >> 1;
+        if (R.de[2 * mid + 1] < s)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    while (lo < hi && R.de[2 * lo + 1] < s) ++lo;
+    return lo < m.dq_hi && R.de[2 * lo + 1] <= e;
+}
+
+// DEG: the run has regions with start > end (Overlap only): their clauses are evaluated for the lines the PM test did not
+// keep (for every line, side by side with the PM lookup, was faster at 1 M regions -- 35 vs 40 us -- and twice slower at 10 M,
+// where PM keeps every line).
+template <int MODE, bool META_LDS, bool DEG>
 __global__ __launch_bounds__(256) void k_lines_exists(LinesView L, RegionsView R, uint8_t *keep) {
     __shared__ uint4 s_meta[META_LDS ? 2 * kMetaLds : 2];
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,20 +177,10 @@ __global__ __launch_bounds__(256) void k_lines_exists(LinesView L, RegionsView R
             } else if (s <= e) {
                 uint32_t u = 0;
                 bool any = pm_at(R, m, e, pm, &u) && pm >= s;
-                if (!any && R.n_deg) {  // the degenerate regions (qs > qe): one of their two ends in [s, e]
+                if (DEG && !any) {  // the degenerate regions (qs > qe): one of their two ends in [s, e]
                     const uint32_t l = lower_qs(R, m, s);
-                    any = R.T[u].w != R.T[l].w;
-                    if (!any && m.dq_hi > m.dq_lo) {
-                        uint32_t lo = m.dq_lo, hi = m.dq_hi;
-                        while (lo < hi) {  // first degenerate end >= s
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (R.de[2 * mid + 1] < s)
-                                lo = mid + 1;
-                            else
-                                hi = mid;
-                        }
-                        any = lo < m.dq_hi && R.de[2 * lo + 1] <= e;
-                    }
+                    const bool d4 = deg_end_in(R, m, s, e);  // (independent of the line above: their loads travel together)
+                    any = R.T[u].w != R.T[l].w || d4;
                 }
                 k = any ? 1 : 0;
             } else {
@@ -257,40 +269,113 @@ __device__ __forceinline__ uint32_t block_sum_scan(uint32_t v, uint32_t *s_v, ui
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_b_local(const uint32_t *rec, unsigned long long n, uint32_t n_seq, uint4 *T, uint32_t *q_off,
-                                                        BlockCarry C) {
-    __shared__ uint32_t s_v[kScanWaves], s_f[kScanWaves];
+// 256 threads x 4 consecutive regions = one block of 1024: a thread scans its four regions in registers (three 16-byte loads
+// in, four 16-byte records out), the threads' aggregates are scanned with wave shuffles, the four waves meet at ONE barrier.
+constexpr int kLocalItems = 4, kLocalThreads = kScanBlock / kLocalItems, kLocalWaves = kLocalThreads / 64;
+__global__ __launch_bounds__(kLocalThreads) void k_b_local(const uint32_t *rec, unsigned long long n, uint32_t n_seq, uint4 *T, uint32_t *q_off,
+                                                           BlockCarry C) {
+    __shared__ uint32_t s_v[kLocalWaves], s_f[kLocalWaves], s_c[kLocalWaves], s_bv[kLocalWaves], s_bf[kLocalWaves];
     __shared__ uint32_t s_first, s_last;
     if (threadIdx.x == 0) s_first = kScanBlock, s_last = 0xFFFFFFFFu;
-    const unsigned long long i = (unsigned long long)blockIdx.x * kScanBlock + threadIdx.x;
-    const bool live = i < n;
-    uint32_t seq = 0xFFFFFFFFu, qs = 0, qe = 0;
-    bool head = true, tail = true;  // (a thread past the end is its own segment)
-    if (live) {
-        seq = rec[3 * i], qs = rec[3 * i + 1], qe = rec[3 * i + 2];
-        head = i == 0 || rec[3 * (i - 1)] != seq;
-        tail = i + 1 == n || rec[3 * (i + 1)] != seq;
-        if (head) {  // q_off[c] = first sorted position of seqid c: every boundary fills the seqids it skips over
-            const uint32_t c1 = min(seq, n_seq);  // (a seqid out of range is reported by the sort's histogram kernel)
-            const long long c0 = i ? (long long)min(rec[3 * (i - 1)], n_seq) : -1;
-            for (long long c = c0 + 1; c <= (long long)c1; ++c) q_off[c] = (uint32_t)i;
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * kScanBlock + (unsigned long long)threadIdx.x * kLocalItems;
+    uint32_t seq[kLocalItems], qs[kLocalItems], qe[kLocalItems];
+    if (i0 + kLocalItems <= n) {
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(rec + 3 * i0);  // (i0 is a multiple of 4: 48-byte steps, 16-byte aligned)
+        const uint4 a = r4[0], b = r4[1], c = r4[2];
+        seq[0] = a.x, qs[0] = a.y, qe[0] = a.z, seq[1] = a.w, qs[1] = b.x, qe[1] = b.y;
+        seq[2] = b.z, qs[2] = b.w, qe[2] = c.x, seq[3] = c.y, qs[3] = c.z, qe[3] = c.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kLocalItems; ++k) {
+            const bool live = i0 + k < n;
+            seq[k] = live ? rec[3 * (i0 + k)] : 0xFFFFFFFFu, qs[k] = live ? rec[3 * (i0 + k) + 1] : 0u, qe[k] = live ? rec[3 * (i0 + k) + 2] : 0u;
         }
-        if (i + 1 == n)
-            for (uint32_t c = min(seq, n_seq) + 1; c <= n_seq; ++c) q_off[c] = (uint32_t)n;
     }
+    const uint32_t seq_before = (i0 > 0 && i0 < n) ? rec[3 * (i0 - 1)] : 0xFFFFFFFEu;
+    const uint32_t seq_after = i0 + kLocalItems < n ? rec[3 * (i0 + kLocalItems)] : 0xFFFFFFFEu;
     __syncthreads();
-    if (live && head) atomicMin(&s_first, threadIdx.x);
-    if (live && tail) atomicMax((int *)&s_last, (int)threadIdx.x);
-    uint32_t ff = head ? 1u : 0u, fb = tail ? 1u : 0u;
-    const uint32_t pm = block_seg_scan<true, false>(live ? qe : 0u, ff, s_v, s_f);
-    const uint32_t sm = block_seg_scan<false, true>(live ? qe : 0xFFFFFFFFu, fb, s_v, s_f);
-    uint32_t n_deg = 0;
-    const uint32_t cd = block_sum_scan((live && qs > qe) ? 1u : 0u, s_v, &n_deg);
-    if (live) T[i] = make_uint4(qs, pm, sm, cd);
-    if (live && (threadIdx.x == kScanBlock - 1 || i + 1 == n)) C.max_out[blockIdx.x] = pm;
+    // a region past the end is its own segment (head and tail) with neutral values
+    bool head[kLocalItems], tail[kLocalItems];
+    uint32_t pm[kLocalItems], sm[kLocalItems], cd[kLocalItems];
+    uint32_t run = 0, tf = 0, n_deg = 0;
+    int first_head = kLocalItems, last_tail = -1;
+#pragma unroll
+    for (int k = 0; k < kLocalItems; ++k) {
+        const bool live = i0 + k < n;
+        head[k] = !live || seq[k] != (k ? seq[k - 1] : seq_before);
+        tail[k] = !live || i0 + k + 1 == n || seq[k] != (k + 1 < kLocalItems ? seq[k + 1] : seq_after);
+        if (live && head[k]) {  // q_off[c] = first sorted position of seqid c: every boundary fills the seqids it skips over
+            const uint32_t c1 = min(seq[k], n_seq);  // (a seqid out of range is reported by the sort's histogram kernel)
+            const long long c0 = i0 + k ? (long long)min(k ? seq[k - 1] : seq_before, n_seq) : -1;
+            for (long long c = c0 + 1; c <= (long long)c1; ++c) q_off[c] = (uint32_t)(i0 + k);
+            if (first_head == kLocalItems) first_head = k;
+        }
+        if (live && i0 + k + 1 == n)
+            for (uint32_t c = min(seq[k], n_seq) + 1; c <= n_seq; ++c) q_off[c] = (uint32_t)n;
+        if (live && tail[k]) last_tail = k;
+        run = head[k] ? (live ? qe[k] : 0u) : max(run, qe[k]);
+        tf |= head[k] ? 1u : 0u;
+        pm[k] = run;
+        cd[k] = n_deg;
+        n_deg += (live && qs[k] > qe[k]) ? 1u : 0u;
+    }
+    uint32_t brun = 0xFFFFFFFFu, tb = 0;
+#pragma unroll
+    for (int k = kLocalItems - 1; k >= 0; --k) {
+        const bool live = i0 + k < n;
+        brun = tail[k] ? (live ? qe[k] : 0xFFFFFFFFu) : min(brun, qe[k]);
+        tb |= tail[k] ? 1u : 0u;
+        sm[k] = brun;
+    }
+    if (first_head < kLocalItems) atomicMin(&s_first, threadIdx.x * kLocalItems + first_head);  // (read after the barrier below)
+    if (last_tail >= 0) atomicMax((int *)&s_last, (int)(threadIdx.x * kLocalItems + last_tail));
+    // inclusive scans of the threads' aggregates inside the wave: running max from the left (restarts at a head), running
+    // min from the right (restarts at a tail), degenerate regions
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t iv = run, ff = tf, bv = brun, fb = tb, ic = n_deg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t pv = __shfl_up(iv, o, 64), pf = __shfl_up(ff, o, 64), nv = __shfl_down(bv, o, 64), nf = __shfl_down(fb, o, 64),
+                       pc = __shfl_up(ic, o, 64);
+        if (lane >= o) {
+            if (!ff) iv = max(pv, iv);
+            ff |= pf;
+            ic += pc;
+        }
+        if (lane + o < 64) {
+            if (!fb) bv = min(nv, bv);
+            fb |= nf;
+        }
+    }
+    if (lane == 63) s_v[wave] = iv, s_f[wave] = ff, s_c[wave] = ic;
+    if (lane == 0) s_bv[wave] = bv, s_bf[wave] = fb;
+    __syncthreads();
+    // what the thread's open segments bring in: from the lanes / waves before me, and from those after me
+    uint32_t cv = 0, cb = 0xFFFFFFFFu, cbase = 0, block_deg = 0;
+#pragma unroll
+    for (int w = 0; w < kLocalWaves; ++w) {
+        if (w < wave) cv = s_f[w] ? s_v[w] : max(cv, s_v[w]);
+        cbase += w < wave ? s_c[w] : 0u;
+        block_deg += s_c[w];
+    }
+#pragma unroll
+    for (int w = kLocalWaves - 1; w >= 0; --w)
+        if (w > wave) cb = s_bf[w] ? s_bv[w] : min(cb, s_bv[w]);
+    uint32_t ev = __shfl_up(iv, 1, 64), ef = __shfl_up(ff, 1, 64), nbv = __shfl_down(bv, 1, 64), nbf = __shfl_down(fb, 1, 64);
+    if (lane == 0) ev = 0u, ef = 0u;
+    if (lane == 63) nbv = 0xFFFFFFFFu, nbf = 0u;
+    const uint32_t in_max = ef ? ev : max(cv, ev), in_min = nbf ? nbv : min(cb, nbv);
+    const uint32_t cd0 = cbase + ic - n_deg;
+#pragma unroll
+    for (int k = 0; k < kLocalItems; ++k) {
+        if (k < first_head && !(head[k])) pm[k] = max(pm[k], in_max);
+        if (k > last_tail && !(tail[k])) sm[k] = min(sm[k], in_min);
+        if (i0 + k < n) T[i0 + k] = make_uint4(qs[k], pm[k], sm[k], cd0 + cd[k]);
+    }
+    if (threadIdx.x == kLocalThreads - 1) C.max_out[blockIdx.x] = pm[kLocalItems - 1];  // (past the end: the last block's is never read)
     if (threadIdx.x == 0) {
-        C.min_out[blockIdx.x] = sm;
-        C.deg[blockIdx.x] = n_deg;
+        C.min_out[blockIdx.x] = sm[0];
+        C.deg[blockIdx.x] = block_deg;
         C.first_head[blockIdx.x] = s_first;
         C.last_tail[blockIdx.x] = s_last;
         C.head_any[blockIdx.x] = (s_first < kScanBlock ? 1u : 0u) | (s_last != 0xFFFFFFFFu ? 2u : 0u);
@@ -373,36 +458,69 @@ __global__ __launch_bounds__(kScanBlock) void k_b_carry(uint32_t n_blocks, Block
 }
 
 // Folds the carries into T, fills the directory, writes the sentinel T[n] and the degenerate regions' {seqid, qe} (in
-// (seqid, start) order, position = CD) for the sort by (seqid, qe).
-__global__ __launch_bounds__(256) void k_b_finish(const uint32_t *rec, unsigned long long n, uint32_t n_seq, uint4 *T, BlockCarry C,
-                                                  const SeqMeta *meta, uint32_t *dir, uint32_t *deg_out, const uint32_t *cnt) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t blk = (uint32_t)(i / kScanBlock), tid = (uint32_t)(i % kScanBlock);
-    uint4 t = T[i];
-    const uint32_t c = rec[3 * i], qe = rec[3 * i + 2];
-    if (tid < C.first_head[blk]) t.y = max(t.y, C.max_in[blk]);  // (block 0 starts with a head)
-    if ((int)tid > (int)C.last_tail[blk]) t.z = min(t.z, C.min_in[blk]);
-    t.w += C.deg_in[blk];
-    T[i] = t;
-    if (t.x > qe) deg_out[2 * (size_t)t.w] = c, deg_out[2 * (size_t)t.w + 1] = qe;
-    if (i + 1 == n) T[n] = make_uint4(0u, 0u, 0u, cnt[0]);
-    if (c >= n_seq) return;  // (reported by the sort's histogram kernel)
-    const SeqMeta m = meta[c];
-    uint32_t *d = dir + m.d_base;
-    const uint32_t b = t.x >> m.shift;
-    const long long bprev = i > m.q_lo ? (long long)(T[i - 1].x >> m.shift) : -1;
-    for (long long x = bprev + 1; x <= (long long)b; ++x) d[x] = (uint32_t)i;
-    if (i + 1 == m.q_hi)
-        for (uint32_t x = b + 1; x <= m.nb; ++x) d[x] = m.q_hi;
+// (seqid, start) order, position = CD) for the sort by (seqid, qe).  Same shape as k_b_local: a block = one block of 1024
+// regions (its carries are five scalar loads), a thread = four consecutive regions.
+__global__ __launch_bounds__(kLocalThreads) void k_b_finish(const uint32_t *rec, unsigned long long n, uint32_t n_seq, uint4 *T, BlockCarry C,
+                                                            const SeqMeta *meta, uint32_t *dir, uint32_t *deg_out, const uint32_t *cnt) {
+    const uint32_t blk = blockIdx.x;
+    const unsigned long long i0 = (unsigned long long)blk * kScanBlock + (unsigned long long)threadIdx.x * kLocalItems;
+    if (i0 >= n) return;
+    const uint32_t first_head = C.first_head[blk], max_in = C.max_in[blk], min_in = C.min_in[blk], deg_in = C.deg_in[blk];
+    const int last_tail = (int)C.last_tail[blk];
+    uint4 t[kLocalItems];
+    uint32_t seq[kLocalItems], qe[kLocalItems];
+    if (i0 + kLocalItems <= n) {
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(rec + 3 * i0);
+        const uint4 a = r4[0], b = r4[1], c = r4[2];
+        seq[0] = a.x, qe[0] = a.z, seq[1] = a.w, qe[1] = b.y, seq[2] = b.z, qe[2] = c.x, seq[3] = c.y, qe[3] = c.w;
+#pragma unroll
+        for (int k = 0; k < kLocalItems; ++k) t[k] = T[i0 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < kLocalItems; ++k) {
+            const bool live = i0 + k < n;
+            seq[k] = live ? rec[3 * (i0 + k)] : 0xFFFFFFFFu, qe[k] = live ? rec[3 * (i0 + k) + 2] : 0u;
+            t[k] = live ? T[i0 + k] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    const uint32_t x_before = i0 ? T[i0 - 1].x : 0u;  // (the start never changes: no race with the thread that rewrites T[i0 - 1])
+    uint4 ma[kLocalItems], mb[kLocalItems];  // SeqMeta; every load before the first store: the stores below may alias as far as the compiler knows
+#pragma unroll
+    for (int k = 0; k < kLocalItems; ++k) {
+        const uint32_t c = min(seq[k], n_seq ? n_seq - 1 : 0u);
+        ma[k] = reinterpret_cast<const uint4 *>(meta)[2 * (size_t)c], mb[k] = reinterpret_cast<const uint4 *>(meta)[2 * (size_t)c + 1];
+    }
+    const uint32_t total_deg = cnt[0];
+#pragma unroll
+    for (int k = 0; k < kLocalItems; ++k) {
+        const unsigned long long i = i0 + k;
+        if (i >= n) break;
+        const uint32_t tid = threadIdx.x * kLocalItems + k;
+        if (tid < first_head) t[k].y = max(t[k].y, max_in);  // (block 0 starts with a head)
+        if ((int)tid > last_tail) t[k].z = min(t[k].z, min_in);
+        t[k].w += deg_in;
+        T[i] = t[k];
+        if (t[k].x > qe[k]) deg_out[2 * (size_t)t[k].w] = seq[k], deg_out[2 * (size_t)t[k].w + 1] = qe[k];
+        if (i + 1 == n) T[n] = make_uint4(0u, 0u, 0u, total_deg);
+        if (seq[k] >= n_seq) continue;  // (reported by the sort's histogram kernel)
+        const uint32_t q_lo = ma[k].x, q_hi = ma[k].y, shift = ma[k].z, nb = ma[k].w;
+        uint32_t *d = dir + mb[k].x;
+        const uint32_t b = t[k].x >> shift;
+        const long long bprev = i > q_lo ? (long long)((k ? t[k - 1].x : x_before) >> shift) : -1;
+        for (long long x = bprev + 1; x <= (long long)b; ++x) d[x] = (uint32_t)i;
+        if (i + 1 == q_hi)
+            for (uint32_t x = b + 1; x <= nb; ++x) d[x] = q_hi;
+    }
 }
 
-// the sorted {seqid, qe} pairs of the degenerate regions -> every seqid's range [dq_lo, dq_hi) in SeqMeta
-__global__ __launch_bounds__(256) void k_b_deg_ranges(const uint32_t *pairs, uint32_t n, uint32_t n_seq, SeqMeta *meta) {
+// the sorted {seqid, qe} pairs of the degenerate regions -> every seqid's range [dq_lo, dq_hi) in SeqMeta and its directory
+// (the bins of the seqid's start directory: an end is below its start, so below the largest start)
+__global__ __launch_bounds__(256) void k_b_deg_ranges(const uint32_t *pairs, uint32_t n, uint32_t n_seq, SeqMeta *meta, uint32_t *dird) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t c1 = min(pairs[2 * i], n_seq);
+    const uint32_t c1 = min(pairs[2 * i], n_seq), qe = pairs[2 * i + 1];
     const long long c0 = i ? (long long)min(pairs[2 * (i - 1)], n_seq) : -1;
+    const bool last_of_seq = i + 1 == n || pairs[2 * (i + 1)] != pairs[2 * i];
     // seqids (c0, c1] start at i; seqids [c0, c1) end at i
     for (long long c = c0 + 1; c <= (long long)c1 && c < (long long)n_seq; ++c) meta[c].dq_lo = i;
     for (long long c = max(c0, 0ll); c < (long long)c1; ++c) meta[c].dq_hi = i;
@@ -410,11 +528,22 @@ __global__ __launch_bounds__(256) void k_b_deg_ranges(const uint32_t *pairs, uin
         if (c1 < n_seq) meta[c1].dq_hi = n;
         for (uint32_t c = c1 + 1; c < n_seq; ++c) meta[c].dq_lo = meta[c].dq_hi = n;
     }
+    if (c1 >= n_seq) return;  // (reported by the sort's histogram kernel)
+    const uint32_t shift = meta[c1].shift, nb = meta[c1].nb;  // (k_b_carry wrote them; this kernel only writes dq_lo / dq_hi)
+    uint32_t *d = dird + meta[c1].d_base;
+    const uint32_t b = min(qe >> shift, nb);
+    const long long bprev = c0 == (long long)c1 ? (long long)min(pairs[2 * (i - 1) + 1] >> shift, nb) : -1;
+    for (long long x = bprev + 1; x <= (long long)b; ++x) d[x] = i;
+    if (last_of_seq)
+        for (uint32_t x = b + 1; x <= nb; ++x) d[x] = i + 1;
 }
 
 }  // namespace gffx
 
 using namespace gffx;
+
+constexpr int kSortPassesMax = 4 + 4;  // the coordinate's four bytes + up to four of the seqid
+constexpr size_t kWorkFront = 64;      // words of d_work in front of the sort's work space (d_err, d_cnt)
 
 struct gffx_hip_lines {
     int device = 0;
@@ -424,6 +553,7 @@ struct gffx_hip_lines {
     hipStream_t stream = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;  // bracket k_lines_exists of the last _test
     hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // ... and the device preparation of the region tables
+    uint32_t note_seq = 0;                        // h_cnt = {degenerate regions, note_seq}, posted by the sort's histogram kernel
     double last_kernel_ms = 0.0, last_prep_ms = 0.0;
     // region tables of the last _test (grow-only device buffers)
     uint64_t cap_q = 0, cap_seq = 0, cap_work = 0, cap_dir = 0, cap_blocks = 0;
@@ -434,9 +564,11 @@ struct gffx_hip_lines {
     uint32_t *d_qoff = nullptr;      // cap_seq + 1
     SeqMeta *d_meta = nullptr;       // cap_seq
     uint32_t *d_dir = nullptr;       // cap_dir
-    uint32_t *d_err = nullptr;       // 4 words
-    uint32_t *d_cnt = nullptr;       // {degenerate regions, directory words}
-    uint32_t *h_cnt = nullptr;       // pinned copy
+    uint32_t *d_dird = nullptr;      // cap_dird: the directory of the degenerate ends (allocated by the first run that has any)
+    uint64_t cap_dird = 0;
+    uint32_t *d_err = nullptr;       // 4 words at the front of d_work
+    uint32_t *d_cnt = nullptr;       // d_work + 4: {degenerate regions (k_b_carry), directory words, degenerate regions (the sort's histogram kernel)}
+    uint32_t *h_cnt = nullptr;       // pinned, coherent: the kernel writes it
     const uint32_t *d_de = nullptr;  // the sorted degenerate pairs of the last Overlap _test (inside d_rec_a / d_rec_b)
     uint64_t last_nq = 0;
     uint32_t last_n_seq = 0, last_n_deg = 0;
@@ -460,8 +592,7 @@ extern "C" void gffx_hip_lines_destroy(gffx_hip_lines *L) {
     (void)hipSetDevice(L->device);
     if (L->stream) (void)hipStreamSynchronize(L->stream);
     for (void *p : {(void *)L->d_seq, (void *)L->d_start, (void *)L->d_end, (void *)L->d_keep, (void *)L->d_rec_a, (void *)L->d_rec_b,
-                    (void *)L->d_T, (void *)L->d_carry, (void *)L->d_work, (void *)L->d_qoff, (void *)L->d_meta, (void *)L->d_dir,
-                    (void *)L->d_err, (void *)L->d_cnt})
+                    (void *)L->d_T, (void *)L->d_carry, (void *)L->d_work, (void *)L->d_qoff, (void *)L->d_meta, (void *)L->d_dir, (void *)L->d_dird})
         (void)hipFree(p);
     if (L->h_cnt) (void)hipHostFree(L->h_cnt);
     for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_p0, L->ev_p1})
@@ -489,10 +620,12 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
     L->n = n_lines;
     int rc;
     if ((rc = dalloc(&L->d_seq, n_lines)) || (rc = dalloc(&L->d_start, n_lines)) ||
-        (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)) || (rc = dalloc(&L->d_err, 4)) ||
-        (rc = dalloc(&L->d_cnt, 4)))
+        (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)) || (rc = dalloc(&L->d_work, kWorkFront)))
         return rc;
-    GFFX_HIP_TRY(hipHostMalloc((void **)&L->h_cnt, 16, hipHostMallocDefault));
+    L->cap_work = kWorkFront;
+    L->d_err = L->d_work, L->d_cnt = L->d_work + 4;
+    GFFX_HIP_TRY(hipHostMalloc((void **)&L->h_cnt, 64, hipHostMallocCoherent | hipHostMallocMapped));
+    L->h_cnt[0] = L->h_cnt[1] = 0;
     GFFX_HIP_TRY(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&L->ev_a, &L->ev_b, &L->ev_p0, &L->ev_p1}) GFFX_HIP_TRY(hipEventCreate(e));
     if (n_lines) {
@@ -505,7 +638,6 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
     return GFFX_OK;
 }
 
-constexpr int kSortPassesMax = 4 + 4;  // the coordinate's four bytes + up to four of the seqid
 
 static int lines_reserve(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq) {
     int rc;
@@ -530,10 +662,12 @@ static int lines_reserve(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq) {
         if ((rc = regrow(&L->d_qoff, cap + 1)) || (rc = regrow(&L->d_meta, cap))) return rc;
         L->cap_seq = cap;
     }
-    const uint64_t want_work = DeviceSort::work_words(L->cap_q, kSortPassesMax);
+    // d_err (4 words) and d_cnt (4) sit in front of the sort's work space: ONE memset clears them and the sort's head
+    const uint64_t want_work = kWorkFront + DeviceSort::work_words(L->cap_q, kSortPassesMax);
     if (want_work > L->cap_work) {
         if ((rc = regrow(&L->d_work, want_work))) return rc;
         L->cap_work = want_work;
+        L->d_err = L->d_work, L->d_cnt = L->d_work + 4;
     }
     return GFFX_OK;
 }
@@ -542,10 +676,17 @@ template <int MODE>
 static void launch_lines(gffx_hip_lines *L, const RegionsView &rv) {
     const LinesView lv{L->d_seq, L->d_start, L->d_end, (unsigned long long)L->n};
     const unsigned blocks = (unsigned)((L->n + 255) / 256);
-    if (rv.n_seq <= kMetaLds)
-        hipLaunchKernelGGL((k_lines_exists<MODE, true>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
-    else
-        hipLaunchKernelGGL((k_lines_exists<MODE, false>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+    constexpr bool kOverlap = MODE == GFFX_MODE_OVERLAP;
+    if (kOverlap && rv.n_deg) {
+        if (rv.n_seq <= kMetaLds)
+            hipLaunchKernelGGL((k_lines_exists<MODE, true, kOverlap>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+        else
+            hipLaunchKernelGGL((k_lines_exists<MODE, false, kOverlap>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+    } else if (rv.n_seq <= kMetaLds) {
+        hipLaunchKernelGGL((k_lines_exists<MODE, true, false>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+    } else {
+        hipLaunchKernelGGL((k_lines_exists<MODE, false, false>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+    }
 }
 
 // Region tables from the records in d_rec_a (AoS {seqid, qs, qe}, any order), then k_lines_exists.
@@ -558,35 +699,52 @@ static int lines_run(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int mode, u
     for (int b = 0; b < seq_bytes; ++b) p1.word[p1.n_passes] = 0, p1.shift[p1.n_passes++] = (uint8_t)(8 * b);
     p2 = p1;
     GFFX_HIP_TRY(hipEventRecord(L->ev_p0, L->stream));
-    GFFX_HIP_TRY(hipMemsetAsync(L->d_err, 0, 16, L->stream));
-    GFFX_HIP_TRY(hipMemsetAsync(L->d_cnt, 0, 16, L->stream));
+    GFFX_HIP_TRY(hipMemsetAsync(L->d_work, 0, (kWorkFront + (nq ? DeviceSort::head_words(p1.n_passes) : 0)) * 4, L->stream));  // d_err, d_cnt, the sort's head
     L->d_de = nullptr;
     L->last_n_deg = 0;
     L->last_deg_known = false;
     if (nq) {
-        const uint32_t n_blocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock), g256 = (uint32_t)((n + 255) / 256);
+        const uint32_t n_blocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
         const size_t stride = L->cap_blocks + 1;
         uint32_t *c = L->d_carry;
         const BlockCarry C{c, c + stride, c + 2 * stride, c + 3 * stride, c + 4 * stride, c + 5 * stride, c + 6 * stride, c + 7 * stride, c + 8 * stride};
         uint32_t *s1 = nullptr;
-        int rc = DeviceSort::run<3>(L->stream, L->d_rec_a, L->d_rec_b, n, p1, n_seq, L->d_work, L->d_err, &s1);
+        // Only Overlap looks at the ends of the regions with start > end, and how many there are decides what is launched
+        // after the table kernels: the histogram kernel counts them, and the host reads the count while the passes run.
+        const bool want_deg = mode == GFFX_MODE_OVERLAP;
+        const uint32_t note_seq = ++L->note_seq;
+        int rc = DeviceSort::run<3>(L->stream, L->d_rec_a, L->d_rec_b, n, p1, n_seq, L->d_work + kWorkFront, L->d_err, &s1,
+                                    want_deg ? SortNote{L->d_cnt + 2, L->h_cnt, note_seq} : SortNote{nullptr, nullptr, 0}, true);
         if (rc) return rc;
         uint32_t *other = s1 == L->d_rec_a ? L->d_rec_b : L->d_rec_a;
-        hipLaunchKernelGGL(k_b_local, dim3(n_blocks), dim3(kScanBlock), 0, L->stream, s1, n, n_seq, L->d_T, L->d_qoff, C);
+        hipLaunchKernelGGL(k_b_local, dim3(n_blocks), dim3(kLocalThreads), 0, L->stream, s1, n, n_seq, L->d_T, L->d_qoff, C);
         hipLaunchKernelGGL(k_b_carry, dim3(1), dim3(kScanBlock), 0, L->stream, n_blocks, C, L->d_qoff, L->d_T, n_seq, L->d_meta, L->d_cnt);
-        hipLaunchKernelGGL(k_b_finish, dim3(g256), dim3(256), 0, L->stream, s1, n, n_seq, L->d_T, C, L->d_meta, L->d_dir, other, L->d_cnt);
+        hipLaunchKernelGGL(k_b_finish, dim3(n_blocks), dim3(kLocalThreads), 0, L->stream, s1, n, n_seq, L->d_T, C, L->d_meta, L->d_dir, other, L->d_cnt);
         GFFX_HIP_TRY(hipGetLastError());
-        if (mode == GFFX_MODE_OVERLAP) {
-            // only Overlap looks at the degenerate regions' ends; how many there are decides what is launched next
-            GFFX_HIP_TRY(hipMemcpyAsync(L->h_cnt, L->d_cnt, 16, hipMemcpyDeviceToHost, L->stream));
-            GFFX_HIP_TRY(hipStreamSynchronize(L->stream));
-            const uint32_t n_deg = L->h_cnt[0];
+        if (want_deg) {
+            // (posted by the histogram kernel ~0.1 ms ago; should the note never arrive, the stream itself is the clock)
+            const auto t0 = std::chrono::steady_clock::now();
+            bool posted = false;
+            unsigned long long word = 0;
+            while (!(posted = (uint32_t)((word = __atomic_load_n(reinterpret_cast<unsigned long long *>(L->h_cnt), __ATOMIC_ACQUIRE)) >> 32) == note_seq) &&
+                   std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2))
+                std::this_thread::yield();
+            uint32_t n_deg = (uint32_t)word;
+            if (!posted) {
+                GFFX_HIP_TRY(hipStreamSynchronize(L->stream));
+                GFFX_HIP_TRY(hipMemcpy(&n_deg, L->d_cnt + 2, 4, hipMemcpyDeviceToHost));
+            }
             L->last_n_deg = n_deg;
             L->last_deg_known = true;
             if (n_deg) {
                 uint32_t *sd = nullptr;
-                if ((rc = DeviceSort::run<2>(L->stream, other, s1, n_deg, p2, n_seq, L->d_work, L->d_err, &sd))) return rc;
-                hipLaunchKernelGGL(k_b_deg_ranges, dim3((n_deg + 255) / 256), dim3(256), 0, L->stream, sd, n_deg, n_seq, L->d_meta);
+                if ((rc = DeviceSort::run<2>(L->stream, other, s1, n_deg, p2, n_seq, L->d_work + kWorkFront, L->d_err, &sd))) return rc;
+                if (L->cap_dird < L->cap_dir) {  // (only a run with degenerate regions ever pays for their directory)
+                    GFFX_HIP_TRY(hipStreamSynchronize(L->stream));
+                    if ((rc = regrow(&L->d_dird, L->cap_dir))) return rc;
+                    L->cap_dird = L->cap_dir;
+                }
+                hipLaunchKernelGGL(k_b_deg_ranges, dim3((n_deg + 255) / 256), dim3(256), 0, L->stream, sd, n_deg, n_seq, L->d_meta, L->d_dird);
                 GFFX_HIP_TRY(hipGetLastError());
                 L->d_de = sd;
             }
@@ -597,7 +755,7 @@ static int lines_run(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int mode, u
     }
     GFFX_HIP_TRY(hipEventRecord(L->ev_p1, L->stream));
     if (L->n) {
-        const RegionsView rv{L->d_T, L->d_dir, L->d_meta, L->d_de, n_seq, L->last_n_deg};
+        const RegionsView rv{L->d_T, L->d_dir, L->d_meta, L->d_de, L->d_dird, n_seq, L->last_n_deg};
         GFFX_HIP_TRY(hipEventRecord(L->ev_a, L->stream));
         if (mode == GFFX_MODE_CONTAINED)
             launch_lines<GFFX_MODE_CONTAINED>(L, rv);

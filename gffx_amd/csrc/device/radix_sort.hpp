@@ -20,12 +20,18 @@
 // Stability: wave w of a tile ranks records [1024 w, 1024 w + 1024) in order (step j holds records j*64 + lane), waves and
 // tiles are prefix-summed in order; the LDS reorder keeps the rank order inside a byte's run.  Roofline bound: HBM, 8 W bytes per record and pass.
 #pragma once
+#include <type_traits>
+
 #include "gffx_device.hpp"
 
 namespace gffx {
 
 constexpr int kSortThreads = 256;
-constexpr int kSortItems = 16;
+#ifndef GFFX_SORT_ITEMS
+#define GFFX_SORT_ITEMS 16
+#endif
+constexpr int kSortItems = GFFX_SORT_ITEMS;
+constexpr int kHistThreads = 1024;
 constexpr uint32_t kSortTile = kSortThreads * kSortItems;  // 4096 records (48 KB of LDS for the reorder)
 constexpr int kSortMaxPasses = 12;
 constexpr uint32_t kSortFlagAgg = 1u << 30, kSortFlagPrefix = 2u << 30, kSortValueMask = (1u << 30) - 1;
@@ -36,19 +42,31 @@ struct SortPlan {
     uint8_t shift[kSortMaxPasses];  // which byte (bit shift)
 };
 
-// histograms of every pass in one read: hist[p * 256 + byte]; err bit1 = word 0 of a record >= limit0 (seqid out of range)
+// histograms of every pass in one read: hist[p * 256 + byte]; err bit1 = word 0 of a record >= limit0 (seqid out of range);
+// note.inverted (W = 3, may be NULL): += the records with word 1 > word 2 (Join B's regions with start > end); with note.note
+// (pinned host memory) k_radix_scan, the next kernel, posts {inverted total, note_seq} there, so the host learns the count while
+// the passes run.  The kernel also clears the passes' status words (zero[0 .. zero_words)).
+struct SortNote {
+    uint32_t *inverted, *note;
+    uint32_t note_seq;
+};
 template <int W>
-__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t *rec, unsigned long long n, SortPlan plan, uint32_t *hist,
-                                                    uint32_t limit0, uint32_t *err) {
+__global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec, unsigned long long n, SortPlan plan, uint32_t *hist,
+                                                    uint32_t limit0, uint32_t *err, SortNote note, uint32_t *zero, unsigned long long zero_words) {
     __shared__ uint32_t s_h[kSortMaxPasses * 256];
-    for (int i = threadIdx.x; i < plan.n_passes * 256; i += 256) s_h[i] = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kHistThreads + threadIdx.x; i < zero_words; i += (unsigned long long)gridDim.x * kHistThreads)
+        zero[i] = 0u;
+    uint32_t *inverted = note.inverted;
+    for (int i = threadIdx.x; i < plan.n_passes * 256; i += kHistThreads) s_h[i] = 0;
     __syncthreads();
     bool bad = false;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+    uint32_t n_inv = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kHistThreads + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kHistThreads) {
         uint32_t w[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) w[k] = rec[W * i + k];
         bad |= w[0] >= limit0;
+        if (W == 3 && w[1] > w[W - 1]) n_inv++;
         for (int p = 0; p < plan.n_passes; ++p) {
             const uint32_t d = (w[plan.word[p]] >> plan.shift[p]) & 255u;
             // a byte that is the same in the whole wave (high bytes of coordinates, seqids of a sorted BED) is one add
@@ -62,14 +80,26 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t *rec, unsigne
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < plan.n_passes * 256; i += 256)
+    for (int i = threadIdx.x; i < plan.n_passes * 256; i += kHistThreads)
         if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
     if (bad) atomicOr(err, 2u);
+    if (W == 3 && inverted) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n_inv += __shfl_down(n_inv, o, 64);
+        if ((threadIdx.x & 63) == 0 && n_inv) atomicAdd(inverted, n_inv);
+    }
 }
 
 // exclusive scan of each pass's 256 bins (block p = pass p); same_byte[p] = 1 when one bin holds all n records
-__global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned long long n, uint32_t *same_byte) {
+__global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned long long n, uint32_t *same_byte, SortNote note) {
     __shared__ uint32_t s_w[4];
+    if (note.note && blockIdx.x == 0 && threadIdx.x == 0) {
+        // ONE relaxed 8-byte store {count, seq}: both values come from registers (the count was complete when the histogram
+        // kernel ended), so nothing has to be released -- a fence here would write the L2 back
+        const uint32_t total = __hip_atomic_load(note.inverted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(note.note), (unsigned long long)total | ((unsigned long long)note.note_seq << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     uint32_t *h = hist + blockIdx.x * 256;
     const uint32_t v = h[threadIdx.x];
     if (v == n) same_byte[blockIdx.x] = 1u;
@@ -91,8 +121,8 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned lon
 // The tile is reordered in LDS first (digit by digit, stable), so that a wave's 64 consecutive stores cover a few runs of
 // consecutive global records instead of 64 scattered 8- or 12-byte writes.
 constexpr int kSortLookBack = 4;
-template <int W>
-__global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in, uint32_t *out, unsigned long long n, int word,
+template <int W, int WORD>
+__global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in, uint32_t *out, unsigned long long n,
                                                              int shift, const uint32_t *bin_start, const uint32_t *same_byte,
                                                              uint32_t *status, uint32_t *ticket, uint32_t *err) {
     __shared__ uint32_t s_cnt[kSortThreads / 64][256];  // per wave: records of the byte so far; then: first rank of the wave's run
@@ -115,24 +145,21 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     const unsigned long long tile_i = (unsigned long long)tile * kSortTile;
     const unsigned long long base_i = tile_i + (unsigned long long)wave * (64 * kSortItems);
     const uint32_t n_tile = (uint32_t)min((unsigned long long)kSortTile, n - tile_i);
-    uint32_t r[W][kSortItems], rank[kSortItems];
+    uint32_t r[W][kSortItems], rank[kSortItems], dig[kSortItems / 4];  // dig: the records' bytes, four per register
+#pragma unroll
+    for (int j = 0; j < kSortItems / 4; ++j) dig[j] = 0;
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
         const unsigned long long i = base_i + j * 64 + lane;
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k][j] = i < n ? in[W * i + k] : 0u;
+        dig[j / 4] |= ((r[WORD][j] >> shift) & 255u) << (8 * (j % 4));
     }
-    auto key_of = [&](int j) -> uint32_t {
-        uint32_t key = r[0][j];
-#pragma unroll
-        for (int k = 1; k < W; ++k) key = word == k ? r[k][j] : key;
-        return (key >> shift) & 255u;
-    };
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
         const bool valid = base_i + j * 64 + lane < n;
-        const uint32_t d = key_of(j);
+        const uint32_t d = (dig[j / 4] >> (8 * (j % 4))) & 255u;
         unsigned long long peers = __ballot(valid);  // lanes of this step with my byte
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -176,21 +203,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
             for (int k = 0; k < kSortLookBack; ++k)  // (tile 0 always carries the prefix flag: nothing below it is ever needed)
                 v[k] = __hip_atomic_load(status + (size_t)(t > (uint32_t)k ? t - 1 - k : 0) * 256 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int k = 0; k < kSortLookBack; ++k) {
-                if (done) break;
-                const uint32_t *ps = status + (size_t)(t - 1 - k) * 256 + d;
-                uint32_t x = v[k];
-                for (uint32_t spin = 0; !(x >> 30) && spin < (1u << 26); ++spin) {
-                    __builtin_amdgcn_s_sleep(1);
-                    x = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < kSortLookBack; ++k) {  // (no break: the loop stays unrolled and v[] in registers)
+                if (!done) {
+                    const uint32_t *ps = status + (size_t)(t - 1 - k) * 256 + d;
+                    uint32_t x = v[k];
+                    for (uint32_t spin = 0; !(x >> 30) && spin < (1u << 26); ++spin) {
+                        __builtin_amdgcn_s_sleep(1);
+                        x = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (!(x >> 30)) atomicOr(err, 4u);  // an earlier tile never published: give up loudly instead of spinning forever
+                    excl += x & kSortValueMask;
+                    done = (x >> 30) != 1u || t - 1 - k == 0;
                 }
-                if (!(x >> 30)) {  // an earlier tile never published: give up loudly instead of spinning forever
-                    atomicOr(err, 4u);
-                    done = true;
-                    break;
-                }
-                excl += x & kSortValueMask;
-                if ((x >> 30) == 2u || t - 1 - k == 0) done = true;
             }
             t -= done ? 0 : kSortLookBack;
         }
@@ -205,7 +229,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {  // into LDS at the record's place inside the byte-sorted tile
         if (base_i + j * 64 + lane >= n) continue;
-        const uint32_t d = key_of(j);
+        const uint32_t d = (dig[j / 4] >> (8 * (j % 4))) & 255u;
         const uint32_t lp = s_dstart[d] + s_cnt[wave][d] + rank[j];
 #pragma unroll
         for (int k = 0; k < W; ++k) s_rec[W * lp + k] = r[k][j];
@@ -215,10 +239,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         uint32_t w[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) w[k] = s_rec[W * x + k];
-        uint32_t key = w[0];
-#pragma unroll
-        for (int k = 1; k < W; ++k) key = word == k ? w[k] : key;
-        const uint32_t d = (key >> shift) & 255u;
+        const uint32_t d = (w[WORD] >> shift) & 255u;
         const unsigned long long pos = (unsigned long long)s_base[d] + (x - s_dstart[d]);
 #pragma unroll
         for (int k = 0; k < W; ++k) out[W * pos + k] = w[k];
@@ -226,30 +247,37 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
 }
 
 // Sorts n W-word records stably by the passes of `plan`.  buf_a holds the input; the result is in *sorted (buf_a or
-// buf_b).  work: work_words(n, n_passes) u32 words, zeroed here.  Everything is enqueued on `stream`.
+// buf_b).  work: work_words(n, n_passes) u32 words; its head (histograms, tickets, flags: head_words) is cleared by one small
+// memset (or by the caller: head_is_clear), the status words by the histogram kernel.  Everything is enqueued on `stream`.
 struct DeviceSort {
+    // (a multiple of 64 words: one fill kernel, no unaligned tail)
+    static size_t head_words(int n_passes) { return ((size_t)n_passes * 256 + 2 * (size_t)n_passes + 16 + 63) / 64 * 64; }
     static size_t work_words(unsigned long long n, int n_passes) {
         const size_t tiles = (size_t)((n + kSortTile - 1) / kSortTile);
-        return (size_t)n_passes * 256 + tiles * (size_t)n_passes * 256 + 16 + 2 * (size_t)n_passes;
+        return head_words(n_passes) + tiles * (size_t)n_passes * 256;
     }
+    // note: {device counter of the records with word 1 > word 2, pinned host words {count, seq}, seq} or all NULL
     template <int W>
     static int run(hipStream_t stream, uint32_t *buf_a, uint32_t *buf_b, unsigned long long n, const SortPlan &plan, uint32_t limit0,
-                   uint32_t *work, uint32_t *err, uint32_t **sorted) {
+                   uint32_t *work, uint32_t *err, uint32_t **sorted, SortNote note = SortNote{nullptr, nullptr, 0},
+                   bool head_is_clear = false) {
         *sorted = buf_a;
         if (n == 0) return GFFX_OK;
         if (n >= (1ull << 30)) return fail(GFFX_E_INVALID, "device sort: %llu records exceed the limit of 2^30 - 1", n);
         const size_t tiles = (size_t)((n + kSortTile - 1) / kSortTile);
-        GFFX_HIP_TRY(hipMemsetAsync(work, 0, work_words(n, plan.n_passes) * 4, stream));
+        if (!head_is_clear) GFFX_HIP_TRY(hipMemsetAsync(work, 0, head_words(plan.n_passes) * 4, stream));
         uint32_t *hist = work, *tickets = work + (size_t)plan.n_passes * 256, *same = tickets + plan.n_passes,
-                 *status = same + plan.n_passes + 16;
+                 *status = work + head_words(plan.n_passes);
         // (few blocks: every block ends with one global atomic per non-empty bin and pass)
         const uint32_t hgrid = (uint32_t)std::max<unsigned long long>(1, std::min<unsigned long long>((n + 4095) / 4096, 256));
-        hipLaunchKernelGGL(k_radix_hist<W>, dim3(hgrid), dim3(256), 0, stream, buf_a, n, plan, hist, limit0, err);
-        hipLaunchKernelGGL(k_radix_scan, dim3(plan.n_passes), dim3(256), 0, stream, hist, n, same);
+        hipLaunchKernelGGL(k_radix_hist<W>, dim3(hgrid), dim3(kHistThreads), 0, stream, buf_a, n, plan, hist, limit0, err, note, status,
+                           (unsigned long long)(tiles * (size_t)plan.n_passes * 256));
+        hipLaunchKernelGGL(k_radix_scan, dim3(plan.n_passes), dim3(256), 0, stream, hist, n, same, note);
         uint32_t *src = buf_a, *dst = buf_b;
         for (int p = 0; p < plan.n_passes; ++p) {
-            hipLaunchKernelGGL(k_radix_pass<W>, dim3((uint32_t)tiles), dim3(kSortThreads), 0, stream, src, dst, n, (int)plan.word[p],
-                               (int)plan.shift[p], hist + (size_t)p * 256, same + p, status + (size_t)p * tiles * 256, tickets + p, err);
+            auto *pass = plan.word[p] == 0 ? k_radix_pass<W, 0> : plan.word[p] == 1 ? k_radix_pass<W, 1> : k_radix_pass<W, W - 1>;
+            hipLaunchKernelGGL(pass, dim3((uint32_t)tiles), dim3(kSortThreads), 0, stream, src, dst, n, (int)plan.shift[p],
+                               hist + (size_t)p * 256, same + p, status + (size_t)p * tiles * 256, tickets + p, err);
             std::swap(src, dst);
         }
         GFFX_HIP_TRY(hipGetLastError());
