@@ -773,9 +773,10 @@ def join_b_leg(engine, synth, roots, regions, mode):
         prep.append(1e3 * lt.last_prep_ms)
     avg = float(np.mean(us))
     out = {"kernel": "k_lines_exists", "avg_us": avg, "prep_us": float(np.mean(prep)), "lines": int(lt.n), "regions": int(len(regions)),
-           "lines_per_s": lt.n / (avg * 1e-6), "achieved_GBps": 13.0 * lt.n / (avg * 1e-6) / 1e9, "kept_lines": int(kept.sum()),
+           "lines_per_s": lt.n / (avg * 1e-6), "achieved_GBps": 13.0 * lt.n / (avg * 1e-6) / 1e9,
+           "frac_of_hbm_peak": 13.0 * lt.n / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "kept_lines": int(kept.sum()),
            "note": "13 B per line (seq, start, end in; keep flag out); prep_us = the region tables built on the device per call "
-                   "(k_radix_hist/_pass x 14, segmented scans, directories; was ~10 ms on the host)"}
+                   "(one stable radix sort by (seqid, start): k_radix_hist + 5 x k_radix_pass, then k_b_local / _carry / _finish)"}
     lt.close()
     return out
 

@@ -30,6 +30,15 @@ constexpr int kSortThreads = 256;
 #ifndef GFFX_SORT_ITEMS
 #define GFFX_SORT_ITEMS 16
 #endif
+#ifndef GFFX_SORT_RANK_ATOMIC
+#define GFFX_SORT_RANK_ATOMIC 1
+#endif
+#ifndef GFFX_SORT_LOOKBACK
+#define GFFX_SORT_LOOKBACK 4
+#endif
+#ifndef GFFX_SORT_ABL
+#define GFFX_SORT_ABL 0  // timing ablations (wrong results): 1 no look-back, 2 no ranking, 3 no global stores, 4 no global loads
+#endif
 constexpr int kSortItems = GFFX_SORT_ITEMS;
 constexpr int kHistThreads = 1024;
 constexpr uint32_t kSortTile = kSortThreads * kSortItems;  // 4096 records (48 KB of LDS for the reorder)
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned lon
 // one LSD pass: in -> out, stable by byte (word, shift).  status: n_tiles x 256 words, zero on entry; ticket: zero on entry.
 // The tile is reordered in LDS first (digit by digit, stable), so that a wave's 64 consecutive stores cover a few runs of
 // consecutive global records instead of 64 scattered 8- or 12-byte writes.
-constexpr int kSortLookBack = 4;
+constexpr int kSortLookBack = GFFX_SORT_LOOKBACK;
 template <int W, int WORD>
 __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in, uint32_t *out, unsigned long long n,
                                                              int shift, const uint32_t *bin_start, const uint32_t *same_byte,
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     for (int j = 0; j < kSortItems; ++j) {
         const unsigned long long i = base_i + j * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < W; ++k) r[k][j] = i < n ? in[W * i + k] : 0u;
+        for (int k = 0; k < W; ++k) r[k][j] = GFFX_SORT_ABL == 4 ? (uint32_t)(i * 2654435761u + k) : (i < n ? in[W * i + k] : 0u);
         dig[j / 4] |= ((r[WORD][j] >> shift) & 255u) << (8 * (j % 4));
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -160,6 +169,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     for (int j = 0; j < kSortItems; ++j) {
         const bool valid = base_i + j * 64 + lane < n;
         const uint32_t d = (dig[j / 4] >> (8 * (j % 4))) & 255u;
+#if GFFX_SORT_ABL == 2
+        rank[j] = 0;
+        continue;
+#endif
         unsigned long long peers = __ballot(valid);  // lanes of this step with my byte
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -168,10 +181,16 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         }
         uint32_t pre = 0;
         const int leader = __ffsll((long long)peers) - 1;
+#if GFFX_SORT_RANK_ATOMIC
+        // one returning LDS add per distinct byte and step: the LDS runs a wave's operations in order, so the sixteen steps'
+        // adds queue up back to back instead of waiting for a read-modify-write round trip each
+        if (valid && lane == leader) pre = atomicAdd(&s_cnt[wave][d], (uint32_t)__popcll(peers));
+#else
         if (valid && lane == leader) {
             pre = s_cnt[wave][d];
             s_cnt[wave][d] = pre + (uint32_t)__popcll(peers);
         }
+#endif
         pre = __shfl(pre, leader < 0 ? 0 : leader, 64);
         rank[j] = pre + (uint32_t)__popcll(peers & lt);
     }
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         uint32_t *st = status + (size_t)tile * 256 + d;
         __hip_atomic_store(st, total | (tile == 0 ? kSortFlagPrefix : kSortFlagAgg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
-        bool done = tile == 0;
+        bool done = tile == 0 || GFFX_SORT_ABL == 1;
         for (uint32_t t = tile; !done;) {  // t = the nearest tile not yet summed + 1
             uint32_t v[kSortLookBack];
 #pragma unroll
@@ -230,7 +249,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     for (int j = 0; j < kSortItems; ++j) {  // into LDS at the record's place inside the byte-sorted tile
         if (base_i + j * 64 + lane >= n) continue;
         const uint32_t d = (dig[j / 4] >> (8 * (j % 4))) & 255u;
-        const uint32_t lp = s_dstart[d] + s_cnt[wave][d] + rank[j];
+        uint32_t lp = s_dstart[d] + s_cnt[wave][d] + rank[j];
+        if (GFFX_SORT_ABL) lp = min(lp, kSortTile - 1);
 #pragma unroll
         for (int k = 0; k < W; ++k) s_rec[W * lp + k] = r[k][j];
     }
@@ -240,7 +260,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
 #pragma unroll
         for (int k = 0; k < W; ++k) w[k] = s_rec[W * x + k];
         const uint32_t d = (w[WORD] >> shift) & 255u;
-        const unsigned long long pos = (unsigned long long)s_base[d] + (x - s_dstart[d]);
+        unsigned long long pos = (unsigned long long)s_base[d] + (x - s_dstart[d]);
+        if (GFFX_SORT_ABL) pos = min(pos, n - 1);
+        if (GFFX_SORT_ABL == 3 && w[0] != 0xFFFFFFF0u) continue;
 #pragma unroll
         for (int k = 0; k < W; ++k) out[W * pos + k] = w[k];
     }
