@@ -157,7 +157,7 @@ def _host_tables(regions, n_seq):
 
 
 @pytest.mark.parametrize("case", ["tiny", "ties", "tile_edges", "many_seqids", "extremes", "one_seqid_small_coords", "all_degenerate",
-                                  "no_degenerate", "bed_1m"])
+                                  "no_degenerate", "bed_1m", "bed_3m_mixed"])
 def test_device_region_tables_equal_the_host_definition(case):
     """The device preparation (stable radix sort by (seqid, start), segmented running max / min, degenerate counts, the bin
     directory, the sorted ends of the start > end regions: radix_sort.hpp, join_b.hip) gives bit-identical tables to the
@@ -190,6 +190,10 @@ def test_device_region_tables_equal_the_host_definition(case):
         n_seq, n = 6, 40000
         p = rng.integers(0, 1 << 22, n)
         regions = np.stack([rng.integers(0, n_seq, n), p, p + rng.integers(0, 1000, n)], axis=1).astype(np.uint32)
+    elif case == "bed_3m_mixed":  # > 1024 blocks of 1024 regions: k_b_carry walks its carries in several chunks; 3 % start > end
+        n_seq, regions = 25, synth.synth_bed(3_000_000, seed=1005).copy()
+        sel = rng.random(len(regions)) < 0.03
+        regions[sel, 2] = regions[sel, 1] - rng.integers(1, 500, int(sel.sum())).astype(np.uint32).clip(0, regions[sel, 1])
     else:
         n_seq, regions = 25, synth.synth_bed(1_000_000, seed=1001)
     lt = engine.LineTable(np.zeros(4, np.uint32), np.arange(4, dtype=np.uint32), np.arange(4, dtype=np.uint32) + 3)
@@ -205,6 +209,17 @@ def test_device_region_tables_equal_the_host_definition(case):
     if case == "bed_1m":
         assert lt.last_prep_ms < 5.0, lt.last_prep_ms  # (the host preparation it replaces took ~10 ms per 1 M regions)
     lt.close()
+    if case == "bed_3m_mixed":  # ... and the flags those tables give, against the literal scan on sampled lines
+        n_lines = 200_000
+        seq = rng.integers(0, n_seq, n_lines).astype(np.uint32)
+        s = rng.integers(0, 150_000_000, n_lines).astype(np.uint32)
+        e = (s + rng.integers(-3, 3000, n_lines)).clip(0).astype(np.uint32)
+        lt = engine.LineTable(seq, s, e)
+        sel = rng.choice(n_lines, 300, replace=False)
+        for mode in OverlapMode:
+            got = lt.test(regions, n_seq, mode)
+            assert np.array_equal(got[sel], _oracle_keep(seq[sel], s[sel], e[sel], regions, n_seq, mode)), mode
+        lt.close()
 
 
 def test_lines_test_on_the_regions_join_a_uploaded():

@@ -10,7 +10,7 @@ subprocess.run([G, "index", "-i", gff], check=True)
 n = 100_000_000
 bed = d + "/q.bed"
 synth.write_bed_fast(bed, synth.synth_bed(n, seed=1003), roots["names"])
-for flags in (["-e", "-t", "64"], ["-e", "-t", "128"], ["-t", "64"], ["-t", "128"], ["-e", "-t", "64", "-v"]):
+for flags in (["-e", "-t", "64"], ["-t", "64"], ["-e", "-t", "64", "-v"], ["-t", "64", "-v"]):
     best = None
     for rep in range(3):
         t0 = time.perf_counter()
