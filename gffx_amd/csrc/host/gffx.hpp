@@ -74,9 +74,10 @@ struct CommonArgs {  // common.rs:17-52
     std::optional<std::string> types;   // -T/--types
     size_t threads = 12;                // -t/--threads
     bool verbose = false;               // -v/--verbose
-    size_t effective_threads() const;   // common.rs:59-67
+    size_t effective_threads() const;   // common.rs:59-67 (an explicit -t is capped at twice available_parallelism())
 };
 
+size_t available_parallelism();  // affinity mask and cgroup CPU quota, as Rust's std::thread::available_parallelism
 std::string append_suffix(const std::string &path, const std::string &suffix);  // common.rs:123-127
 bool check_index_files_exist(const std::string &gff);                           // common.rs:151-170
 
