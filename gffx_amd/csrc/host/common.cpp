@@ -43,11 +43,12 @@ size_t available_parallelism() {
 // common.rs:59-67.  `-t 0` = available_parallelism(), as there.  An explicit `-t N` is the user's number up to twice the CPUs
 // the process may use: beyond that the extra threads of the parsers only add context switches -- and, under a cgroup quota,
 // throttling (GPU box, quota 16 CPUs of 256: `-t 64` parsed a 100 M-row BED 20 % slower than `-t 16`).
-size_t CommonArgs::effective_threads() const {
+size_t capped_threads(size_t requested) {
     static const size_t avail = available_parallelism();
-    if (threads == 0) return avail;
-    return std::min(threads, 2 * avail);
+    if (requested == 0) return avail;
+    return std::min(requested, 2 * avail);
 }
+size_t CommonArgs::effective_threads() const { return capped_threads(threads); }
 
 std::string append_suffix(const std::string &path, const std::string &suffix) {
     // parent.join(filename + suffix) == path + suffix for every path with a file name

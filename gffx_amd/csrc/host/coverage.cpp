@@ -76,7 +76,7 @@ void run(const CoverageArgs &args) {
         throw Error("BAM/SAM/CRAM sources need htslib, which this build does not carry; use a .bed source");
     if (ext != "bed")
         throw Error("Unsupported file type: \"" + args.source + "\". Expected .bam/.sam/.cram or .bed");  // :535-540
-    const std::vector<intersect::Region> regions = depth::parse_bed_rows(args.source, index_data.seqid_to_num, args.threads);  // :230-256
+    const std::vector<intersect::Region> regions = depth::parse_bed_rows(args.source, index_data.seqid_to_num, capped_threads(args.threads));  // :230-256
     if (verbose) std::fprintf(stderr, "[INFO] %zu BED rows kept\n", regions.size());
     timer.lap("Loading index + parsing BED");
 
@@ -87,7 +87,7 @@ void run(const CoverageArgs &args) {
         const std::vector<uint32_t> hit_roots =
             intersect::query_unique_roots(index_data, regions, intersect::OverlapMode::Overlap, false, verbose, args.device);
         timer.lap("Join A on the device (root bitmap)");
-        const depth::BlockTable t = depth::load_or_build_block_table(args.input, gof, gff.view(), args.threads, verbose);
+        const depth::BlockTable t = depth::load_or_build_block_table(args.input, gof, gff.view(), capped_threads(args.threads), verbose);
         timer.lap("Line table (image or parse)");
         // the tree intervals of every root_fid (several when root lines share an ID)
         const uint32_t n_seq = static_cast<uint32_t>(index_data.chr_offsets.size() - 1);
@@ -210,7 +210,7 @@ void run(const CoverageArgs &args) {
                 r.b += breadth[g];
             }
         }
-        append_rows_parallel(out, order.size(), args.threads, [&](size_t k, std::string &o) {  // coverage.rs:465-473
+        append_rows_parallel(out, order.size(), capped_threads(args.threads), [&](size_t k, std::string &o) {  // coverage.rs:465-473
             const uint32_t i = order[k];
             const Row &r = rows[i];
             const uint64_t length = r.e > r.s ? r.e - r.s : 0;

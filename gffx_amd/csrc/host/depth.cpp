@@ -11,6 +11,10 @@
 #include <cstdio>
 #include <thread>
 
+#include <atomic>
+#include <cstring>
+
+#include "fast_fields.hpp"
 #include "gffx.hpp"
 
 namespace gffx {
@@ -44,12 +48,60 @@ std::string_view trim_end_unicode_ws(std::string_view s) {  // str::trim_end()
 
 // depth.rs:450-495: lines are cut at '\n' and keep it; fields split on tab or space, empty ones dropped;
 // fewer than 3 fields, '#', a non-UTF-8 / unparsable field, s >= e or an unknown seqid drop the row.
+// Rows out as flat (seqid number, start, end) words -- what the device reads.
 namespace {
 void parse_rows_chunk(std::string_view d, size_t pos, size_t z, const std::unordered_map<std::string, uint32_t> &seqid_to_num,
-                      std::vector<intersect::Region> &out) {
+                      const ShortNameTable &short_names, std::vector<uint32_t> &out) {
     std::string key;
     const std::pair<const std::string, uint32_t> *hit = nullptr;  // the seqid of the previous row, usually this row's too
+    // rows of the word-at-a-time path wait here, 64 at a time; every other way through a line flushes first (file order)
+    uint32_t pend[192];
+    size_t n_pend = 0;
+    auto flush = [&] {
+        out.insert(out.end(), pend, pend + n_pend);
+        n_pend = 0;
+    };
+    const char *base = d.data();
     while (pos < z) {
+        // The plainest row -- a name of 1-7 bytes (0x21..0x7F), TAB, 1-9 digits, TAB, 1-9 digits, then the line's end, CR LF or
+        // more tab / space separated columns -- eight bytes at a time (fast_fields.hpp); anything else takes the loop below.
+        if (pos + 48 <= d.size()) {  // (every load below stays inside the text)
+            const char *q = base + pos;
+            const uint64_t nw = load8(q);
+            const unsigned nl = first_below_21(nw);
+            if (nl >= 1 && nl <= 7 && q[nl] == '\t' && q[0] != '#') {
+                const uint64_t word = nw & ((1ull << (8 * nl)) - 1);
+                uint32_t v1 = 0, v2 = 0;
+                const char *p1 = q + nl + 1;
+                const unsigned n1 = (word & 0x8080808080808080ull) ? 0 : digits_1_to_9(p1, v1);
+                if (n1 && p1[n1] == '\t') {
+                    const char *p2 = p1 + n1 + 1;
+                    const unsigned n2 = digits_1_to_9(p2, v2);
+                    const char *e = p2 + n2;
+                    size_t next = 0;
+                    if (n2 && e < base + z) {
+                        if (*e == '\n') {
+                            next = static_cast<size_t>(e - base) + 1;
+                        } else if (*e == '\r' && e[1] == '\n') {  // (the CR is the tail of field 3: str::trim_end takes it off)
+                            next = static_cast<size_t>(e - base) + 2;
+                        } else if (*e == '\t' || *e == ' ') {  // more columns: nothing in them matters
+                            const char *nlp = static_cast<const char *>(std::memchr(e, '\n', static_cast<size_t>(base + z - e)));
+                            next = nlp ? static_cast<size_t>(nlp - base) + 1 : z;
+                        }
+                    }
+                    if (next) {
+                        uint32_t id;
+                        if (v1 < v2 && short_names.find(word, id)) {
+                            pend[n_pend] = id, pend[n_pend + 1] = v1, pend[n_pend + 2] = v2;
+                            if ((n_pend += 3) == 192) flush();
+                        }
+                        pos = next;
+                        continue;
+                    }
+                }
+            }
+        }
+        if (n_pend) flush();
         size_t nl = d.find('\n', pos);
         const size_t end = (nl == std::string_view::npos || nl >= z) ? z : nl + 1;
         const std::string_view line = d.substr(pos, end - pos);
@@ -79,14 +131,17 @@ void parse_rows_chunk(std::string_view d, size_t pos, size_t z, const std::unord
             if (it == seqid_to_num.end()) continue;
             hit = &*it;
         }
-        out.emplace_back(hit->second, *s, *e);
+        out.push_back(hit->second);
+        out.push_back(*s);
+        out.push_back(*e);
     }
+    flush();
 }
 }  // namespace
 
-// (cut at line starts and parsed on `threads` host threads; the rows keep the file's order)
-std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
-                                              const std::unordered_map<std::string, uint32_t> &seqid_to_num, size_t threads) {
+// (cut at line starts and parsed on up to `threads` host threads; part[c] = the rows of the c-th cut as flat triples, file order)
+std::vector<std::vector<uint32_t>> parse_bed_rows_flat(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_to_num,
+                                                       size_t threads) {
     MappedFile f;
     try {
         f = MappedFile(bed_path);
@@ -94,20 +149,39 @@ std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
         throw Error("No such file or directory (os error 2)");  // File::open(bed_path)? (depth.rs:441)
     }
     const std::string_view d = f.view();
-    const size_t parts = d.size() < (1u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(threads, 64));
+    ShortNameTable short_names;
+    short_names.build(seqid_to_num);
+    // four pieces per thread, taken in turn (the slowest of equal pieces takes 1.7x the average)
+    const size_t workers = std::max<size_t>(1, std::min<size_t>(threads, 64));
+    const size_t parts = d.size() < (1u << 20) ? 1 : workers * 4;
     const std::vector<size_t> cut = intersect::line_chunks(d, parts);
     const size_t n = cut.size() - 1;
-    std::vector<std::vector<intersect::Region>> part(n);
+    std::vector<std::vector<uint32_t>> part(n);
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= n) return;
+            part[c].reserve((cut[c + 1] - cut[c]) / 8);
+            parse_rows_chunk(d, cut[c], cut[c + 1], seqid_to_num, short_names, part[c]);
+        }
+    };
     std::vector<std::thread> pool;
-    for (size_t c = 1; c < n; ++c) pool.emplace_back([&, c] { parse_rows_chunk(d, cut[c], cut[c + 1], seqid_to_num, part[c]); });
-    parse_rows_chunk(d, cut[0], cut[1], seqid_to_num, part[0]);
+    for (size_t t = 1; t < workers && t < n; ++t) pool.emplace_back(work);
+    work();
     for (auto &t : pool) t.join();
-    if (n == 1) return std::move(part[0]);
-    std::vector<intersect::Region> out;
+    return part;
+}
+
+std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
+                                              const std::unordered_map<std::string, uint32_t> &seqid_to_num, size_t threads) {
+    const std::vector<std::vector<uint32_t>> part = parse_bed_rows_flat(bed_path, seqid_to_num, threads);
     size_t total = 0;
-    for (const auto &v : part) total += v.size();
+    for (const auto &v : part) total += v.size() / 3;
+    std::vector<intersect::Region> out;
     out.reserve(total);
-    for (const auto &v : part) out.insert(out.end(), v.begin(), v.end());
+    for (const auto &v : part)
+        for (size_t i = 0; i + 2 < v.size(); i += 3) out.emplace_back(v[i], v[i + 1], v[i + 2]);
     return out;
 }
 
@@ -136,16 +210,21 @@ void run(const DepthArgs &args) {
     if (ext != "bed")
         throw Error("Unsupported file type: \"" + args.source + "\". Expected .bam/.sam/.cram or .bed");  // :597-600
     timer.lap("Loading index");
-    const std::vector<intersect::Region> regions = parse_bed_rows(args.source, index_data.seqid_to_num, args.threads);
-    if (verbose) std::fprintf(stderr, "[INFO] %zu BED rows kept\n", regions.size());
+    const size_t threads = capped_threads(args.threads);
+    // the kept rows as flat triples, one vector per parsed piece (file order); part_row[p] = rows before piece p
+    const std::vector<std::vector<uint32_t>> part = parse_bed_rows_flat(args.source, index_data.seqid_to_num, threads);
+    std::vector<size_t> part_row(part.size() + 1, 0);
+    for (size_t p = 0; p < part.size(); ++p) part_row[p + 1] = part_row[p] + part[p].size() / 3;
+    const size_t n_rows = part_row.back();
+    if (verbose) std::fprintf(stderr, "[INFO] %zu BED rows kept\n", n_rows);
     timer.lap("Parsing BED");
 
-    const BlockTable t = load_or_build_block_table(args.input, gof, gff.view(), args.threads, verbose);
+    const BlockTable t = load_or_build_block_table(args.input, gof, gff.view(), threads, verbose);
     timer.lap("Line table (image or parse)");
     const uint32_t n_groups = static_cast<uint32_t>(t.group_id.size());
     std::vector<uint64_t> depth(std::max<size_t>(n_groups, 1), 0);
     std::vector<uint32_t> mn(std::max<size_t>(n_groups, 1), 0xFFFFFFFFu), mx(std::max<size_t>(n_groups, 1), 0);
-    if (!regions.empty()) {
+    if (n_rows) {
         // --gpus N: the BED rows go to the devices in batches, round robin (every per-group result is a sum / min / max over
         // regions, so any partition of the rows gives the same rows out: depth.rs:264-291 merges its own batches the same
         // way); index and line table are replicated; one host thread drives each device.
@@ -181,7 +260,7 @@ void run(const DepthArgs &args) {
         // regions stream through Join A in batches (the reference's BATCH_SIZE, depth.rs:24, only bounds memory:
         // every merge is min / max / sum)
         const size_t kBatch = 4u << 20;
-        const size_t cap = std::min(regions.size(), kBatch);
+        const size_t cap = std::min(n_rows, kBatch);
         auto device_work = [&](size_t d) {
             PerDevice &P = pd[d];
             auto fail_hip = [&](const char *what) { P.error = std::string(what) + ": " + gffx_hip_last_error(); };
@@ -196,13 +275,15 @@ void run(const DepthArgs &args) {
                 return fail_hip("gffx_hip_depth_create");
             if (gffx_hip_batch_create(P.ix, cap, &P.b) != GFFX_OK) return fail_hip("gffx_hip_batch_create");
             std::vector<uint32_t> flat;
-            for (size_t a = d * kBatch; a < regions.size(); a += D * kBatch) {
-                const size_t n = std::min(kBatch, regions.size() - a);
+            for (size_t a = d * kBatch; a < n_rows; a += D * kBatch) {
+                const size_t n = std::min(kBatch, n_rows - a);
                 flat.resize(3 * n);
-                for (size_t i = 0; i < n; ++i) {
-                    flat[3 * i] = std::get<0>(regions[a + i]);
-                    flat[3 * i + 1] = std::get<1>(regions[a + i]);
-                    flat[3 * i + 2] = std::get<2>(regions[a + i]);
+                // rows [a, a + n) of the file: the tails / heads of the pieces they lie in
+                size_t p = static_cast<size_t>(std::upper_bound(part_row.begin(), part_row.end(), a) - part_row.begin()) - 1;
+                for (size_t done = 0; done < n; ++p) {
+                    const size_t from = a + done - part_row[p], take = std::min(n - done, part_row[p + 1] - (a + done));
+                    std::memcpy(flat.data() + 3 * done, part[p].data() + 3 * from, take * 12);
+                    done += take;
                 }
                 if (gffx_hip_batch_set_regions_host(P.b, flat.data(), n) != GFFX_OK) return fail_hip("set_regions");
                 if (gffx_hip_batch_run(P.b, GFFX_MODE_OVERLAP, 0, GFFX_OUT_FIDS | GFFX_OUT_OFFSETS, GFFX_STRATEGY_AUTO) != GFFX_OK)
@@ -280,7 +361,7 @@ void run(const DepthArgs &args) {
     }
     // depth.rs:515-546 write_depth_results (rows in first-contribution order; the reference's is a hash walk)
     std::string out = "id\tchr\tstart\tend\tdepth\n";
-    append_rows_parallel(out, order.size(), args.threads, [&](size_t k, std::string &o) {
+    append_rows_parallel(out, order.size(), threads, [&](size_t k, std::string &o) {
         const uint32_t i = order[k];
         const Row &r = rows[i];
         o += t.id(i);

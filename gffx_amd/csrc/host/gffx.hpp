@@ -78,6 +78,7 @@ struct CommonArgs {  // common.rs:17-52
 };
 
 size_t available_parallelism();  // affinity mask and cgroup CPU quota, as Rust's std::thread::available_parallelism
+size_t capped_threads(size_t requested);  // 0 -> available_parallelism(); else min(requested, 2 x available_parallelism())
 std::string append_suffix(const std::string &path, const std::string &suffix);  // common.rs:123-127
 bool check_index_files_exist(const std::string &gff);                           // common.rs:151-170
 
@@ -270,6 +271,9 @@ struct DepthArgs {  // depth.rs:34-72
 // depth.rs:450-495: the rows `depth` keeps from a BED file (its rules differ from intersect's parser)
 std::vector<intersect::Region> parse_bed_rows(const std::string &bed_path,
                                               const std::unordered_map<std::string, uint32_t> &seqid_to_num, size_t threads = 1);
+// ... as flat (seqid number, start, end) words, one vector per parsed piece of the file, in file order
+std::vector<std::vector<uint32_t>> parse_bed_rows_flat(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_to_num,
+                                                       size_t threads = 1);
 struct BlockTable {  // the device line table (include/gffx_hip.h "gffx depth") + what names the groups
     std::vector<uint64_t> block_line_off{0};
     std::vector<uint32_t> line_start, line_end, line_group, block_of_fid;

@@ -16,6 +16,7 @@
 #include <thread>
 
 #include "gffx.hpp"
+#include "fast_fields.hpp"
 
 namespace gffx {
 namespace commands {
@@ -96,28 +97,7 @@ class SeqidTable {
             while (slot_[i].p) i = (i + 1) & mask_;
             slot_[i] = Slot{kv.first.data(), static_cast<uint32_t>(kv.first.size()), kv.second, h};
         }
-        // names of 1-7 bytes, every byte in 0x21..0x7F, as the little-endian word of their bytes (the word encodes the
-        // length: no zero byte inside): the table of parse_bed_chunk's word-at-a-time path
-        size_t wcap = 16;
-        while (wcap < 4 * m.size() + 4) wcap <<= 1;
-        word_.assign(wcap, WordSlot{0, 0});
-        wshift_ = 64;
-        for (size_t c = wcap; c > 1; c >>= 1) --wshift_;
-        for (const auto &kv : m) {
-            const std::string &n = kv.first;
-            if (n.empty() || n.size() > 7) continue;
-            uint64_t w = 0;
-            bool ok = true;
-            for (size_t k = 0; k < n.size(); ++k) {
-                const unsigned char c = static_cast<unsigned char>(n[k]);
-                ok &= c >= 0x21 && c < 0x80;
-                w |= static_cast<uint64_t>(c) << (8 * k);
-            }
-            if (!ok) continue;
-            size_t i = (w * kWordMul) >> wshift_;
-            while (word_[i].key) i = (i + 1) & (wcap - 1);
-            word_[i] = WordSlot{w, kv.second};
-        }
+        short_.build(m);
     }
     static uint64_t hash(const char *p, size_t n) {
         uint64_t h = 1469598103934665603ull;
@@ -126,15 +106,8 @@ class SeqidTable {
     }
     static constexpr uint64_t kHashSeed = 1469598103934665603ull, kHashPrime = 1099511628211ull;
     bool find(const char *p, size_t n, uint32_t &id) const { return find_hashed(p, n, hash(p, n), id); }
-    // a name of 1-7 bytes given as the word of its bytes (zero above them)
-    bool find_word(uint64_t w, uint32_t &id) const {
-        for (size_t i = (w * kWordMul) >> wshift_; word_[i].key; i = (i + 1) & (word_.size() - 1))
-            if (word_[i].key == w) {
-                id = word_[i].id;
-                return true;
-            }
-        return false;
-    }
+    // a name of 1-7 bytes given as the word of its bytes (zero above them): parse_bed_chunk's word-at-a-time path
+    bool find_word(uint64_t w, uint32_t &id) const { return short_.find(w, id); }
     // h = hash(p, n), computed by the caller while it scanned the field
     bool find_hashed(const char *p, size_t n, uint64_t h, uint32_t &id) const {
         for (size_t i = h & mask_; slot_[i].p; i = (i + 1) & mask_)
@@ -151,59 +124,10 @@ class SeqidTable {
         uint32_t n, id;
         uint64_t h;
     };
-    struct WordSlot {
-        uint64_t key;
-        uint32_t id;
-    };
-    static constexpr uint64_t kWordMul = 0x9E3779B97F4A7C15ull;
     std::vector<Slot> slot_;
     size_t mask_ = 0;
-    std::vector<WordSlot> word_;
-    unsigned wshift_ = 60;
+    ShortNameTable short_;
 };
-
-// ---- eight bytes at a time (little-endian words) ----
-inline uint64_t load8(const char *p) {
-    uint64_t w;
-    std::memcpy(&w, p, 8);
-    return w;
-}
-// index of the first byte of w below 0x21 (8: none).  Exact for the FIRST such byte: a borrow only disturbs the bytes above it.
-inline unsigned first_below_21(uint64_t w) {
-    const uint64_t m = (w - 0x2121212121212121ull) & ~w & 0x8080808080808080ull;
-    return m ? static_cast<unsigned>(__builtin_ctzll(m)) >> 3 : 8u;
-}
-// index of the first byte of w that is not an ASCII digit (8: all eight are digits)
-inline unsigned first_non_digit(uint64_t w) {
-    const uint64_t x = w ^ 0x3030303030303030ull;  // digits -> 0x00..0x09
-    const uint64_t m = ((x + 0x0606060606060606ull) | x) & 0xF0F0F0F0F0F0F0F0ull;  // (a carry only reaches the bytes above a non-digit)
-    return m ? static_cast<unsigned>(__builtin_ctzll(m)) >> 3 : 8u;
-}
-// the value of eight ASCII digits, first byte = most significant
-inline uint32_t eight_digits(uint64_t w) {
-    w = (w & 0x0F0F0F0F0F0F0F0Full) * 2561 >> 8;
-    w = (w & 0x00FF00FF00FF00FFull) * 6553601 >> 16;
-    return static_cast<uint32_t>((w & 0x0000FFFF0000FFFFull) * 42949672960001ull >> 32);
-}
-// A field of 1-9 digits at p (at least 9 readable bytes): its value and length; 0: something else (no digit, 10+ digits)
-inline unsigned digits_1_to_9(const char *p, uint32_t &v) {
-    const uint64_t w = load8(p);
-    const unsigned nd = first_non_digit(w);
-    if (nd == 0) return 0;
-    if (nd < 8) {
-        const unsigned s = 8 * (8 - nd);  // leading '0's in front of the nd digits
-        v = eight_digits((w << s) | (0x3030303030303030ull >> (64 - s)));
-        return nd;
-    }
-    const unsigned d9 = static_cast<unsigned char>(p[8]) - '0';
-    if (d9 > 9) {
-        v = eight_digits(w);
-        return 8;
-    }
-    if (static_cast<unsigned>(static_cast<unsigned char>(p[9]) - '0') <= 9) return 0;  // ten or more digits: the general path decides
-    v = eight_digits(w) * 10 + d9;
-    return 9;
-}
 
 // u8::is_ascii_whitespace as a table (split_ascii_whitespace, intersect.rs:214): space, \t, \n, \x0C, \r
 struct WsTable {

@@ -276,3 +276,42 @@ def test_line_table_image_roundtrip_stale_and_corrupt(host, tmp_path):
     assert subprocess.run([gffx, "index", "-i", gff2], env=dict(os.environ, GFFX_LINE_TABLE="off")).returncode == 0
     assert not os.path.exists(gff2 + ".lsoa")
     assert host.gffx_host_line_table_check(gff2.encode(), 2, err, len(err)) == 0 and err.value == b"absent"
+
+
+def test_host_depth_bed_parser_random_rows_equal_the_oracle(host, tmp_path):
+    """The word-at-a-time path of depth's BED parser (name of 1-7 bytes, TAB, 1-9 digits, TAB, 1-9 digits) next to its general
+    loop: random files of plain rows, rows at the path's edges (names of 1-9 bytes, 1-10 digits, every kind of tail,
+    other separators) and rows depth.rs:450-495 drops -- the kept rows must be the oracle's, file by file."""
+    roots = synth.gencode_like_roots(150, seed=9, chroms=synth.SMALL2)
+    gff = str(tmp_path / "s.gff")
+    synth.write_gff3(gff, roots, seed=9, quirks=True)
+    err = C.create_string_buffer(2048)
+    assert host.gffx_host_build_index(gff.encode(), b"gene_name", ob.DEFAULT_SKIP.encode(), 0, err, len(err)) == 0
+    oix = ob.OracleIndex.load(gff)
+    names = [b"chr1", b"chr2", b"c", b"chr1x", b"chrUn_7", b"chrUn_78", b"chrUn_789", b"chr1#", b"ch\x01r", b"#chr1", b"chr\xc3\xa9", b"chr\xff"]
+    tails = [b"", b"", b"", b"\tgene\t1", b"\tname\t0\t+", b"\r", b" x", b"\t", b" ", b"\t\xc3\xa9", b"\x0c", b"x", b"\r\t5", b"\x0b",
+             b"\t\xff\xfe", b"\t" + b"y" * 40, b"\xc2\xa0"]
+    seps = [b"\t", b"\t", b"\t", b" ", b"\t\t", b"\x0c", b" \t"]
+    weird = [b"+5", b"", b"5a", b"0000000012", b"-3", b"4294967295", b"4294967296", b"1e3"]
+    bed = str(tmp_path / "f.bed")
+    rp, n = u32p(), C.c_uint64()
+    kept_total = 0
+    for seed in range(400):
+        rng = np.random.default_rng(7000 + seed)
+        lines = []
+        for _ in range(int(rng.integers(1, 50))):
+            name = names[int(rng.integers(len(names)))] if rng.random() < 0.5 else b"chr%d" % rng.integers(1, 3)
+            a, b = (int(rng.integers(0, 10 ** int(rng.integers(1, 11)))) for _ in range(2))
+            fa = b"%d" % a if rng.random() > 0.03 else weird[int(rng.integers(len(weird)))]
+            fb = b"%d" % b if rng.random() > 0.03 else weird[int(rng.integers(len(weird)))]
+            lines.append(name + seps[int(rng.integers(len(seps)))] + fa + seps[int(rng.integers(len(seps)))] + fb + tails[int(rng.integers(len(tails)))])
+        sep = b"\r\n" if seed % 5 == 0 else b"\n"
+        body = sep.join(lines) + (sep if seed % 2 else b"")
+        open(bed, "wb").write(body)
+        want = oix.depth_parse_bed(bed)
+        assert host.gffx_host_depth_parse_bed(gff.encode(), bed.encode(), C.byref(rp), C.byref(n), err, len(err)) == 0, body
+        got = np.ctypeslib.as_array(rp, shape=(max(n.value, 1), 3))[: n.value].copy()
+        host.gffx_host_free(rp)
+        assert np.array_equal(got, want), body
+        kept_total += len(want)
+    assert kept_total > 1000
