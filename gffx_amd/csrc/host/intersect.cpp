@@ -573,7 +573,15 @@ struct IndexClone {
     }
 };
 
-constexpr size_t kChunkBytes = 64u << 20;  // BED text per chunk; a row is at least 6 bytes ("a\t1\t2\n")
+// BED text per chunk; a row is at least 6 bytes ("a\t1\t2\n"), and the two pinned staging buffers and the two batches of a
+// device are sized for a chunk of such rows: creating them is on the critical path once the parser is fast (100 M rows,
+// "region stores + batches": 101 ms with 128 MB chunks, 70 with 64, 43 with 32, 36 with 16; whole run 0.73 / 0.65 / 0.58 /
+// 0.53 s).  GFFX_CHUNK_MB (1..1024) overrides the 16 MB for experiments.
+static const size_t kChunkBytes = [] {
+    const char *e = std::getenv("GFFX_CHUNK_MB");
+    const long v = e ? std::atol(e) : 0;
+    return static_cast<size_t>(v >= 1 && v <= 1024 ? v : 16) << 20;
+}();
 constexpr size_t kMinRowBytes = 6;
 
 }  // namespace
@@ -630,7 +638,9 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
                 pos = z;
                 pc.last = pos >= text.size();
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return queue.size() < 48 || stop; });  // (up to 3 GB of text = ~1.5 GB of parsed rows ahead while the devices come up: HIP start-up + index upload take ~0.25 s, in which 64 host threads parse ~1.3 GB)
+                // (up to 3 GB of text = ~1.5 GB of parsed rows ahead while the devices come up: HIP start-up + index upload take
+                //  ~0.25 s, in which the host threads parse more than that)
+                cv.wait(lk, [&] { return queue.size() < std::max<size_t>(4, (size_t(3) << 30) / kChunkBytes) || stop; });
                 if (stop) return;
                 queue.push_back(std::move(pc));
                 cv.notify_all();
