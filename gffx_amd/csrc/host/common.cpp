@@ -50,6 +50,12 @@ size_t capped_threads(size_t requested) {
 }
 size_t CommonArgs::effective_threads() const { return capped_threads(threads); }
 
+DeviceWarmup::DeviceWarmup(int device) : t_([device] { (void)gffx_hip_warmup(device); }) {}
+void DeviceWarmup::wait() {
+    if (t_.joinable()) t_.join();
+}
+DeviceWarmup::~DeviceWarmup() { wait(); }
+
 std::string append_suffix(const std::string &path, const std::string &suffix) {
     // parent.join(filename + suffix) == path + suffix for every path with a file name
     return path + suffix;

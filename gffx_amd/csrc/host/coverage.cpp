@@ -71,6 +71,7 @@ void run(const CoverageArgs &args) {
     } catch (const Error &) {
         throw Error("Cannot open GFF file: \"" + args.input + "\"");
     }
+    DeviceWarmup warm(args.device);  // (the runtime comes up beside the loaders and the BED parser)
     TreeIndexData index_data = TreeIndexData::load_tree_index(args.input);  // :511
     if (ext == "bam" || ext == "sam" || ext == "cram")
         throw Error("BAM/SAM/CRAM sources need htslib, which this build does not carry; use a .bed source");
@@ -84,6 +85,7 @@ void run(const CoverageArgs &args) {
     size_t written = 0;
     if (!regions.empty()) {
         // which roots are hit (by_root's key set, coverage.rs:258-268): Join A's unique-root output
+        warm.wait();
         const std::vector<uint32_t> hit_roots =
             intersect::query_unique_roots(index_data, regions, intersect::OverlapMode::Overlap, false, verbose, args.device);
         timer.lap("Join A on the device (root bitmap)");

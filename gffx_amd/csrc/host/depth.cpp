@@ -197,6 +197,7 @@ void run(const DepthArgs &args) {
         if (dot != std::string::npos && dot > 0) ext = base.substr(dot + 1);
         for (char &c : ext) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
     }
+    DeviceWarmup warm(args.device);  // (the runtime comes up beside the loaders and the BED parser)
     const index_loader::GofMap gof = index_loader::load_gof(args.input);  // :563
     MappedFile gff;
     try {
@@ -228,6 +229,7 @@ void run(const DepthArgs &args) {
         // --gpus N: the BED rows go to the devices in batches, round robin (every per-group result is a sum / min / max over
         // regions, so any partition of the rows gives the same rows out: depth.rs:264-291 merges its own batches the same
         // way); index and line table are replicated; one host thread drives each device.
+        warm.wait();
         const int visible = gffx_hip_device_count();
         if (visible <= 0) throw Error("no HIP device visible (the engine has no CPU fallback)");
         const size_t D = static_cast<size_t>(std::max(1, args.gpus));
@@ -245,13 +247,16 @@ void run(const DepthArgs &args) {
             gffx_hip_index *ix = nullptr;  // clone (owned) unless it is the first device's
             bool own_ix = false;
             gffx_hip_depth *dt = nullptr;
-            gffx_hip_batch *b = nullptr;
+            gffx_hip_batch *b[2] = {nullptr, nullptr};
+            gffx_hip_regions *store = nullptr;  // two pinned staging buffers + a ring of two batch slots in HBM
             std::vector<uint64_t> depth;
             std::vector<uint32_t> mn, mx;
             uint64_t rows = 0;
             std::string error;
             ~PerDevice() {
-                if (b) gffx_hip_batch_destroy(b);
+                for (gffx_hip_batch *x : b)
+                    if (x) gffx_hip_batch_destroy(x);
+                if (store) gffx_hip_regions_destroy(store);
                 if (dt) gffx_hip_depth_destroy(dt);
                 if (own_ix && ix) gffx_hip_index_destroy(ix);
             }
@@ -273,25 +278,59 @@ void run(const DepthArgs &args) {
                                       t.line_start.data(), t.line_end.data(), t.line_group.data(),
                                       static_cast<uint32_t>(t.block_of_fid.size()), t.block_of_fid.data(), &P.dt) != GFFX_OK)
                 return fail_hip("gffx_hip_depth_create");
-            if (gffx_hip_batch_create(P.ix, cap, &P.b) != GFFX_OK) return fail_hip("gffx_hip_batch_create");
-            std::vector<uint32_t> flat;
-            for (size_t a = d * kBatch; a < n_rows; a += D * kBatch) {
+            if (gffx_hip_regions_create(dev[d], 0, cap, 0, &P.store) != GFFX_OK) return fail_hip("gffx_hip_regions_create");
+            for (int k = 0; k < 2; ++k)
+                if (gffx_hip_batch_create(P.ix, cap, &P.b[k]) != GFFX_OK) return fail_hip("gffx_hip_batch_create");
+            // Batch i goes through staging buffer / batch i & 1: while its rows cross PCIe and Join A runs on them, the host
+            // waits for batch i - 1 and adds its depth, then fills the other staging buffer.  (One batch at a time was 19 ms per
+            // 4 M rows, nearly all of it the flat copy and the pageable upload.)
+            auto finish = [&](int k) -> bool {
+                if (gffx_hip_batch_wait(P.b[k]) != GFFX_OK) return fail_hip("query_features"), false;
+                if (gffx_hip_depth_accumulate(P.dt, P.b[k]) != GFFX_OK) return fail_hip("gffx_hip_depth_accumulate"), false;
+                return true;
+            };
+            const size_t fill_threads = std::max<size_t>(1, std::min<size_t>(threads / D, 8));
+            size_t i = 0;
+            for (size_t a = d * kBatch; a < n_rows; a += D * kBatch, ++i) {
+                const int k = static_cast<int>(i & 1);
                 const size_t n = std::min(kBatch, n_rows - a);
-                flat.resize(3 * n);
-                // rows [a, a + n) of the file: the tails / heads of the pieces they lie in
+                if (gffx_hip_regions_wait_staging(P.store, k) != GFFX_OK) return fail_hip("wait_staging");
+                uint32_t *stage = gffx_hip_regions_staging(P.store, k);
+                // rows [a, a + n) of the file: the tails / heads of the pieces they lie in, copied by a few threads
+                struct Move {
+                    const uint32_t *src;
+                    size_t at, rows;
+                };
+                std::vector<Move> moves;
                 size_t p = static_cast<size_t>(std::upper_bound(part_row.begin(), part_row.end(), a) - part_row.begin()) - 1;
                 for (size_t done = 0; done < n; ++p) {
                     const size_t from = a + done - part_row[p], take = std::min(n - done, part_row[p + 1] - (a + done));
-                    std::memcpy(flat.data() + 3 * done, part[p].data() + 3 * from, take * 12);
+                    for (size_t x = 0; x < take; x += 1u << 18)  // (256 K-row slices: pieces are much larger than a fair share)
+                        moves.push_back({part[p].data() + 3 * (from + x), done + x, std::min<size_t>(take - x, 1u << 18)});
                     done += take;
                 }
-                if (gffx_hip_batch_set_regions_host(P.b, flat.data(), n) != GFFX_OK) return fail_hip("set_regions");
-                if (gffx_hip_batch_run(P.b, GFFX_MODE_OVERLAP, 0, GFFX_OUT_FIDS | GFFX_OUT_OFFSETS, GFFX_STRATEGY_AUTO) != GFFX_OK)
+                std::atomic<size_t> next_move{0};
+                auto fill = [&] {
+                    for (;;) {
+                        const size_t m = next_move.fetch_add(1);
+                        if (m >= moves.size()) return;
+                        std::memcpy(stage + 3 * moves[m].at, moves[m].src, moves[m].rows * 12);
+                    }
+                };
+                {
+                    std::vector<std::thread> pool;
+                    for (size_t w = 1; w < fill_threads && w < moves.size(); ++w) pool.emplace_back(fill);
+                    fill();
+                    for (auto &th : pool) th.join();
+                }
+                if (gffx_hip_regions_append(P.store, k, n) != GFFX_OK) return fail_hip("regions_append");
+                if (gffx_hip_batch_set_regions_store(P.b[k], P.store, k, 0, n) != GFFX_OK) return fail_hip("set_regions_store");
+                if (gffx_hip_batch_run(P.b[k], GFFX_MODE_OVERLAP, 0, GFFX_OUT_FIDS | GFFX_OUT_OFFSETS, GFFX_STRATEGY_AUTO) != GFFX_OK)
                     return fail_hip("gffx_hip_batch_run");
-                if (gffx_hip_batch_wait(P.b) != GFFX_OK) return fail_hip("query_features");
-                if (gffx_hip_depth_accumulate(P.dt, P.b) != GFFX_OK) return fail_hip("gffx_hip_depth_accumulate");
+                if (i > 0 && !finish(1 - k)) return;
                 P.rows += n;
             }
+            if (i > 0 && !finish(static_cast<int>((i - 1) & 1))) return;
             P.depth.assign(std::max<size_t>(n_groups, 1), 0);
             P.mn.assign(std::max<size_t>(n_groups, 1), 0xFFFFFFFFu);
             P.mx.assign(std::max<size_t>(n_groups, 1), 0);

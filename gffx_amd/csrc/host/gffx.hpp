@@ -78,7 +78,18 @@ struct CommonArgs {  // common.rs:17-52
 };
 
 size_t available_parallelism();  // affinity mask and cgroup CPU quota, as Rust's std::thread::available_parallelism
-size_t capped_threads(size_t requested);  // 0 -> available_parallelism(); else min(requested, 2 x available_parallelism())
+size_t capped_threads(size_t requested);
+// Brings the HIP runtime, the device's context and the code objects up on a side thread (~0.2 s) while the caller parses its
+// inputs; wait() before the first device call.  Errors are not reported here: the first real call meets them again.
+class DeviceWarmup {
+  public:
+    explicit DeviceWarmup(int device);
+    void wait();
+    ~DeviceWarmup();
+
+  private:
+    std::thread t_;
+};  // 0 -> available_parallelism(); else min(requested, 2 x available_parallelism())
 std::string append_suffix(const std::string &path, const std::string &suffix);  // common.rs:123-127
 bool check_index_files_exist(const std::string &gff);                           // common.rs:151-170
 
