@@ -85,7 +85,7 @@ __device__ __forceinline__ bool pm_at(const RegionsView &R, const SeqMeta &m, ui
     if (b >= m.nb) {
         u = m.q_hi;  // beyond the largest start of the seqid
     } else {
-        const uint32_t a = R.dir[m.d_base + b], c = R.dir[m.d_base + b + 1];
+        const uint32_t a = min(max(R.dir[m.d_base + b], m.q_lo), m.q_hi), c = min(max(R.dir[m.d_base + b + 1], a), m.q_hi);  // (clamped: see k_b_carry)
         const uint4 t0 = R.T[a], tm = R.T[a > m.q_lo ? a - 1 : a];
         if (c == a || t0.x > x) {
             if (pos) *pos = a;
@@ -109,7 +109,7 @@ __device__ __forceinline__ bool pm_at(const RegionsView &R, const SeqMeta &m, ui
 __device__ __forceinline__ uint32_t lower_qs(const RegionsView &R, const SeqMeta &m, uint32_t x, uint4 *t = nullptr) {
     const uint32_t b = x >> m.shift;
     if (b >= m.nb) return m.q_hi;
-    const uint32_t a = R.dir[m.d_base + b], c = R.dir[m.d_base + b + 1];
+    const uint32_t a = min(max(R.dir[m.d_base + b], m.q_lo), m.q_hi - 1), c = min(max(R.dir[m.d_base + b + 1], a), m.q_hi);  // (clamped: see k_b_carry)
     const uint4 t0 = R.T[a], t1 = R.T[a + 1];  // (T has n + 1 records)
     uint32_t l;
     if (c == a || t0.x >= x) {
@@ -130,7 +130,7 @@ __device__ __forceinline__ bool deg_end_in(const RegionsView &R, const SeqMeta &
     if (m.dq_hi == m.dq_lo) return false;
     const uint32_t b = s >> m.shift;
     if (b >= m.nb) return false;
-    uint32_t lo = R.dird[m.d_base + b], hi = R.dird[m.d_base + b + 1];
+    uint32_t lo = min(max(R.dird[m.d_base + b], m.dq_lo), m.dq_hi), hi = min(max(R.dird[m.d_base + b + 1], lo), m.dq_hi);
     while (hi - lo > 2) {  // first end >= s inside the bin (a bin holds ~0.5 ends; clustered ones are halved down first)
         const uint32_t mid = (lo + hi) >> 1;
         if (R.de[2 * mid + 1] < s)
@@ -386,8 +386,8 @@ __global__ __launch_bounds__(kLocalThreads) void k_b_local(const uint32_t *rec, 
 // min_in[b] = running min of the seqid open at the start of block b + 1, deg_in[b] = degenerate regions before block b;
 // (2) per seqid the directory geometry {shift, nb} over its largest start (~2 bins per region, >= 16) and its place d_base.
 // cnt[0] = degenerate regions in total, cnt[1] = directory words in total.
-__global__ __launch_bounds__(kScanBlock) void k_b_carry(uint32_t n_blocks, BlockCarry C, const uint32_t *q_off, const uint4 *T, uint32_t n_seq,
-                                                        SeqMeta *meta, uint32_t *cnt) {
+__global__ __launch_bounds__(kScanBlock) void k_b_carry(uint32_t n_blocks, BlockCarry C, const uint32_t *q_off, const uint4 *T, uint32_t n, uint32_t n_seq,
+                                                        SeqMeta *meta, uint32_t *cnt, unsigned long long cap_dir) {
     __shared__ uint32_t s_v[kScanWaves], s_f[kScanWaves];
     __shared__ uint32_t s_run, s_runf;
     // forward: running max
@@ -436,7 +436,9 @@ __global__ __launch_bounds__(kScanBlock) void k_b_carry(uint32_t n_blocks, Block
         SeqMeta m{0, 0, 0, 0, 0, 0, 0, 0};
         uint32_t size = 0;
         if (c < n_seq) {
-            m.q_lo = q_off[c], m.q_hi = q_off[c + 1];
+            // (a run with a seqid out of range fails on the host, but its kernels still run to the end: whatever the broken
+            //  order left in q_off, no range may leave [0, n])
+            m.q_lo = min(q_off[c], n), m.q_hi = min(q_off[c + 1], n);
             if (m.q_hi > m.q_lo) {
                 const uint32_t vmax = T[m.q_hi - 1].x;
                 const unsigned long long budget = max(2ull * (m.q_hi - m.q_lo), 16ull);
@@ -450,6 +452,8 @@ __global__ __launch_bounds__(kScanBlock) void k_b_carry(uint32_t n_blocks, Block
         const uint32_t ex = block_sum_scan(size, s_v, &total);
         if (c < n_seq) {
             m.d_base = run + ex;
+            if ((unsigned long long)m.d_base + m.nb + 1 > cap_dir)  // (ranges that overlap: only the broken order of a failing run)
+                m.q_hi = m.q_lo, m.nb = 0, m.shift = 0, m.d_base = 0;
             meta[c] = m;
         }
         run += total;
@@ -505,8 +509,8 @@ __global__ __launch_bounds__(kLocalThreads) void k_b_finish(const uint32_t *rec,
         if (seq[k] >= n_seq) continue;  // (reported by the sort's histogram kernel)
         const uint32_t q_lo = ma[k].x, q_hi = ma[k].y, shift = ma[k].z, nb = ma[k].w;
         uint32_t *d = dir + mb[k].x;
-        const uint32_t b = t[k].x >> shift;
-        const long long bprev = i > q_lo ? (long long)((k ? t[k - 1].x : x_before) >> shift) : -1;
+        const uint32_t b = min(t[k].x >> shift, nb);  // (min: only a run that fails anyway -- a seqid out of range breaks the order -- gets there)
+        const long long bprev = i > q_lo ? (long long)min((k ? t[k - 1].x : x_before) >> shift, nb) : -1;
         for (long long x = bprev + 1; x <= (long long)b; ++x) d[x] = (uint32_t)i;
         if (i + 1 == q_hi)
             for (uint32_t x = b + 1; x <= nb; ++x) d[x] = q_hi;
@@ -718,7 +722,7 @@ static int lines_run(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int mode, u
         if (rc) return rc;
         uint32_t *other = s1 == L->d_rec_a ? L->d_rec_b : L->d_rec_a;
         hipLaunchKernelGGL(k_b_local, dim3(n_blocks), dim3(kLocalThreads), 0, L->stream, s1, n, n_seq, L->d_T, L->d_qoff, C);
-        hipLaunchKernelGGL(k_b_carry, dim3(1), dim3(kScanBlock), 0, L->stream, n_blocks, C, L->d_qoff, L->d_T, n_seq, L->d_meta, L->d_cnt);
+        hipLaunchKernelGGL(k_b_carry, dim3(1), dim3(kScanBlock), 0, L->stream, n_blocks, C, L->d_qoff, L->d_T, (uint32_t)n, n_seq, L->d_meta, L->d_cnt, (unsigned long long)L->cap_dir);
         hipLaunchKernelGGL(k_b_finish, dim3(n_blocks), dim3(kLocalThreads), 0, L->stream, s1, n, n_seq, L->d_T, C, L->d_meta, L->d_dir, other, L->d_cnt);
         GFFX_HIP_TRY(hipGetLastError());
         if (want_deg) {

@@ -91,6 +91,26 @@ def test_u32_extremes_and_empty_table():
         lt.test(np.array([[3, 1, 2]], np.uint32), 1)
 
 
+def test_seqids_out_of_range_fail_cleanly_whatever_they_do_to_the_sort():
+    """Regions whose seqid is >= n_seq make the call fail with GFFX_E_CHR_RANGE -- after its kernels have run over a sort
+    whose order those seqids broke (their low byte files them among the valid ones): no fault, and the table still works."""
+    rng = np.random.default_rng(3)
+    n_seq, n = 25, 300_000
+    good = np.stack([rng.integers(0, n_seq, n), rng.integers(0, 1 << 27, n), rng.integers(0, 1 << 27, n)], axis=1).astype(np.uint32)
+    seq = rng.integers(0, n_seq, 50_000).astype(np.uint32)
+    s = rng.integers(0, 1 << 27, 50_000).astype(np.uint32)
+    lt = engine.LineTable(seq, s, s + 1000)
+    want = lt.test(good, n_seq, OverlapMode.Overlap)
+    for bad_seq in (n_seq, 256 + 3, 0x10003, 0xFFFFFFFF):
+        bad = good.copy()
+        bad[rng.random(n) < 0.2, 0] = bad_seq
+        for mode in OverlapMode:
+            with pytest.raises(engine._ffi.GffxHipError):
+                lt.test(bad, n_seq, mode)
+    assert np.array_equal(lt.test(good, n_seq, OverlapMode.Overlap), want)
+    lt.close()
+
+
 def test_gencode_like_lines_against_sampled_oracle():
     """~200 k lines (genes + children) x 100 k regions: sampled literal-scan parity + the
     property that a line kept in contained mode is kept in overlap mode."""
