@@ -87,8 +87,8 @@ int main(int argc, char **argv) {
     if (presort) {
         std::vector<uint32_t> o(nq);
         for (uint64_t i = 0; i < nq; i++) o[i] = (uint32_t)i;
-        std::sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) {
-            return qc[a] != qc[b] ? qc[a] < qc[b] : qe[a] < qe[b];
+        std::sort(o.begin(), o.end(), [&](uint32_t a, uint32_t b) {  // (2: by (chr, start), as BED files usually are)
+            return qc[a] != qc[b] ? qc[a] < qc[b] : presort == 2 ? qs[a] < qs[b] : qe[a] < qe[b];
         });
         std::vector<uint32_t> c2(nq), s2(nq), e2(nq);
         for (uint64_t i = 0; i < nq; i++) {
