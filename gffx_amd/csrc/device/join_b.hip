@@ -213,37 +213,28 @@ template <bool MAXOP>
 __device__ __forceinline__ uint32_t scan_op(uint32_t a, uint32_t b) {
     return MAXOP ? max(a, b) : min(a, b);
 }
-// segmented inclusive scan over the 1024 threads of a block, in thread order (BACKWARD: from thread 1023 down); f = 1 starts
-// a segment.  Returns the scanned value; f becomes "a segment start at or before me inside the block".  s_v / s_f: 16 words each.
-template <bool MAXOP, bool BACKWARD>
+// segmented inclusive scan over the 1024 threads of a block, in thread order; f = 1 starts a segment.  Returns the scanned
+// value; f becomes "a segment start at or before me inside the block".  s_v / s_f: 16 words each.
+template <bool MAXOP>
 __device__ __forceinline__ uint32_t block_seg_scan(uint32_t v, uint32_t &f, uint32_t *s_v, uint32_t *s_f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t pv = BACKWARD ? __shfl_down(v, o, 64) : __shfl_up(v, o, 64);
-        const uint32_t pf = BACKWARD ? __shfl_down(f, o, 64) : __shfl_up(f, o, 64);
-        if (BACKWARD ? lane + o < 64 : lane >= o) {
+        const uint32_t pv = __shfl_up(v, o, 64), pf = __shfl_up(f, o, 64);
+        if (lane >= o) {
             if (!f) v = scan_op<MAXOP>(pv, v);
             f |= pf;
         }
     }
-    if (lane == (BACKWARD ? 0 : 63)) s_v[wave] = v, s_f[wave] = f;
+    if (lane == 63) s_v[wave] = v, s_f[wave] = f;
     __syncthreads();
-    // carry of the waves before me (in scan order): the value of the segment still open where this wave starts
+    // carry of the waves before me: the value of the segment still open where this wave starts
     uint32_t cv = 0, cf = 0;
-    if (BACKWARD) {
-        for (int w = kScanWaves - 1; w > wave; --w) {
-            cv = (w == kScanWaves - 1 || s_f[w]) ? s_v[w] : scan_op<MAXOP>(cv, s_v[w]);
-            cf |= s_f[w];
-        }
-        if (wave < kScanWaves - 1 && !f) v = scan_op<MAXOP>(cv, v);
-    } else {
-        for (int w = 0; w < wave; ++w) {
-            cv = (w == 0 || s_f[w]) ? s_v[w] : scan_op<MAXOP>(cv, s_v[w]);
-            cf |= s_f[w];
-        }
-        if (wave > 0 && !f) v = scan_op<MAXOP>(cv, v);
+    for (int w = 0; w < wave; ++w) {
+        cv = (w == 0 || s_f[w]) ? s_v[w] : scan_op<MAXOP>(cv, s_v[w]);
+        cf |= s_f[w];
     }
+    if (wave > 0 && !f) v = scan_op<MAXOP>(cv, v);
     f |= cf;
     __syncthreads();  // (s_v / s_f are reused by the next scan)
     return v;
@@ -389,15 +380,15 @@ __global__ __launch_bounds__(kLocalThreads) void k_b_local(const uint32_t *rec, 
 __global__ __launch_bounds__(kScanBlock) void k_b_carry(uint32_t n_blocks, BlockCarry C, const uint32_t *q_off, const uint4 *T, uint32_t n, uint32_t n_seq,
                                                         SeqMeta *meta, uint32_t *cnt, unsigned long long cap_dir) {
     __shared__ uint32_t s_v[kScanWaves], s_f[kScanWaves];
-    __shared__ uint32_t s_run, s_runf;
+    __shared__ uint32_t s_run;
     // forward: running max
-    if (threadIdx.x == 0) s_run = 0, s_runf = 1;
+    if (threadIdx.x == 0) s_run = 0;
     __syncthreads();
     for (uint32_t b0 = 0; b0 < n_blocks; b0 += kScanBlock) {
         const uint32_t b = b0 + threadIdx.x;
         const bool live = b < n_blocks;
         uint32_t f = live ? (C.head_any[b] & 1u) : 1u;
-        uint32_t v = block_seg_scan<true, false>(live ? C.max_out[b] : 0u, f, s_v, s_f);
+        uint32_t v = block_seg_scan<true>(live ? C.max_out[b] : 0u, f, s_v, s_f);
         if (!f) v = max(v, s_run);  // the chunks before this one
         if (live) C.max_in[b + 1] = v;
         __syncthreads();
@@ -412,7 +403,7 @@ __global__ __launch_bounds__(kScanBlock) void k_b_carry(uint32_t n_blocks, Block
         const bool live = x < n_blocks;
         const uint32_t b = live ? n_blocks - 1 - x : 0;
         uint32_t f = live ? ((C.head_any[b] >> 1) & 1u) : 1u;
-        uint32_t v = block_seg_scan<false, false>(live ? C.min_out[b] : 0xFFFFFFFFu, f, s_v, s_f);
+        uint32_t v = block_seg_scan<false>(live ? C.min_out[b] : 0xFFFFFFFFu, f, s_v, s_f);
         if (!f) v = min(v, s_run);
         if (live && b > 0) C.min_in[b - 1] = v;
         __syncthreads();
