@@ -60,7 +60,10 @@ struct RegionsView {
     const uint32_t *dird;  // their directory, same bins as `dir`: dird[d_base + b] = first pair of the seqid whose end >= b << shift
     uint32_t n_seq, n_deg;
 };
-constexpr uint32_t kMetaLds = 256;  // seqids whose SeqMeta a block stages in LDS (more: read through the caches)
+#ifndef GFFX_META_LDS_MAX
+#define GFFX_META_LDS_MAX 256
+#endif
+constexpr uint32_t kMetaLds = GFFX_META_LDS_MAX;  // seqids whose SeqMeta a block stages in LDS (more: read through the caches)
 
 // first position in [lo, hi) whose start is > x (UPPER) / >= x
 template <bool UPPER>
@@ -147,7 +150,7 @@ __device__ __forceinline__ bool deg_end_in(const RegionsView &R, const SeqMeta &
 // where PM keeps every line).
 template <int MODE, bool META_LDS, bool DEG>
 __global__ __launch_bounds__(256) void k_lines_exists(LinesView L, RegionsView R, uint8_t *keep) {
-    __shared__ uint4 s_meta[META_LDS ? 2 * kMetaLds : 2];
+    __shared__ uint4 s_meta[META_LDS && kMetaLds ? 2 * kMetaLds : 2];
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < L.n;
     const uint32_t seq = live ? L.seq[i] : 0xFFFFFFFFu;
@@ -191,6 +194,121 @@ __global__ __launch_bounds__(256) void k_lines_exists(LinesView L, RegionsView R
         }
     }
     keep[i] = k;
+}
+
+// ---- the usual run (no degenerate regions): kLinesPerThread lines per thread, their lookups issued side by side -------------
+// One line per thread is a chain of three dependent loads (SeqMeta from LDS aside): line -> directory pair -> T pair, and the
+// 53 k waves of a 3.4 M-line table pass through the chip in ~6.5 generations of that chain (20 us).  Here a thread probes
+// its lines TOGETHER -- the probe is branch-free up to the T loads, so the directory pairs of all of them are in flight at
+// once, then their T pairs -- and resolves them afterwards (bins of 0 / 1 regions from the pair at hand; longer bins by the
+// binary search, rare).
+#ifndef GFFX_LINES_PER_THREAD
+#define GFFX_LINES_PER_THREAD 2
+#endif
+constexpr int kLinesPerThread = GFFX_LINES_PER_THREAD;
+struct Probe {
+    uint32_t a, c;  // the bin's regions are T[a, c)
+    uint4 t0, t1;   // T[a]; T[a - 1] (running-max lookups) or T[a + 1] (running-min lookups)
+    bool in;        // x's bin exists (x is not beyond the seqid's largest start)
+};
+template <bool SM>
+__device__ __forceinline__ Probe probe(const RegionsView &R, const SeqMeta &m, uint32_t x) {
+    Probe p;
+    const uint32_t b = x >> m.shift;
+    p.in = b < m.nb;
+    const uint32_t bi = m.d_base + (p.in ? b : 0u);  // (out of range, or a seqid without regions: any valid directory word)
+    const uint32_t a = min(max(R.dir[bi], m.q_lo), SM ? max(m.q_hi, 1u) - 1u : m.q_hi);
+    p.a = a;
+    p.c = min(max(R.dir[bi + 1], a), m.q_hi);
+    p.t0 = R.T[a];
+    p.t1 = SM ? R.T[a + 1] : R.T[a > m.q_lo ? a - 1 : a];  // (T has n + 1 records)
+    return p;
+}
+// PM(x) = max{qe : qs <= x}; false: no region of the seqid starts at or before x
+__device__ __forceinline__ bool resolve_pm(const RegionsView &R, const SeqMeta &m, uint32_t x, const Probe &p, uint32_t &pm) {
+    if (!p.in) {  // beyond the largest start
+        if (m.q_hi == m.q_lo) return false;
+        pm = R.T[m.q_hi - 1].y;
+        return true;
+    }
+    if (p.c == p.a || p.t0.x > x) {
+        pm = p.t1.y;
+        return p.a > m.q_lo;
+    }
+    if (p.c == p.a + 1) {
+        pm = p.t0.y;
+        return true;
+    }
+    pm = R.T[bound_qs<true>(R.T, p.a + 1, p.c, x) - 1].y;
+    return true;
+}
+// SM(x) = min{qe : qs >= x}; false: no region of the seqid starts at or after x
+__device__ __forceinline__ bool resolve_sm(const RegionsView &R, const SeqMeta &m, uint32_t x, const Probe &p, uint32_t &sm) {
+    if (!p.in || m.q_hi == m.q_lo) return false;
+    if (p.c == p.a || p.t0.x >= x) {
+        sm = p.t0.z;
+        return true;  // (an empty bin below the seqid's last one: a < q_hi)
+    }
+    uint32_t l = p.c;
+    uint4 t = p.t1;
+    if (p.c != p.a + 1) {
+        l = bound_qs<false>(R.T, p.a + 1, p.c, x);
+        if (l < m.q_hi) t = R.T[l];
+    }
+    sm = t.z;
+    return l < m.q_hi;
+}
+
+template <int MODE, bool META_LDS>
+__global__ __launch_bounds__(256) void k_lines_exists2(LinesView L, RegionsView R, uint8_t *keep) {
+    __shared__ uint4 s_meta[META_LDS && kMetaLds ? 2 * kMetaLds : 2];
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * (256 * kLinesPerThread) + threadIdx.x;
+    uint32_t seq[kLinesPerThread], s[kLinesPerThread], e[kLinesPerThread];
+#pragma unroll
+    for (int r = 0; r < kLinesPerThread; ++r) {
+        const unsigned long long i = i0 + 256ull * r;
+        const bool live = i < L.n;
+        seq[r] = live ? L.seq[i] : 0xFFFFFFFFu, s[r] = live ? L.start[i] : 0u, e[r] = live ? L.end[i] : 0u;
+    }
+    if (META_LDS) {
+        for (uint32_t t = threadIdx.x; t < 2 * R.n_seq; t += 256) s_meta[t] = reinterpret_cast<const uint4 *>(R.meta)[t];
+        __syncthreads();
+    }
+    SeqMeta m[kLinesPerThread];
+    Probe p[kLinesPerThread];
+#pragma unroll
+    for (int r = 0; r < kLinesPerThread; ++r) {
+        m[r] = SeqMeta{0, 0, 0, 0, 0, 0, 0, 0};  // (a line of no seqid: a seqid without regions)
+        if (seq[r] < R.n_seq) {
+            if (META_LDS) {
+                const uint4 m0 = s_meta[2 * seq[r]], m1 = s_meta[2 * seq[r] + 1];
+                m[r] = SeqMeta{m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            } else {
+                m[r] = R.meta[seq[r]];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kLinesPerThread; ++r)  // Contained / ContainsRegion look s up; Overlap (s <= e) looks e up
+        p[r] = probe<MODE == GFFX_MODE_CONTAINS_REGION>(R, m[r], MODE == GFFX_MODE_OVERLAP ? e[r] : s[r]);
+#pragma unroll
+    for (int r = 0; r < kLinesPerThread; ++r) {
+        const unsigned long long i = i0 + 256ull * r;
+        if (i >= L.n) continue;
+        uint32_t v = 0;
+        bool k;
+        if (MODE == GFFX_MODE_CONTAINED) {
+            k = resolve_pm(R, m[r], s[r], p[r], v) && v >= e[r];
+        } else if (MODE == GFFX_MODE_CONTAINS_REGION) {
+            k = resolve_sm(R, m[r], s[r], p[r], v) && v <= e[r];
+        } else if (s[r] <= e[r]) {
+            k = resolve_pm(R, m[r], e[r], p[r], v) && v >= s[r];
+        } else {  // s > e: clauses 3 / 4 are empty (rare: one lookup more)
+            k = resolve_pm(R, m[r], e[r], p[r], v) && v >= e[r];  // qs <= e <= qe
+            if (!k) k = m[r].q_hi > m[r].q_lo && pm_at(R, m[r], s[r], v) && v >= s[r];  // qs <= s <= qe
+        }
+        keep[i] = (k && m[r].q_hi > m[r].q_lo) ? 1 : 0;
+    }
 }
 
 // ---- region tables on the device (what the reference builds per run as `query_ivmap`, intersect.rs:621-633) --------------
@@ -615,8 +733,11 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
     L->n = n_lines;
     int rc;
     if ((rc = dalloc(&L->d_seq, n_lines)) || (rc = dalloc(&L->d_start, n_lines)) ||
-        (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)) || (rc = dalloc(&L->d_work, kWorkFront)))
+        (rc = dalloc(&L->d_end, n_lines)) || (rc = dalloc(&L->d_keep, n_lines)) || (rc = dalloc(&L->d_work, kWorkFront)) ||
+        (rc = dalloc(&L->d_T, 2)) || (rc = dalloc(&L->d_dir, 4)))  // (k_lines_exists2 probes T[0..1] / dir[0..1] even for a run without regions)
         return rc;
+    GFFX_HIP_TRY(hipMemset(L->d_T, 0, 2 * sizeof(uint4)));
+    GFFX_HIP_TRY(hipMemset(L->d_dir, 0, 16));
     L->cap_work = kWorkFront;
     L->d_err = L->d_work, L->d_cnt = L->d_work + 4;
     GFFX_HIP_TRY(hipHostMalloc((void **)&L->h_cnt, 64, hipHostMallocCoherent | hipHostMallocMapped));
@@ -671,16 +792,21 @@ template <int MODE>
 static void launch_lines(gffx_hip_lines *L, const RegionsView &rv) {
     const LinesView lv{L->d_seq, L->d_start, L->d_end, (unsigned long long)L->n};
     const unsigned blocks = (unsigned)((L->n + 255) / 256);
-    constexpr bool kOverlap = MODE == GFFX_MODE_OVERLAP;
-    if (kOverlap && rv.n_deg) {
+    if constexpr (MODE == GFFX_MODE_OVERLAP) {
+        if (rv.n_deg) {  // regions with start > end: the one-line-per-thread kernel with their clauses
+            if (rv.n_seq <= kMetaLds)
+                hipLaunchKernelGGL((k_lines_exists<MODE, true, true>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+            else
+                hipLaunchKernelGGL((k_lines_exists<MODE, false, true>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+            return;
+        }
+    }
+    {
+        const unsigned blocks2 = (unsigned)((L->n + 256 * kLinesPerThread - 1) / (256 * kLinesPerThread));
         if (rv.n_seq <= kMetaLds)
-            hipLaunchKernelGGL((k_lines_exists<MODE, true, kOverlap>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+            hipLaunchKernelGGL((k_lines_exists2<MODE, true>), dim3(blocks2), dim3(256), 0, L->stream, lv, rv, L->d_keep);
         else
-            hipLaunchKernelGGL((k_lines_exists<MODE, false, kOverlap>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
-    } else if (rv.n_seq <= kMetaLds) {
-        hipLaunchKernelGGL((k_lines_exists<MODE, true, false>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
-    } else {
-        hipLaunchKernelGGL((k_lines_exists<MODE, false, false>), dim3(blocks), dim3(256), 0, L->stream, lv, rv, L->d_keep);
+            hipLaunchKernelGGL((k_lines_exists2<MODE, false>), dim3(blocks2), dim3(256), 0, L->stream, lv, rv, L->d_keep);
     }
 }
 
