@@ -285,7 +285,8 @@ int gffx_hip_lines_test_device(gffx_hip_lines *, const uint32_t *d_regions, uint
                                int mode, uint8_t *keep_host);
 /* ... or in a region store (keep_all = 1): all rows appended so far */
 int gffx_hip_lines_test_store(gffx_hip_lines *, const gffx_hip_regions *, uint32_t n_seq, int mode, uint8_t *keep_host);
-/* HIP-event duration (ms) of k_lines_exists in the last _test call, on the table's own stream */
+/* HIP-event duration (ms) of the line kernel (k_lines_exists2; k_lines_exists when regions with start > end exist) in the last
+ * _test call, on the table's own stream */
 double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *);
 /* ... and of the device preparation of the region tables before it: radix sort by (seqid, start), running max / min of the
  * ends, the bin directory and -- Overlap mode, when the run has regions with start > end -- the sort of those regions' ends
