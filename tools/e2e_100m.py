@@ -12,7 +12,7 @@ bed = d + "/q.bed"
 synth.write_bed_fast(bed, synth.synth_bed(n, seed=1003), roots["names"])
 for flags in (["-e", "-t", "64"], ["-t", "64"], ["-e", "-t", "64", "-v"], ["-t", "64", "-v"]):
     best = None
-    for rep in range(3):
+    for rep in range(2):
         t0 = time.perf_counter()
         r = subprocess.run([G, "intersect", "-i", gff, "-b", bed, "-o", d + "/out.gff"] + flags, capture_output=True, text=True)
         dt = time.perf_counter() - t0
