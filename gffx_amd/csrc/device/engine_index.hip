@@ -194,6 +194,78 @@ static void build_window_tails(uint32_t n_chr, const std::vector<uint32_t> &h_st
     twords = (uint32_t)nw;
 }
 
+// Split windows (gffx_device.hpp): every window with a list of 5..kWinMaxList entries on a seqid whose windows are at least
+// 2^kWinSplit bp wide is cut into 2^kWinSplit sub-windows; a root is listed in sub-window g of the seqid iff
+// start >> sub_shift <= g <= (end + wmax - 1) >> sub_shift -- the rule of build_window_index_at at the finer width, so a
+// region of width <= wmax whose last base lies in g finds every root that overlaps it there.  `meta` still holds {first
+// window, windows, shift, wmax}.  Output: the bitmap (+ one zero word at least, in multiples of 4 words), and per sub-line its
+// line number in the window table (n_win + ...) and its two halves (root_fids / positions); sub-lists longer than 4 append
+// their tails to `spill`.  Nothing is built when the second level would not fit 31-bit byte offsets or GFFX_HIP_WIN_SPLIT=0.
+static void build_window_splits(uint32_t n_chr, const std::vector<uint32_t> &h_start, const std::vector<uint4> &h_aux,
+                                const std::vector<uint4> &meta, const std::vector<uint4> &win, const std::vector<uint4> &win_pos,
+                                std::vector<uint4> &spill, std::vector<uint32_t> &bits, std::vector<uint32_t> &sub_at,
+                                std::vector<uint4> &sub_lines, std::vector<uint4> &sub_lines_pos) {
+    bits.clear(), sub_at.clear(), sub_lines.clear(), sub_lines_pos.clear();
+    const size_t n_win = win.size() / 2;
+    if (!n_win || !env_long("GFFX_HIP_WIN_SPLIT", 1, 0, 1)) return;
+    if ((uint64_t)n_win * ((1u << kWinSplit) + 1) * kWinLineBytes >= (1ull << 31)) return;
+    const size_t nw = (n_win + 31) / 32;
+    bits.assign((nw + 4) / 4 * 4, 0u);
+    const uint32_t *wp = reinterpret_cast<const uint32_t *>(win_pos.data());
+    std::vector<uint32_t> list;
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint4 m = meta[c];
+        if (m.y == 0 || m.z > kWinMaxShift || m.z < kWinSplit || m.w == 0) continue;
+        const uint32_t sshift = m.z - kWinSplit;
+        const uint64_t Ws = 1ull << sshift, wmax = m.w;
+        for (uint64_t b = 0; b < m.y; b++) {
+            const size_t w = (size_t)m.x + b;
+            const uint32_t *l = wp + 8 * w;
+            if (l[3] != kWinTailMark) continue;
+            const uint32_t n = l[7] & 255u;
+            if (n == 255u) continue;  // dense: the sweep
+            if (spill.size() + (size_t)(n << kWinSplit) >= (1ull << 24)) continue;  // (24-bit spill offsets)
+            list.clear();
+            for (uint32_t j = 0; j < kWinInlineTail; j++) list.push_back(l[4 + j]);  // positions of entries 0..2
+            for (uint32_t j = kWinInlineTail; j < n; j++) list.push_back(spill[(l[7] >> 8) + j - kWinInlineTail].w);
+            bits[w >> 5] |= 1u << (w & 31);
+            for (uint32_t j = 0; j < (1u << kWinSplit); j++) {
+                const uint64_t g = (b << kWinSplit) + j;  // the seqid's sub-window
+                uint32_t t[8] = {kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent, 0, 0, 0, 0}, tp[8];
+                uint32_t cnt = 0;
+                for (uint32_t i : list)
+                    if (((uint64_t)h_start[i] >> sshift) <= g && g <= (((uint64_t)h_aux[i].x + wmax - 1) >> sshift)) cnt++;
+                const bool over = cnt > kWinInline;
+                const size_t sp0 = spill.size();
+                if (over) spill.resize(sp0 + cnt - kWinInlineTail);
+                const int64_t org = (int64_t)(g << sshift) - (int64_t)wmax;
+                uint32_t k = 0;
+                memcpy(tp, t, sizeof t);
+                for (uint32_t i : list) {  // (ascending start, like the window's own list)
+                    if (!(((uint64_t)h_start[i] >> sshift) <= g && g <= (((uint64_t)h_aux[i].x + wmax - 1) >> sshift))) continue;
+                    if (k < (over ? kWinInlineTail : kWinInline)) {
+                        const int64_t rs = std::max<int64_t>((int64_t)h_start[i] - org, 0);
+                        const int64_t re = std::min<int64_t>((int64_t)h_aux[i].x - org, (int64_t)(Ws + wmax + 1));
+                        t[k] = tp[k] = (uint32_t)rs | ((uint32_t)re << 16);
+                        t[4 + k] = h_aux[i].w;
+                        tp[4 + k] = i;
+                    } else {
+                        spill[sp0 + k - kWinInlineTail] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
+                    }
+                    k++;
+                }
+                if (over) t[3] = tp[3] = kWinTailMark, t[7] = tp[7] = cnt | (uint32_t)(sp0 << 8);
+                if (cnt == 0) continue;  // (the zeroed second level already says "nothing")
+                sub_at.push_back((uint32_t)(n_win + (w << kWinSplit) + j));
+                sub_lines.push_back(make_uint4(t[0], t[1], t[2], t[3]));
+                sub_lines.push_back(make_uint4(t[4], t[5], t[6], t[7]));
+                sub_lines_pos.push_back(make_uint4(tp[0], tp[1], tp[2], tp[3]));
+                sub_lines_pos.push_back(make_uint4(tp[4], tp[5], tp[6], tp[7]));
+            }
+        }
+    }
+}
+
 // Coverage filter of the window index (gffx_device.hpp): the smallest cell size whose bitmap fits GFFX_HIP_WIN_FILTER_KB
 // (default 24 KB of LDS per block; 48 KB measured 1.5 % faster at 10 M regions, 1.5 % slower at 1 M), but never so small that a region the lines answer (width <= wmax) spans more than 32 cells.
 static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
@@ -268,6 +340,40 @@ extern "C" void gffx_hip_free_host(void *p) { free(p); }
 
 // ------------------------------------------------------------------------------------ index
 
+// the sub-lines of the split windows into the zeroed second level of a line table (thread t: half t & 1 of sub-line t >> 1)
+__global__ void k_scatter_lines(uint4 *table, const uint32_t *at, const uint4 *lines, uint32_t n_halves) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_halves) table[2ull * at[t >> 1] + (t & 1u)] = lines[t];
+}
+
+// A line table = the windows' lines, followed -- when the index has split windows -- by 2^kWinSplit sub-lines per window, zero but
+// for the sub-lines of the split ones (gffx_device.hpp).  The second level is zeroed and filled on the device: only the
+// compact list of sub-lines crosses the bus.  *bytes = the array's size (gffx_hip_index_clone).
+static int upload_line_table(uint4 **dst, const std::vector<uint4> &lines, bool split, const std::vector<uint32_t> &sub_at,
+                             const std::vector<uint4> &sub_lines, size_t *bytes) {
+    const size_t n_win = lines.size() / 2, total = 2 * n_win * (split ? (1u << kWinSplit) + 1 : 1);
+    int rc = dev_alloc(dst, total);
+    if (rc) return rc;
+    *bytes = std::max<size_t>(total, 1) * sizeof(uint4);
+    if (!lines.empty()) GFFX_HIP_TRY(hipMemcpy(*dst, lines.data(), lines.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!split) return GFFX_OK;
+    GFFX_HIP_TRY(hipMemset(*dst + lines.size(), 0, (total - lines.size()) * sizeof(uint4)));
+    if (sub_at.empty()) return GFFX_OK;
+    uint32_t *d_at = nullptr;
+    uint4 *d_sub = nullptr;
+    if ((rc = dev_upload(&d_at, sub_at)) || (rc = dev_upload(&d_sub, sub_lines))) {
+        (void)hipFree(d_at), (void)hipFree(d_sub);
+        return rc;
+    }
+    const uint32_t n_halves = (uint32_t)sub_lines.size();
+    hipLaunchKernelGGL(k_scatter_lines, dim3((n_halves + 255) / 256), dim3(256), 0, 0, *dst, d_at, d_sub, n_halves);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_at), (void)hipFree(d_sub);
+    if (e != hipSuccess) return fail(GFFX_E_HIP, "k_scatter_lines failed: %s", hipGetErrorString(e));
+    return GFFX_OK;
+}
+
 extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets,
                                      const uint32_t *start, const uint32_t *end,
                                      const uint32_t *root_fid, int device, gffx_hip_index **out) {
@@ -295,7 +401,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     // the bin directory of the direct / fused strategies (~2 bins per entry, >= 64).
     std::vector<uint32_t> h_start(R);
     std::vector<uint4> h_aux(R);
-    std::vector<uint4> chr_meta(n_chr);
+    std::vector<uint4> chr_meta(n_chr + 1);  // (+ one record without roots: what a row with a seqid out of range is clamped to)
     std::vector<uint4> bins;
     std::vector<uint32_t> order, stack;
     std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
@@ -343,6 +449,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         bins.push_back(make_uint4(hi, pmax_incl(hi - 1), 0xFFFFFFFFu, 0xFFFFFFFFu));
     }
 
+    chr_meta[n_chr] = make_uint4(R, R, (uint32_t)bins.size(), 0u);
     std::vector<uint4> win_meta, win, win_pos, win_spill;
     if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill)) return wrc;
     ix->n_win = (uint32_t)(win.size() / 2);
@@ -350,11 +457,23 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     std::vector<uint32_t> win_tailtab;
     build_window_tails(n_chr, h_start, h_aux, win_meta, win, win_spill, win_tail, win_tailtab, ix->win_twords);
     ix->n_tail = (uint32_t)(win_tail.size() / 2);
+    // split windows (gffx_device.hpp): their sub-lines, compact on the host ({line number, line} pairs), scattered into the
+    // zeroed second level on the device
+    std::vector<uint32_t> win_splittab, sub_at;
+    std::vector<uint4> sub_lines, sub_lines_pos;
+    build_window_splits(n_chr, h_start, h_aux, win_meta, win, win_pos, win_spill, win_splittab, sub_at, sub_lines, sub_lines_pos);
+    ix->win_swords = win_splittab.empty() ? 0u : (uint32_t)((ix->n_win + 31) / 32);
     std::vector<uint32_t> win_filter;
     std::vector<uint2> win_fmeta;
     build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);
     // the kernel's seqid record: {first window, windows, shift | wmax << 8, first filter bit}
-    for (uint32_t c = 0; c <= n_chr; c++) win_meta[c] = make_uint4(win_meta[c].x, win_meta[c].y, win_meta[c].z | (win_meta[c].w << 8), win_fmeta[c].x);
+    // (a seqid without windows AND without roots -- and the extra record -- answers "fits, but beyond my last window" for every
+    //  sane row: wmax = 2^24 - 1, no windows; only its empty / reversed / absurdly wide rows reach the sweep, which returns at once)
+    for (uint32_t c = 0; c <= n_chr; c++) {
+        const bool rootless = c == n_chr || chr_offsets[c + 1] == chr_offsets[c];
+        win_meta[c] = rootless ? make_uint4(0, 0, 0xFFFFFFu << 8, 0)
+                               : make_uint4(win_meta[c].x, win_meta[c].y, win_meta[c].z | (win_meta[c].w << 8), win_fmeta[c].x);
+    }
     ix->win_fwords = (uint32_t)win_filter.size();
 
     // Partitioned strategy: cells of 2^cshift bp (<= kMaxCells in total, >= 1 per seqid) merged into
@@ -446,12 +565,13 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     ix->cshift = cshift;
     ix->partition_ok = plan_ok && ix->n_tiles >= 1 && ix->n_tiles <= kMaxTiles;
     int rc;
+    size_t win_bytes = 0, win_pos_bytes = 0;
     if ((rc = dev_upload(&ix->d_start, h_start)) || (rc = dev_upload(&ix->d_aux, h_aux)) ||
         (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
-        (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = dev_upload(&ix->d_win, win)) ||
-        (rc = dev_upload(&ix->d_win_pos, win_pos)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
+        (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = upload_line_table(&ix->d_win, win, ix->win_swords != 0, sub_at, sub_lines, &win_bytes)) ||
+        (rc = upload_line_table(&ix->d_win_pos, win_pos, ix->win_swords != 0, sub_at, sub_lines_pos, &win_pos_bytes)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
         (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_tail, win_tail)) ||
-        (rc = dev_upload(&ix->d_win_tailtab, win_tailtab)) ||
+        (rc = dev_upload(&ix->d_win_tailtab, win_tailtab)) || (rc = dev_upload(&ix->d_win_splittab, win_splittab)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -460,8 +580,8 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     }
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
     ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),
-                       bytes(win_meta),  bytes(win),        bytes(win_pos),   bytes(win_spill), bytes(win_filter),
-                       bytes(win_tail),  bytes(win_tailtab),
+                       bytes(win_meta),  win_bytes,         win_pos_bytes,    bytes(win_spill), bytes(win_filter),
+                       bytes(win_tail),  bytes(win_tailtab), bytes(win_splittab),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
     GFFX_HIP_TRY(hipDeviceSynchronize());
@@ -508,6 +628,7 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_win_filter);
     (void)hipFree(ix->d_win_tail);
     (void)hipFree(ix->d_win_tailtab);
+    (void)hipFree(ix->d_win_splittab);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);
     (void)hipFree(ix->d_tile_meta);

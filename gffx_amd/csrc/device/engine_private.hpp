@@ -84,6 +84,8 @@ struct gffx_hip_index {
     uint4 *d_win_tail = nullptr;          // tail lines (k_join_wave)
     uint32_t *d_win_tailtab = nullptr;
     uint32_t n_tail = 0, win_twords = 0;
+    uint32_t *d_win_splittab = nullptr;  // split windows (k_join_pairs): one bit per window; their sub-lines follow the lines in d_win / d_win_pos
+    uint32_t win_swords = 0;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
     uint32_t *d_cell_base = nullptr;
     uint16_t *d_cell_tile = nullptr;
@@ -101,6 +103,7 @@ struct gffx_hip_index {
     std::vector<void **> arrays() {
         return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_win_meta,   (void **)&d_win,
                 (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_win_tail,   (void **)&d_win_tailtab,
+                (void **)&d_win_splittab,
                 (void **)&d_cell_base,
                 (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
     }
@@ -123,6 +126,8 @@ struct gffx_hip_index {
         v.win_tailtab = d_win_tailtab;
         v.n_tail = n_tail;
         v.win_twords = win_twords;
+        v.win_splittab = d_win_splittab;
+        v.win_swords = win_swords;
         v.n_chr = n_chr;
         v.n_roots = n_roots;
         return v;

@@ -1,7 +1,7 @@
 // engine_windows.hip -- the windows strategy (AUTO's choice): k_join_wave for pair passes (counts, root_fids, segment bases /
 // offsets), k_join_win for triples and root-bitmap passes.
 #include "engine_private.hpp"
-#include "join_wave_kernels.hpp"
+#include "join_pairs_kernels.hpp"
 
 // ------------------------------------------------------------------------------------ windows strategy
 
@@ -130,9 +130,102 @@ static int run_wave_pass(gffx_hip_batch *b) {
     return GFFX_OK;
 }
 
+// ---- pair passes since round 4: k_join_pairs (join_pairs_kernels.hpp); same block widths as k_join_wave
+
+// dynamic LDS of k_join_pairs: coverage filter + split bitmap + seqid records + header + strips + parked offsets + per-thread strips
+static uint32_t pairs_lds_bytes(const gffx_hip_index *ix, uint32_t threads, uint32_t keep_words, uint32_t fwords, uint32_t swords, bool ml) {
+    const uint32_t sw4 = swords ? (swords + 4) / 4 * 4 : 0;
+    return 4 * fwords + 4 * sw4 + (ml ? (ix->n_chr + 1) * 16 : 0) + kWaveHdrBytes + 4 * (threads / 64) * kWaveDepth * pair_stage_words(threads) +
+           4 * threads * kWaveDepth * keep_words + 4 * kWaveStash * threads;
+}
+
+template <int MODE, bool INV, bool AOS, bool ML, int T, bool OFFS>
+static int launch_pairs3(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t lds) {
+    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_pairs<MODE, INV, AOS, ML, T, OFFS, false>), b->ix->device, lds,
+                              T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_join_pairs<MODE, INV, AOS, ML, T, OFFS, false>), dim3(grid), dim3(T), lds, b->stream, a);
+    return GFFX_OK;
+}
+
+template <int MODE, bool INV, bool AOS, bool ML>
+static int launch_pairs(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, uint32_t lds) {
+    if (threads == 1024) return offs ? launch_pairs3<MODE, INV, AOS, ML, 1024, true>(b, grid, a, lds) : launch_pairs3<MODE, INV, AOS, ML, 1024, false>(b, grid, a, lds);
+    return offs ? launch_pairs3<MODE, INV, AOS, ML, 512, true>(b, grid, a, lds) : launch_pairs3<MODE, INV, AOS, ML, 512, false>(b, grid, a, lds);
+}
+
+static int run_pairs_pass(gffx_hip_batch *b) {
+    const gffx_hip_index *ix = b->ix;
+    PairArgs a{};
+    WaveOut &o = a.out;
+    o.counts = b->d_counts;
+    o.err = reinterpret_cast<uint32_t *>(b->d_status);
+    o.slow = b->d_status + 4;
+    b->fused_word = 2 + b->fused_phase;
+    o.pair_cursor = b->d_status + b->fused_word;
+    o.pair_cursor_next = b->d_status + 2 + (b->fused_phase ^ 1);
+    b->fused_phase ^= 1;
+    o.segbase = (b->flags & GFFX_OUT_SEGBASE) ? b->d_segbase : nullptr;
+    o.offsets = (b->flags & GFFX_OUT_OFFSETS) ? b->d_offsets : nullptr;
+    o.offsets32 = (b->flags & GFFX_OUT_OFFSETS32) ? b->d_offsets32 : nullptr;
+    o.fids = (b->flags & GFFX_OUT_FIDS) ? b->d_fids : nullptr;
+    o.capacity = o.fids ? b->cap_fids : UINT64_MAX;
+    bool ml = meta_bytes(ix) <= kMetaLdsBytes;
+    const uint32_t threads = wave_pair_threads(b);
+    const bool offs = o.offsets || o.offsets32;
+    const uint32_t keep_words = offs ? 2u : 0u;
+    uint32_t fwords = (ix->win_fwords + 3) / 4 * 4, swords = ix->win_swords;
+    if (fwords < 4) fwords = 0;
+    // What does not fit the block's LDS goes in this order: the split bitmap (lists longer than 4 are then walked from win_spill), the
+    // seqid records (read through the caches instead), the coverage filter.  What is left -- header, strips, parked offsets,
+    // per-thread strips, exchange -- fits by construction (checked: a launch over the limit would fail or run one block per CU).
+    const uint32_t max_lds = threads == 1024 ? 2 * kWinMaxLds : kWinMaxLds;
+    if (pairs_lds_bytes(ix, threads, keep_words, fwords, swords, ml) > max_lds) swords = 0;
+    if (pairs_lds_bytes(ix, threads, keep_words, fwords, swords, ml) > max_lds) ml = false;
+    if (pairs_lds_bytes(ix, threads, keep_words, fwords, swords, ml) > max_lds) fwords = 0;
+    if (pairs_lds_bytes(ix, threads, keep_words, fwords, swords, ml) > max_lds)
+        return fail(GFFX_E_INVALID, "k_join_pairs: %u bytes of LDS per block exceed the limit of %u", pairs_lds_bytes(ix, threads, keep_words, fwords, swords, ml), max_lds);
+    b->win_threads = threads;
+    const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", threads == 1024 ? 256 : 512, 1, 65535));
+    const uint32_t lds = pairs_lds_bytes(ix, threads, keep_words, fwords, swords, ml);
+    const bool aos = b->q.aos != nullptr;
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    a.vec_ok = aos ? al(b->q.aos) : (al(b->q.chr) && al(b->q.start) && al(b->q.end));
+    a.pv.lines = ix->d_win;
+    a.pv.meta = ix->d_win_meta;
+    a.pv.filter = ix->d_win_filter;
+    a.pv.splittab = ix->d_win_splittab;
+    a.pv.n_win = ix->n_win;
+    a.pv.n_chr = ix->n_chr;
+    a.pv.fshift = ix->win_fshift;
+    a.q = b->q;
+    a.nq = b->nq;
+    a.fwords = fwords;
+    a.swords = swords;
+    a.grid = grid;
+    a.spill = ix->d_win_spill;
+    a.ix = ix->view();
+    ProfEvent pe;
+    int lrc = GFFX_OK;
+    prof_begin(b, GFFX_K_WAVE, &pe);
+#define GFFX_CASE2(M, I, A, L) \
+    if (b->mode == M && (b->invert != 0) == I && aos == A && ml == L) lrc = launch_pairs<M, I, A, L>(b, grid, a, threads, offs, lds);
+#define GFFX_CASE(M, I, A) GFFX_CASE2(M, I, A, true) GFFX_CASE2(M, I, A, false)
+    GFFX_CASE(0, false, false) GFFX_CASE(0, false, true) GFFX_CASE(0, true, false) GFFX_CASE(0, true, true)
+    GFFX_CASE(1, false, false) GFFX_CASE(1, false, true) GFFX_CASE(1, true, false) GFFX_CASE(1, true, true)
+    GFFX_CASE(2, false, false) GFFX_CASE(2, false, true) GFFX_CASE(2, true, false) GFFX_CASE(2, true, true)
+#undef GFFX_CASE
+#undef GFFX_CASE2
+    prof_end(b, &pe);
+    if (lrc) return lrc;
+    GFFX_HIP_TRY(hipGetLastError());
+    return GFFX_OK;
+}
+
 static int run_windows_pass(gffx_hip_batch *b, int out_kind, bool second) {
     // pair passes (counts / offsets / root_fids) are the wave kernel's; k_join_win keeps the triples and root-bitmap passes
-    if (out_kind == 1 && !second) return run_wave_pass(b);
+    if (out_kind == 1 && !second) return env_long("GFFX_HIP_PAIR_KERNEL", 4, 3, 4) == 3 ? run_wave_pass(b) : run_pairs_pass(b);
     const gffx_hip_index *ix = b->ix;
     WinOut o{};
     o.counts = b->d_counts;

@@ -94,6 +94,15 @@ struct IndexView {
     const uint32_t *win_tailtab;
     uint32_t n_tail;      // tail lines
     uint32_t win_twords;  // bitmap words (= ceil(n_win / 32)), 0 = none
+    // Round 4 (k_join_pairs): SPLIT windows.  A window whose list is longer than 4 (and not dense) is cut into 2^kWinSplit
+    // sub-windows of W >> kWinSplit bp, each with a line of its own in the same format (coordinates relative to the sub-window's
+    // start - wmax; a sub-list that is still longer than 4 keeps 3 + mark + spill records like any line).  The sub-lines of
+    // window w are lines n_win + (w << kWinSplit) .. + 2^kWinSplit - 1 of the SAME arrays (win / win_pos are allocated
+    // n_win * (1 + 2^kWinSplit) lines when win_split is set; everything but the sub-lines of split windows is zero and never
+    // read: a sparse second level).  win_splittab (staged in LDS) has one bit per window, padded with at least one zero word:
+    // a region reads EXACTLY ONE line -- its window's, or the sub-line of the sub-window its last base lies in.
+    const uint32_t *win_splittab;
+    uint32_t win_swords;  // bitmap words (= ceil(n_win / 32)); 0 = no split level (the lists then continue in win_spill)
     uint32_t n_chr;
     uint32_t n_roots;
 };
@@ -105,6 +114,7 @@ constexpr uint32_t kWinMaxShift = 15;            // widest window: W + wmax + 1 
 constexpr uint32_t kWinTailMark = 0xFFFFFFFFu;   // word 3 of a line whose list continues in win_spill
 constexpr uint32_t kWinAbsent = 0x0000FFFFu;     // coordinate word of an absent entry
 constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (n = 255)
+constexpr uint32_t kWinSplit = 3;                // a split window has 2^kWinSplit sub-windows (round 4)
 constexpr uint32_t kWaveGroup = 256;             // regions per GFFX_OUT_SEGBASE entry: 64 lanes x 4 regions, one wave's share of a round
 constexpr uint32_t kPosBits = 27;
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1;

@@ -1,0 +1,730 @@
+// join_pairs_kernels.hpp -- Join A over the window index: the pair passes (counts + root_fids / positions + segment bases)
+// and the root-flag passes of the windows strategy, round 4's rewrite of k_join_wave (round 3) for instruction count.
+//
+// What it computes (reference: utils/tree.rs:98-121 + commands/intersect.rs:139-165): for every region (chr, qs, qe) every
+// root interval of seqid chr with start < qe && end > qs, kept iff invert ^ predicate(mode).
+//
+// Same index (gffx_device.hpp: one 32-byte LINE per genome window, 16-bit window-relative coordinates, tail lines located
+// through an LDS bitmap, coverage filter in LDS), the same cooperation of the waves of a block as k_join_wave had (a wave
+// is the unit; ONE pair segment per block round reserved by ARRIVAL in LDS, the last wave to arrive issues the device
+// atomic; the answer is collected two rounds later, so nobody waits for the atomic, for the slowest wave or for another
+// wave's rare paths) -- and the same result set, bit for bit.  What changed is what a round costs: round 3's kernel was
+// VALU-issue bound (670 VALU wave instructions per 256-region wave round, a fifth of them v_readlane / v_writelane / v_mov
+// of spilled lane masks: 102 SGPRs, 76 spills).  Here
+//   * a test is THREE VALU instructions: two SDWA compares on the packed 16-bit coordinates straight into lane masks, one
+//     s_and (scalar unit), and one v_addc that shifts the outcome into a per-region bit string (m = 2 m + kept);
+//   * a kept root_fid is parked by TWO: v_add_co shifts the bit string's top bit into vcc, the LDS write and the advance of
+//     the lane's cursor run under that lane mask (s_and_saveexec / s_mov exec: scalar unit) -- no per-entry position
+//     arithmetic, no branch;
+//   * what the round loop keeps in scalar registers is two buffer descriptors and a handful of words: the index view's
+//     twenty pointers stay in the kernarg segment and are only read on the rare paths (list tails in win_spill, sweeps);
+//   * a parked round leaves through immediate-offset LDS reads and buffer stores from the run's own descriptor (the range
+//     check drops the lanes past the run): no per-trip address or bounds arithmetic;
+//   * rare-event bookkeeping (deferred regions, sweeps, bad seqids) lives in lane masks until a wave actually has one.
+// Roofline bound: HBM.  Algorithmic bytes per region: 12 in + 4 + 4*h out.
+#pragma once
+#include "join_wave_kernels.hpp"  // (development: the round-3 kernel stays in the build for A/B runs; the shared helpers are its)
+
+namespace gffx {
+
+typedef const __attribute__((address_space(3))) uint32_t *LdsWords;  // an LDS address as a pointer
+
+// what the MAIN path of a pass reads of the index: two line tables (root_fids, or index positions: root flags, triples)
+// and the three small tables every block stages in LDS
+struct PairView {
+    const uint4 *lines;        // IndexView::win or ::win_pos (with the split windows' sub-lines behind the windows' lines)
+    const uint4 *meta;         // IndexView::win_meta
+    const uint32_t *filter;    // IndexView::win_filter
+    const uint32_t *splittab;  // IndexView::win_splittab
+    uint32_t n_win, n_chr, fshift;
+};
+
+// The kernel's one argument.  The main path reads `pv`, `q`, `out` and the scalars; `ix` is never touched by value: the rare
+// paths read it where it already lies, in the kernarg segment, through a pointer made inside the rare block (as by-value
+// arguments used inside the loop its twenty-odd pointers would be loaded once and held -- i.e. spilled -- across the loop).
+struct PairArgs {
+    PairView pv;
+    QueryView q;
+    unsigned long long nq;
+    WaveOut out;
+    int vec_ok;
+    uint32_t fwords, swords;  // filter / split-bitmap words staged in LDS (0: that table did not fit, or does not exist)
+    const uint4 *spill;  // IndexView::win_spill (list tails: the one rare path that is walked in line)
+    uint32_t grid;  // blocks of the launch (read from the dispatch packet it would be a scalar load per round)
+    IndexView ix;
+};
+
+// The four entries of a line against one region: m = a bit per entry (entry 0 = bit 3), set iff the entry
+// w = start_rel | end_rel << 16 is kept by the region [rqs, rqe1 + 1) in the line's coordinates.
+// Overlap mode: per entry two SDWA compares on the packed 16-bit coordinates straight into lane masks, one s_and (scalar
+// unit) and one v_addc that shifts the outcome into the bit string (m = 2 m + kept): 3 VALU + 1 SALU.  One asm block per
+// line (the compiler fences every asm block with hazard nops).
+template <int MODE, bool INVERT>
+__device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rqs, uint32_t rqe1) {
+    uint32_t m;
+    if (MODE == GFFX_MODE_OVERLAP && !INVERT) {
+        unsigned long long t;
+        asm("v_cmp_le_u32_sdwa %[t], %[w0], %[qe] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %[w0], %[qs] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "s_and_b64 vcc, vcc, %[t]\n\t"
+            "v_addc_co_u32 %[m], vcc, 0, 0, vcc\n\t"
+            "v_cmp_le_u32_sdwa %[t], %[w1], %[qe] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %[w1], %[qs] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "s_and_b64 vcc, vcc, %[t]\n\t"
+            "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t"
+            "v_cmp_le_u32_sdwa %[t], %[w2], %[qe] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %[w2], %[qs] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "s_and_b64 vcc, vcc, %[t]\n\t"
+            "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t"
+            "v_cmp_le_u32_sdwa %[t], %[w3], %[qe] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+            "v_cmp_gt_u32_sdwa vcc, %[w3], %[qs] src0_sel:WORD_1 src1_sel:DWORD\n\t"
+            "s_and_b64 vcc, vcc, %[t]\n\t"
+            "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc"
+            : [m] "=&v"(m), [t] "=&s"(t)
+            : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [qs] "v"(rqs), [qe] "v"(rqe1)
+            : "vcc");
+    } else {
+        const uint32_t rqe = rqe1 + 1u;
+        m = (win_test<MODE, INVERT>(w0 & 0xFFFFu, w0 >> 16, rqs, rqe) ? 8u : 0u) | (win_test<MODE, INVERT>(w1 & 0xFFFFu, w1 >> 16, rqs, rqe) ? 4u : 0u) |
+            (win_test<MODE, INVERT>(w2 & 0xFFFFu, w2 >> 16, rqs, rqe) ? 2u : 0u) | (win_test<MODE, INVERT>(w3 & 0xFFFFu, w3 >> 16, rqs, rqe) ? 1u : 0u);
+    }
+    return m;
+}
+
+// Park the kept words of a line in LDS: for each of the four entries, if the top bit of x is set { LDS[pos] = word, pos += 4 },
+// x <<= 1.  Per entry: v_add_co shifts the bit into vcc, the LDS write and the advance of the cursor run under that lane mask
+// (s_and_saveexec / s_mov exec: scalar unit) -- 2 VALU + 2 SALU + the write, no position arithmetic, no branch.
+__device__ __forceinline__ void pair_park4(uint32_t x, uint32_t &pos, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    unsigned long long sv;
+    asm volatile("v_add_co_u32 %[x], vcc, %[x], %[x]\n\t"
+                 "s_and_saveexec_b64 %[sv], vcc\n\t"
+                 "ds_write_b32 %[pos], %[f0]\n\t"
+                 "v_add_u32 %[pos], 4, %[pos]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_add_co_u32 %[x], vcc, %[x], %[x]\n\t"
+                 "s_and_saveexec_b64 %[sv], vcc\n\t"
+                 "ds_write_b32 %[pos], %[f1]\n\t"
+                 "v_add_u32 %[pos], 4, %[pos]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_add_co_u32 %[x], vcc, %[x], %[x]\n\t"
+                 "s_and_saveexec_b64 %[sv], vcc\n\t"
+                 "ds_write_b32 %[pos], %[f2]\n\t"
+                 "v_add_u32 %[pos], 4, %[pos]\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "v_add_co_u32 %[x], vcc, %[x], %[x]\n\t"
+                 "s_and_saveexec_b64 %[sv], vcc\n\t"
+                 "ds_write_b32 %[pos], %[f3]\n\t"
+                 "v_add_u32 %[pos], 4, %[pos]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [x] "+v"(x), [pos] "+v"(pos), [sv] "=&s"(sv)
+                 : [f0] "v"(f0), [f1] "v"(f1), [f2] "v"(f2), [f3] "v"(f3)
+                 : "vcc", "memory");
+}
+
+// A parked run of `total` words leaves the wave's strip four trips at a time: a trip at word X is one LDS read and one buffer
+// store at immediate offsets from the run's own descriptor, whose range check drops the lanes -- and whole trips -- past the
+// run: no per-trip address or bounds arithmetic, one uniform compare per 256 words.
+template <uint32_t X, uint32_t END, bool DONE = (X >= END)>
+struct PairFlush {
+    static __device__ __forceinline__ void run(const uint32_t *st /* strip + lane */, __amdgpu_buffer_rsrc_t rf, uint32_t lane4, uint32_t total) {
+        if (X < total) {
+            const uint32_t a = st[X], b = st[X + 64], c = st[X + 128], d = st[X + 192];
+            __builtin_amdgcn_raw_buffer_store_b32(a, rf, lane4 + X * 4u, 0, 2 /* nt */);
+            __builtin_amdgcn_raw_buffer_store_b32(b, rf, lane4 + (X + 64) * 4u, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b32(c, rf, lane4 + (X + 128) * 4u, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b32(d, rf, lane4 + (X + 192) * 4u, 0, 2);
+            PairFlush<X + 256, END>::run(st, rf, lane4, total);
+        }
+    }
+};
+template <uint32_t X, uint32_t END>
+struct PairFlush<X, END, true> {
+    static __device__ __forceinline__ void run(const uint32_t *, __amdgpu_buffer_rsrc_t, uint32_t, uint32_t) {}
+};
+
+// every kept pair of ONE region, generic walk (the synchronous path of an overfull round and nothing else): f(word)
+template <int MODE, bool INVERT, bool POS, typename F>
+__device__ __forceinline__ void pair_walk_region(const IndexView &ix, const uint4 *lines, const uint4 *cm, uint32_t chr, uint32_t qs,
+                                                 uint32_t qe, F &&f) {
+    if (chr >= ix.n_chr) return;
+    if (MODE == GFFX_MODE_OVERLAP && INVERT) return;
+    const uint4 m = cm[chr];
+    const uint32_t shift = m.z & 31u, wmax = m.z >> 8;
+    if (m.y == 0) return;
+    const bool fits = qe > qs && qe - qs <= wmax;
+    const uint32_t b = (qe - 1) >> shift;
+    bool sweep = !fits;
+    if (fits) {
+        if (b >= m.y) return;  // beyond the last window nothing reaches the region
+        const uint32_t *l = reinterpret_cast<const uint32_t *>(lines + 2ull * (m.x + b));
+        const uint32_t rel = wmax - (b << shift), rqs = qs + rel, rqe = qe + rel;
+        const bool tail = l[3] == kWinTailMark;
+        const uint32_t hdr = tail ? l[7] : 0u;
+        if ((hdr & 255u) == 255u) {
+            sweep = true;
+        } else {
+            for (uint32_t j = 0; j < (tail ? kWinInlineTail : kWinInline); ++j) {
+                const uint32_t w = l[j];
+                if (win_test<MODE, INVERT>(w & 0xFFFFu, w >> 16, rqs, rqe)) f(l[4 + j]);
+            }
+            if (tail) {
+                const uint4 *sp = ix.win_spill + (hdr >> 8);
+                for (uint32_t j = kWinInlineTail; j < (hdr & 255u); ++j) {
+                    const uint4 x = sp[j - kWinInlineTail];
+                    if (win_test<MODE, INVERT>(x.x, x.y, qs, qe)) f(POS ? x.w : x.z);
+                }
+            }
+        }
+    }
+    if (sweep)
+        for_each_kept<MODE, INVERT>(ix, ix.chr_meta[chr], qs, qe, [&](uint32_t j, uint32_t, const uint4 &a) {
+            f(POS ? j : a.w);
+            return true;
+        });
+}
+
+// The rare paths as a FUNCTION CALL: what a line does not hold of one deferred region (win_rest) walked out of line.  Inlined,
+// this code -- twice, with the sweep's bin search and skip-link walk inside -- is most of the round loop's body: the hot
+// path then branches over it ~100 times a round, and its live ranges decide the loop's register allocation (40 SGPRs spilled
+// to VGPR lanes).  Writes the first `cap` kept words (root_fids, or positions) to out[0 ..] and returns how many there are.
+template <int MODE, bool INVERT, bool POS>
+__device__ __attribute__((noinline)) uint32_t pair_sweep_call(const IndexView *ix, uint32_t chr, uint32_t qs, uint32_t qe, uint32_t *out, uint32_t cap) {
+    uint32_t c = 0;
+    for_each_kept<MODE, INVERT>(*ix, ix->chr_meta[chr], qs, qe, [&](uint32_t j, uint32_t, const uint4 &a) {
+        if (c < cap) out[c] = POS ? j : a.w;
+        ++c;
+        return true;
+    });
+    return c;
+}
+// ... and the frequent, small case in line: the tail of a list longer than 4 (entries 3 .. n - 1, 16-byte records with absolute
+// coordinates in win_spill, four in flight); sweeps (wide / empty regions, dense windows) go through the call
+template <int MODE, bool INVERT, bool POS>
+__device__ __forceinline__ uint32_t pair_rest(const IndexView *ix, const uint4 *spill, uint32_t sweep, uint32_t chr, uint32_t qs, uint32_t qe,
+                                              uint32_t hdr, uint32_t *out, uint32_t cap) {
+    if (sweep) return pair_sweep_call<MODE, INVERT, POS>(ix, chr, qs, qe, out, cap);
+    uint32_t c = 0;
+    const uint32_t n = hdr & 255u;
+    const uint4 *sp = spill + (hdr >> 8);
+    for (uint32_t j = kWinInlineTail; j < n; j += 4) {
+        uint4 x[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            x[t] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+            if (j + t < n) x[t] = sp[j - kWinInlineTail + t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (win_test<MODE, INVERT>(x[t].x, x[t].y, qs, qe)) {
+                if (c < cap) out[c] = POS ? x[t].w : x[t].z;
+                ++c;
+            }
+    }
+    return c;
+}
+
+// words a wave parks in LDS per round (a strip): 1.5 kept pairs per region at 1024 threads, 1 at 512 (two blocks share a CU's LDS);
+// a fuller round takes all kWaveDepth strips, beyond that the synchronous path
+__host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads) { return threads == 1024 ? 384u : 256u; }
+// T: threads per block (512: two blocks per CU; 1024: one, half the reservation atomics)
+// OFFS: per-region offsets are written (GFFX_OUT_OFFSETS / _OFFSETS32): each lane parks its place inside the round's segment
+// POS: the words a pass emits are index positions (tables win_pos / win_tail_pos), not root_fids
+template <int MODE, bool INVERT, bool AOS, bool META_LDS, int T, bool OFFS, bool POS>
+__global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
+    constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
+    constexpr uint32_t kWaves = T / 64;
+    constexpr uint32_t D = kWaveDepth;
+    constexpr uint32_t keep_words = OFFS ? 2u : 0u;
+    constexpr uint32_t kStage = pair_stage_words(T);  // words a wave parks per round
+    auto rare_ix = [&]() -> const IndexView & {
+        typedef const unsigned char __attribute__((address_space(4))) * KernargBytes;
+        KernargBytes p = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return *(const IndexView *)(p + __builtin_offsetof(PairArgs, ix));
+    };
+    const QueryView &q = A.q;
+    const WaveOut &out = A.out;
+    const unsigned long long nq = A.nq;
+    const uint32_t fwords = A.fwords, swords = A.swords, n_chr = A.pv.n_chr;
+
+    // LDS: the coverage filter FIRST (at the block's LDS base: its word pairs are read at immediate offsets), the split bitmap,
+    // the seqid records, then the waves' machinery
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t sw4 = swords ? (swords + 4) / 4 * 4 : 0;  // bitmap words staged: swords + at least one zero word
+    uint32_t *s_filter = reinterpret_cast<uint32_t *>(smem);                                  // fwords (a multiple of 4)
+    uint32_t *s_sbits = s_filter + fwords;                                                    // sw4
+    uint4 *s_meta = reinterpret_cast<uint4 *>(s_sbits + sw4);                                 // n_chr + 1 (META_LDS)
+    unsigned char *s_work = reinterpret_cast<unsigned char *>(s_meta + (META_LDS ? n_chr + 1 : 0));
+    unsigned long long *s_arrive = reinterpret_cast<unsigned long long *>(s_work);              // [D] arrivals << 56 | pairs so far
+    unsigned long long *s_post_base = reinterpret_cast<unsigned long long *>(s_work + 8 * D);   // [D] the round's segment base
+    uint32_t *s_post_seq = reinterpret_cast<uint32_t *>(s_work + 16 * D);                       // [D] block round + 1 it belongs to
+    uint32_t *s_stage_all = reinterpret_cast<uint32_t *>(s_work + kWaveHdrBytes);               // waves x D x kStage
+    uint32_t *s_keep_all = s_stage_all + kWaves * D * kStage;                               // T x D x keep_words
+    uint32_t *s_stash = s_keep_all + (size_t)T * D * keep_words + kWaveStash * threadIdx.x;     // this thread's kWaveStash words
+    // (where the dynamic LDS starts, as an LDS address: what ds_write takes)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const uint32_t tid = threadIdx.x, t4 = 4u * tid;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t *s_stage = s_stage_all + (size_t)wave * D * kStage;  // this wave's strips
+
+    uint32_t qc[4], qs[4], qe[4];  // the round's 4 consecutive regions of the thread
+    bool bad = false;              // a region's seqid is out of range
+    auto round_rsrc = [&](const uint32_t *col, unsigned long long first, uint32_t words) {
+        const unsigned long long left = first < nq ? nq - first : 0ull;
+        const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(col + words * first), 0, rows * 4u * words, 0x00020000);
+    };
+    auto load_round = [&](unsigned long long r) {
+        const unsigned long long base = r * kChunk;  // (uniform)
+        constexpr int kNt = 2;                       // nt: streamed once
+#if defined(GFFX_ABL_NOREGION)
+        {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t h = (uint32_t)(base + t4 + k) * 2654435761u;
+                h ^= h >> 15, h *= 2246822519u, h ^= h >> 13;
+                qc[k] = (h >> 8) % 24u;
+                qs[k] = (h * 3266489917u) % 40000000u;
+                qe[k] = qs[k] + 100u + (h & 8191u);
+            }
+            return;
+        }
+#endif
+        if (AOS) {
+            const __amdgpu_buffer_rsrc_t ra = round_rsrc(q.aos, base, 3);
+            const gffx_v4u a = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4, 0, kNt),
+                           b = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 16, 0, kNt),
+                           c = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 32, 0, kNt);
+            qc[0] = a.x, qs[0] = a.y, qe[0] = a.z;
+            qc[1] = a.w, qs[1] = b.x, qe[1] = b.y;
+            qc[2] = b.z, qs[2] = b.w, qe[2] = c.x;
+            qc[3] = c.y, qs[3] = c.z, qe[3] = c.w;
+        } else {
+            const gffx_v4u c = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.chr, base, 1), 4u * t4, 0, kNt),
+                           s = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.start, base, 1), 4u * t4, 0, kNt),
+                           e = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.end, base, 1), 4u * t4, 0, kNt);
+            qc[0] = c.x, qc[1] = c.y, qc[2] = c.z, qc[3] = c.w;
+            qs[0] = s.x, qs[1] = s.y, qs[2] = s.z, qs[3] = s.w;
+            qe[0] = e.x, qe[1] = e.y, qe[2] = e.z, qe[3] = e.w;
+        }
+        if (base < nq && !(A.vec_ok && base + kChunk <= nq)) {
+            // the batch's last, partial round (and unaligned columns), element by element; a row beyond the batch becomes
+            // the "no region" row {n_chr, 0, 0}: the seqid table's extra record has no windows, so it reads nothing and
+            // keeps nothing; a real row with a seqid out of range is flagged HERE and becomes the same row (the round loop
+            // flags rows of full rounds only)
+            const unsigned long long i0 = base + t4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                qc[k] = n_chr;
+                qs[k] = qe[k] = 0;
+                if (i0 + k < nq) {
+                    load_query<AOS>(q, i0 + k, qc[k], qs[k], qe[k]);
+                    bad |= qc[k] >= n_chr;
+                    qc[k] = min(qc[k], n_chr);
+                }
+            }
+        }
+    };
+    const unsigned long long n_rounds = (nq + kChunk - 1) / kChunk;
+    if (blockIdx.x < n_rounds) load_round(blockIdx.x);  // in flight while the tables are staged
+    const uint4 *cm;
+    if (META_LDS) {
+        for (uint32_t i = tid; i <= n_chr; i += T) s_meta[i] = A.pv.meta[i];
+        cm = s_meta;
+    } else {
+        cm = A.pv.meta;
+    }
+    for (uint32_t x = tid; x < fwords / 4; x += T)
+        reinterpret_cast<uint4 *>(s_filter)[x] = reinterpret_cast<const uint4 *>(A.pv.filter)[x];
+    for (uint32_t x = tid; x < sw4 / 4; x += T)
+        reinterpret_cast<uint4 *>(s_sbits)[x] = reinterpret_cast<const uint4 *>(A.pv.splittab)[x];
+    if (tid < D) {
+        s_arrive[tid] = 0ull;
+        s_post_seq[tid] = 0u;
+    }
+    win_barrier();  // the ONLY block barrier: tables staged, arrival words zero
+    if (blockIdx.x == 0 && tid == 0) {
+        *out.pair_cursor_next = 0ull;
+        if (lds0 != 0) atomicOr(out.err, 2u);  // (the filter lookups assume the dynamic LDS starts at LDS address 0)
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
+    const bool nofilt = fwords == 0, split_on = swords != 0;  // (uniform) a table that did not fit the block's LDS
+    uint32_t n_slow = 0;
+
+    // ---- what is left to do for the wave's previous D - 1 rounds once their segment bases are known (all wave-uniform;
+    // entry 0 = the latest round)
+    constexpr int P = (int)D - 1;
+    bool p_valid[P], p_poster[P];
+    uint32_t p_total[P], p_seq[P], p_slot[P], p_strip[P];  // (p_slot: the round's arrival / post slot; p_strip: where its words wait)
+    unsigned long long p_off[P], p_round[P];
+    // lane 0 of the wave that issued the LATEST round's reservation atomic: what it returned.  (One register pair, never
+    // copied while the atomic is in flight: a copy would be a wait for it.  The base is posted during the next round, before
+    // the entries shift.)
+    unsigned long long p_got = 0;
+    bool p_big = false;  // the latest round took ALL of the wave's strips (see `big` below): it is flushed before anything is parked again
+#pragma unroll
+    for (int i = 0; i < P; ++i) p_valid[i] = p_poster[i] = false, p_total[i] = p_seq[i] = p_slot[i] = p_strip[i] = 0, p_off[i] = p_round[i] = 0;
+
+    auto post = [&](uint32_t par, uint32_t seq, unsigned long long got) {  // the wave that issued the round's atomic
+        if (lane == 0) {
+            s_post_base[par] = got;
+            __hip_atomic_store(&s_post_seq[par], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto await_base = [&](uint32_t par, uint32_t seq) -> unsigned long long {
+        while ((uint32_t)__builtin_amdgcn_readfirstlane(
+                   (int)__hip_atomic_load(&s_post_seq[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != seq)
+            __builtin_amdgcn_s_sleep(1);
+        const unsigned long long b = s_post_base[par];
+        return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
+    };
+    // per-region offsets of a round from the parked {place inside the wave's run, counts}
+    auto put_offsets = [&](unsigned long long round, unsigned long long seg, uint32_t lp0, uint32_t c0, uint32_t c1, uint32_t c2) {
+        const unsigned long long base = round * kChunk, i0 = base + t4, pos = seg + lp0;
+        if (base + kChunk <= nq) {
+            if (out.offsets) {
+                gffx_v2ul v0, v1;
+                v0.x = pos, v0.y = pos + c0, v1.x = pos + c0 + c1, v1.y = pos + c0 + c1 + c2;
+                GFFX_NT_STORE(v0, reinterpret_cast<gffx_v2ul *>(out.offsets + i0));
+                GFFX_NT_STORE(v1, reinterpret_cast<gffx_v2ul *>(out.offsets + i0 + 2));
+            }
+            if (out.offsets32) {
+                const uint32_t p32 = (uint32_t)pos;
+                gffx_v4u v;
+                v.x = p32, v.y = p32 + c0, v.z = p32 + c0 + c1, v.w = p32 + c0 + c1 + c2;
+                GFFX_NT_STORE(v, reinterpret_cast<gffx_v4u *>(out.offsets32 + i0));
+            }
+        } else {
+            const uint32_t c[3] = {c0, c1, c2};
+            unsigned long long o = pos;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k < nq) {
+                    if (out.offsets) out.offsets[i0 + k] = o;
+                    if (out.offsets32) out.offsets32[i0 + k] = (uint32_t)o;
+                }
+                if (k < 3) o += c[k];
+            }
+        }
+    };
+    auto group_base = [&](unsigned long long round, unsigned long long seg) {  // GFFX_OUT_SEGBASE: one word per wave and round
+        const unsigned long long g = round * kWaves + (uint32_t)wave;
+        if (out.segbase && lane == 0 && g * kWaveGroup < nq) out.segbase[g] = seg;
+    };
+    // a round's segment base is posted by the wave that issued its atomic: as soon as that wave has its next round's
+    // gathers in flight (the atomic's answer is there by then) -- a full round before anybody has to have it
+    auto post_pending = [&]() {  // (only the latest round can still be unposted)
+        asm volatile("" : "+v"(p_got));  // (an ordinary register from here on: the next round's atomic may overwrite it)
+        if (p_valid[0] && p_poster[0]) {
+            post(p_slot[0], p_seq[0], p_got);
+            p_poster[0] = false;
+        }
+    };
+    const uint32_t lane4 = 4u * (uint32_t)lane;
+    auto finish = [&](int i) {  // (i: compile-time after unrolling)
+        if (!p_valid[i]) return;
+        const uint32_t slot = p_slot[i];
+#if defined(GFFX_ABL_NOSYNC)
+        const unsigned long long seg = (p_round[i] * kWaves + (uint32_t)wave) * kStage;
+#else
+        const unsigned long long seg = await_base(slot, p_seq[i]) + p_off[i];
+#endif
+        group_base(p_round[i], seg);
+        if (out.fids) {
+            const uint32_t total = p_total[i];  // (uniform)
+            const uint32_t *st = s_stage + p_strip[i] * kStage + lane;
+            uint32_t *dst = out.fids + seg;  // (uniform)
+            if (seg + total <= out.capacity) {
+                // a buffer store from the run's own base: the range check drops the lanes past the run, so a trip is an LDS
+                // read and a store at immediate offsets -- no per-trip address or bounds arithmetic
+#if defined(GFFX_ABL_NOSTORE)
+                const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0u, 0x00020000);
+#else
+                const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(dst, 0, total * 4u, 0x00020000);
+#endif
+                uint32_t l4 = lane4;
+                asm volatile("" : "+v"(l4));  // (made here: hoisted out of the round loop, lane4 + X would be a register per trip)
+                PairFlush<0, D * kStage>::run(st, rf, l4, total);
+            } else {
+                for (uint32_t x = lane; x < total; x += 64)
+                    if (seg + x < out.capacity) dst[x] = s_stage[p_strip[i] * kStage + x];
+            }
+        }
+        if (OFFS) {
+            const uint32_t *kp = s_keep_all + ((size_t)slot * T + tid) * 2;
+            const uint32_t a = kp[0], b = kp[1];
+            put_offsets(p_round[i], seg, a & 0xFFFFu, a >> 16, b & 0xFFFFu, b >> 16);
+        }
+        p_valid[i] = false;
+    };
+    uint32_t k_round = 0, slot_now = 0;  // the block's rounds, counted; k_round % D
+    // The first round's regions are waited for HERE, once: pending at the loop's entry (with possibly nothing issued after them)
+    // they would turn the wait at the top of EVERY round into s_waitcnt vmcnt(0) -- a drain of the previous round's stores
+    // and of its reservation atomic -- because the compiler merges the entry's state with the back edge's.
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(qc[k]), "+v"(qs[k]), "+v"(qe[k]));
+    for (unsigned long long r = blockIdx.x; r < n_rounds; r += A.grid, ++k_round) {
+        const unsigned long long base = r * kChunk;  // (uniform) first region of the round
+        const unsigned long long i0 = base + t4;     // this thread's 4 consecutive regions
+        const bool full = base + kChunk <= nq;       // (uniform) every thread has its 4 regions
+        GFFX_WIN_STAMP(0);
+        // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
+        uint32_t off[4], rqs[4], rqe1[4];  // the line's byte offset; the region in the line's coordinates (rqe1 = its last base)
+        bool swp[4];  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bad |= full && qc[k] >= n_chr;  // (a partial round's rows were checked when they were loaded)
+            const uint4 m = cm[min(qc[k], n_chr)];
+            const uint32_t wmax = m.z >> 8, e1 = qe[k] - 1u, wd1 = e1 - qs[k];
+            const bool fits = wd1 < wmax;  // 0 < qe - qs <= wmax (unsigned: an empty or reversed row wraps)
+            const uint32_t b = e1 >> (m.z & 31u);
+            // coverage filter: is any cell the region touches covered by a root?  (clear = no hit, exactly.)  No clamps: the
+            // span only matters when the region fits, i.e. spans <= 31 cells; past a seqid's cells a fitting region has no hit
+            // whatever the bits say (it then reads another seqid's bits, or -- beyond the bitmap -- other LDS words: a set bit
+            // costs a line read, never a pair); without a filter (nofilt) the outcome is ignored.
+            const uint32_t a2 = qs[k] >> A.pv.fshift, bit = m.w + a2;
+            const LdsWords fw = (LdsWords)((bit >> 3) & ~3u);  // (the filter starts at LDS address 0: checked at kernel entry)
+            uint32_t v = __builtin_amdgcn_alignbit(fw[1], fw[0], bit);
+            asm volatile("" : "+v"(v));  // (computed HERE for every lane: sunk under `fits` it becomes a branch per region)
+            const bool cov = (__builtin_amdgcn_ubfe(v, 0, (e1 >> A.pv.fshift) - a2 + 1u) != 0) | nofilt;
+            // the window -- or, when its list was too long for a line, the sub-window the region's last base lies in: the LDS
+            // bitmap says which BEFORE any line is read, so every region reads exactly one line (a window number beyond the
+            // table -- a region the lines do not answer -- lands on the bitmap's spare zero word)
+            const uint32_t w = m.x + b;
+            const bool split = (__builtin_amdgcn_ubfe(s_sbits[min(w >> 5, swords)], w, 1) != 0) & split_on;
+            const uint32_t sh = (m.z & 31u) - (split ? kWinSplit : 0u);  // log2 of the width of what the line covers
+            const uint32_t line = split ? A.pv.n_win + (w << kWinSplit) + __builtin_amdgcn_ubfe(e1, sh, kWinSplit) : w;
+#if defined(GFFX_ABL_NOGATHER)
+            off[k] = (fits & (b < m.y) & cov & (qs[k] == 0xFFFFFFF0u)) ? line * kWinLineBytes : kWinNoLine;
+#else
+            off[k] = (fits & (b < m.y) & cov) ? line * kWinLineBytes : kWinNoLine;
+#endif
+            // relative to the line's origin (its first base - wmax): qe - 1 -> (qe - 1) mod width + wmax, qs -> that - (qe - 1 - qs)
+            rqe1[k] = __builtin_amdgcn_ubfe(e1, 0, sh) + wmax;
+            rqs[k] = rqe1[k] - wd1;
+            swp[k] = !fits;  // (a seqid without roots has wmax = 2^24 - 1 and no windows: only absurd rows of it come here)
+        }
+        GFFX_WIN_STAMP(1);
+        gffx_v4u wc[4], wf[4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        GFFX_WIN_STAMP(2);
+        // (Nothing that MAY issue a vector memory operation stands between these loads and their use: a conditional store there
+        //  makes the compiler wait for the loads with vmcnt(0) -- i.e. for the stores' acknowledgements as well, every round.
+        //  The previous rounds are flushed after this round's lines have been used.)
+        // ---- four exact tests per region, in the line's relative coordinates: a bit string per region (entry 0 = bit 3)
+        // (a region without a line read zeros: {start 0, end 0} never passes end > qs)
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = pair_test4<MODE, INVERT>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k]);
+        GFFX_WIN_STAMP(3);
+        // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept words wait in
+        // the thread's LDS strip)
+        uint32_t tc[4] = {0, 0, 0, 0}, hdr[4] = {0, 0, 0, 0};
+        uint32_t deferred = 0, sweep = 0, n_rest = 0;
+        {
+            bool dfr[4];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dfr[k] = swp[k] || wc[k].w == kWinTailMark;
+                any |= dfr[k];
+            }
+#if defined(GFFX_ABL_NODEFER)
+            any = false;
+#endif
+            if (__builtin_amdgcn_ballot_w64(any)) {  // (uniform: some lane of the wave has deferred work)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool tail = wc[k].w == kWinTailMark;
+                    hdr[k] = tail ? wf[k].w : 0u;
+                    const bool sw = swp[k] || (hdr[k] & 255u) == 255u;
+                    deferred |= dfr[k] ? 1u << k : 0u;
+                    sweep |= sw ? 1u << k : 0u;
+                }
+                if (deferred) {
+                    n_slow += __popc(sweep);
+                    uint32_t d = deferred;
+                    while (d) {
+                        const int k = __ffs(d) - 1;
+                        d &= d - 1;
+                        const uint32_t c = pair_rest<MODE, INVERT, POS>(&rare_ix(), A.spill, sweep >> k & 1u, min(win_sel(qc, k), n_chr), win_sel(qs, k),
+                                                                             win_sel(qe, k), win_sel(hdr, k), s_stash + min(n_rest, kWaveStash),
+                                                                             kWaveStash - min(n_rest, kWaveStash));
+                        n_rest += c;
+                        tc[0] += k == 0 ? c : 0u;
+                        tc[1] += k == 1 ? c : 0u;
+                        tc[2] += k == 2 ? c : 0u;
+                        tc[3] += k == 3 ? c : 0u;
+                    }
+                }
+            }
+        }
+        GFFX_WIN_STAMP(4);
+        uint32_t cnt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt[k] = __popc(m[k]) + tc[k];
+        GFFX_WIN_STAMP(5);
+        // ---- the wave that issued the previous round's reservation atomic posts what it returned: every load of this round
+        // has been waited for, so the atomic -- issued before them -- is back without another wait
+        post_pending();
+        {
+            // counts: ONE 16-byte buffer store per thread on every path (rows beyond the batch fall outside the descriptor and
+            // are dropped by the range check).  A conditional store here would make "no memory operation was issued after the
+            // region prefetch" a possible path, and the wait for the prefetched regions at the top of the next round would
+            // become s_waitcnt vmcnt(0): a full drain of this round's stores and of the reservation atomic, every round.
+            const unsigned long long left = nq - base;  // (base < nq inside the loop)
+            const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
+            gffx_v4u cv;
+            cv.x = cnt[0], cv.y = cnt[1], cv.z = cnt[2], cv.w = cnt[3];
+#if defined(GFFX_ABL_NOSTORE)
+            __builtin_amdgcn_raw_buffer_store_b128(cv, __builtin_amdgcn_make_buffer_rsrc(out.counts + base, 0, 0u, 0x00020000),
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(cv, __builtin_amdgcn_make_buffer_rsrc(out.counts + base, 0, rows * 4u, 0x00020000),
+#endif
+                                                   4u * t4, 0, 2 /* nt */);
+        }
+        // ---- the oldest round in flight leaves (its segment base was posted a round ago), THEN the next round's regions are
+        // requested -- the regions of this one are done with, their registers are free: the stores above are older than the
+        // loads the top of the next round waits for, and nothing conditional but the reservation atomic is younger
+        GFFX_WIN_STAMP(6);
+        finish(P - 1);
+        GFFX_WIN_STAMP(7);
+        load_round(r + A.grid);
+        const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        const uint32_t inc = win_wave_scan(mine);
+        const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);  // (uniform) the wave's kept pairs
+        const uint32_t lp0 = inc - mine;  // this thread's first pair inside the wave's run
+        // ---- park the round's words in this wave's strip (by final position inside the wave's run)
+        // A wave whose round keeps more pairs than one strip holds (gene-dense stretches of a SORTED BED file do that to whole
+        // blocks) takes all D strips for it -- they are contiguous -- after flushing what they still hold, and flushes the
+        // round before it parks anything again: such rounds run one round deep instead of D - 1, through the same code.
+        // Only a round beyond D strips (> 1536 pairs of 256 regions) is written synchronously from a second walk.
+        const bool big = wtotal > kStage && wtotal <= D * kStage;  // (uniform)
+        if (p_big || big) {
+            post_pending();
+#pragma unroll
+            for (int i = P - 1; i >= 0; --i) finish(i);
+            p_big = false;
+        }
+        const uint32_t par = slot_now;  // the round's slot: arrival word, posted base (the same for every wave of the block)
+        const uint32_t strip = big ? 0u : slot_now;
+        const bool staged = wtotal <= D * kStage;  // (uniform)
+        if (staged) {
+#if defined(GFFX_ABL_NOPARK)
+            if (out.fids && qs[0] == 0xFFFFFFF1u) {
+#else
+            if (out.fids) {
+#endif
+                uint32_t *st = s_stage + strip * kStage;
+                // LDS byte address of the thread's first word; region k's words start at pb, the cursor `pos` runs through
+                // its kept inline entries, and where it stops is where a tail line's / a deferred walk's words go
+                uint32_t pb = lds0 + (uint32_t)(reinterpret_cast<unsigned char *>(st + lp0) - smem), pd[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t pos = pb;
+                    pair_park4(m[k] << 28, pos, wf[k].x, wf[k].y, wf[k].z, wf[k].w);
+                    pd[k] = pos;
+                    pb += 4u * cnt[k];
+                }
+                if (__builtin_amdgcn_ballot_w64(deferred != 0)) {
+                    uint32_t d = deferred, taken = 0;
+                    while (d) {  // list tails / sweeps: from the strip, or (rare) walked again
+                        const int k = __ffs(d) - 1;
+                        d &= d - 1;
+                        uint32_t *e = reinterpret_cast<uint32_t *>(smem + (win_sel(pd, k) - lds0));
+                        if (n_rest <= kWaveStash) {
+                            for (uint32_t t = win_sel(tc, k); t; --t) *e++ = s_stash[taken++];
+                        } else {
+                            uint32_t c_, s_, e_;
+                            load_query<AOS>(q, i0 + k, c_, s_, e_);
+                            (void)pair_rest<MODE, INVERT, POS>(&rare_ix(), A.spill, sweep >> k & 1u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
+                            // (rare path, late in the round: leave no load of it in flight -- registers the compiler must treat as
+                            //  "maybe still being loaded" at the top of the next round would turn the wait there into vmcnt(0) for
+                            //  EVERY round, a drain of the counts store and of the reservation atomic)
+                            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                        }
+                    }
+                }
+            }
+            if (OFFS) {
+                uint32_t *kp = s_keep_all + ((size_t)par * T + tid) * 2;
+                kp[0] = lp0 | cnt[0] << 16;
+                kp[1] = cnt[1] | cnt[2] << 16;
+            }
+        }
+        GFFX_WIN_STAMP(8);
+        // ---- arrive: this wave's share of the round's segment; the last wave to arrive reserves the segment
+        unsigned long long old = 0;
+#if !defined(GFFX_ABL_NOSYNC)
+        if (lane == 0) old = atomicAdd(&s_arrive[par], (1ull << 56) | (unsigned long long)wtotal);
+#endif
+        old = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(old >> 32)) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)old);
+        const unsigned long long my_off = old & ((1ull << 56) - 1);
+        const bool last = (uint32_t)(old >> 56) == kWaves - 1;  // (uniform)
+        p_got = 0;  // (the previous round's answer was posted above, after this round's gathers were issued)
+        if (last) {
+            const unsigned long long btotal = my_off + wtotal;
+            if (lane == 0) {
+                __hip_atomic_store(&s_arrive[par], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (btotal) p_got = atomicAdd(out.pair_cursor, btotal);
+            }
+        }
+#pragma unroll
+        for (int i = P - 1; i > 0; --i) {  // (entry P - 1 was finished above)
+            p_valid[i] = p_valid[i - 1], p_poster[i] = p_poster[i - 1], p_total[i] = p_total[i - 1];
+            p_off[i] = p_off[i - 1], p_round[i] = p_round[i - 1], p_seq[i] = p_seq[i - 1], p_slot[i] = p_slot[i - 1];
+            p_strip[i] = p_strip[i - 1];
+        }
+        p_valid[0] = false;
+        if (staged) {
+            p_valid[0] = true;
+            p_poster[0] = last;
+            p_total[0] = wtotal;
+            p_off[0] = my_off;
+            p_round[0] = r;
+            p_seq[0] = k_round + 1;
+            p_slot[0] = par;
+            p_strip[0] = strip;
+            p_big = big;
+        } else {
+            // more pairs than the strips hold: wait for the base now and write them from a second walk of the regions
+            // (the rounds before were posted above, right after this round's gathers: nobody waits for THIS wave while it waits)
+            if (last) post(par, k_round + 1, p_got);
+            const unsigned long long seg = await_base(par, k_round + 1) + my_off;
+            group_base(r, seg);
+            if (OFFS) put_offsets(r, seg, lp0, cnt[0], cnt[1], cnt[2]);
+            if (out.fids) {
+                unsigned long long o = seg + lp0;
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (i0 + k >= nq) break;
+                    uint32_t c_, s_, e_;
+                    load_query<AOS>(q, i0 + k, c_, s_, e_);
+                    pair_walk_region<MODE, INVERT, POS>(rare_ix(), A.pv.lines, cm, c_, s_, e_, [&](uint32_t word) {
+                        if (o < out.capacity) out.fids[o] = word;
+                        ++o;
+                    });
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): as above (rare path at the end of a round)
+        }
+        slot_now = slot_now + 1 == D ? 0u : slot_now + 1;
+        GFFX_WIN_STAMP(9);
+    }
+    post_pending();
+#pragma unroll
+    for (int i = P - 1; i >= 0; --i) finish(i);
+    if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64);
+    if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow);
+}
+
+}  // namespace gffx
