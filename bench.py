@@ -366,6 +366,16 @@ def xfer_leg(engine, torch, ix, regions, mode, pairs, reps=8):
                     "never the headline value (PCIe Gen5 x16 bounds it at ~63 GB/s)"}
 
 
+def _same_file(a, b):
+    """byte equality of two outputs (b None: just 'a exists and is not empty')"""
+    try:
+        if b is None:
+            return os.path.getsize(a) > 0
+        return os.path.getsize(a) == os.path.getsize(b) and open(a, 'rb').read() == open(b, 'rb').read()
+    except OSError:
+        return False
+
+
 def e2e_leg(synth, roots, regions, tmp):
     """T_e2e: the product CLI, end to end, on text inputs: GENCODE-shaped GFF3 (~3.5 M lines) x the 1 M-row BED."""
     gff, bed = os.path.join(tmp, "anno.gff"), os.path.join(tmp, "q.bed")
@@ -380,16 +390,58 @@ def e2e_leg(synth, roots, regions, tmp):
         best, stages, size = None, "", 0
         for _ in range(2):  # (second run: page cache warm)
             t0 = time.perf_counter()
-            r = subprocess.run([G, "intersect", "-v", "-i", gff, "-b", bed, "-o", os.path.join(tmp, "out.gff")] + extra,
+            sj = os.path.join(tmp, "stats.json")
+            r = subprocess.run([G, "intersect", "--stats-json", sj, "-i", gff, "-b", bed, "-o", os.path.join(tmp, "out.gff")] + extra,
                                capture_output=True, text=True)
             dt = time.perf_counter() - t0
             if r.returncode != 0:
                 return {"error": r.stderr[-300:]}
             if best is None or dt < best:
                 best = dt
-                stages = [ln.strip() for ln in r.stderr.splitlines() if "[TIMER]" in ln]
+                try:  # the run's own stage timers and counts (gffx intersect --stats-json), not scraped from stderr
+                    stages = json.load(open(sj))
+                except Exception as exc:
+                    stages = {"error": repr(exc)[:200]}
                 size = os.path.getsize(os.path.join(tmp, "out.gff"))
         out["runs"][name] = {"wall_s": best, "regions_per_s": len(regions) / best, "output_MB": size / 1e6, "stages": stages}
+    # ---- the CPU path on the SAME files, next to it: the oracle's intersect_run (commands/intersect.rs:541-655 restated in C:
+    # load the index, parse the BED, Join A serial, then merged blocks with -e, or the per-line scan of every line of the hit
+    # blocks against every region of its seqid).  One thread, as the restatement is written (the reference runs the per-line
+    # scan under rayon: cpu_baseline.join_b_allcore has the all-core figure of that stage).  `-e`: the full 1 M-row BED.
+    # Per-line mode is O(lines x regions per seqid): on the full BED it would run for hours, so it is timed -- GPU CLI and
+    # oracle -- on the first `small` rows of the same BED.
+    small = 20000
+    bed_small = os.path.join(tmp, "q_small.bed")
+    with open(bed) as f, open(bed_small, "w") as g:
+        for i, ln in enumerate(f):
+            if i >= small:
+                break
+            g.write(ln)
+    t0 = time.perf_counter()
+    r = subprocess.run([G, "intersect", "-i", gff, "-b", bed_small, "-o", os.path.join(tmp, "out_small.gff")], capture_output=True, text=True)
+    gpu_small = time.perf_counter() - t0
+    if r.returncode != 0:
+        return {"error": r.stderr[-300:]}
+    code = ("import sys, time, json; sys.path.insert(0, %r); from oracle import binding as ob; t0 = time.perf_counter(); "
+            "rc, err = ob.intersect_run(sys.argv[1], sys.argv[3], bed=sys.argv[2], mode=2, entire_group=sys.argv[4] == '1'); "
+            "print(json.dumps({'rc': rc, 'err': err[:200], 'wall_s': time.perf_counter() - t0}))" % ROOT)
+    for name, b_, eg, key in (("intersect -e", bed, "1", "out_o.gff"), ("intersect", bed_small, "0", "out_o_small.gff")):
+        try:
+            rr = subprocess.run([sys.executable, "-c", code, gff, b_, os.path.join(tmp, key), eg], capture_output=True, text=True, timeout=900)
+            oj = json.loads(rr.stdout.strip().splitlines()[-1])
+        except Exception as exc:
+            oj = {"error": repr(exc)[:200]}
+        if name == "intersect -e":
+            out["runs"][name]["cpu_oracle_wall_s"] = oj.get("wall_s")
+            out["runs"][name]["cpu_oracle"] = dict(oj, cores=1, kind="port", bed_rows=len(regions),
+                                                   outputs_identical=_same_file(os.path.join(tmp, key), os.path.join(tmp, "out.gff")))
+        else:
+            same = _same_file(os.path.join(tmp, key), os.path.join(tmp, "out_small.gff"))
+            out["runs"]["intersect, first %d rows" % small] = {
+                "wall_s": gpu_small, "bed_rows": small, "cpu_oracle_wall_s": oj.get("wall_s"), "cpu_oracle": dict(oj, cores=1, kind="port"),
+                "outputs_identical": same,
+                "note": "per-line mode: the oracle's scan is O(lines of the hit blocks x regions of the seqid), so both sides run "
+                        "the first %d rows of the BED; the full-size GPU run is runs['intersect']" % small}
     # BASELINE configs[3]'s size through the streaming CLI: 100 M rows (2.4 GB of BED text), --entire-group and per-line mode,
     # 64 host threads (the reference's default of 12 is the first table column of DESIGN 5.2); best of 2, page cache warm
     try:
@@ -570,7 +622,10 @@ def main():
         kern = run.kernel_us(max(5, min(args.steps, 30)), timed_threads)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        if world > 1:
+            traffic = {"hbm_bytes_per_launch": None, "note": "not measured in this run (the PMC passes are child runs of the 1-GPU "
+                       "workload; a multi-GPU line does not copy them)"}
+        elif os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = {"hbm_bytes_per_launch": tj.get("hbm_bytes_per_pass"), "kernel": tj.get("kernel"),
@@ -680,6 +735,9 @@ def main():
         bm10.close()
         result["cli_pass"] = cli
         del cols10, reg10
+        # ---- cold input: three distinct resident 12 M-region batches (432 MB of regions, more than the 256 MB Infinity Cache),
+        # one QueryBatch pointed at them in turn, pass after pass on one stream: no pass finds its regions in any cache
+        result["roofline_cold"] = cold_leg(engine, synth, torch, ix, dev, mode, out_flags, strategy, out_b)
         # ---- regions the window lines cannot answer (wider than wmax = 16 Ki): AUTO moves the batch to the sweep kernel
         regw = synth.synth_bed(nq, seed=1004, width=(100, 200000))
         colsw = to_dev(torch, regw, dev)
@@ -710,9 +768,12 @@ def main():
             result["t_e2e"] = {"error": repr(exc)[:300]}
         result["join_b"] = join_b_leg(engine, synth, roots, regions, mode)
         result["depth"] = depth_leg(engine, synth, roots, ix, cols, nq)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # (N > 1: rank 0 times the same 1-thread leg on ITS shard, after the timed region and the exchange)
         cb = cpu_baseline(roots, regions, mode, args.cpu_seconds)
-        if not args.quick:
+        if world > 1:
+            cb["sample"] += "; rank 0's shard of the %d-GPU batch" % world
+        if not args.quick and world == 1:
             cb["join_a_allcore"] = child_json([os.path.join(ROOT, "tools", "cpu_allcore.py"), str(nq), str(mode), "4"])
             cb["join_b_allcore"] = child_json([os.path.join(ROOT, "tools", "cpu_joinb_allcore.py"), str(nq), str(mode), "6"])
         result["cpu_baseline"] = cb
@@ -723,6 +784,43 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cold_leg(engine, synth, torch, ix, dev, mode, out_flags, strategy, out_b, n_each=12_000_000, n_sets=3, rounds=3):
+    sets, pairs = [], []
+    for k in range(n_sets):
+        sets.append(to_dev(torch, synth.synth_bed(n_each, seed=1005 + k), dev))
+    torch.cuda.synchronize()
+    b = engine.QueryBatch(ix, n_each)
+    for c in sets:  # size the pair buffers, learn every set's pair count
+        b.set_regions_device(c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), n_each, keep=c)
+        b.run(mode, False, out_flags, strategy)
+        b.wait()
+        pairs.append(b.total_hits)
+    b.reserve_hits(max(pairs) + max(pairs) // 8 + 1024)
+    b.set_profiling(True)
+    b.reset_profile()
+    for _ in range(rounds):
+        for c in sets:
+            b.set_regions_device(c[0].data_ptr(), c[1].data_ptr(), c[2].data_ptr(), n_each, keep=c)
+            b.run(mode, False, out_flags, strategy)
+    b.sync()
+    b.set_profiling(False)
+    kern = {}
+    for kid, name in engine.KERNEL_NAMES.items():
+        ms, n = b.kernel_ms(kid)
+        if n:
+            kern[name] = {"avg_us": 1e3 * ms / n, "launches_per_step": n / (rounds * n_sets)}
+    threads = b.block_threads
+    b.wait()
+    b.close()
+    obj = roofline_obj(kern, n_each, sum(pairs) / len(pairs), out_b,
+                       "%d passes over %d distinct resident batches of %d regions (seeds 1005..), %d MB of regions in rotation -- more "
+                       "than the 256 MB Infinity Cache -- on ONE stream: every pass streams its regions from HBM.  Durations: a HIP "
+                       "event pair per launch (~2.5 us of event cost in each)" % (rounds * n_sets, n_sets, n_each, 12 * n_each * n_sets // 1000000),
+                       None, None, threads)
+    obj["input_MB_in_rotation"] = 12.0 * n_each * n_sets / 1e6
+    return obj
 
 
 def depth_leg(engine, synth, roots, ix, cols, nq):

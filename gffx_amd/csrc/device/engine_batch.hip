@@ -514,7 +514,9 @@ extern "C" int gffx_hip_batch_sync(gffx_hip_batch *b) {
 extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_wait: batch is NULL");
     if (!b->ran) return fail(GFFX_E_STATE, "gffx_hip_batch_wait: nothing was run");
-    int rc = gffx_hip_batch_sync(b);
+    int rc = windows_pack_roots(b);  // (the root flags of the windows strategy's passes -> the bitmap, behind them on the stream)
+    if (rc) return rc;
+    rc = gffx_hip_batch_sync(b);
     if (rc) return rc;
     if (b->nq == 0) {
         b->total = 0;
@@ -528,6 +530,10 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     if (!part && !fused)
         GFFX_HIP_TRY(hipMemcpy(b->h_status + 1, b->d_block_sums, b->n_blocks * sizeof(unsigned long long),
                                hipMemcpyDeviceToHost));
+    if (b->h_status[0] & 2ull) {
+        GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
+        return fail(GFFX_E_HIP, "internal: the dynamic LDS of a windows pass does not start at LDS address 0");
+    }
     if (b->h_status[0] & 1ull) {
         // the flag is sticky on the device (kernels only ever set it): clear it for the next pass
         GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
@@ -545,7 +551,11 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     b->total = 0;
     if (part)
         b->total = b->h_status[1];
-    else if (fused)
+    else if (fused && b->strategy == GFFX_STRATEGY_WINDOWS && b->roots_blocks) {  // a root pass of its own: per-block pair counts
+        std::vector<unsigned long long> sums(b->roots_blocks);
+        GFFX_HIP_TRY(hipMemcpy(sums.data(), b->d_block_sums, sums.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (unsigned long long x : sums) b->total += x;
+    } else if (fused)
         b->total = b->h_status[b->fused_word];
     else
         for (uint32_t i = 0; i < b->n_blocks; i++) b->total += b->h_status[1 + i];
@@ -572,6 +582,7 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         rc = part ? run_partitioned(b) : b->strategy == GFFX_STRATEGY_WINDOWS ? run_windows(b) : fused ? run_fused(b) : enqueue_emit(b);
         b->flags = keep_flags;
         if (rc) return rc;
+        if ((rc = windows_pack_roots(b))) return rc;
         if ((rc = gffx_hip_batch_sync(b))) return rc;
         if (b->strategy == GFFX_STRATEGY_WINDOWS) {
             GFFX_HIP_TRY(hipMemcpy(b->h_status + 4, b->d_status + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -3,7 +3,7 @@
 // HBM layout of an index (uploaded once, immutable; gffx_device.hpp has the field meanings):
 //   start[R] u32, aux[R] uint4 {end, pmax_prev, skip, root_fid} 20 B/root, seqid after seqid, by start
 //   chr_meta[n_chr] uint4, bins[...] uint4                      per-seqid bin directory (direct / fused strategies)
-//   win_meta[n_chr + 1] uint4, win[...] 32 B lines, win_spill, win_tail + tables, win_filter    window index (windows strategy)
+//   win_meta[n_chr + 1] uint4, win[...] 32 B lines (+ the split windows' sub-lines), win_spill, win_splittab, win_filter    window index (windows strategy)
 //   cell_base / cell_tile / tile_meta / tile_aux / tile_bins    genome-window tile plan (partitioned strategy)
 // At GENCODE scale (63 k roots, 25 seqids) that is ~1.3 MB + ~2 MB of directory + ~0.2 MB of tile
 // plan: resident in every XCD's 4 MiB L2, so the only HBM streams of a pass are the queries in and
@@ -24,7 +24,7 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
-// Window index (gffx_device.hpp, join_win_kernels.hpp): per seqid ~GFFX_HIP_WIN_PER_ENTRY windows per root (a power of
+// Window index (gffx_device.hpp, join_pairs_kernels.hpp): per seqid ~GFFX_HIP_WIN_PER_ENTRY windows per root (a power of
 // two wide, at most 2^15 bp: the lines hold 16-bit coordinates relative to the window); the line of window b lists, by
 // ascending start, the roots with start < (b+1) << shift and end + wmax > b << shift.  `start` / `aux` are the sorted
 // arrays of the index.  A seqid whose lists would be absurdly long at 2^15 bp (> 64 entries per root) gets NO windows but
@@ -84,7 +84,7 @@ static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, co
         len.assign(ns, 0);
         for (uint32_t i = lo; i < hi; i++)
             for (uint64_t b = first_w(i); b <= last_w(i) && last_w(i) >= first_w(i); b++) len[b]++;
-        // a line = 8 words {coordinates x 4, root_fid (or position) x 4}, join_win_kernels.hpp
+        // a line = 8 words {coordinates x 4, root_fid (or position) x 4}, join_pairs_kernels.hpp
         win.resize(2 * total_win, make_uint4(kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent));
         win_pos.resize(2 * total_win, make_uint4(kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent));
         uint32_t *ww = reinterpret_cast<uint32_t *>(win.data()), *wp = reinterpret_cast<uint32_t *>(win_pos.data());
@@ -136,62 +136,6 @@ static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const
         if (rc <= 0) return rc;
     }
     return fail(GFFX_E_INVALID, "index too large for the window directory (%u seqids need more than 2^25 lines)", n_chr);
-}
-
-// Tail lines of the window index (gffx_device.hpp, join_wave_kernels.hpp): for every window whose list has 5..7 entries a
-// second line with entries 3..6 in the line's own format, plus the LDS tables that locate it (bitmap + u16 ranks per 32
-// windows).  Derived from the finished lines and spill records; `meta` still holds {first window, windows, shift, wmax}.
-// Nothing is built when the tables exceed GFFX_HIP_WIN_TAIL_KB (default 19 KB of LDS) or 65535 tail lines.
-static void build_window_tails(uint32_t n_chr, const std::vector<uint32_t> &h_start, const std::vector<uint4> &h_aux,
-                               const std::vector<uint4> &meta, const std::vector<uint4> &win, const std::vector<uint4> &spill,
-                               std::vector<uint4> &tail_lines, std::vector<uint32_t> &tab, uint32_t &twords) {
-    tail_lines.clear(), tab.clear();
-    twords = 0;
-    const size_t n_win = win.size() / 2;
-    const size_t nw = (n_win + 31) / 32;
-    const size_t tab_words = (nw + (nw + 1) / 2 + 3) / 4 * 4;
-    const uint64_t budget = (uint64_t)env_long("GFFX_HIP_WIN_TAIL_KB", 19, 0, 64) * 1024;
-    if (!n_win || tab_words * 4 > budget) return;
-    std::vector<uint32_t> bits(nw, 0);
-    const uint32_t *ww = reinterpret_cast<const uint32_t *>(win.data());
-    for (uint32_t c = 0; c < n_chr; c++) {
-        const uint4 m = meta[c];
-        if (m.z > kWinMaxShift || m.w == 0) continue;  // no windows on this seqid
-        const uint64_t W = 1ull << m.z, wmax = m.w;
-        for (uint64_t b = 0; b < m.y; b++) {
-            const size_t w = (size_t)m.x + b;
-            const uint32_t *l = ww + 8 * w;
-            if (l[3] != kWinTailMark) continue;
-            const uint32_t n = l[7] & 255u;
-            if (n <= kWinInline || n > kWinInlineTail + 4) continue;  // (dense: n = 255)
-            bits[w >> 5] |= 1u << (w & 31);
-            uint32_t t[8] = {kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent, 0, 0, 0, 0};
-            const int64_t org = (int64_t)(b * W) - (int64_t)wmax;
-            for (uint32_t j = kWinInlineTail; j < n; j++) {
-                const uint4 r = spill[(l[7] >> 8) + j - kWinInlineTail];  // {start, end, root_fid, position}
-                const int64_t rs = std::max<int64_t>((int64_t)r.x - org, 0);
-                const int64_t re = std::min<int64_t>((int64_t)r.y - org, (int64_t)(W + wmax + 1));
-                t[j - kWinInlineTail] = (uint32_t)rs | ((uint32_t)re << 16);
-                t[4 + j - kWinInlineTail] = r.z;
-            }
-            tail_lines.push_back(make_uint4(t[0], t[1], t[2], t[3]));
-            tail_lines.push_back(make_uint4(t[4], t[5], t[6], t[7]));
-        }
-    }
-    if (tail_lines.size() / 2 > 65535 || tail_lines.empty()) {
-        tail_lines.clear();
-        return;
-    }
-    (void)h_start, (void)h_aux;
-    tab.assign(tab_words, 0u);
-    uint16_t *rank = reinterpret_cast<uint16_t *>(tab.data() + nw);
-    uint32_t acc = 0;
-    for (size_t x = 0; x < nw; x++) {
-        tab[x] = bits[x];
-        rank[x] = (uint16_t)acc;
-        acc += (uint32_t)__builtin_popcount(bits[x]);
-    }
-    twords = (uint32_t)nw;
 }
 
 // Split windows (gffx_device.hpp): every window with a list of 5..kWinMaxList entries on a seqid whose windows are at least
@@ -453,10 +397,6 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     std::vector<uint4> win_meta, win, win_pos, win_spill;
     if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill)) return wrc;
     ix->n_win = (uint32_t)(win.size() / 2);
-    std::vector<uint4> win_tail;
-    std::vector<uint32_t> win_tailtab;
-    build_window_tails(n_chr, h_start, h_aux, win_meta, win, win_spill, win_tail, win_tailtab, ix->win_twords);
-    ix->n_tail = (uint32_t)(win_tail.size() / 2);
     // split windows (gffx_device.hpp): their sub-lines, compact on the host ({line number, line} pairs), scattered into the
     // zeroed second level on the device
     std::vector<uint32_t> win_splittab, sub_at;
@@ -570,8 +510,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
         (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = upload_line_table(&ix->d_win, win, ix->win_swords != 0, sub_at, sub_lines, &win_bytes)) ||
         (rc = upload_line_table(&ix->d_win_pos, win_pos, ix->win_swords != 0, sub_at, sub_lines_pos, &win_pos_bytes)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
-        (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_tail, win_tail)) ||
-        (rc = dev_upload(&ix->d_win_tailtab, win_tailtab)) || (rc = dev_upload(&ix->d_win_splittab, win_splittab)) ||
+        (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_splittab, win_splittab)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -581,7 +520,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
     ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),
                        bytes(win_meta),  win_bytes,         win_pos_bytes,    bytes(win_spill), bytes(win_filter),
-                       bytes(win_tail),  bytes(win_tailtab), bytes(win_splittab),
+                       bytes(win_splittab),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
     GFFX_HIP_TRY(hipDeviceSynchronize());
@@ -626,8 +565,6 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_win_pos);
     (void)hipFree(ix->d_win_spill);
     (void)hipFree(ix->d_win_filter);
-    (void)hipFree(ix->d_win_tail);
-    (void)hipFree(ix->d_win_tailtab);
     (void)hipFree(ix->d_win_splittab);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);

@@ -2,7 +2,7 @@
 // opaque handles of include/gffx_hip.h, and the few functions that cross a file boundary.
 //   engine_index.hip    index builders (window lines, tail lines, coverage filter, bin directory, tile plan), create / clone / destroy
 //   engine_batch.hip    batches: regions in, run / wait / results out, profiling; the direct, fused and partitioned strategies
-//   engine_windows.hip  the windows strategy: k_join_wave (pair passes) and k_join_win (triples, root bitmap)
+//   engine_windows.hip  the windows strategy: k_join_pairs (pair passes, triples through positions) and k_join_roots (root passes)
 //   engine_regions.hip  region stores (streaming BED ingestion) and the RCCL hit-count exchange
 //   engine_depth.hip    `gffx depth`
 // (join_b.hip and coverage.hip were separate translation units already; engine.hip includes all five for the tools that
@@ -77,13 +77,10 @@ struct gffx_hip_index {
     uint4 *d_aux = nullptr;
     uint4 *d_chr_meta = nullptr;
     uint4 *d_bins = nullptr;
-    uint4 *d_win_meta = nullptr, *d_win = nullptr, *d_win_pos = nullptr, *d_win_spill = nullptr;  // window index (join_win_kernels.hpp)
+    uint4 *d_win_meta = nullptr, *d_win = nullptr, *d_win_pos = nullptr, *d_win_spill = nullptr;  // window index (join_pairs_kernels.hpp)
     uint32_t n_win = 0;
     uint32_t *d_win_filter = nullptr;
     uint32_t win_fwords = 0, win_fshift = 0;
-    uint4 *d_win_tail = nullptr;          // tail lines (k_join_wave)
-    uint32_t *d_win_tailtab = nullptr;
-    uint32_t n_tail = 0, win_twords = 0;
     uint32_t *d_win_splittab = nullptr;  // split windows (k_join_pairs): one bit per window; their sub-lines follow the lines in d_win / d_win_pos
     uint32_t win_swords = 0;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
@@ -102,7 +99,7 @@ struct gffx_hip_index {
     // every device array of the index, in a fixed order
     std::vector<void **> arrays() {
         return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_win_meta,   (void **)&d_win,
-                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter, (void **)&d_win_tail,   (void **)&d_win_tailtab,
+                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter,
                 (void **)&d_win_splittab,
                 (void **)&d_cell_base,
                 (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
@@ -122,10 +119,6 @@ struct gffx_hip_index {
         v.win_filter = d_win_filter;
         v.win_fwords = win_fwords;
         v.win_fshift = win_fshift;
-        v.win_tail = d_win_tail;
-        v.win_tailtab = d_win_tailtab;
-        v.n_tail = n_tail;
-        v.win_twords = win_twords;
         v.win_splittab = d_win_splittab;
         v.win_swords = win_swords;
         v.n_chr = n_chr;
@@ -164,8 +157,11 @@ struct gffx_hip_batch {
     unsigned long long *d_offsets = nullptr;
     uint32_t *d_offsets32 = nullptr;            // GFFX_OUT_OFFSETS32
     unsigned long long *d_segbase = nullptr;    // GFFX_OUT_SEGBASE: ceil(max_q / 256)
-    uint32_t *d_slabs = nullptr;                // windows strategy, root-bitmap passes: one LDS bitmap image per block
-    uint32_t slab_blocks = 0;
+    uint32_t *d_slabs = nullptr;                // windows strategy, root passes: one bitmap image per block (k_join_roots)
+    uint32_t slab_blocks = 0, slab_words = 0;   // ... allocated; words per slab
+    uint32_t slab_valid = 0;                    // ... slabs that hold something since the last clear
+    bool root_flags_dirty = false;              // ... newer than d_bitmap (windows_pack_roots)
+    uint32_t roots_blocks = 0;                  // last pass was a root pass of its own: its blocks (their pair counts are in d_block_sums)
     uint64_t cap_fids = 0, cap_triples = 0;
     uint64_t reserve = 0;
     // partitioned strategy workspace (allocated on first use)
@@ -207,6 +203,7 @@ void prof_end(gffx_hip_batch *b, ProfEvent *pe);
 void prof_resolve(gffx_hip_batch *b);
 uint32_t meta_bytes(const gffx_hip_index *ix);
 int run_windows(gffx_hip_batch *b);  // engine_windows.hip
+int windows_pack_roots(gffx_hip_batch *b);
 int batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who);  // engine_batch.hip
 int need_input_order(gffx_hip_batch *b);
 

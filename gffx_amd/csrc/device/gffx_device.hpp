@@ -66,7 +66,7 @@ struct IndexView {
     // it still reach the query" -- queries in gene deserts end after this single access.
     // kPosMask limits an index to 2^27 roots.
     const uint4 *bins;
-    // Window index (join_win_kernels.hpp): windows of 2^shift bp (shift <= 15), one 32-byte LINE per window holding up to
+    // Window index (join_pairs_kernels.hpp): windows of 2^shift bp (shift <= 15), one 32-byte LINE per window holding up to
     // 4 entries as words {start_rel | end_rel << 16 x 4, root_fid x 4}, coordinates relative to (window start - wmax) and
     // clamped to 16 bits; win_pos is a copy with index positions in place of the root_fids (root-bitmap and triples
     // passes).  A longer list keeps 3 entries in the line, word 3 = 0xFFFFFFFF, word 7 = n | spill << 8 (n = 255: dense
@@ -78,23 +78,13 @@ struct IndexView {
     const uint4 *win_pos;
     const uint4 *win_spill;
     uint32_t n_win;
-    // Coverage filter of the window index (staged in LDS by k_join_win): the genome in cells of 2^win_fshift bp, one bit per
+    // Coverage filter of the window index (staged in LDS by the kernels): the genome in cells of 2^win_fshift bp, one bit per
     // cell = "some root overlaps the cell".  A region whose cells are all clear has no hit and reads no index line.
     //   (a seqid's first bit, a multiple of 32, is word 3 of its win_meta record)
     const uint32_t *win_filter;
     uint32_t win_fwords;  // 0 = no filter
     uint32_t win_fshift;
-    // Tail lines (k_join_wave): a window whose list has 5..7 entries keeps entries 0..2 in its line (word 3 = 0xFFFFFFFF) and
-    // entries 3..6 in a second 32-byte line of the same format (window-relative 16-bit coordinates + root_fids) in win_tail,
-    // one per such window, in window order.  win_tailtab (staged in LDS) = win_twords bitmap words, one bit per window
-    // ("has a tail line"), followed by win_twords u16 ranks (tail lines before the word's first window): a region knows
-    // BEFORE its line arrives whether and where a tail line exists, so both loads are in flight together.
-    // win_twords = 0: no tail lines (the tables would not fit LDS); such lists are walked from win_spill.
-    const uint4 *win_tail;
-    const uint32_t *win_tailtab;
-    uint32_t n_tail;      // tail lines
-    uint32_t win_twords;  // bitmap words (= ceil(n_win / 32)), 0 = none
-    // Round 4 (k_join_pairs): SPLIT windows.  A window whose list is longer than 4 (and not dense) is cut into 2^kWinSplit
+    // SPLIT windows (round 4, k_join_pairs / k_join_roots).  A window whose list is longer than 4 (and not dense) is cut into 2^kWinSplit
     // sub-windows of W >> kWinSplit bp, each with a line of its own in the same format (coordinates relative to the sub-window's
     // start - wmax; a sub-list that is still longer than 4 keeps 3 + mark + spill records like any line).  The sub-lines of
     // window w are lines n_win + (w << kWinSplit) .. + 2^kWinSplit - 1 of the SAME arrays (win / win_pos are allocated
@@ -106,7 +96,7 @@ struct IndexView {
     uint32_t n_chr;
     uint32_t n_roots;
 };
-// format of a window-index line (join_win_kernels.hpp has the description)
+// format of a window-index line (join_pairs_kernels.hpp has the description)
 constexpr uint32_t kWinLineBytes = 32;           // one index line: two 16-byte loads
 constexpr uint32_t kWinInline = 4;               // list entries inside the line when the whole list fits
 constexpr uint32_t kWinInlineTail = 3;           // ... when it does not: word 3 / word 7 mark and locate the tail

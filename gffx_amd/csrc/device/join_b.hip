@@ -849,7 +849,7 @@ static int lines_run(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int mode, u
             unsigned long long word = 0;
             while (!(posted = (uint32_t)((word = __atomic_load_n(reinterpret_cast<unsigned long long *>(L->h_cnt), __ATOMIC_ACQUIRE)) >> 32) == note_seq) &&
                    std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2))
-                std::this_thread::yield();
+                std::this_thread::sleep_for(std::chrono::microseconds(20));  // (a queued stream would otherwise burn a quota CPU)
             uint32_t n_deg = (uint32_t)word;
             if (!posted) {
                 GFFX_HIP_TRY(hipStreamSynchronize(L->stream));

@@ -1,36 +1,100 @@
-// join_pairs_kernels.hpp -- Join A over the window index: the pair passes (counts + root_fids / positions + segment bases)
-// and the root-flag passes of the windows strategy, round 4's rewrite of k_join_wave (round 3) for instruction count.
+// join_pairs_kernels.hpp -- Join A over the window index (the windows strategy, AUTO's choice): k_join_pairs, the pair passes
+// (counts + root_fids or index positions + segment bases / offsets), and k_join_roots, the root passes (which roots are in at
+// least one kept pair: what `gffx intersect` needs, commands/intersect.rs:598-615).  Round 4's rewrite of round 3's
+// k_join_wave / round 2's k_join_win.
 //
-// What it computes (reference: utils/tree.rs:98-121 + commands/intersect.rs:139-165): for every region (chr, qs, qe) every
+// What they compute (reference: utils/tree.rs:98-121 + commands/intersect.rs:139-165): for every region (chr, qs, qe) every
 // root interval of seqid chr with start < qe && end > qs, kept iff invert ^ predicate(mode).
 //
-// Same index (gffx_device.hpp: one 32-byte LINE per genome window, 16-bit window-relative coordinates, tail lines located
-// through an LDS bitmap, coverage filter in LDS), the same cooperation of the waves of a block as k_join_wave had (a wave
-// is the unit; ONE pair segment per block round reserved by ARRIVAL in LDS, the last wave to arrive issues the device
-// atomic; the answer is collected two rounds later, so nobody waits for the atomic, for the slowest wave or for another
-// wave's rare paths) -- and the same result set, bit for bit.  What changed is what a round costs: round 3's kernel was
-// VALU-issue bound (670 VALU wave instructions per 256-region wave round, a fifth of them v_readlane / v_writelane / v_mov
-// of spilled lane masks: 102 SGPRs, 76 spills).  Here
+// The index (gffx_device.hpp, engine_index.hip): every seqid is cut into windows of W = 2^shift bp (shift <= 15, ~2 per
+// root); the LINE of window b lists, by ascending start, every root that can overlap a region of width <= wmax whose last
+// base lies in the window (start < (b+1) W and end + wmax > b W).  Such a region lies inside [b W - wmax + 1, (b+1) W], so
+// coordinates RELATIVE to b W - wmax fit 16 bits (W + wmax + 1 <= 65535), a root's start clamped from below to 0 and its end
+// from above to W + wmax + 1: every comparison of the predicates has the same outcome on the clamped relative values as on
+// the absolute ones.  A line is 32 bytes:
+//       words 0..3    start_rel | end_rel << 16 of entries 0..3   (absent entry: 0x0000FFFF -- start 0xFFFF is never < qe)
+//       words 4..7    root_fid of entries 0..3  (the "pos" copy of the table carries index positions instead)
+//   a list longer than 4 keeps entries 0..2 in the line; word 3 = 0xFFFFFFFF marks it and word 7 = n | spill << 8: entries
+//   3.. are 16-byte records {start, end, root_fid, position} (absolute) at win_spill[spill ...]; n = 255: dense window.
+// SPLIT windows (round 4): such a window is cut into 2^kWinSplit sub-windows, each with a line of its own (same format,
+// relative to the sub-window) in a sparse second level of the same table, and a one-bit-per-window table in LDS says which
+// windows those are BEFORE anything is read: every region reads exactly ONE line -- two 16-byte loads from one cache line,
+// all in flight together for a thread's four regions, no dependent second gather -- and four exact tests.
+// What the line cannot answer -- the tail of a (sub-)list still longer than 4, dense windows, regions wider than wmax,
+// qs >= qe rows (the reference keeps them), seqids without windows -- is DEFERRED: list tails are walked in line (a few
+// 16-byte records), exact sweeps (join_a_kernels.hpp) through a function call.
+//
+// What bounds a pass, measured in round 4: the CU's vector memory path -- one line request per ~2.9 cycles and CU
+// for the gathers, ~10 B per cycle and CU for the region and result streams, and they add up -- and, next to it, instruction
+// issue of every kind (not VALU alone) and how often the deferred loop is entered.  Hence:
 //   * a test is THREE VALU instructions: two SDWA compares on the packed 16-bit coordinates straight into lane masks, one
 //     s_and (scalar unit), and one v_addc that shifts the outcome into a per-region bit string (m = 2 m + kept);
-//   * a kept root_fid is parked by TWO: v_add_co shifts the bit string's top bit into vcc, the LDS write and the advance of
-//     the lane's cursor run under that lane mask (s_and_saveexec / s_mov exec: scalar unit) -- no per-entry position
-//     arithmetic, no branch;
-//   * what the round loop keeps in scalar registers is two buffer descriptors and a handful of words: the index view's
-//     twenty pointers stay in the kernarg segment and are only read on the rare paths (list tails in win_spill, sweeps);
-//   * a parked round leaves through immediate-offset LDS reads and buffer stores from the run's own descriptor (the range
-//     check drops the lanes past the run): no per-trip address or bounds arithmetic;
-//   * rare-event bookkeeping (deferred regions, sweeps, bad seqids) lives in lane masks until a wave actually has one.
+//   * a kept word is parked by TWO: v_add_co shifts the bit string's top bit into vcc, the LDS write and the advance of the
+//     lane's cursor run under that lane mask (s_and_saveexec / s_mov exec: scalar unit) -- no position arithmetic, no branch;
+//   * nothing that MAY issue a vector memory operation stands between the line loads and their use (a conditional store
+//     there makes the compiler wait for the loads with vmcnt(0), i.e. for the stores' acknowledgements too);
+//   * the index view's twenty pointers stay in the kernarg segment and are only read on the rare paths.
+// The waves of a block cooperate as in round 3: a wave is the unit (no block barrier in the round loop); ONE pair segment per
+// block round is reserved by ARRIVAL in LDS -- the last wave to arrive issues the device atomic (same-address device atomics
+// serialise at ~90 per us across the chip) -- and the answer is collected two rounds later.
 // Roofline bound: HBM.  Algorithmic bytes per region: 12 in + 4 + 4*h out.
 #pragma once
-#include "join_wave_kernels.hpp"  // (development: the round-3 kernel stays in the build for A/B runs; the shared helpers are its)
+#include "join_fused_kernels.hpp"
 
 namespace gffx {
 
+typedef uint32_t gffx_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned long long gffx_v2ul __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) uint32_t *LdsWords;  // an LDS address as a pointer
 
-// what the MAIN path of a pass reads of the index: two line tables (root_fids, or index positions: root flags, triples)
-// and the three small tables every block stages in LDS
+// tools/kbench.hip: phase stamps of one round per block; compiled out of the product
+#ifndef GFFX_WIN_STAMP
+#define GFFX_WIN_STAMP(slot) \
+    do {                     \
+    } while (0)
+#endif
+
+// Block barrier that orders LDS traffic only (__syncthreads() also drains every outstanding global load and store).
+__device__ __forceinline__ void win_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// inclusive prefix sum over the wave's 64 lanes in 6 DPP adds (row shifts inside the rows of 16, then the row totals
+// broadcast to the rows above) -- no LDS round trips
+__device__ __forceinline__ uint32_t win_wave_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// tree.rs:110 + intersect.rs:145-161 on one interval [s, e), invert at run time (Overlap + invert keeps nothing: the engine
+// never launches such a pass)
+template <int MODE>
+__device__ __forceinline__ bool pair_keep(uint32_t s, uint32_t e, uint32_t qs, uint32_t qe, bool inv) {
+    if (!(s < qe && e > qs)) return false;
+    if (MODE == GFFX_MODE_CONTAINED) return (s >= qs && e <= qe) != inv;
+    if (MODE == GFFX_MODE_CONTAINS_REGION) return (s <= qs && e >= qe) != inv;
+    return true;
+}
+
+constexpr uint32_t kWinNoLine = 0x80000000u;  // byte offset beyond every window table (< 2^31 bytes): reads as zeros
+
+// a[k] for a per-lane k without making `a` addressable (an indexed private array would live in scratch memory)
+__device__ __forceinline__ uint32_t win_sel(const uint32_t (&a)[4], int k) {
+    return (a[0] & (k == 0 ? ~0u : 0u)) | (a[1] & (k == 1 ? ~0u : 0u)) | (a[2] & (k == 2 ? ~0u : 0u)) | (a[3] & (k == 3 ? ~0u : 0u));
+}
+
+constexpr uint32_t kWaveDepth = 3;     // strips per wave: a round's words wait kWaveDepth - 1 rounds for their place
+constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequence numbers (kWaveDepth of each)
+constexpr uint32_t kWaveStash = 2;     // per thread: kept words of deferred regions wait here (LDS) for the parking
+// words a wave parks in LDS per round (a strip): 1.5 kept pairs per region at 1024 threads, 1 at 512 (two blocks share a CU's LDS);
+// a fuller round takes all kWaveDepth strips, beyond that the synchronous path
+__host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads) { return threads == 1024 ? 384u : 256u; }
+
+// what the MAIN path of a pass reads of the index: the line table (root_fids, or index positions: root passes, triples) and
+// the three small tables every block stages in LDS
 struct PairView {
     const uint4 *lines;        // IndexView::win or ::win_pos (with the split windows' sub-lines behind the windows' lines)
     const uint4 *meta;         // IndexView::win_meta
@@ -39,7 +103,22 @@ struct PairView {
     uint32_t n_win, n_chr, fshift;
 };
 
-// The kernel's one argument.  The main path reads `pv`, `q`, `out` and the scalars; `ix` is never touched by value: the rare
+struct WaveOut {
+    uint32_t *counts;               // nq, input order
+    unsigned long long *segbase;    // ceil(nq / 256): start of every group's run of pairs (or nullptr)
+    unsigned long long *offsets;    // nq, input order: start of the region's pair segment (or nullptr)
+    uint32_t *offsets32;            // the same as u32 (or nullptr)
+    uint32_t *fids;                 // pair segments: root_fids, or positions (or nullptr: counts only)
+    uint8_t *root_flags;            // k_join_roots without an LDS bitmap: the batch's bitmap (device atomics)
+    uint32_t *err;                  // bit0 = chr out of range, bit1 = internal (LDS base)
+    unsigned long long *slow;       // regions that took the exact sweep (AUTO's heuristic)
+    unsigned long long *block_sums;        // k_join_roots: kept pairs per block (or nullptr)
+    unsigned long long *pair_cursor;       // kept pairs of this pass (zero on entry)
+    unsigned long long *pair_cursor_next;  // the other cursor word: zeroed here for the next pass
+    unsigned long long capacity;
+};
+
+// The kernels' one argument.  The main path reads `pv`, `q`, `out` and the scalars; `ix` is never touched by value: the rare
 // paths read it where it already lies, in the kernarg segment, through a pointer made inside the rare block (as by-value
 // arguments used inside the loop its twenty-odd pointers would be loaded once and held -- i.e. spilled -- across the loop).
 struct PairArgs {
@@ -48,21 +127,38 @@ struct PairArgs {
     unsigned long long nq;
     WaveOut out;
     int vec_ok;
+    uint32_t invert;          // intersect.rs:161 (never set with Overlap)
     uint32_t fwords, swords;  // filter / split-bitmap words staged in LDS (0: that table did not fit, or does not exist)
-    const uint4 *spill;  // IndexView::win_spill (list tails: the one rare path that is walked in line)
-    uint32_t grid;  // blocks of the launch (read from the dispatch packet it would be a scalar load per round)
+    const uint4 *spill;       // IndexView::win_spill (list tails: the one rare path that is walked in line)
+    uint32_t grid;            // blocks of the launch (read from the dispatch packet it would be a scalar load per round)
     IndexView ix;
 };
+
+__device__ __forceinline__ const IndexView &pair_rare_ix() {
+    typedef const unsigned char __attribute__((address_space(4))) * KernargBytes;
+    KernargBytes p = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const IndexView *)(p + __builtin_offsetof(PairArgs, ix));
+}
+
+__device__ __forceinline__ void pair_load_region(const QueryView &q, unsigned long long i, uint32_t &chr, uint32_t &qs, uint32_t &qe) {
+    if (q.aos) {
+        const uint32_t *p = q.aos + 3ull * i;
+        chr = p[0], qs = p[1], qe = p[2];
+    } else {
+        chr = q.chr[i], qs = q.start[i], qe = q.end[i];
+    }
+}
 
 // The four entries of a line against one region: m = a bit per entry (entry 0 = bit 3), set iff the entry
 // w = start_rel | end_rel << 16 is kept by the region [rqs, rqe1 + 1) in the line's coordinates.
 // Overlap mode: per entry two SDWA compares on the packed 16-bit coordinates straight into lane masks, one s_and (scalar
 // unit) and one v_addc that shifts the outcome into the bit string (m = 2 m + kept): 3 VALU + 1 SALU.  One asm block per
 // line (the compiler fences every asm block with hazard nops).
-template <int MODE, bool INVERT>
-__device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rqs, uint32_t rqe1) {
+template <int MODE>
+__device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rqs, uint32_t rqe1, bool inv) {
     uint32_t m;
-    if (MODE == GFFX_MODE_OVERLAP && !INVERT) {
+    if (MODE == GFFX_MODE_OVERLAP) {
         unsigned long long t;
         asm("v_cmp_le_u32_sdwa %[t], %[w0], %[qe] src0_sel:WORD_0 src1_sel:DWORD\n\t"
             "v_cmp_gt_u32_sdwa vcc, %[w0], %[qs] src0_sel:WORD_1 src1_sel:DWORD\n\t"
@@ -85,8 +181,8 @@ __device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_
             : "vcc");
     } else {
         const uint32_t rqe = rqe1 + 1u;
-        m = (win_test<MODE, INVERT>(w0 & 0xFFFFu, w0 >> 16, rqs, rqe) ? 8u : 0u) | (win_test<MODE, INVERT>(w1 & 0xFFFFu, w1 >> 16, rqs, rqe) ? 4u : 0u) |
-            (win_test<MODE, INVERT>(w2 & 0xFFFFu, w2 >> 16, rqs, rqe) ? 2u : 0u) | (win_test<MODE, INVERT>(w3 & 0xFFFFu, w3 >> 16, rqs, rqe) ? 1u : 0u);
+        m = (pair_keep<MODE>(w0 & 0xFFFFu, w0 >> 16, rqs, rqe, inv) ? 8u : 0u) | (pair_keep<MODE>(w1 & 0xFFFFu, w1 >> 16, rqs, rqe, inv) ? 4u : 0u) |
+            (pair_keep<MODE>(w2 & 0xFFFFu, w2 >> 16, rqs, rqe, inv) ? 2u : 0u) | (pair_keep<MODE>(w3 & 0xFFFFu, w3 >> 16, rqs, rqe, inv) ? 1u : 0u);
     }
     return m;
 }
@@ -121,6 +217,28 @@ __device__ __forceinline__ void pair_park4(uint32_t x, uint32_t &pos, uint32_t f
                  : "vcc", "memory");
 }
 
+// k_join_roots: for each of the four entries, if the top bit of x is set { set bit `position` of the block's LDS bitmap at
+// LDS address bm }, x <<= 1.  (ds_or without return under the lane mask; the word's address and the bit are three VALU.)
+__device__ __forceinline__ void pair_flag4(uint32_t x, uint32_t bm, uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3) {
+    unsigned long long sv;
+    uint32_t a, m;
+    const uint32_t one = 1u, m3 = ~3u;
+#define GFFX_FLAG1(P)                                  \
+    "v_add_co_u32 %[x], vcc, %[x], %[x]\n\t"           \
+    "v_lshrrev_b32 %[a], 3, " P "\n\t"                 \
+    "v_and_b32 %[a], %[m3], %[a]\n\t"                  \
+    "v_add_u32 %[a], %[bm], %[a]\n\t"                  \
+    "v_lshlrev_b32 %[m], " P ", %[one]\n\t"            \
+    "s_and_saveexec_b64 %[sv], vcc\n\t"                \
+    "ds_or_b32 %[a], %[m]\n\t"                         \
+    "s_mov_b64 exec, %[sv]\n\t"
+    asm volatile(GFFX_FLAG1("%[p0]") GFFX_FLAG1("%[p1]") GFFX_FLAG1("%[p2]") GFFX_FLAG1("%[p3]") "s_nop 0"
+                 : [x] "+v"(x), [sv] "=&s"(sv), [a] "=&v"(a), [m] "=&v"(m)
+                 : [bm] "v"(bm), [one] "v"(one), [m3] "v"(m3), [p0] "v"(p0), [p1] "v"(p1), [p2] "v"(p2), [p3] "v"(p3)
+                 : "vcc", "memory");
+#undef GFFX_FLAG1
+}
+
 // A parked run of `total` words leaves the wave's strip four trips at a time: a trip at word X is one LDS read and one buffer
 // store at immediate offsets from the run's own descriptor, whose range check drops the lanes -- and whole trips -- past the
 // run: no per-trip address or bounds arithmetic, one uniform compare per 256 words.
@@ -142,12 +260,72 @@ struct PairFlush<X, END, true> {
     static __device__ __forceinline__ void run(const uint32_t *, __amdgpu_buffer_rsrc_t, uint32_t, uint32_t) {}
 };
 
-// every kept pair of ONE region, generic walk (the synchronous path of an overfull round and nothing else): f(word)
-template <int MODE, bool INVERT, bool POS, typename F>
-__device__ __forceinline__ void pair_walk_region(const IndexView &ix, const uint4 *lines, const uint4 *cm, uint32_t chr, uint32_t qs,
+// The rare paths.  Sweeps (regions wider than wmax, qs >= qe rows, dense windows, seqids without windows) as a FUNCTION
+// CALL: inlined -- twice, with the bin search and the skip-link walk inside -- that code was most of the round loop's body;
+// the hot path then branches over it ~100 times a round and its live ranges decide the loop's register allocation.  f(word)
+// for every kept pair's root_fid (or position).
+template <int MODE, bool POS, typename F>
+__device__ __forceinline__ void pair_sweep(const IndexView &ix, bool inv, uint32_t chr, uint32_t qs, uint32_t qe, F &&f) {
+    auto g = [&](uint32_t j, uint32_t, const uint4 &a) {
+        f(POS ? j : a.w);
+        return true;
+    };
+    if (inv)
+        for_each_kept<MODE, true>(ix, ix.chr_meta[chr], qs, qe, g);
+    else
+        for_each_kept<MODE, false>(ix, ix.chr_meta[chr], qs, qe, g);
+}
+// ... writing the first `cap` kept words to out[0 ..], returning how many there are; bits != nullptr (root passes): set bit
+// `word` of that bitmap instead
+template <int MODE, bool POS>
+__device__ __attribute__((noinline)) uint32_t pair_sweep_call(const IndexView *ix, uint32_t inv, uint32_t chr, uint32_t qs, uint32_t qe,
+                                                              uint32_t *out, uint32_t cap, uint32_t *bits) {
+    uint32_t c = 0;
+    pair_sweep<MODE, POS>(*ix, inv != 0, chr, qs, qe, [&](uint32_t word) {
+        if (bits)
+            atomicOr(&bits[word >> 5], 1u << (word & 31));
+        else if (c < cap)
+            out[c] = word;
+        ++c;
+    });
+    return c;
+}
+// ... and the frequent, small case in line: the tail of a list longer than 4 (entries 3 .. n - 1, 16-byte records with absolute
+// coordinates in win_spill, four in flight).  Same outputs.
+template <int MODE, bool POS>
+__device__ __forceinline__ uint32_t pair_rest(const IndexView *ix, const uint4 *spill, bool inv, uint32_t sweep, uint32_t chr, uint32_t qs,
+                                              uint32_t qe, uint32_t hdr, uint32_t *out, uint32_t cap, uint32_t *bits = nullptr) {
+    if (sweep) return pair_sweep_call<MODE, POS>(ix, inv, chr, qs, qe, out, cap, bits);
+    uint32_t c = 0;
+    const uint32_t n = hdr & 255u;
+    const uint4 *sp = spill + (hdr >> 8);
+    for (uint32_t j = kWinInlineTail; j < n; j += 4) {
+        uint4 x[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            x[t] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+            if (j + t < n) x[t] = sp[j - kWinInlineTail + t];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (pair_keep<MODE>(x[t].x, x[t].y, qs, qe, inv)) {
+                const uint32_t word = POS ? x[t].w : x[t].z;
+                if (bits)
+                    atomicOr(&bits[word >> 5], 1u << (word & 31));
+                else if (c < cap)
+                    out[c] = word;
+                ++c;
+            }
+    }
+    return c;
+}
+
+// every kept pair of ONE region, generic walk over the window's own line (the synchronous path of an overfull round and
+// nothing else): f(word)
+template <int MODE, bool POS, typename F>
+__device__ __forceinline__ void pair_walk_region(const IndexView &ix, const uint4 *lines, const uint4 *cm, bool inv, uint32_t chr, uint32_t qs,
                                                  uint32_t qe, F &&f) {
     if (chr >= ix.n_chr) return;
-    if (MODE == GFFX_MODE_OVERLAP && INVERT) return;
     const uint4 m = cm[chr];
     const uint32_t shift = m.z & 31u, wmax = m.z >> 8;
     if (m.y == 0) return;
@@ -165,87 +343,118 @@ __device__ __forceinline__ void pair_walk_region(const IndexView &ix, const uint
         } else {
             for (uint32_t j = 0; j < (tail ? kWinInlineTail : kWinInline); ++j) {
                 const uint32_t w = l[j];
-                if (win_test<MODE, INVERT>(w & 0xFFFFu, w >> 16, rqs, rqe)) f(l[4 + j]);
+                if (pair_keep<MODE>(w & 0xFFFFu, w >> 16, rqs, rqe, inv)) f(l[4 + j]);
             }
             if (tail) {
                 const uint4 *sp = ix.win_spill + (hdr >> 8);
                 for (uint32_t j = kWinInlineTail; j < (hdr & 255u); ++j) {
                     const uint4 x = sp[j - kWinInlineTail];
-                    if (win_test<MODE, INVERT>(x.x, x.y, qs, qe)) f(POS ? x.w : x.z);
+                    if (pair_keep<MODE>(x.x, x.y, qs, qe, inv)) f(POS ? x.w : x.z);
                 }
             }
         }
     }
-    if (sweep)
-        for_each_kept<MODE, INVERT>(ix, ix.chr_meta[chr], qs, qe, [&](uint32_t j, uint32_t, const uint4 &a) {
-            f(POS ? j : a.w);
-            return true;
-        });
+    if (sweep) pair_sweep<MODE, POS>(ix, inv, chr, qs, qe, f);
 }
 
-// The rare paths as a FUNCTION CALL: what a line does not hold of one deferred region (win_rest) walked out of line.  Inlined,
-// this code -- twice, with the sweep's bin search and skip-link walk inside -- is most of the round loop's body: the hot
-// path then branches over it ~100 times a round, and its live ranges decide the loop's register allocation (40 SGPRs spilled
-// to VGPR lanes).  Writes the first `cap` kept words (root_fids, or positions) to out[0 ..] and returns how many there are.
-template <int MODE, bool INVERT, bool POS>
-__device__ __attribute__((noinline)) uint32_t pair_sweep_call(const IndexView *ix, uint32_t chr, uint32_t qs, uint32_t qe, uint32_t *out, uint32_t cap) {
-    uint32_t c = 0;
-    for_each_kept<MODE, INVERT>(*ix, ix->chr_meta[chr], qs, qe, [&](uint32_t j, uint32_t, const uint4 &a) {
-        if (c < cap) out[c] = POS ? j : a.w;
-        ++c;
-        return true;
-    });
-    return c;
+// ---- what both kernels do with a region before any line is read: which line, and the region in that line's coordinates
+struct PairLds {
+    const uint4 *cm;         // seqid records (LDS or global)
+    const uint32_t *sbits;   // split bitmap (LDS)
+    uint32_t n_chr, n_win, fshift, swords;
+    bool nofilt, split_on;   // (uniform) a table that did not fit the block's LDS
+};
+__device__ __forceinline__ void pair_locate(const PairLds &L, uint32_t qc, uint32_t qs, uint32_t qe, uint32_t &off, uint32_t &rqs, uint32_t &rqe1,
+                                            bool &swp) {
+    const uint4 m = L.cm[min(qc, L.n_chr)];
+    const uint32_t wmax = m.z >> 8, e1 = qe - 1u, wd1 = e1 - qs;
+    const bool fits = wd1 < wmax;  // 0 < qe - qs <= wmax (unsigned: an empty or reversed row wraps)
+    const uint32_t b = e1 >> (m.z & 31u);
+    // coverage filter: is any cell the region touches covered by a root?  (clear = no hit, exactly.)  No clamps: the span only
+    // matters when the region fits, i.e. spans <= 31 cells; past a seqid's cells a fitting region has no hit whatever the bits
+    // say (it then reads another seqid's bits, or -- beyond the bitmap -- other LDS words: a set bit costs a line read, never a
+    // pair); without a filter (nofilt) the outcome is ignored.
+    const uint32_t a2 = qs >> L.fshift, bit = m.w + a2;
+    const LdsWords fw = (LdsWords)((bit >> 3) & ~3u);  // (the filter starts at LDS address 0: checked at kernel entry)
+    uint32_t v = __builtin_amdgcn_alignbit(fw[1], fw[0], bit);
+    asm volatile("" : "+v"(v));  // (computed HERE for every lane: sunk under `fits` it becomes a branch per region)
+    const bool cov = (__builtin_amdgcn_ubfe(v, 0, (e1 >> L.fshift) - a2 + 1u) != 0) | L.nofilt;
+    // the window -- or, when its list was too long for a line, the sub-window the region's last base lies in: the LDS bitmap
+    // says which BEFORE any line is read (a window number beyond the table -- a region the lines do not answer -- lands on
+    // the bitmap's spare zero word)
+    const uint32_t w = m.x + b;
+    const bool split = (__builtin_amdgcn_ubfe(L.sbits[min(w >> 5, L.swords)], w, 1) != 0) & L.split_on;
+    const uint32_t sh = (m.z & 31u) - (split ? kWinSplit : 0u);  // log2 of the width of what the line covers
+    const uint32_t line = split ? L.n_win + (w << kWinSplit) + __builtin_amdgcn_ubfe(e1, sh, kWinSplit) : w;
+    off = (fits & (b < m.y) & cov) ? line * kWinLineBytes : kWinNoLine;
+    // relative to the line's origin (its first base - wmax): qe - 1 -> (qe - 1) mod width + wmax, qs -> that - (qe - 1 - qs)
+    rqe1 = __builtin_amdgcn_ubfe(e1, 0, sh) + wmax;
+    rqs = rqe1 - wd1;
+    swp = !fits;  // (a seqid without roots has wmax = 2^24 - 1 and no windows: only absurd rows of it come here)
 }
-// ... and the frequent, small case in line: the tail of a list longer than 4 (entries 3 .. n - 1, 16-byte records with absolute
-// coordinates in win_spill, four in flight); sweeps (wide / empty regions, dense windows) go through the call
-template <int MODE, bool INVERT, bool POS>
-__device__ __forceinline__ uint32_t pair_rest(const IndexView *ix, const uint4 *spill, uint32_t sweep, uint32_t chr, uint32_t qs, uint32_t qe,
-                                              uint32_t hdr, uint32_t *out, uint32_t cap) {
-    if (sweep) return pair_sweep_call<MODE, INVERT, POS>(ix, chr, qs, qe, out, cap);
-    uint32_t c = 0;
-    const uint32_t n = hdr & 255u;
-    const uint4 *sp = spill + (hdr >> 8);
-    for (uint32_t j = kWinInlineTail; j < n; j += 4) {
-        uint4 x[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            x[t] = make_uint4(0xFFFFFFFFu, 0, 0, 0);
-            if (j + t < n) x[t] = sp[j - kWinInlineTail + t];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (win_test<MODE, INVERT>(x[t].x, x[t].y, qs, qe)) {
-                if (c < cap) out[c] = POS ? x[t].w : x[t].z;
-                ++c;
-            }
+
+// a round's regions: buffer loads from a descriptor of exactly the round's rows (scalar work), 16 bytes per thread and column
+// at a fixed offset -- straight-line code: no per-thread bounds, and a round beyond the batch (the prefetch of the last
+// rounds) reads zeros without touching memory.  Only the batch's last, partial round and unaligned columns take the
+// element-wise path afterwards (uniform branch); a row beyond the batch becomes the "no region" row {n_chr, 0, 0}: the seqid
+// table's extra record has no windows, so it reads nothing and keeps nothing; a real row with a seqid out of range is flagged
+// there and becomes the same row (the round loops flag rows of full rounds only).
+template <uint32_t kChunk>
+__device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned long long nq, int vec_ok, uint32_t n_chr, unsigned long long r,
+                                                uint32_t t4, uint32_t (&qc)[4], uint32_t (&qs)[4], uint32_t (&qe)[4], bool &bad) {
+    const unsigned long long base = r * kChunk;  // (uniform)
+    constexpr int kNt = 2;                       // nt: streamed once
+    auto rsrc = [&](const uint32_t *col, uint32_t words) {
+        const unsigned long long left = base < nq ? nq - base : 0ull;
+        const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(col + words * base), 0, rows * 4u * words, 0x00020000);
+    };
+    if (q.aos) {  // (uniform)
+        const __amdgpu_buffer_rsrc_t ra = rsrc(q.aos, 3);
+        const gffx_v4u a = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4, 0, kNt), b = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 16, 0, kNt),
+                       c = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 32, 0, kNt);
+        qc[0] = a.x, qs[0] = a.y, qe[0] = a.z;
+        qc[1] = a.w, qs[1] = b.x, qe[1] = b.y;
+        qc[2] = b.z, qs[2] = b.w, qe[2] = c.x;
+        qc[3] = c.y, qs[3] = c.z, qe[3] = c.w;
+    } else {
+        const gffx_v4u c = __builtin_amdgcn_raw_buffer_load_b128(rsrc(q.chr, 1), 4u * t4, 0, kNt), s = __builtin_amdgcn_raw_buffer_load_b128(rsrc(q.start, 1), 4u * t4, 0, kNt),
+                       e = __builtin_amdgcn_raw_buffer_load_b128(rsrc(q.end, 1), 4u * t4, 0, kNt);
+        qc[0] = c.x, qc[1] = c.y, qc[2] = c.z, qc[3] = c.w;
+        qs[0] = s.x, qs[1] = s.y, qs[2] = s.z, qs[3] = s.w;
+        qe[0] = e.x, qe[1] = e.y, qe[2] = e.z, qe[3] = e.w;
     }
-    return c;
+    if (base < nq && !(vec_ok && base + kChunk <= nq)) {
+        const unsigned long long i0 = base + t4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            qc[k] = n_chr;
+            qs[k] = qe[k] = 0;
+            if (i0 + k < nq) {
+                pair_load_region(q, i0 + k, qc[k], qs[k], qe[k]);
+                bad |= qc[k] >= n_chr;
+                qc[k] = min(qc[k], n_chr);
+            }
+        }
+    }
 }
 
-// words a wave parks in LDS per round (a strip): 1.5 kept pairs per region at 1024 threads, 1 at 512 (two blocks share a CU's LDS);
-// a fuller round takes all kWaveDepth strips, beyond that the synchronous path
-__host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads) { return threads == 1024 ? 384u : 256u; }
 // T: threads per block (512: two blocks per CU; 1024: one, half the reservation atomics)
 // OFFS: per-region offsets are written (GFFX_OUT_OFFSETS / _OFFSETS32): each lane parks its place inside the round's segment
-// POS: the words a pass emits are index positions (tables win_pos / win_tail_pos), not root_fids
-template <int MODE, bool INVERT, bool AOS, bool META_LDS, int T, bool OFFS, bool POS>
+// POS: the words a pass emits are index positions (table win_pos), not root_fids
+template <int MODE, bool META_LDS, int T, bool OFFS, bool POS>
 __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     constexpr uint32_t kWaves = T / 64;
     constexpr uint32_t D = kWaveDepth;
     constexpr uint32_t keep_words = OFFS ? 2u : 0u;
     constexpr uint32_t kStage = pair_stage_words(T);  // words a wave parks per round
-    auto rare_ix = [&]() -> const IndexView & {
-        typedef const unsigned char __attribute__((address_space(4))) * KernargBytes;
-        KernargBytes p = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(p));
-        return *(const IndexView *)(p + __builtin_offsetof(PairArgs, ix));
-    };
+    auto rare_ix = [&]() -> const IndexView & { return pair_rare_ix(); };
     const QueryView &q = A.q;
     const WaveOut &out = A.out;
     const unsigned long long nq = A.nq;
     const uint32_t fwords = A.fwords, swords = A.swords, n_chr = A.pv.n_chr;
+    const bool inv = A.invert != 0;
 
     // LDS: the coverage filter FIRST (at the block's LDS base: its word pairs are read at immediate offsets), the split bitmap,
     // the seqid records, then the waves' machinery
@@ -259,7 +468,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     unsigned long long *s_post_base = reinterpret_cast<unsigned long long *>(s_work + 8 * D);   // [D] the round's segment base
     uint32_t *s_post_seq = reinterpret_cast<uint32_t *>(s_work + 16 * D);                       // [D] block round + 1 it belongs to
     uint32_t *s_stage_all = reinterpret_cast<uint32_t *>(s_work + kWaveHdrBytes);               // waves x D x kStage
-    uint32_t *s_keep_all = s_stage_all + kWaves * D * kStage;                               // T x D x keep_words
+    uint32_t *s_keep_all = s_stage_all + kWaves * D * kStage;                                   // T x D x keep_words
     uint32_t *s_stash = s_keep_all + (size_t)T * D * keep_words + kWaveStash * threadIdx.x;     // this thread's kWaveStash words
     // (where the dynamic LDS starts, as an LDS address: what ds_write takes)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
@@ -269,62 +478,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 
     uint32_t qc[4], qs[4], qe[4];  // the round's 4 consecutive regions of the thread
     bool bad = false;              // a region's seqid is out of range
-    auto round_rsrc = [&](const uint32_t *col, unsigned long long first, uint32_t words) {
-        const unsigned long long left = first < nq ? nq - first : 0ull;
-        const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(col + words * first), 0, rows * 4u * words, 0x00020000);
-    };
-    auto load_round = [&](unsigned long long r) {
-        const unsigned long long base = r * kChunk;  // (uniform)
-        constexpr int kNt = 2;                       // nt: streamed once
-#if defined(GFFX_ABL_NOREGION)
-        {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t h = (uint32_t)(base + t4 + k) * 2654435761u;
-                h ^= h >> 15, h *= 2246822519u, h ^= h >> 13;
-                qc[k] = (h >> 8) % 24u;
-                qs[k] = (h * 3266489917u) % 40000000u;
-                qe[k] = qs[k] + 100u + (h & 8191u);
-            }
-            return;
-        }
-#endif
-        if (AOS) {
-            const __amdgpu_buffer_rsrc_t ra = round_rsrc(q.aos, base, 3);
-            const gffx_v4u a = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4, 0, kNt),
-                           b = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 16, 0, kNt),
-                           c = __builtin_amdgcn_raw_buffer_load_b128(ra, 12u * t4 + 32, 0, kNt);
-            qc[0] = a.x, qs[0] = a.y, qe[0] = a.z;
-            qc[1] = a.w, qs[1] = b.x, qe[1] = b.y;
-            qc[2] = b.z, qs[2] = b.w, qe[2] = c.x;
-            qc[3] = c.y, qs[3] = c.z, qe[3] = c.w;
-        } else {
-            const gffx_v4u c = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.chr, base, 1), 4u * t4, 0, kNt),
-                           s = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.start, base, 1), 4u * t4, 0, kNt),
-                           e = __builtin_amdgcn_raw_buffer_load_b128(round_rsrc(q.end, base, 1), 4u * t4, 0, kNt);
-            qc[0] = c.x, qc[1] = c.y, qc[2] = c.z, qc[3] = c.w;
-            qs[0] = s.x, qs[1] = s.y, qs[2] = s.z, qs[3] = s.w;
-            qe[0] = e.x, qe[1] = e.y, qe[2] = e.z, qe[3] = e.w;
-        }
-        if (base < nq && !(A.vec_ok && base + kChunk <= nq)) {
-            // the batch's last, partial round (and unaligned columns), element by element; a row beyond the batch becomes
-            // the "no region" row {n_chr, 0, 0}: the seqid table's extra record has no windows, so it reads nothing and
-            // keeps nothing; a real row with a seqid out of range is flagged HERE and becomes the same row (the round loop
-            // flags rows of full rounds only)
-            const unsigned long long i0 = base + t4;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                qc[k] = n_chr;
-                qs[k] = qe[k] = 0;
-                if (i0 + k < nq) {
-                    load_query<AOS>(q, i0 + k, qc[k], qs[k], qe[k]);
-                    bad |= qc[k] >= n_chr;
-                    qc[k] = min(qc[k], n_chr);
-                }
-            }
-        }
-    };
+    auto load_round = [&](unsigned long long r) { pair_load_round<kChunk>(q, nq, A.vec_ok, n_chr, r, t4, qc, qs, qe, bad); };
     const unsigned long long n_rounds = (nq + kChunk - 1) / kChunk;
     if (blockIdx.x < n_rounds) load_round(blockIdx.x);  // in flight while the tables are staged
     const uint4 *cm;
@@ -349,7 +503,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
-    const bool nofilt = fwords == 0, split_on = swords != 0;  // (uniform) a table that did not fit the block's LDS
+    const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
     uint32_t n_slow = 0;
 
     // ---- what is left to do for the wave's previous D - 1 rounds once their segment bases are known (all wave-uniform;
@@ -426,11 +580,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     auto finish = [&](int i) {  // (i: compile-time after unrolling)
         if (!p_valid[i]) return;
         const uint32_t slot = p_slot[i];
-#if defined(GFFX_ABL_NOSYNC)
-        const unsigned long long seg = (p_round[i] * kWaves + (uint32_t)wave) * kStage;
-#else
         const unsigned long long seg = await_base(slot, p_seq[i]) + p_off[i];
-#endif
         group_base(p_round[i], seg);
         if (out.fids) {
             const uint32_t total = p_total[i];  // (uniform)
@@ -439,11 +589,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             if (seg + total <= out.capacity) {
                 // a buffer store from the run's own base: the range check drops the lanes past the run, so a trip is an LDS
                 // read and a store at immediate offsets -- no per-trip address or bounds arithmetic
-#if defined(GFFX_ABL_NOSTORE)
-                const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 0u, 0x00020000);
-#else
                 const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(dst, 0, total * 4u, 0x00020000);
-#endif
                 uint32_t l4 = lane4;
                 asm volatile("" : "+v"(l4));  // (made here: hoisted out of the round loop, lane4 + X would be a register per trip)
                 PairFlush<0, D * kStage>::run(st, rf, l4, total);
@@ -476,35 +622,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;  // (a partial round's rows were checked when they were loaded)
-            const uint4 m = cm[min(qc[k], n_chr)];
-            const uint32_t wmax = m.z >> 8, e1 = qe[k] - 1u, wd1 = e1 - qs[k];
-            const bool fits = wd1 < wmax;  // 0 < qe - qs <= wmax (unsigned: an empty or reversed row wraps)
-            const uint32_t b = e1 >> (m.z & 31u);
-            // coverage filter: is any cell the region touches covered by a root?  (clear = no hit, exactly.)  No clamps: the
-            // span only matters when the region fits, i.e. spans <= 31 cells; past a seqid's cells a fitting region has no hit
-            // whatever the bits say (it then reads another seqid's bits, or -- beyond the bitmap -- other LDS words: a set bit
-            // costs a line read, never a pair); without a filter (nofilt) the outcome is ignored.
-            const uint32_t a2 = qs[k] >> A.pv.fshift, bit = m.w + a2;
-            const LdsWords fw = (LdsWords)((bit >> 3) & ~3u);  // (the filter starts at LDS address 0: checked at kernel entry)
-            uint32_t v = __builtin_amdgcn_alignbit(fw[1], fw[0], bit);
-            asm volatile("" : "+v"(v));  // (computed HERE for every lane: sunk under `fits` it becomes a branch per region)
-            const bool cov = (__builtin_amdgcn_ubfe(v, 0, (e1 >> A.pv.fshift) - a2 + 1u) != 0) | nofilt;
-            // the window -- or, when its list was too long for a line, the sub-window the region's last base lies in: the LDS
-            // bitmap says which BEFORE any line is read, so every region reads exactly one line (a window number beyond the
-            // table -- a region the lines do not answer -- lands on the bitmap's spare zero word)
-            const uint32_t w = m.x + b;
-            const bool split = (__builtin_amdgcn_ubfe(s_sbits[min(w >> 5, swords)], w, 1) != 0) & split_on;
-            const uint32_t sh = (m.z & 31u) - (split ? kWinSplit : 0u);  // log2 of the width of what the line covers
-            const uint32_t line = split ? A.pv.n_win + (w << kWinSplit) + __builtin_amdgcn_ubfe(e1, sh, kWinSplit) : w;
-#if defined(GFFX_ABL_NOGATHER)
-            off[k] = (fits & (b < m.y) & cov & (qs[k] == 0xFFFFFFF0u)) ? line * kWinLineBytes : kWinNoLine;
-#else
-            off[k] = (fits & (b < m.y) & cov) ? line * kWinLineBytes : kWinNoLine;
-#endif
-            // relative to the line's origin (its first base - wmax): qe - 1 -> (qe - 1) mod width + wmax, qs -> that - (qe - 1 - qs)
-            rqe1[k] = __builtin_amdgcn_ubfe(e1, 0, sh) + wmax;
-            rqs[k] = rqe1[k] - wd1;
-            swp[k] = !fits;  // (a seqid without roots has wmax = 2^24 - 1 and no windows: only absurd rows of it come here)
+            pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
         }
         GFFX_WIN_STAMP(1);
         gffx_v4u wc[4], wf[4];
@@ -522,7 +640,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         // (a region without a line read zeros: {start 0, end 0} never passes end > qs)
         uint32_t m[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = pair_test4<MODE, INVERT>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k]);
+        for (int k = 0; k < 4; ++k) m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
         GFFX_WIN_STAMP(3);
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept words wait in
         // the thread's LDS strip)
@@ -536,9 +654,6 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 dfr[k] = swp[k] || wc[k].w == kWinTailMark;
                 any |= dfr[k];
             }
-#if defined(GFFX_ABL_NODEFER)
-            any = false;
-#endif
             if (__builtin_amdgcn_ballot_w64(any)) {  // (uniform: some lane of the wave has deferred work)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -554,9 +669,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                     while (d) {
                         const int k = __ffs(d) - 1;
                         d &= d - 1;
-                        const uint32_t c = pair_rest<MODE, INVERT, POS>(&rare_ix(), A.spill, sweep >> k & 1u, min(win_sel(qc, k), n_chr), win_sel(qs, k),
-                                                                             win_sel(qe, k), win_sel(hdr, k), s_stash + min(n_rest, kWaveStash),
-                                                                             kWaveStash - min(n_rest, kWaveStash));
+                        const uint32_t c = pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, sweep >> k & 1u, min(win_sel(qc, k), n_chr), win_sel(qs, k),
+                                                                win_sel(qe, k), win_sel(hdr, k), s_stash + min(n_rest, kWaveStash),
+                                                                kWaveStash - min(n_rest, kWaveStash));
                         n_rest += c;
                         tc[0] += k == 0 ? c : 0u;
                         tc[1] += k == 1 ? c : 0u;
@@ -583,11 +698,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
             gffx_v4u cv;
             cv.x = cnt[0], cv.y = cnt[1], cv.z = cnt[2], cv.w = cnt[3];
-#if defined(GFFX_ABL_NOSTORE)
-            __builtin_amdgcn_raw_buffer_store_b128(cv, __builtin_amdgcn_make_buffer_rsrc(out.counts + base, 0, 0u, 0x00020000),
-#else
             __builtin_amdgcn_raw_buffer_store_b128(cv, __builtin_amdgcn_make_buffer_rsrc(out.counts + base, 0, rows * 4u, 0x00020000),
-#endif
                                                    4u * t4, 0, 2 /* nt */);
         }
         // ---- the oldest round in flight leaves (its segment base was posted a round ago), THEN the next round's regions are
@@ -617,11 +728,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         const uint32_t strip = big ? 0u : slot_now;
         const bool staged = wtotal <= D * kStage;  // (uniform)
         if (staged) {
-#if defined(GFFX_ABL_NOPARK)
-            if (out.fids && qs[0] == 0xFFFFFFF1u) {
-#else
             if (out.fids) {
-#endif
                 uint32_t *st = s_stage + strip * kStage;
                 // LDS byte address of the thread's first word; region k's words start at pb, the cursor `pos` runs through
                 // its kept inline entries, and where it stops is where a tail line's / a deferred walk's words go
@@ -643,8 +750,8 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                             for (uint32_t t = win_sel(tc, k); t; --t) *e++ = s_stash[taken++];
                         } else {
                             uint32_t c_, s_, e_;
-                            load_query<AOS>(q, i0 + k, c_, s_, e_);
-                            (void)pair_rest<MODE, INVERT, POS>(&rare_ix(), A.spill, sweep >> k & 1u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
+                            pair_load_region(q, i0 + k, c_, s_, e_);
+                            (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, sweep >> k & 1u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
                             // (rare path, late in the round: leave no load of it in flight -- registers the compiler must treat as
                             //  "maybe still being loaded" at the top of the next round would turn the wait there into vmcnt(0) for
                             //  EVERY round, a drain of the counts store and of the reservation atomic)
@@ -659,12 +766,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 kp[1] = cnt[1] | cnt[2] << 16;
             }
         }
-        GFFX_WIN_STAMP(8);
         // ---- arrive: this wave's share of the round's segment; the last wave to arrive reserves the segment
         unsigned long long old = 0;
-#if !defined(GFFX_ABL_NOSYNC)
         if (lane == 0) old = atomicAdd(&s_arrive[par], (1ull << 56) | (unsigned long long)wtotal);
-#endif
         old = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(old >> 32)) << 32) |
               (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)old);
         const unsigned long long my_off = old & ((1ull << 56) - 1);
@@ -706,8 +810,8 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 for (uint32_t k = 0; k < 4; ++k) {
                     if (i0 + k >= nq) break;
                     uint32_t c_, s_, e_;
-                    load_query<AOS>(q, i0 + k, c_, s_, e_);
-                    pair_walk_region<MODE, INVERT, POS>(rare_ix(), A.pv.lines, cm, c_, s_, e_, [&](uint32_t word) {
+                    pair_load_region(q, i0 + k, c_, s_, e_);
+                    pair_walk_region<MODE, POS>(rare_ix(), A.pv.lines, cm, inv, c_, s_, e_, [&](uint32_t word) {
                         if (o < out.capacity) out.fids[o] = word;
                         ++o;
                     });
@@ -716,7 +820,6 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): as above (rare path at the end of a round)
         }
         slot_now = slot_now + 1 == D ? 0u : slot_now + 1;
-        GFFX_WIN_STAMP(9);
     }
     post_pending();
 #pragma unroll
@@ -725,6 +828,181 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64);
     if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow);
+}
+
+// ---- root passes: which roots are in at least one kept pair.  The same regions, the same lines (the position copy of the
+// table), the same tests -- and nothing else: no counts, no scan, no reservation, no parking.  A kept entry sets a bit of an
+// LDS-private bitmap (7.9 KB at 63 k roots; ds_or without return); when its rounds are done the block ORs the bitmap into ITS
+// OWN slab in global memory (plain loads and stores: nobody else touches the slab), and the slabs are folded into the batch's
+// bitmap when somebody asks for it (k_bitmap_fold: once per gffx_hip_batch_wait, not once per pass -- a streaming caller runs
+// many passes with GFFX_OUT_BITMAP_KEEP between two waits).  Measured alternatives: device atomics straight into the 8 KB bitmap
+// serialise on its 62 cache lines (51 us per 1 M regions); a byte flag per root with plain stores (no atomic needed: every
+// writer writes the same value) 58 us -- scattered sub-dword stores are no cheaper than atomics on this memory system.
+// An index whose bitmap does not fit LDS next to the tables takes test-before-set device atomics.
+// out.fids = the slabs (grid x bm_words words); out.capacity = bm_words (0: no LDS bitmap); out.segbase (as a number) = how many
+// slabs hold something to OR with (GFFX_OUT_BITMAP_KEEP), the others are overwritten.  out.block_sums[block] = the block's kept
+// pairs (summed on the host: one same-address device atomic per wave cost 43 us per 1 M regions, per block still 5).
+template <int MODE, bool META_LDS, int T>
+__global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
+    constexpr uint32_t kChunk = 4u * T;
+    const QueryView &q = A.q;
+    const WaveOut &out = A.out;
+    const unsigned long long nq = A.nq;
+    const uint32_t fwords = A.fwords, swords = A.swords, n_chr = A.pv.n_chr;
+    const bool inv = A.invert != 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t sw4 = swords ? (swords + 4) / 4 * 4 : 0;
+    uint32_t *s_filter = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *s_sbits = s_filter + fwords;
+    uint4 *s_meta = reinterpret_cast<uint4 *>(s_sbits + sw4);
+    unsigned long long *s_total = reinterpret_cast<unsigned long long *>(s_meta + (META_LDS ? n_chr + 1 : 0));  // the block's kept pairs (16 bytes)
+    uint32_t *s_bm = reinterpret_cast<uint32_t *>(s_total + 2);  // bm_words: the block's root bitmap
+    const uint32_t bm_words = (uint32_t)out.capacity;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    const uint32_t tid = threadIdx.x, t4 = 4u * tid;
+    const int lane = tid & 63;
+    uint32_t qc[4], qs[4], qe[4];
+    bool bad = false;
+    auto load_round = [&](unsigned long long r) { pair_load_round<kChunk>(q, nq, A.vec_ok, n_chr, r, t4, qc, qs, qe, bad); };
+    const unsigned long long n_rounds = (nq + kChunk - 1) / kChunk;
+    if (blockIdx.x < n_rounds) load_round(blockIdx.x);
+    const uint4 *cm;
+    if (META_LDS) {
+        for (uint32_t i = tid; i <= n_chr; i += T) s_meta[i] = A.pv.meta[i];
+        cm = s_meta;
+    } else {
+        cm = A.pv.meta;
+    }
+    for (uint32_t x = tid; x < fwords / 4; x += T)
+        reinterpret_cast<uint4 *>(s_filter)[x] = reinterpret_cast<const uint4 *>(A.pv.filter)[x];
+    for (uint32_t x = tid; x < sw4 / 4; x += T)
+        reinterpret_cast<uint4 *>(s_sbits)[x] = reinterpret_cast<const uint4 *>(A.pv.splittab)[x];
+    for (uint32_t x = tid; x < bm_words; x += T) s_bm[x] = 0u;
+    if (tid == 0) s_total[0] = 0ull;
+    win_barrier();
+    if (blockIdx.x == 0 && tid == 0) {
+        *out.pair_cursor_next = 0ull;
+        if (lds0 != 0) atomicOr(out.err, 2u);
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
+    const uint32_t bm = lds0 + (uint32_t)(reinterpret_cast<unsigned char *>(s_bm) - smem);  // the bitmap's LDS address
+    uint32_t *g_bitmap = reinterpret_cast<uint32_t *>(out.root_flags);                       // ... or the batch's bitmap (no LDS bitmap)
+    auto set_global = [&](uint32_t p) {
+        if (!(__hip_atomic_load(&g_bitmap[p >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (p & 31) & 1u)) atomicOr(&g_bitmap[p >> 5], 1u << (p & 31));
+    };
+    const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
+    uint32_t n_slow = 0, kept = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(qc[k]), "+v"(qs[k]), "+v"(qe[k]));
+    for (unsigned long long r = blockIdx.x; r < n_rounds; r += A.grid) {
+        const unsigned long long base = r * kChunk;
+        const bool full = base + kChunk <= nq;
+        uint32_t off[4], rqs[4], rqe1[4];
+        bool swp[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bad |= full && qc[k] >= n_chr;
+            pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
+        }
+        gffx_v4u wc[4], wf[4];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
+            kept += __popc(m[k]);
+        }
+        {  // the rare rest: list tails and sweeps set their flags themselves
+            bool any = false;
+            uint32_t deferred = 0, sweep = 0, hdr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) any |= swp[k] || wc[k].w == kWinTailMark;
+            if (__builtin_amdgcn_ballot_w64(any)) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool tail = wc[k].w == kWinTailMark;
+                    hdr[k] = tail ? wf[k].w : 0u;
+                    deferred |= (swp[k] || tail) ? 1u << k : 0u;
+                    sweep |= (swp[k] || (hdr[k] & 255u) == 255u) ? 1u << k : 0u;
+                }
+                n_slow += __popc(sweep);
+                uint32_t d = deferred;
+                while (d) {
+                    const int k = __ffs(d) - 1;
+                    d &= d - 1;
+                    kept += pair_rest<MODE, true>(&pair_rare_ix(), A.spill, inv, sweep >> k & 1u, min(win_sel(qc, k), n_chr), win_sel(qs, k),
+                                                  win_sel(qe, k), win_sel(hdr, k), nullptr, 0u, bm_words ? s_bm : g_bitmap);
+                }
+            }
+        }
+        // the regions are done with: the next round's take their registers; then the flags (stores younger than every load
+        // that is waited for)
+        load_round(r + A.grid);
+        if (bm_words) {  // (uniform)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pair_flag4(m[k] << 28, bm, wf[k].x, wf[k].y, wf[k].z, wf[k].w);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (m[k] & 8u) set_global(wf[k].x);
+                if (m[k] & 4u) set_global(wf[k].y);
+                if (m[k] & 2u) set_global(wf[k].z);
+                if (m[k] & 1u) set_global(wf[k].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64), kept += __shfl_xor(kept, o, 64);
+    if (lane == 0 && kept) atomicAdd(s_total, (unsigned long long)kept);
+    win_barrier();
+    if (bm_words) {  // the block's bitmap into the block's slab
+        uint32_t *slab = out.fids + (size_t)blockIdx.x * bm_words;
+        const bool merge = blockIdx.x < (uint32_t)(uintptr_t)out.segbase;
+        for (uint32_t x = tid; x < bm_words; x += T) slab[x] = merge ? (slab[x] | s_bm[x]) : s_bm[x];
+    }
+    if (tid == 0 && out.block_sums) out.block_sums[blockIdx.x] = s_total[0];
+    if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);
+    if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow);
+}
+
+// the blocks' slabs -> the batch's root bitmap (overwritten): block x takes 64 words, its 16 rows of threads a sixteenth of the slabs each
+__global__ void k_bitmap_fold(const uint32_t *slabs, uint32_t n_slabs, uint32_t words, uint32_t *bitmap) {
+    __shared__ uint32_t part[16][64];
+    const uint32_t w = blockIdx.x * 64 + (threadIdx.x & 63), row = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    if (w < words)
+        for (uint32_t s = row; s < n_slabs; s += 16) acc |= slabs[(size_t)s * words + w];
+    part[row][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (row == 0 && w < words) {
+#pragma unroll
+        for (int r = 1; r < 16; ++r) acc |= part[r][threadIdx.x];
+        bitmap[w] = acc;
+    }
+}
+
+// triples passes: a position pass, then every pair's (root_fid, start, end) -- the reference's Vec<(u32,u32,u32)>,
+// intersect.rs:163 -- from the index arrays by position (coalesced over the pairs; the arrays are L2-resident).
+// words[i] = position of pair i on entry; on exit its root_fid when `fids_too`.
+__global__ void k_expand_pairs(const uint32_t *start, const uint4 *aux, uint32_t *words, uint32_t *triples, const unsigned long long *n_pairs,
+                               unsigned long long capacity, int fids_too) {
+    const unsigned long long n = min(*n_pairs, capacity);
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t p = words[i];
+        const uint4 a = aux[p];
+        if (triples) {
+            triples[3 * i] = a.w;
+            triples[3 * i + 1] = start[p];
+            triples[3 * i + 2] = a.x;
+        }
+        if (fids_too) words[i] = a.w;
+    }
 }
 
 }  // namespace gffx

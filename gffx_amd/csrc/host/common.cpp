@@ -243,4 +243,28 @@ void write_gff_output(const std::string &gff_path, const std::vector<Block> &blo
     if (verbose) std::fprintf(stderr, "Wrote %zu merged GFF block(s) with vectored I/O\n", merged.size());
 }
 
+// --stats-json: one object {"command", "total_ms", "stages_ms": [[name, ms], ...] in the order they ended, "counts": {...}}
+void RunStats::write(const char *command, double total_ms) {
+    if (!on()) return;
+    std::lock_guard<std::mutex> lock(mu);
+    auto esc = [](const std::string &x) {
+        std::string o;
+        for (char c : x) {
+            if (c == '"' || c == '\\') o += '\\';
+            o += (unsigned char)c < 0x20 ? ' ' : c;
+        }
+        return o;
+    };
+    std::string j = std::string("{\"command\": \"") + command + "\", \"total_ms\": " + std::to_string(total_ms) + ", \"stages_ms\": [";
+    for (size_t i = 0; i < stages_ms.size(); ++i)
+        j += std::string(i ? ", " : "") + "[\"" + esc(stages_ms[i].first) + "\", " + std::to_string(stages_ms[i].second) + "]";
+    j += "], \"counts\": {";
+    for (size_t i = 0; i < counts.size(); ++i) j += std::string(i ? ", " : "") + "\"" + esc(counts[i].first) + "\": " + std::to_string(counts[i].second);
+    j += "}}\n";
+    FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) throw Error("Cannot write --stats-json file " + path);
+    std::fwrite(j.data(), 1, j.size(), f);
+    std::fclose(f);
+}
+
 }  // namespace gffx

@@ -240,7 +240,7 @@ void run(const CoverageArgs &args) {
     }
     if (verbose) std::fprintf(stderr, "[INFO] Wrote %zu feature coverage rows.\n", written);
     timer.lap("Merging groups and writing rows");
-    timer.total();
+    g_run_stats.write("coverage", timer.total());
 }
 
 }  // namespace coverage

@@ -422,7 +422,7 @@ void run(const DepthArgs &args) {
     }
     if (verbose) std::fprintf(stderr, "[INFO] Wrote %zu ID depth records\n", order.size());
     timer.lap("Merging groups and writing rows");
-    timer.total();
+    g_run_stats.write("depth", timer.total());
 }
 
 }  // namespace depth

@@ -33,7 +33,7 @@ inline uint32_t eight_digits(uint64_t w) {
     w = (w & 0x00FF00FF00FF00FFull) * 6553601 >> 16;
     return static_cast<uint32_t>((w & 0x0000FFFF0000FFFFull) * 42949672960001ull >> 32);
 }
-// A field of 1-9 digits at p (at least 9 readable bytes): its value and length; 0: something else (no digit, 10+ digits)
+// A field of 1-9 digits at p (at least 10 readable bytes: p[9] is looked at): its value and length; 0: something else (no digit, 10+ digits)
 inline unsigned digits_1_to_9(const char *p, uint32_t &v) {
     const uint64_t w = load8(p);
     const unsigned nd = first_non_digit(w);

@@ -12,6 +12,7 @@
 #pragma once
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <optional>
@@ -29,21 +30,48 @@ namespace gffx {
 
 constexpr uint64_t MISSING = UINT64_MAX;  // index_loader/gof.rs:7, commands/intersect.rs:18
 
+// `--stats-json <path>` (intersect / depth / coverage; not a reference flag): the stage timers and a few counts of the run as
+// ONE JSON object -- what `-v` prints as "[TIMER]" lines (the reference's own style, depth.rs:562-632) in a form a harness can
+// read without scraping stderr.  Stages are recorded whether or not -v is set once a path is given.
+struct RunStats {
+    std::string path;  // empty: off
+    std::mutex mu;
+    std::vector<std::pair<std::string, double>> stages_ms;
+    std::vector<std::pair<std::string, double>> counts;
+    bool on() const { return !path.empty(); }
+    void stage(const char *what, double ms) {
+        if (!on()) return;
+        std::lock_guard<std::mutex> lock(mu);
+        std::string name(what);
+        const size_t first = name.find_first_not_of(' ');
+        stages_ms.emplace_back(first == std::string::npos ? name : name.substr(first), ms);
+    }
+    void count(const char *what, double v) {
+        if (!on()) return;
+        std::lock_guard<std::mutex> lock(mu);
+        counts.emplace_back(what, v);
+    }
+    void write(const char *command, double total_ms);  // common.cpp
+};
+inline RunStats g_run_stats;
+
 // stage timers under --verbose, in the reference's style (depth.rs:562-632 "[TIMER] [run] Step n: ...";
 // `intersect` itself has none)
 struct StageTimer {
     bool on;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
     void lap(const char *what) {
-        if (!on) return;
+        if (!on && !g_run_stats.on()) return;
         const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[TIMER] [run] %s took %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        const double ms = std::chrono::duration<double, std::milli>(now - last).count();
+        if (on) std::fprintf(stderr, "[TIMER] [run] %s took %.3f ms\n", what, ms);
+        g_run_stats.stage(what, ms);
         last = now;
     }
-    void total() {
-        if (on)
-            std::fprintf(stderr, "[TIMER] [run] Total pipeline time: %.3f ms\n",
-                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    double total() {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (on) std::fprintf(stderr, "[TIMER] [run] Total pipeline time: %.3f ms\n", ms);
+        return ms;
     }
 };
 

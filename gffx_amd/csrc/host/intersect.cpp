@@ -1192,6 +1192,9 @@ void run(const IntersectArgs &args) {
     if (verbose) {
         std::fprintf(stderr, "[DEBUG] Starting processing of \"%s\"\n", args.common.input.c_str());
         std::fprintf(stderr, "[DEBUG] Thread pool initialized with %zu threads\n", args.common.effective_threads());
+        if (args.common.threads && args.common.effective_threads() != args.common.threads)
+            std::fprintf(stderr, "[INFO] --threads %zu capped at %zu: twice the CPUs this process may use (cgroup quota / affinity)\n",
+                         args.common.threads, args.common.effective_threads());
     }
     const OverlapMode mode = args.contained         ? OverlapMode::Contained
                              : args.contains_region ? OverlapMode::ContainsRegion
@@ -1237,7 +1240,13 @@ void run(const IntersectArgs &args) {
     else
         write_gff_output(args.common.input, blocks, args.common.output, verbose);
     timer.lap(!args.common.entire_group || args.common.types ? "Join B + writing matched lines" : "Writing blocks");
-    timer.total();
+    const double total_ms = timer.total();
+    g_run_stats.count("regions", args.bed ? (double)sr.n_regions : (double)regions.size());
+    g_run_stats.count("unique_roots", (double)roots.size());
+    g_run_stats.count("blocks", (double)blocks.size());
+    g_run_stats.count("threads", (double)args.common.effective_threads());
+    g_run_stats.count("gpus", (double)args.gpus);
+    g_run_stats.write("intersect", total_ms);
 }
 
 }  // namespace intersect

@@ -109,7 +109,8 @@ const char *kIntersectUsage =
     "  -O, --overlap            Return any overlapping features (default)\n"
     "  -I, --invert             Invert the selection (exclude matching features)\n"
     "      --device <N>         HIP device to run on [default: 0]\n"
-    "      --gpus <N>           Shard the BED regions by chromosome bucket over N devices [default: 1]\n";
+    "      --gpus <N>           Shard the BED regions by chromosome bucket over N devices [default: 1]\n"
+    "      --stats-json <FILE>  Write the run's stage timers and counts as one JSON object\n";
 
 const char *kDepthUsage =
     "Usage: gffx depth [OPTIONS] --input <FILE> --source <SOURCE>\n\nOptions:\n"
@@ -149,7 +150,8 @@ int run_intersect_cli(int argc, char **argv) {
         {'i', "input", true},   {'o', "output", true},     {'e', "entire_group", false}, {'T', "types", true},
         {'t', "threads", true}, {'v', "verbose", false},   {'r', "region", true},        {'b', "bed", true},
         {'c', "contained", false}, {'C', "contains-region", false}, {'O', "overlap", false},
-        {'I', "invert", false}, {0, "device", true},       {0, "gpus", true},           {'h', "help", false}};
+        {'I', "invert", false}, {0, "device", true},       {0, "gpus", true},           {0, "stats-json", true},
+        {'h', "help", false}};
     const auto o = parse_opts(argc, argv, 2, specs);
     if (o.count("help")) {
         std::fputs(kIntersectUsage, stdout);
@@ -178,6 +180,7 @@ int run_intersect_cli(int argc, char **argv) {
     a.invert = o.count("invert") > 0;
     if (o.count("device")) a.device = static_cast<int>(parse_size(o.at("device")[0], "--device <N>"));
     if (o.count("gpus")) a.gpus = static_cast<int>(std::max<size_t>(1, std::min<size_t>(64, parse_size(o.at("gpus")[0], "--gpus <N>"))));
+    if (o.count("stats-json")) g_run_stats.path = o.at("stats-json")[0];
     commands::intersect::run(a);
     return 0;
 }
@@ -185,7 +188,7 @@ int run_intersect_cli(int argc, char **argv) {
 int run_depth_cli(int argc, char **argv) {
     static const std::vector<OptSpec> specs = {{'i', "input", true},   {'s', "source", true},   {'o', "output", true},
                                                {0, "bin-shift", true}, {'t', "threads", true},  {'v', "verbose", false},
-                                               {0, "device", true},    {0, "gpus", true},       {'h', "help", false}};
+                                               {0, "device", true},    {0, "gpus", true},       {0, "stats-json", true}, {'h', "help", false}};
     const auto o = parse_opts(argc, argv, 2, specs);
     if (o.count("help")) {
         std::fputs(kDepthUsage, stdout);
@@ -203,6 +206,7 @@ int run_depth_cli(int argc, char **argv) {
     a.verbose = o.count("verbose") > 0;
     if (o.count("device")) a.device = static_cast<int>(parse_size(o.at("device")[0], "--device <N>"));
     if (o.count("gpus")) a.gpus = static_cast<int>(std::max<size_t>(1, std::min<size_t>(64, parse_size(o.at("gpus")[0], "--gpus <N>"))));
+    if (o.count("stats-json")) g_run_stats.path = o.at("stats-json")[0];
     commands::depth::run(a);
     return 0;
 }
@@ -210,7 +214,7 @@ int run_depth_cli(int argc, char **argv) {
 int run_coverage_cli(int argc, char **argv) {
     static const std::vector<OptSpec> specs = {{'i', "input", true},   {'s', "source", true},   {'o', "output", true},
                                                {'t', "threads", true}, {'v', "verbose", false}, {0, "device", true},
-                                               {'h', "help", false}};
+                                               {0, "stats-json", true}, {'h', "help", false}};
     const auto o = parse_opts(argc, argv, 2, specs);
     if (o.count("help")) {
         std::fputs(kCoverageUsage, stdout);
@@ -226,6 +230,7 @@ int run_coverage_cli(int argc, char **argv) {
     if (o.count("threads")) a.threads = parse_size(o.at("threads")[0], "--threads <NUM>");
     a.verbose = o.count("verbose") > 0;
     if (o.count("device")) a.device = static_cast<int>(parse_size(o.at("device")[0], "--device <N>"));
+    if (o.count("stats-json")) g_run_stats.path = o.at("stats-json")[0];
     commands::coverage::run(a);
     return 0;
 }
@@ -256,13 +261,26 @@ int run_index_cli(int argc, char **argv) {
         const index_loader::GofMap gof = index_loader::load_gof(input);
         const MappedFile text(input);
         unsigned hw = std::thread::hardware_concurrency();
-        const auto t = commands::depth::build_block_table(gof, text.view(), std::min(hw ? hw : 1u, 12u));
-        commands::depth::write_block_table(append_suffix(input, ".lsoa"), t, text.size(), commands::depth::line_table_key(input, gof));
-        if (verbose) std::printf("Line table image: %zu lines in %zu blocks.\n", t.line_start.size(), t.block_line_off.size() - 1);
+        // Both images are optional accelerators (the commands fall back to the text walk without them): a failure to write one
+        // -- a full or read-only directory, a quota -- is a warning, the partial file is removed, and the index the reference
+        // defines (the eight side-cars above) stands.
+        try {
+            const auto t = commands::depth::build_block_table(gof, text.view(), std::min(hw ? hw : 1u, 12u));
+            commands::depth::write_block_table(append_suffix(input, ".lsoa"), t, text.size(), commands::depth::line_table_key(input, gof));
+            if (verbose) std::printf("Line table image: %zu lines in %zu blocks.\n", t.line_start.size(), t.block_line_off.size() - 1);
+        } catch (const Error &e) {
+            std::fprintf(stderr, "[WARN] line table image %s not written: %s\n", append_suffix(input, ".lsoa").c_str(), e.what());
+            std::remove(append_suffix(input, ".lsoa").c_str());
+        }
         // ... and the all-line table `<gff>.lall` of intersect's per-line mode (line_index.cpp)
-        const auto all = commands::intersect::build_all_lines(text.view(), std::min(hw ? hw : 1u, 12u));
-        commands::intersect::write_all_lines(append_suffix(input, ".lall"), all, text.size(), commands::depth::line_table_key(input, gof));
-        if (verbose) std::printf("All-line table: %zu lines, %zu seqid names, %zu types.\n", all.ls.size(), all.seq_names.size(), all.type_names.size());
+        try {
+            const auto all = commands::intersect::build_all_lines(text.view(), std::min(hw ? hw : 1u, 12u));
+            commands::intersect::write_all_lines(append_suffix(input, ".lall"), all, text.size(), commands::depth::line_table_key(input, gof));
+            if (verbose) std::printf("All-line table: %zu lines, %zu seqid names, %zu types.\n", all.ls.size(), all.seq_names.size(), all.type_names.size());
+        } catch (const Error &e) {
+            std::fprintf(stderr, "[WARN] all-line table %s not written: %s\n", append_suffix(input, ".lall").c_str(), e.what());
+            std::remove(append_suffix(input, ".lall").c_str());
+        }
     } else {
         std::remove(append_suffix(input, ".lsoa").c_str());  // an image of an earlier index run would be stale
         std::remove(append_suffix(input, ".lall").c_str());

@@ -38,7 +38,7 @@ K_WINDOWS, K_BITMAP_OR, K_WAVE = 9, 10, 11
 KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT: "k_partition",
                 K_LINES: "k_lines_exists", K_FUSED: "k_tile_join", K_UNPERMUTE: "k_unpermute",
                 K_FUSED_DIRECT: "k_join_fused", K_DEPTH: "k_depth_regions",
-                K_WINDOWS: "k_join_win", K_BITMAP_OR: "k_bitmap_or", K_WAVE: "k_join_wave"}
+                K_WINDOWS: "k_join_roots", K_BITMAP_OR: "k_bitmap_fold", K_WAVE: "k_join_pairs"}
 
 
 def device_count() -> int:

@@ -126,9 +126,9 @@ enum gffx_kernel_id { /* for gffx_hip_batch_kernel_ms */
     GFFX_K_FUSED_DIRECT = 6,
     GFFX_K_DEPTH = 7,
     GFFX_K_SLOTS = 8, /* (retired with the slots strategy; the number stays reserved) */
-    GFFX_K_WINDOWS = 9,
-    GFFX_K_BITMAP_OR = 10,
-    GFFX_K_WAVE = 11, /* k_join_wave: the windows strategy's pair passes (counts + root_fids) */
+    GFFX_K_WINDOWS = 9,    /* k_join_roots: the windows strategy's root passes */
+    GFFX_K_BITMAP_OR = 10, /* (k_bitmap_fold runs at gffx_hip_batch_wait, outside the profiled passes; the number stays reserved) */
+    GFFX_K_WAVE = 11,      /* k_join_pairs: the windows strategy's pair passes (counts + root_fids / positions) */
     GFFX_K__COUNT = 12
 };
 

@@ -148,10 +148,21 @@ impl HipIndex {
     }
 }
 
+/// One region / one result row as the C-ABI lays them out: three consecutive u32.  A Rust tuple `(u32, u32, u32)` has NO
+/// guaranteed layout (`repr(Rust)` may reorder or pad fields), so tuple slices are never cast to `*const u32`: rows are copied
+/// into / out of this `repr(C)` type.  (12 bytes per row, once per call: noise next to the PCIe transfer of the same rows.)
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq, Eq)]
+pub struct Row3 {
+    pub a: u32,
+    pub b: u32,
+    pub c: u32,
+}
+const _: () = assert!(std::mem::size_of::<Row3>() == 12 && std::mem::align_of::<Row3>() == 4);
+
 /// Drop-in for `commands::intersect::query_features` (src/commands/intersect.rs:105-169): same
 /// arguments, one `(root_fid, iv.start, iv.end)` per kept (region, root) pair, order unspecified
 /// (as in the reference, whose order is an FxHashMap walk plus a tree DFS).
-/// `&[(u32, u32, u32)]` is passed as-is: a tuple of three u32 is three consecutive u32.
 pub fn query_features(
     index: &HipIndex,
     regions: &[(u32, u32, u32)],
@@ -165,14 +176,18 @@ pub fn query_features(
         OverlapMode::ContainsRegion => GFFX_MODE_CONTAINS_REGION,
         OverlapMode::Overlap => GFFX_MODE_OVERLAP,
     };
+    let rows: Vec<Row3> = regions.iter().map(|&(chr, start, end)| Row3 { a: chr, b: start, c: end }).collect();
     let rc = unsafe {
-        gffx_hip_query_features(index.0, regions.as_ptr() as *const u32, regions.len() as u64, m, invert as c_int, &mut p, &mut n)
+        gffx_hip_query_features(index.0, rows.as_ptr() as *const u32, rows.len() as u64, m, invert as c_int, &mut p, &mut n)
     };
     if rc != 0 {
         // GFFX_E_CHR_RANGE (-5) stands where the reference panics on `b[chr as usize]` (intersect.rs:117)
         anyhow::bail!("gffx_hip_query_features: {}", last_error());
     }
-    let out = unsafe { std::slice::from_raw_parts(p as *const (u32, u32, u32), n as usize) }.to_vec();
+    let out = unsafe { std::slice::from_raw_parts(p as *const Row3, n as usize) }
+        .iter()
+        .map(|r| (r.a, r.b, r.c)) // (root_fid, iv.start, iv.end)
+        .collect();
     unsafe { gffx_hip_free_host(p as *mut _) };
     Ok(out)
 }

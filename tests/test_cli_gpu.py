@@ -162,3 +162,22 @@ def test_rccl_allgather_of_hit_counts_through_the_c_abi():
     assert np.array_equal(cin, cout)
     two = (C.c_int * 2)(0, 0)
     assert L.gffx_hip_allgather_counts(2, two, cin.ctypes.data_as(_ffi.u64p), cout.ctypes.data_as(_ffi.u64p)) != 0  # same device twice
+
+
+def test_stats_json_carries_the_stage_timers_and_counts(tmp_path, golden_dir):
+    """`gffx intersect --stats-json <file>`: what -v prints as [TIMER] lines, as one JSON object (bench.py's t_e2e reads it)."""
+    gff = str(tmp_path / "t.gff")
+    shutil.copy(os.path.join(golden_dir, "appendix_e.gff"), gff)
+    shutil.copy(os.path.join(golden_dir, "appendix_e.bed"), tmp_path / "q.bed")
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    sj = str(tmp_path / "stats.json")
+    plain = subprocess.run([GFFX, "intersect", "-i", gff, "-b", str(tmp_path / "q.bed")], capture_output=True)
+    r = subprocess.run([GFFX, "intersect", "--stats-json", sj, "-i", gff, "-b", str(tmp_path / "q.bed")], capture_output=True)
+    assert r.returncode == 0 and r.stdout == plain.stdout and r.stderr == plain.stderr  # (the flag changes nothing else)
+    st = json.load(open(sj))
+    assert st["command"] == "intersect" and st["total_ms"] > 0
+    names = [n for n, _ in st["stages_ms"]]
+    assert "Loading tree index" in names and "Root offsets" in names and all(ms >= 0 for _, ms in st["stages_ms"])
+    n_rows = sum(1 for ln in open(tmp_path / "q.bed") if ln.strip() and not ln.startswith("#"))
+    # (rows on a seqid the index does not know are skipped, intersect.rs:215-219: the fixture has one of its two)
+    assert 1 <= st["counts"]["regions"] <= n_rows and st["counts"]["gpus"] == 1 and st["counts"]["unique_roots"] >= 1

@@ -441,7 +441,7 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
     wide = synth.synth_bed(5000, seed=1, chroms=synth.SMALL2, width=(200_000, 900_000))
     narrow = synth.synth_bed(5000, seed=2, chroms=synth.SMALL2, width=(100, 5000))
     b = engine.QueryBatch(ix, 5000)
-    for regions, want_second in ((wide, "k_join_fused"), (narrow, "k_join_wave")):
+    for regions, want_second in ((wide, "k_join_fused"), (narrow, "k_join_pairs")):
         b.set_regions(regions)
         _, want_c = oix.query_features(regions, 2, False)
         used = []
@@ -453,7 +453,7 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
             b.set_profiling(False)
             used.append([name for kid, name in engine.KERNEL_NAMES.items() if b.kernel_ms(kid)[1]])
             assert np.array_equal(b.counts(), want_c)
-        assert used[0] == ["k_join_wave"] and used[1] == [want_second]
+        assert used[0] == ["k_join_pairs"] and used[1] == [want_second]
 
 
 def test_offsets32_and_bitmap_accumulation():
@@ -617,7 +617,7 @@ def test_window_directory_is_coarsened_not_refused(monkeypatch):
 
 
 def test_wide_block_variant(monkeypatch):
-    """k_join_win<..., T = 1024> (one block per CU, rounds of 4096 regions): forced through GFFX_HIP_WIN_THREADS on the small
+    """k_join_pairs<..., T = 1024> (one block per CU, rounds of 4096 regions): forced through GFFX_HIP_WIN_THREADS on the small
     and ragged cases, then the engine's own choice -- a 0.5-2.5 M-region pass that runs ALONE takes it, a pass launched while
     another batch of the index is in flight takes 512-thread blocks -- with full parity of the 1 M-region pass either way."""
     monkeypatch.setenv("GFFX_HIP_WIN_THREADS", "1024")

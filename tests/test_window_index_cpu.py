@@ -1,4 +1,4 @@
-"""The window index of k_join_win (32-byte lines, 16-bit window-relative coordinates, list tails in win_spill, sweep-only
+"""The window index of k_join_pairs / k_join_roots (32-byte lines, 16-bit window-relative coordinates, list tails in win_spill, sweep-only
 seqids) against a brute-force scan, on the CPU: tools/win_index_check.hip includes the engine's builder and restates how the
 kernel reads a line.  The GPU parity tests cover the kernel itself; this covers the table it reads where no GPU exists."""
 import os

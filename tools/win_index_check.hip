@@ -1,5 +1,5 @@
-// win_index_check.hip -- host-only check of the window index (engine.hip::build_window_index_at + the line format of
-// join_win_kernels.hpp): random indexes (seqids of 1 Kbp .. 4 Gbp, nested / empty / long roots), random regions that the
+// win_index_check.hip -- host-only check of the window index (engine.hip::build_window_index_at, build_window_splits + the
+// line format of join_pairs_kernels.hpp): random indexes (seqids of 1 Kbp .. 4 Gbp, nested / empty / long roots), random regions that the
 // lines answer, all three modes.  Restates the kernel's use of a line on the CPU -- window of the region's last base,
 // 16-bit relative coordinates, the four inline tests, the list tail from win_spill -- and compares the kept root_fids with
 // a brute-force scan of the roots.  Runs without a GPU (tests/test_window_index_cpu.py); built by the Makefile of
@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <random>
 #include <vector>
+#include <map>
 #include <set>
 #include "../gffx_amd/csrc/device/engine.hip"
 static bool keep(int mode, uint32_t s, uint32_t e, uint32_t qs, uint32_t qe) {
@@ -19,6 +20,7 @@ static bool keep(int mode, uint32_t s, uint32_t e, uint32_t qs, uint32_t qe) {
 }
 int main(int argc, char **argv) {
     uint64_t seed = argc > 1 ? atoll(argv[1]) : 1;
+    unsigned long long n_checked = 0, n_split_reads = 0;
     std::mt19937_64 rng(seed);
     for (int iter = 0; iter < 200; iter++) {
         uint32_t n_chr = 1 + rng() % 4;
@@ -54,6 +56,13 @@ int main(int argc, char **argv) {
         uint32_t fshift = 0;
         gffx::build_window_filter(n_chr, co.data(), start, aux, meta, fbits, fmeta, fshift);
         const uint32_t fwords = (uint32_t)fbits.size();
+        // the split windows (round 4): the sub-lines as the builder hands them to the device, by line number
+        std::vector<uint32_t> sbits, sub_at;
+        std::vector<uint4> sub_lines, sub_lines_pos;
+        gffx::build_window_splits(n_chr, start, aux, meta, win, wpos, spill, sbits, sub_at, sub_lines, sub_lines_pos);
+        std::map<uint32_t, size_t> sub_of;  // line number -> index into sub_lines / 2
+        for (size_t i = 0; i < sub_at.size(); i++) sub_of[sub_at[i]] = i;
+        const size_t n_win = win.size() / 2;
         auto covered = [&](uint32_t c, uint32_t qs, uint32_t qe) {
             if (fwords < 4) return true;
             const uint32_t a2 = qs >> fshift, d = std::min<uint32_t>(((qe - 1) >> fshift) - a2, 30u);
@@ -86,9 +95,27 @@ int main(int argc, char **argv) {
                     continue;
                 }
                 if (b < m.y) {
-                    const uint32_t *l = ww + 8 * ((size_t)m.x + b);
-                    uint32_t rel = m.w - (b << m.z);
-                    uint32_t rqs = qs + rel, rqe = qe + rel;
+                    // the kernel's reading: the window's line, or -- split window -- the sub-line of the region's last base
+                    const size_t w = (size_t)m.x + b;
+                    const bool split = !sbits.empty() && (sbits[w >> 5] >> (w & 31) & 1u);
+                    const uint32_t sh = m.z - (split ? gffx::kWinSplit : 0u);
+                    static const uint32_t kZero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const uint32_t *l = ww + 8 * w;
+                    n_checked++, n_split_reads += split;
+                    if (split) {
+                        const uint32_t line = (uint32_t)(n_win + (w << gffx::kWinSplit) + (((qe - 1) >> sh) & ((1u << gffx::kWinSplit) - 1)));
+                        const auto it = sub_of.find(line);
+                        l = it == sub_of.end() ? kZero : (const uint32_t *)&sub_lines[2 * it->second];
+                        if (it != sub_of.end()) {  // the position copy lists the same entries
+                            const uint32_t *lp = (const uint32_t *)&sub_lines_pos[2 * it->second];
+                            for (int j = 0; j < 4; j++)
+                                if (lp[j] != l[j] || (l[j] != 0x0000FFFFu && l[3] != 0xFFFFFFFFu && aux[lp[4 + j]].w != l[4 + j])) {
+                                    printf("SPLIT POS MISMATCH iter %d line %u entry %d\n", iter, line, j);
+                                    return 1;
+                                }
+                        }
+                    }
+                    const uint32_t rqe1 = ((qe - 1) & ((1u << sh) - 1)) + m.w, rqs = rqe1 - (qe - 1 - qs), rqe = rqe1 + 1;
                     for (int j = 0; j < 4; j++)
                         if (keep(mode, l[j] & 0xFFFF, l[j] >> 16, rqs, rqe)) got.insert(l[4 + j]);
                     if (l[3] == 0xFFFFFFFFu) {
@@ -104,6 +131,6 @@ int main(int argc, char **argv) {
             }
         }
     }
-    printf("ok\n");
+    printf("ok (%llu line reads checked, %llu of them sub-lines of split windows)\n", n_checked, n_split_reads);
     return 0;
 }
