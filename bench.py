@@ -705,7 +705,7 @@ def main():
     if world == 1 and not args.quick:
         # ---- the pass the CLI runs: root bitmap only (commands/intersect.rs:598-615 needs the unique roots, nothing else)
         cli = {}
-        bm = Pass(engine, ix, cols, nq, 1, mode, engine.OUT_ROOT_BITMAP, strategy)
+        bm = Pass(engine, ix, cols, nq, 1, mode, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, strategy)  # (the CLI's flags)
         bm.size_and_warm(1)
         kb = bm.kernel_us(10)
         cli["1m"] = {"bitmap_pass_us": bm.pass_us_one_event_pair, "kernels": kb, "fids_pass_us": result["roofline"]["pass_kernel_us"],
@@ -727,7 +727,7 @@ def main():
         result["roofline_10m_contained"] = roofline_obj(k10c, len(reg10), pairs10c, out_b, "the same 10 M regions, --contained "
                                                         "(BASELINE configs[2]'s mode)", None, p10c.pass_us_one_event_pair, p10c.block_threads)
         p10c.close()
-        bm10 = Pass(engine, ix, cols10, len(reg10), 1, mode, engine.OUT_ROOT_BITMAP, strategy)
+        bm10 = Pass(engine, ix, cols10, len(reg10), 1, mode, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, strategy)
         bm10.size_and_warm(1)
         kb10 = bm10.kernel_us(5)
         cli["10m"] = {"bitmap_pass_us": bm10.pass_us_one_event_pair, "kernels": kb10,

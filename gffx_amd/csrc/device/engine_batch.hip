@@ -424,8 +424,13 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     GFFX_HIP_TRY(hipSetDevice(b->ix->device));
     b->mode = mode;
     b->invert = invert ? 1 : 0;
-    b->flags = out_flags | GFFX_OUT_COUNTS;
+    // counts are always produced -- except by a root pass of its own whose caller waived them (GFFX_OUT_NO_COUNTS: honoured by the
+    // windows strategy; the flag is dropped wherever it does not apply)
+    const bool waive = (out_flags & GFFX_OUT_NO_COUNTS) && (out_flags & GFFX_OUT_ROOT_BITMAP) &&
+                       !(out_flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32 | GFFX_OUT_SEGBASE));
+    b->flags = waive ? out_flags : ((out_flags & ~(uint32_t)GFFX_OUT_NO_COUNTS) | GFFX_OUT_COUNTS);
     b->strategy = pick_strategy(b, strategy);
+    if (waive && b->strategy != GFFX_STRATEGY_WINDOWS) b->flags = (b->flags & ~(uint32_t)GFFX_OUT_NO_COUNTS) | GFFX_OUT_COUNTS;
     if ((out_flags & GFFX_OUT_SEGBASE) && (out_flags & GFFX_OUT_TRIPLES))
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: GFFX_OUT_SEGBASE is an output of the root_fid passes, not of GFFX_OUT_TRIPLES");
     if ((out_flags & (GFFX_OUT_OFFSETS32 | GFFX_OUT_BITMAP_KEEP | GFFX_OUT_SEGBASE)) && b->strategy != GFFX_STRATEGY_WINDOWS) {

@@ -34,6 +34,9 @@ static uint32_t pairs_lds_bytes(const gffx_hip_index *ix, uint32_t threads, bool
 // runs alone, 512 (two per CU) while another batch of the index has passes in flight.  GFFX_HIP_WIN_THREADS forces one.
 static uint32_t pair_threads(const gffx_hip_batch *b) {
     const long forced = env_long("GFFX_HIP_WIN_THREADS", 0, 0, 1024);
+#if defined(GFFX_EXPERIMENT_640)
+    if (forced == 640) return 640u;
+#endif
     if (forced == 512 || forced == 1024) return (uint32_t)forced;
     return (!b->others_busy && b->nq >= 500000) ? 1024u : 512u;
 }
@@ -49,10 +52,13 @@ static int launch_pairs4(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, ui
 template <int MODE, bool ML>
 static int launch_pairs(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, bool pos, uint32_t lds) {
 #define GFFX_P(T, O, P) \
-    if ((threads == 1024) == (T == 1024) && offs == O && pos == P) return launch_pairs4<MODE, ML, T, O, P>(b, grid, a, lds);
+    if (threads == T && offs == O && pos == P) return launch_pairs4<MODE, ML, T, O, P>(b, grid, a, lds);
     GFFX_P(1024, false, false) GFFX_P(1024, true, false) GFFX_P(1024, false, true) GFFX_P(1024, true, true)
     GFFX_P(512, false, false) GFFX_P(512, true, false) GFFX_P(512, false, true) GFFX_P(512, true, true)
 #undef GFFX_P
+#if defined(GFFX_EXPERIMENT_640)
+    if (threads == 640 && !offs && !pos) return launch_pairs4<MODE, ML, 640, false, false>(b, grid, a, lds);
+#endif
     return GFFX_OK;
 }
 template <int MODE, bool ML, int T>
@@ -75,7 +81,8 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     const bool roots = kind == 3, pos = kind != 1;
     PairArgs a{};
     WaveOut &o = a.out;
-    o.counts = b->d_counts;
+    // (a root pass behind a pair pass must not write the counts again; one of its own writes them unless the caller waived them)
+    o.counts = (roots && (second || (b->flags & GFFX_OUT_NO_COUNTS))) ? nullptr : b->d_counts;
     o.err = reinterpret_cast<uint32_t *>(b->d_status);
     o.slow = b->d_status + (second ? 6 : 4);  // (a second pass over the same regions must not count them twice)
     if (second) {

@@ -443,7 +443,7 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 // OFFS: per-region offsets are written (GFFX_OUT_OFFSETS / _OFFSETS32): each lane parks its place inside the round's segment
 // POS: the words a pass emits are index positions (table win_pos), not root_fids
 template <int MODE, bool META_LDS, int T, bool OFFS, bool POS>
-__global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
+__global__ __launch_bounds__(T, T == 640 ? 5 : 4) void k_join_pairs(PairArgs A) {
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     constexpr uint32_t kWaves = T / 64;
     constexpr uint32_t D = kWaveDepth;
@@ -918,7 +918,8 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
             kept += __popc(m[k]);
         }
-        {  // the rare rest: list tails and sweeps set their flags themselves
+        uint32_t tc[4] = {0, 0, 0, 0};
+        {  // the rare rest: list tails and sweeps set their bits themselves
             bool any = false;
             uint32_t deferred = 0, sweep = 0, hdr[4];
 #pragma unroll
@@ -936,10 +937,22 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 while (d) {
                     const int k = __ffs(d) - 1;
                     d &= d - 1;
-                    kept += pair_rest<MODE, true>(&pair_rare_ix(), A.spill, inv, sweep >> k & 1u, min(win_sel(qc, k), n_chr), win_sel(qs, k),
-                                                  win_sel(qe, k), win_sel(hdr, k), nullptr, 0u, bm_words ? s_bm : g_bitmap);
+                    const uint32_t c = pair_rest<MODE, true>(&pair_rare_ix(), A.spill, inv, sweep >> k & 1u, min(win_sel(qc, k), n_chr), win_sel(qs, k),
+                                                             win_sel(qe, k), win_sel(hdr, k), nullptr, 0u, bm_words ? s_bm : g_bitmap);
+                    kept += c;
+                    tc[0] += k == 0 ? c : 0u;
+                    tc[1] += k == 1 ? c : 0u;
+                    tc[2] += k == 2 ? c : 0u;
+                    tc[3] += k == 3 ? c : 0u;
                 }
             }
+        }
+        if (out.counts) {  // (uniform) per-region counts, unless the caller waived them (GFFX_OUT_NO_COUNTS); older than the prefetch below
+            const unsigned long long left = nq - base;
+            const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
+            gffx_v4u cv;
+            cv.x = __popc(m[0]) + tc[0], cv.y = __popc(m[1]) + tc[1], cv.z = __popc(m[2]) + tc[2], cv.w = __popc(m[3]) + tc[3];
+            __builtin_amdgcn_raw_buffer_store_b128(cv, __builtin_amdgcn_make_buffer_rsrc(out.counts + base, 0, rows * 4u, 0x00020000), 4u * t4, 0, 2 /* nt */);
         }
         // the regions are done with: the next round's take their registers; then the flags (stores younger than every load
         // that is waited for)

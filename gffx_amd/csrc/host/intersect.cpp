@@ -492,7 +492,7 @@ std::vector<uint32_t> query_unique_roots(TreeIndexData &index_data, const std::v
     if (gffx_hip_batch_create(index_data.device_index, regions.size(), &b.h) != GFFX_OK) hip_fail("batch_create");
     sub.lap("  batch buffers");
     if (gffx_hip_batch_set_regions_host(b.h, flat.data(), regions.size()) != GFFX_OK) hip_fail("set_regions");
-    if (gffx_hip_batch_run(b.h, static_cast<int>(mode), invert ? 1 : 0, GFFX_OUT_ROOT_BITMAP, GFFX_STRATEGY_AUTO) != GFFX_OK)
+    if (gffx_hip_batch_run(b.h, static_cast<int>(mode), invert ? 1 : 0, GFFX_OUT_ROOT_BITMAP | GFFX_OUT_NO_COUNTS, GFFX_STRATEGY_AUTO) != GFFX_OK)
         hip_fail("batch_run");
     if (gffx_hip_batch_wait(b.h) != GFFX_OK) hip_fail("query_features");
     sub.lap("  regions H2D + Join A kernel");
@@ -831,7 +831,8 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
             if (gffx_hip_regions_append(store[d].h, k, n_up) != GFFX_OK) hip_fail("regions_append");
             gffx_hip_batch *b = batch[2 * d + k].h;
             if (gffx_hip_batch_set_regions_store(b, store[d].h, k, 0, n_dev[d]) != GFFX_OK) hip_fail("set_regions_store");
-            const uint32_t flags = static_cast<uint32_t>(GFFX_OUT_ROOT_BITMAP) | (used[2 * d + k] ? static_cast<uint32_t>(GFFX_OUT_BITMAP_KEEP) : 0u);
+            const uint32_t flags = static_cast<uint32_t>(GFFX_OUT_ROOT_BITMAP) | static_cast<uint32_t>(GFFX_OUT_NO_COUNTS) |
+                                   (used[2 * d + k] ? static_cast<uint32_t>(GFFX_OUT_BITMAP_KEEP) : 0u);
             if (gffx_hip_batch_run(b, static_cast<int>(mode), invert ? 1 : 0, flags, GFFX_STRATEGY_AUTO) != GFFX_OK) hip_fail("batch_run");
             used[2 * d + k] = 1;
             dev_rows[d] += n_dev[d];

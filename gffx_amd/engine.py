@@ -30,7 +30,7 @@ class OverlapMode(enum.IntEnum):
 
 
 OUT_COUNTS, OUT_FIDS, OUT_TRIPLES, OUT_ROOT_BITMAP, OUT_OFFSETS, OUT_EMIT_ORDER = 1, 2, 4, 8, 16, 32
-OUT_OFFSETS32, OUT_BITMAP_KEEP, OUT_SEGBASE = 64, 128, 256
+OUT_OFFSETS32, OUT_BITMAP_KEEP, OUT_SEGBASE, OUT_NO_COUNTS = 64, 128, 256, 512
 SEG_GROUP = 256  # regions per OUT_SEGBASE entry
 STRATEGY_AUTO, STRATEGY_DIRECT, STRATEGY_SORTED, STRATEGY_FUSED, STRATEGY_WINDOWS = 0, 1, 2, 3, 5  # (4: the retired slots strategy)
 K_JOIN_COUNT, K_JOIN_EMIT, K_SORT, K_LINES, K_FUSED, K_UNPERMUTE, K_FUSED_DIRECT, K_DEPTH, K_SLOTS = 0, 1, 2, 3, 4, 5, 6, 7, 8

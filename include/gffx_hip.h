@@ -92,6 +92,9 @@ enum gffx_out {
                                  input order, so region i's segment starts at segbase[i / 256] + the counts of the group's
                                  regions before i: a consumer that reads the counts anyway needs no per-region offsets
                                  (they are not part of the algorithmic bytes).  The runs tile [0, pairs) exactly. */
+    GFFX_OUT_NO_COUNTS = 512, /* with GFFX_OUT_ROOT_BITMAP alone (windows strategy): the per-region counts need not be written -- a
+                                 caller that only wants the unique roots (the CLI: commands/intersect.rs:598-615) saves their 4 bytes
+                                 per region */
     GFFX_OUT_EMIT_ORDER = 32  /* partitioned strategy: leave the per-query results in emission order
                                  ({input row, count, offset} records: gffx_hip_batch_copy_query_records) and
                                  skip the scatter into input-order arrays; _copy_counts / _copy_offsets then

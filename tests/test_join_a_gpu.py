@@ -230,6 +230,21 @@ def test_many_seqids_metadata_outside_lds():
         b.run(OverlapMode.Overlap, False, engine.OUT_FIDS, engine.STRATEGY_SORTED)
 
 
+def test_many_seqids_lds_budget(monkeypatch):
+    """1 200 scaffolds: 19 KB of seqid records on top of filter, split bitmap, strips and -- with per-region offsets, what
+    `gffx depth` asks for -- the parked offsets: at both block widths the pass must shed what does not fit the block's LDS
+    (split bitmap, then the seqid records, then the filter) instead of launching over the limit (round 3's ADVICE), and stay
+    exact whatever it shed."""
+    chroms = [("scaf%d" % i, 80_000 + 17 * i) for i in range(1200)]
+    roots = synth.gencode_like_roots(9000, seed=18, chroms=chroms)
+    regions = synth.synth_bed(30000, seed=19, chroms=chroms, width=(10, 6000), edge_frac=0.05, roots=roots)
+    for threads in ("512", "1024"):
+        monkeypatch.setenv("GFFX_HIP_WIN_THREADS", threads)
+        for mode in (OverlapMode.Overlap, OverlapMode.Contained):
+            _check(roots, regions, mode, False, strategy=engine.STRATEGY_WINDOWS)
+        _check(roots, regions, OverlapMode.ContainsRegion, True, strategy=engine.STRATEGY_WINDOWS)
+
+
 def test_sorted_strategy_long_queries_and_dense_windows():
     """Queries far longer than a genome window (the sweep leaves the LDS tile and continues in
     global memory) and a window with more intervals than fit the LDS tile (gather fallback)."""
@@ -486,6 +501,18 @@ def test_offsets32_and_bitmap_accumulation():
             seen = np.union1d(seen, ct[:, 0])
             assert np.array_equal(b.unique_roots(), seen)
         assert np.array_equal(seen, np.unique(want_t[:, 0]))
+        b.set_regions(regions)
+        # the CLI's pass: roots only, counts waived (GFFX_OUT_NO_COUNTS); several passes between two waits, one fold at the wait;
+        # the pass's pair total still arrives (per-block sums)
+        halves = np.array_split(regions, 2)
+        for hi, half in enumerate(halves):
+            b.set_regions(half)
+            b.run(mode, False, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS | (engine.OUT_BITMAP_KEEP if hi else 0))
+        b.wait()
+        assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+        assert b.total_hits == len(oix.query_features(halves[1], int(mode), False)[0])
+        with pytest.raises(Exception):
+            b.counts()  # (not requested)
         b.set_regions(regions)
     b.close()
     ix.close()
