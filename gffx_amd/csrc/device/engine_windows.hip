@@ -34,9 +34,6 @@ static uint32_t pairs_lds_bytes(const gffx_hip_index *ix, uint32_t threads, bool
 // runs alone, 512 (two per CU) while another batch of the index has passes in flight.  GFFX_HIP_WIN_THREADS forces one.
 static uint32_t pair_threads(const gffx_hip_batch *b) {
     const long forced = env_long("GFFX_HIP_WIN_THREADS", 0, 0, 1024);
-#if defined(GFFX_EXPERIMENT_640)
-    if (forced == 640) return 640u;
-#endif
     if (forced == 512 || forced == 1024) return (uint32_t)forced;
     return (!b->others_busy && b->nq >= 500000) ? 1024u : 512u;
 }
@@ -56,9 +53,7 @@ static int launch_pairs(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uin
     GFFX_P(1024, false, false) GFFX_P(1024, true, false) GFFX_P(1024, false, true) GFFX_P(1024, true, true)
     GFFX_P(512, false, false) GFFX_P(512, true, false) GFFX_P(512, false, true) GFFX_P(512, true, true)
 #undef GFFX_P
-#if defined(GFFX_EXPERIMENT_640)
-    if (threads == 640 && !offs && !pos) return launch_pairs4<MODE, ML, 640, false, false>(b, grid, a, lds);
-#endif
+
     return GFFX_OK;
 }
 template <int MODE, bool ML, int T>

@@ -89,9 +89,9 @@ __device__ __forceinline__ uint32_t win_sel(const uint32_t (&a)[4], int k) {
 constexpr uint32_t kWaveDepth = 3;     // strips per wave: a round's words wait kWaveDepth - 1 rounds for their place
 constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequence numbers (kWaveDepth of each)
 constexpr uint32_t kWaveStash = 2;     // per thread: kept words of deferred regions wait here (LDS) for the parking
-// words a wave parks in LDS per round (a strip): 1.5 kept pairs per region at 1024 threads, 1 at 512 (two blocks share a CU's LDS);
-// a fuller round takes all kWaveDepth strips, beyond that the synchronous path
-__host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads) { return threads == 1024 ? 384u : 256u; }
+// words a wave parks in LDS per round (a strip): 2 kept pairs per region at 1024 threads, 1.5 at 512 (two blocks share a CU's
+// LDS); a fuller round -- gene-dense stretches of a sorted BED file -- takes all kWaveDepth strips, beyond that the synchronous path
+__host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads) { return threads == 1024 ? 512u : 384u; }
 
 // what the MAIN path of a pass reads of the index: the line table (root_fids, or index positions: root passes, triples) and
 // the three small tables every block stages in LDS
@@ -443,7 +443,7 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 // OFFS: per-region offsets are written (GFFX_OUT_OFFSETS / _OFFSETS32): each lane parks its place inside the round's segment
 // POS: the words a pass emits are index positions (table win_pos), not root_fids
 template <int MODE, bool META_LDS, int T, bool OFFS, bool POS>
-__global__ __launch_bounds__(T, T == 640 ? 5 : 4) void k_join_pairs(PairArgs A) {
+__global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     constexpr uint32_t kWaves = T / 64;
     constexpr uint32_t D = kWaveDepth;
