@@ -430,6 +430,16 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
                        !(out_flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32 | GFFX_OUT_SEGBASE));
     b->flags = waive ? out_flags : ((out_flags & ~(uint32_t)GFFX_OUT_NO_COUNTS) | GFFX_OUT_COUNTS);
     b->strategy = pick_strategy(b, strategy);
+    // Wide batches (AUTO, after a pass that sent most regions to the sweep): overlap-mode pair passes take the wide form of the
+    // window kernel; the other modes and the root passes stay with the sweep kernel.  GFFX_HIP_WIN_WIDE: 0 = never, 2 = every
+    // eligible pass of the windows strategy (tests).
+    {
+        const long ww = env_long("GFFX_HIP_WIN_WIDE", 1, 0, 2);
+        const bool eligible = mode == GFFX_MODE_OVERLAP && !invert && b->ix->win_range_ok && !(out_flags & GFFX_OUT_ROOT_BITMAP);
+        b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && b->strategy == GFFX_STRATEGY_FUSED && b->mostly_slow) ||
+                               (ww == 2 && b->strategy == GFFX_STRATEGY_WINDOWS));
+        if (b->wide) b->strategy = GFFX_STRATEGY_WINDOWS;
+    }
     if (waive && b->strategy != GFFX_STRATEGY_WINDOWS) b->flags = (b->flags & ~(uint32_t)GFFX_OUT_NO_COUNTS) | GFFX_OUT_COUNTS;
     if ((out_flags & GFFX_OUT_SEGBASE) && (out_flags & GFFX_OUT_TRIPLES))
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: GFFX_OUT_SEGBASE is an output of the root_fid passes, not of GFFX_OUT_TRIPLES");
@@ -549,7 +559,9 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     }
     if (b->strategy == GFFX_STRATEGY_WINDOWS) {  // regions the passes since the last wait sent to the exact sweep (own 64-bit word)
         const uint64_t passes = std::max<uint64_t>(b->win_passes, 1);
-        b->mostly_slow = (h_slow_win - b->slow_seen_win) / passes > b->nq / 4;
+        // (a wide-form pass answers every width from the lines: it says nothing about the regions' widths -- the batch stays what
+        //  the last narrow pass found it to be until its regions change)
+        if (!b->wide) b->mostly_slow = (h_slow_win - b->slow_seen_win) / passes > b->nq / 4;
         b->slow_seen_win = h_slow_win;
         b->win_passes = 0;
     }
@@ -729,6 +741,7 @@ extern "C" int gffx_hip_batch_kernel_ms(gffx_hip_batch *b, int kernel_id, double
 // n passes back to back on the batch's stream between ONE pair of HIP events: the average launch-to-launch duration without
 // the cost of an event pair per launch (which adds ~3 us to a ~18 us kernel)
 extern "C" uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *b) { return b ? b->win_threads : 0; }
+extern "C" int gffx_hip_batch_wide_form(const gffx_hip_batch *b) { return b && b->wide ? 1 : 0; }
 
 extern "C" int gffx_hip_batch_timed_runs(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags, int strategy, uint32_t n,
                                          double *total_ms) {

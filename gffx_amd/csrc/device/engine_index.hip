@@ -210,6 +210,53 @@ static void build_window_splits(uint32_t n_chr, const std::vector<uint32_t> &h_s
     }
 }
 
+// Ranks (gffx_device.hpp): one record {rank, list-tail header} per line of both levels.  `meta` = {first window, windows, shift,
+// wmax} (as built); the lines say how many entries each list holds.  Returns whether the ranks may be used (no interval
+// with end < start on a seqid with windows).
+static bool build_window_ranks(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
+                               const std::vector<uint4> &h_aux, const std::vector<uint4> &meta, const std::vector<uint4> &win_pos,
+                               const std::vector<uint32_t> &bits, const std::vector<uint32_t> &sub_at,
+                               const std::vector<uint4> &sub_lines_pos, std::vector<uint2> &rank) {
+    const size_t n_win = win_pos.size() / 2;
+    const bool split = !bits.empty();
+    rank.assign(n_win * (split ? (1u << kWinSplit) + 1 : 1), make_uint2(0u, 0u));
+    if (!n_win) return false;
+    // the entries of a line's list and, for a list that continues in win_spill, its header (word 7 of the line: n | spill << 8;
+    // n = 255: a dense window, whose regions take the sweep whatever the rank says)
+    auto entries = [](const uint4 &c, const uint4 &f, uint32_t &hdr) -> uint32_t {
+        hdr = c.w == kWinTailMark ? f.w : 0u;
+        if (hdr) return hdr & 255u;
+        return (c.x != kWinAbsent) + (c.y != kWinAbsent) + (c.z != kWinAbsent) + (c.w != kWinAbsent);
+    };
+    bool ok = true;
+    for (uint32_t c = 0; c < n_chr; c++) {
+        const uint4 m = meta[c];
+        const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
+        if (hi == lo || m.z > kWinMaxShift || m.w == 0) continue;  // no roots / sweep-only
+        for (uint32_t i = lo; i < hi; i++) ok &= h_aux[i].x >= h_start[i];
+        auto below = [&](uint64_t edge) -> uint32_t {  // roots of the seqids so far that start below `edge`
+            if (edge > 0xFFFFFFFFull) return hi;
+            return (uint32_t)(std::lower_bound(h_start.begin() + lo, h_start.begin() + hi, (uint32_t)edge) - h_start.begin());
+        };
+        for (uint64_t b = 0; b < m.y; b++) {
+            const size_t w = (size_t)m.x + b;
+            uint32_t hdr;
+            const uint32_t n = entries(win_pos[2 * w], win_pos[2 * w + 1], hdr);
+            rank[w] = make_uint2(below((b + 1) << m.z) - n, hdr);
+            if (split && (bits[w >> 5] >> (w & 31) & 1u))
+                for (uint64_t j = 0; j < (1u << kWinSplit); j++)
+                    rank[n_win + (w << kWinSplit) + j] = make_uint2(below(((b << kWinSplit) + j + 1) << (m.z - kWinSplit)) - 4u, 0u);
+        }
+    }
+    for (size_t j = 0; j < sub_at.size(); j++) {
+        uint32_t hdr;
+        const uint32_t n = entries(sub_lines_pos[2 * j], sub_lines_pos[2 * j + 1], hdr);
+        rank[sub_at[j]].x += 4u - n;
+        rank[sub_at[j]].y = hdr;
+    }
+    return ok;
+}
+
 // Coverage filter of the window index (gffx_device.hpp): the smallest cell size whose bitmap fits GFFX_HIP_WIN_FILTER_KB
 // (default 24 KB of LDS per block; 48 KB measured 1.5 % faster at 10 M regions, 1.5 % slower at 1 M), but never so small that a region the lines answer (width <= wmax) spans more than 32 cells.
 static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
@@ -403,6 +450,10 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     std::vector<uint4> sub_lines, sub_lines_pos;
     build_window_splits(n_chr, h_start, h_aux, win_meta, win, win_pos, win_spill, win_splittab, sub_at, sub_lines, sub_lines_pos);
     ix->win_swords = win_splittab.empty() ? 0u : (uint32_t)((ix->n_win + 31) / 32);
+    std::vector<uint2> win_rank;
+    std::vector<uint32_t> root_fids(ix->h_sorted_fids);
+    root_fids.resize(root_fids.size() + 4, 0u);  // (runs are read 16 bytes at a time from any position)
+    ix->win_range_ok = build_window_ranks(n_chr, chr_offsets, h_start, h_aux, win_meta, win_pos, win_splittab, sub_at, sub_lines_pos, win_rank);
     std::vector<uint32_t> win_filter;
     std::vector<uint2> win_fmeta;
     build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);
@@ -511,6 +562,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = upload_line_table(&ix->d_win, win, ix->win_swords != 0, sub_at, sub_lines, &win_bytes)) ||
         (rc = upload_line_table(&ix->d_win_pos, win_pos, ix->win_swords != 0, sub_at, sub_lines_pos, &win_pos_bytes)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
         (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_splittab, win_splittab)) ||
+        (rc = dev_upload(&ix->d_win_rank, win_rank)) || (rc = dev_upload(&ix->d_root_fids, root_fids)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -520,7 +572,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
     ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),
                        bytes(win_meta),  win_bytes,         win_pos_bytes,    bytes(win_spill), bytes(win_filter),
-                       bytes(win_splittab),
+                       bytes(win_splittab), bytes(win_rank), bytes(root_fids),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
     GFFX_HIP_TRY(hipDeviceSynchronize());
@@ -566,6 +618,8 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_win_spill);
     (void)hipFree(ix->d_win_filter);
     (void)hipFree(ix->d_win_splittab);
+    (void)hipFree(ix->d_win_rank);
+    (void)hipFree(ix->d_root_fids);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);
     (void)hipFree(ix->d_tile_meta);

@@ -21,12 +21,12 @@ static int lds_opt_in(const void *func, int device, uint32_t lds, uint32_t max_l
 // dynamic LDS: coverage filter + split bitmap + seqid records, and for the pair passes header + strips + parked offsets +
 // per-thread strips
 static uint32_t pairs_lds_bytes(const gffx_hip_index *ix, uint32_t threads, bool roots, uint32_t keep_words, uint32_t fwords, uint32_t swords,
-                                bool ml, uint32_t bm_words = 0) {
+                                bool ml, uint32_t bm_words = 0, bool wide = false) {
     const uint32_t sw4 = swords ? (swords + 4) / 4 * 4 : 0;
     const uint32_t tables = 4 * fwords + 4 * sw4 + (ml ? (ix->n_chr + 1) * 16 : 0);
     if (roots) return tables + 16 + 4 * bm_words;  // (+ the block's pair count)
-    return tables + kWaveHdrBytes + 4 * (threads / 64) * kWaveDepth * pair_stage_words(threads) + 4 * threads * kWaveDepth * keep_words +
-           4 * kWaveStash * threads;
+    return tables + kWaveHdrBytes + 4 * (threads / 64) * pair_depth(wide) * pair_stage_words(threads, wide) +
+           4 * threads * pair_depth(wide) * keep_words + 4 * kWaveStash * threads;
 }
 
 // Threads per block.  The waves of a pass are independent, so the block width only sets how many regions share one
@@ -38,18 +38,22 @@ static uint32_t pair_threads(const gffx_hip_batch *b) {
     return (!b->others_busy && b->nq >= 500000) ? 1024u : 512u;
 }
 
-template <int MODE, bool ML, int T, bool OFFS, bool POS>
+template <int MODE, bool ML, int T, bool OFFS, bool POS, bool WIDE>
 static int launch_pairs4(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t lds) {
-    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_pairs<MODE, ML, T, OFFS, POS>), b->ix->device, lds,
+    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_pairs<MODE, ML, T, OFFS, POS, WIDE>), b->ix->device, lds,
                               T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_join_pairs<MODE, ML, T, OFFS, POS>), dim3(grid), dim3(T), lds, b->stream, a);
+    hipLaunchKernelGGL((k_join_pairs<MODE, ML, T, OFFS, POS, WIDE>), dim3(grid), dim3(T), lds, b->stream, a);
     return GFFX_OK;
 }
 template <int MODE, bool ML>
-static int launch_pairs(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, bool pos, uint32_t lds) {
-#define GFFX_P(T, O, P) \
-    if (threads == T && offs == O && pos == P) return launch_pairs4<MODE, ML, T, O, P>(b, grid, a, lds);
+static int launch_pairs(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, bool pos, bool wide, uint32_t lds) {
+#define GFFX_P(T, O, P)                                                                                          \
+    if (threads == T && offs == O && pos == P) {                                                                 \
+        if constexpr (MODE == GFFX_MODE_OVERLAP)                                                                 \
+            if (wide) return launch_pairs4<MODE, ML, T, O, P, true>(b, grid, a, lds);                            \
+        return launch_pairs4<MODE, ML, T, O, P, false>(b, grid, a, lds);                                         \
+    }
     GFFX_P(1024, false, false) GFFX_P(1024, true, false) GFFX_P(1024, false, true) GFFX_P(1024, true, true)
     GFFX_P(512, false, false) GFFX_P(512, true, false) GFFX_P(512, false, true) GFFX_P(512, true, true)
 #undef GFFX_P
@@ -112,20 +116,22 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     const uint32_t threads = pair_threads(b);
     const bool offs = !roots && (o.offsets || o.offsets32);
     const uint32_t keep_words = offs ? 2u : 0u;
-    uint32_t fwords = (ix->win_fwords + 3) / 4 * 4, swords = ix->win_swords;
+    // the wide form (gffx_device.hpp, "ranks"): pair passes of a batch AUTO found mostly wider than the lines answer; it reads no filter
+    const bool wide = !roots && b->wide;
+    uint32_t fwords = wide ? 0u : (ix->win_fwords + 3) / 4 * 4, swords = ix->win_swords;
     if (fwords < 4) fwords = 0;
     // What does not fit the block's LDS goes in this order: the split bitmap (lists longer than 4 are then walked from
     // win_spill), the seqid records (read through the caches instead), the coverage filter.  What is left -- header, strips,
     // parked offsets, per-thread strips -- fits by construction; checked all the same: a launch over the limit would fail, or
     // silently run one block per CU.
     const uint32_t max_lds = threads == 1024 ? 2 * kWinMaxLds : kWinMaxLds;
-    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml) > max_lds) swords = 0;
-    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml) > max_lds) ml = false;
-    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml) > max_lds) fwords = 0;
+    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, 0, wide) > max_lds) swords = 0;
+    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, 0, wide) > max_lds) ml = false;
+    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, 0, wide) > max_lds) fwords = 0;
     // a root pass keeps the block's root bitmap in LDS when it fits next to the tables (else: device atomics on the batch's bitmap)
     uint32_t bm_words = roots ? ((ix->n_roots + 31) / 32 + 3) / 4 * 4 : 0;
-    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, bm_words) > max_lds) bm_words = 0;
-    const uint32_t lds = pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, bm_words);
+    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, bm_words, wide) > max_lds) bm_words = 0;
+    const uint32_t lds = pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, bm_words, wide);
     if (lds > max_lds) return fail(GFFX_E_INVALID, "windows pass: %u bytes of LDS per block exceed the limit of %u", lds, max_lds);
     if (!roots) b->win_threads = threads;
     const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
@@ -165,6 +171,9 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     a.pv.meta = ix->d_win_meta;
     a.pv.filter = ix->d_win_filter;
     a.pv.splittab = ix->d_win_splittab;
+    a.pv.ranks = ix->d_win_rank;
+    a.pv.rfids = ix->d_root_fids;
+    a.pv.n_roots = ix->n_roots;
     a.pv.n_win = ix->n_win;
     a.pv.n_chr = ix->n_chr;
     a.pv.fshift = ix->win_fshift;
@@ -181,7 +190,7 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     prof_begin(b, roots ? GFFX_K_WINDOWS : GFFX_K_WAVE, &pe);
 #define GFFX_CASE(M, L)                                                                                                  \
     if (b->mode == M && ml == L)                                                                                         \
-        lrc = roots ? launch_roots<M, L>(b, grid, a, threads, lds) : launch_pairs<M, L>(b, grid, a, threads, offs, pos, lds);
+        lrc = roots ? launch_roots<M, L>(b, grid, a, threads, lds) : launch_pairs<M, L>(b, grid, a, threads, offs, pos, wide, lds);
     GFFX_CASE(0, true) GFFX_CASE(0, false) GFFX_CASE(1, true) GFFX_CASE(1, false) GFFX_CASE(2, true) GFFX_CASE(2, false)
 #undef GFFX_CASE
     prof_end(b, &pe);

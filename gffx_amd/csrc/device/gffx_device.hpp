@@ -93,6 +93,19 @@ struct IndexView {
     // a region reads EXACTLY ONE line -- its window's, or the sub-line of the sub-window its last base lies in.
     const uint32_t *win_splittab;
     uint32_t win_swords;  // bitmap words (= ceil(n_win / 32)); 0 = no split level (the lists then continue in win_spill)
+    // RANKS (round 4, the WIDE form of k_join_pairs: regions of any width, overlap mode).  The roots a region [qs, qe) overlaps are
+    // the roots over its first base (what the line of qs answers for the one-base region [qs, qs + 1)) and the roots that start
+    // inside it: positions rank(qs + 1) .. rank(qe) - 1 of the sorted arrays, rank(x) = the roots of the seqid and of the seqids
+    // before it that start below x.  A line lists every root that starts in its (sub-)window, so
+    //   rank(x) = win_rank[line of x - 1].x + the entries of the line's list with start <= x - 1,
+    // win_rank[line] = {(roots starting below the line's right edge) - (entries of the list), the header n | spill << 8 of a list
+    // that continues in win_spill (else 0)}, one record per line of BOTH levels (for the zeroed sub-lines of a split window:
+    // - 4, the four zero words all compare "start <= x").  root_fids[] = the
+    // root_fid column of aux, 4 bytes per root (a region's run of kept roots is read 16 bytes at a time).  Only when
+    // win_range_ok: an interval with end < start is listed by no line but counted by the ranks.
+    const uint2 *win_rank;
+    const uint32_t *root_fids;
+    uint32_t win_range_ok;
     uint32_t n_chr;
     uint32_t n_roots;
 };

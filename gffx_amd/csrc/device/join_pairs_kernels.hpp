@@ -44,6 +44,7 @@
 namespace gffx {
 
 typedef uint32_t gffx_v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t gffx_v2u __attribute__((ext_vector_type(2)));
 typedef unsigned long long gffx_v2ul __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(3))) uint32_t *LdsWords;  // an LDS address as a pointer
 
@@ -91,7 +92,12 @@ constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequ
 constexpr uint32_t kWaveStash = 2;     // per thread: kept words of deferred regions wait here (LDS) for the parking
 // words a wave parks in LDS per round (a strip): 2 kept pairs per region at 1024 threads, 1.5 at 512 (two blocks share a CU's
 // LDS); a fuller round -- gene-dense stretches of a sorted BED file -- takes all kWaveDepth strips, beyond that the synchronous path
-__host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads) { return threads == 1024 ? 512u : 384u; }
+// The wide form keeps several pairs per region (2.6 at bench.py's wide shape: 600 .. 800 a round): strips of ~4 pairs per region,
+// two of them per wave.
+__host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads, bool wide = false) {
+    return wide ? (threads == 1024 ? 1024u : 960u) : (threads == 1024 ? 512u : 384u);
+}
+__host__ __device__ constexpr uint32_t pair_depth(bool wide = false) { return wide ? 2u : kWaveDepth; }
 
 // what the MAIN path of a pass reads of the index: the line table (root_fids, or index positions: root passes, triples) and
 // the three small tables every block stages in LDS
@@ -100,7 +106,9 @@ struct PairView {
     const uint4 *meta;         // IndexView::win_meta
     const uint32_t *filter;    // IndexView::win_filter
     const uint32_t *splittab;  // IndexView::win_splittab
-    uint32_t n_win, n_chr, fshift;
+    const uint2 *ranks;        // IndexView::win_rank   } the wide form only
+    const uint32_t *rfids;     // IndexView::root_fids  }
+    uint32_t n_win, n_chr, fshift, n_roots;
 };
 
 struct WaveOut {
@@ -185,6 +193,23 @@ __device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_
             (pair_keep<MODE>(w2 & 0xFFFFu, w2 >> 16, rqs, rqe, inv) ? 2u : 0u) | (pair_keep<MODE>(w3 & 0xFFFFu, w3 >> 16, rqs, rqe, inv) ? 1u : 0u);
     }
     return m;
+}
+
+// the entries of a line's coordinate half with start_rel <= rel (an absent entry has start_rel 0xFFFF: never)
+__device__ __forceinline__ uint32_t pair_count_le4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rel) {
+    uint32_t c;
+    asm("v_cmp_le_u32_sdwa vcc, %[w0], %[r] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+        "v_addc_co_u32 %[c], vcc, 0, 0, vcc\n\t"
+        "v_cmp_le_u32_sdwa vcc, %[w1], %[r] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+        "v_addc_co_u32 %[c], vcc, 0, %[c], vcc\n\t"
+        "v_cmp_le_u32_sdwa vcc, %[w2], %[r] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+        "v_addc_co_u32 %[c], vcc, 0, %[c], vcc\n\t"
+        "v_cmp_le_u32_sdwa vcc, %[w3], %[r] src0_sel:WORD_0 src1_sel:DWORD\n\t"
+        "v_addc_co_u32 %[c], vcc, 0, %[c], vcc"
+        : [c] "=&v"(c)
+        : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [r] "v"(rel)
+        : "vcc");
+    return c;
 }
 
 // Park the kept words of a line in LDS: for each of the four entries, if the top bit of x is set { LDS[pos] = word, pos += 4 },
@@ -393,6 +418,66 @@ __device__ __forceinline__ void pair_locate(const PairLds &L, uint32_t qc, uint3
     swp = !fits;  // (a seqid without roots has wmax = 2^24 - 1 and no windows: only absurd rows of it come here)
 }
 
+// The wide form's list tails: the entries 3 .. n - 1 of the two lines' lists, in win_spill (h = n | spill << 8 of a marked line,
+// else 0).  First line: an entry that starts at or below qs counts in le0, and is kept -- written to out[], at most `cap`
+// words -- if it ends beyond qs; second line: an entry that starts at or below qe1 = qe - 1 counts in le1.  Two records of
+// each list in flight.  Returns the kept entries.
+template <bool POS>
+__device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t h0, uint32_t h1, uint32_t qs, uint32_t qe1, uint32_t *out,
+                                                    uint32_t cap, uint32_t &le0, uint32_t &le1) {
+    uint32_t c = 0;
+    const uint32_t n0 = h0 ? (h0 & 255u) - kWinInlineTail : 0u, n1 = h1 ? (h1 & 255u) - kWinInlineTail : 0u;
+    const uint4 *s0 = spill + (h0 >> 8), *s1 = spill + (h1 >> 8);
+    for (uint32_t j = 0; j < max(n0, n1); j += 2) {
+        uint4 x[2], y[2];
+#pragma unroll
+        for (uint32_t t = 0; t < 2; ++t) {
+            x[t] = y[t] = make_uint4(0xFFFFFFFFu, 0, 0, 0);  // (no region starts at 2^32 - 1 or beyond)
+            if (j + t < n0) x[t] = s0[j + t];
+            if (j + t < n1) y[t] = s1[j + t];
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 2; ++t) {
+            if (x[t].x <= qs) {
+                ++le0;
+                if (x[t].y > qs) {
+                    if (c < cap) out[c] = POS ? x[t].w : x[t].z;
+                    ++c;
+                }
+            }
+            le1 += y[t].x <= qe1 ? 1u : 0u;
+        }
+    }
+    return c;
+}
+
+// The WIDE form (gffx_device.hpp, "ranks"; overlap mode): a region of ANY width is its first base -- the roots over it are in
+// the line of qs -- and the roots that start inside it, a run of positions between two ranks, each read off a line and its
+// rank word: the line of qs again, and the line of qe - 1.  off0 / rel0: the line of qs and qs in its coordinates; off1 / rel1:
+// the same for qe - 1.  A base beyond the seqid's windows stands for the last base of the last window (nothing overlaps it,
+// every root starts at or below it).  A row on a seqid without roots reads nothing; a seqid without windows, an empty and a
+// reversed row take the sweep.
+__device__ __forceinline__ void pair_locate_wide(const PairLds &L, uint32_t qc, uint32_t qs, uint32_t qe, uint32_t &off0, uint32_t &rel0,
+                                                 uint32_t &off1, uint32_t &rel1, bool &swp) {
+    const uint4 m = L.cm[min(qc, L.n_chr)];
+    const uint32_t wmax = m.z >> 8, shift = m.z & 31u;
+    const bool live = (qs < qe) & (m.y != 0u);
+    swp = (m.y != 0u) & ((wmax == 0u) | (qs >= qe));  // (an empty or reversed row keeps the roots that reach over both its ends: rare, the sweep)
+    const bool lines = live & (wmax != 0u);
+    auto point = [&](uint32_t y, uint32_t &off, uint32_t &rel) {
+        const bool past = (y >> shift) >= m.y;
+        const uint32_t b = past ? m.y - 1u : y >> shift, yy = past ? 0xFFFFFFFFu : y;
+        const uint32_t w = m.x + b;
+        const bool split = (__builtin_amdgcn_ubfe(L.sbits[min(w >> 5, L.swords)], w, 1) != 0) & L.split_on;
+        const uint32_t sh = shift - (split ? kWinSplit : 0u);
+        const uint32_t line = split ? L.n_win + (w << kWinSplit) + __builtin_amdgcn_ubfe(yy, sh, kWinSplit) : w;
+        off = lines ? line * kWinLineBytes : kWinNoLine;
+        rel = __builtin_amdgcn_ubfe(yy, 0, sh) + wmax;
+    };
+    point(qs, off0, rel0);
+    point(qe - 1u, off1, rel1);
+}
+
 // a round's regions: buffer loads from a descriptor of exactly the round's rows (scalar work), 16 bytes per thread and column
 // at a fixed offset -- straight-line code: no per-thread bounds, and a round beyond the batch (the prefetch of the last
 // rounds) reads zeros without touching memory.  Only the batch's last, partial round and unaligned columns take the
@@ -442,13 +527,15 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 // T: threads per block (512: two blocks per CU; 1024: one, half the reservation atomics)
 // OFFS: per-region offsets are written (GFFX_OUT_OFFSETS / _OFFSETS32): each lane parks its place inside the round's segment
 // POS: the words a pass emits are index positions (table win_pos), not root_fids
-template <int MODE, bool META_LDS, int T, bool OFFS, bool POS>
+// WIDE: the wide form (pair_locate_wide; overlap mode, not inverted): batches AUTO found mostly wider than the lines answer
+template <int MODE, bool META_LDS, int T, bool OFFS, bool POS, bool WIDE = false>
 __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
+    static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP, "the wide form answers overlap mode");
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     constexpr uint32_t kWaves = T / 64;
-    constexpr uint32_t D = kWaveDepth;
+    constexpr uint32_t D = pair_depth(WIDE);
     constexpr uint32_t keep_words = OFFS ? 2u : 0u;
-    constexpr uint32_t kStage = pair_stage_words(T);  // words a wave parks per round
+    constexpr uint32_t kStage = pair_stage_words(T, WIDE);  // words a wave parks per round
     auto rare_ix = [&]() -> const IndexView & { return pair_rare_ix(); };
     const QueryView &q = A.q;
     const WaveOut &out = A.out;
@@ -505,6 +592,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
     const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
     uint32_t n_slow = 0;
+    // (the wide form: {rank, list-tail header} per line; the root_fids by position, allocated 4 words beyond the last root)
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint2 *>(A.pv.ranks), 0, WIDE ? (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * 8u) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rfd =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rfids), 0, WIDE ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
 
     // ---- what is left to do for the wave's previous D - 1 rounds once their segment bases are known (all wave-uniform;
     // entry 0 = the latest round)
@@ -619,18 +711,26 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
         uint32_t off[4], rqs[4], rqe1[4];  // the line's byte offset; the region in the line's coordinates (rqe1 = its last base)
         bool swp[4];  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
+        uint32_t off1[4], r0[4], nr[4];  // (wide form) the line of qe - 1 (rqe1[] = qe - 1 in ITS coordinates); the run of roots starting inside
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;  // (a partial round's rows were checked when they were loaded)
-            pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
+            if constexpr (WIDE) {
+                pair_locate_wide(L, qc[k], qs[k], qe[k], off[k], rqs[k], off1[k], rqe1[k], swp[k]);
+            } else {
+                pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
+                off1[k] = r0[k] = nr[k] = 0;
+            }
         }
         GFFX_WIN_STAMP(1);
         gffx_v4u wc[4], wf[4];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+        if constexpr (!WIDE) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+            for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         GFFX_WIN_STAMP(2);
         // (Nothing that MAY issue a vector memory operation stands between these loads and their use: a conditional store there
@@ -639,14 +739,91 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         // ---- four exact tests per region, in the line's relative coordinates: a bit string per region (entry 0 = bit 3)
         // (a region without a line read zeros: {start 0, end 0} never passes end > qs)
         uint32_t m[4];
+        gffx_v4u rg[4];  // (wide form) the first four words of the run
+        uint32_t tc[4] = {0, 0, 0, 0}, hdr[4] = {0, 0, 0, 0};
+        uint32_t deferred = 0, sweep = 0, n_rest = 0;
+        if constexpr (WIDE) {
+            // the second line's coordinates and the two rank records (in flight with the first line's), then: the roots over qs
+            // (the one-base region) and the two ranks.  A line whose list continues in win_spill has the list's header in its rank
+            // record: the tail is walked below (a dense window: the sweep).
+            gffx_v4u wc1[4];
+            gffx_v2u cu0[4], cu1[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
+            for (int k = 0; k < 4; ++k) wc1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off1[k], 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cu0[k] = __builtin_amdgcn_raw_buffer_load_b64(rk, off[k] >> 2, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cu1[k] = __builtin_amdgcn_raw_buffer_load_b64(rk, off1[k] >> 2, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t ra[4], rb[4], h1[4];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqs[k], false);
+                ra[k] = cu0[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);
+                rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rqe1[k]);
+                hdr[k] = wc[k].w == kWinTailMark ? cu0[k].y : 0u;
+                h1[k] = wc1[k].w == kWinTailMark ? cu1[k].y : 0u;
+                swp[k] |= ((hdr[k] & 255u) == 255u) | ((h1[k] & 255u) == 255u);
+                any |= swp[k] | ((hdr[k] | h1[k]) != 0u);
+            }
+            GFFX_WIN_STAMP(8);
+            // second trip, issued BEFORE the tails are walked: the kept entries' words and the head of the run (positions need no
+            // read) -- a region whose rank a tail entry moves reads its head again below
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (m[k] && !swp[k]) ? off[k] + 16 : kWinNoLine, 0, 0);
+            if (!POS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, (rb[k] != ra[k] && !swp[k]) ? 4u * ra[k] : kWinNoLine, 0, 0);
+            }
+            if (__builtin_amdgcn_ballot_w64(any)) {  // (uniform: some lane of the wave has a list tail to walk, or a sweep)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    deferred |= (swp[k] | ((hdr[k] | h1[k]) != 0u)) ? 1u << k : 0u;
+                    sweep |= swp[k] ? 1u << k : 0u;
+                }
+                if (deferred) {
+                    n_slow += __popc(sweep);
+                    uint32_t d = deferred, moved = 0;
+                    while (d) {
+                        const int k = __ffs(d) - 1;
+                        d &= d - 1;
+                        uint32_t c, a0 = 0, b0 = 0;
+                        uint32_t *st = s_stash + min(n_rest, kWaveStash);
+                        const uint32_t cap = kWaveStash - min(n_rest, kWaveStash);
+                        if (sweep >> k & 1u)
+                            c = pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), st, cap, nullptr);
+                        else
+                            c = pair_wide_tails<POS>(A.spill, win_sel(hdr, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, st, cap, a0, b0);
+                        n_rest += c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tc[j] += k == j ? c : 0u, ra[j] += k == j ? a0 : 0u, rb[j] += k == j ? b0 : 0u;
+                        moved |= (a0 | b0) ? 1u << k : 0u;
+                    }
+                    if (!POS) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (moved >> k & 1u) rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, rb[k] != ra[k] ? 4u * ra[k] : kWinNoLine, 0, 0);
+                    }
+                }
+            }
+            GFFX_WIN_STAMP(9);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[k] = swp[k] ? 0u : m[k];
+                r0[k] = ra[k];
+                nr[k] = swp[k] ? 0u : rb[k] - ra[k];
+                if (POS) rg[k].x = r0[k], rg[k].y = r0[k] + 1u, rg[k].z = r0[k] + 2u, rg[k].w = r0[k] + 3u;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
+        }
         GFFX_WIN_STAMP(3);
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept words wait in
         // the thread's LDS strip)
-        uint32_t tc[4] = {0, 0, 0, 0}, hdr[4] = {0, 0, 0, 0};
-        uint32_t deferred = 0, sweep = 0, n_rest = 0;
-        {
+        if constexpr (!WIDE) {
             bool dfr[4];
             bool any = false;
 #pragma unroll
@@ -684,7 +861,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(4);
         uint32_t cnt[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cnt[k] = __popc(m[k]) + tc[k];
+        for (int k = 0; k < 4; ++k) cnt[k] = __popc(m[k]) + tc[k] + (WIDE ? nr[k] : 0u);
         GFFX_WIN_STAMP(5);
         // ---- the wave that issued the previous round's reservation atomic posts what it returned: every load of this round
         // has been waited for, so the atomic -- issued before them -- is back without another wait
@@ -737,9 +914,35 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 for (int k = 0; k < 4; ++k) {
                     uint32_t pos = pb;
                     pair_park4(m[k] << 28, pos, wf[k].x, wf[k].y, wf[k].z, wf[k].w);
+                    if constexpr (WIDE) {
+                        const uint32_t n4 = min(nr[k], 4u);
+                        pair_park4(n4 ? 0xFFFFFFFFu << (32u - n4) : 0u, pos, rg[k].x, rg[k].y, rg[k].z, rg[k].w);
+                    }
                     pd[k] = pos;
                     pb += 4u * cnt[k];
                 }
+                GFFX_WIN_STAMP(10);
+                if constexpr (WIDE) {
+                    // runs longer than four roots: four more words of every region's run per trip, the four regions in step,
+                    // until no lane of the wave has a word left (the cursors pd[] move on: a list tail's words follow the run)
+                    const uint32_t longest = max(max(nr[0], nr[1]), max(nr[2], nr[3]));
+                    for (uint32_t t = 4; __builtin_amdgcn_ballot_w64(t < longest); t += 4) {
+                        gffx_v4u v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (POS)
+                                v[k].x = r0[k] + t, v[k].y = r0[k] + t + 1u, v[k].z = r0[k] + t + 2u, v[k].w = r0[k] + t + 3u;
+                            else
+                                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, t < nr[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t n4 = t < nr[k] ? min(nr[k] - t, 4u) : 0u;
+                            pair_park4(n4 ? 0xFFFFFFFFu << (32u - n4) : 0u, pd[k], v[k].x, v[k].y, v[k].z, v[k].w);
+                        }
+                    }
+                }
+                GFFX_WIN_STAMP(11);
                 if (__builtin_amdgcn_ballot_w64(deferred != 0)) {
                     uint32_t d = deferred, taken = 0;
                     while (d) {  // list tails / sweeps: from the strip, or (rare) walked again
@@ -751,7 +954,15 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                         } else {
                             uint32_t c_, s_, e_;
                             pair_load_region(q, i0 + k, c_, s_, e_);
-                            (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, sweep >> k & 1u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
+                            if constexpr (WIDE) {
+                                uint32_t a0 = 0, b0 = 0;
+                                if (sweep >> k & 1u)
+                                    (void)pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(c_, n_chr), s_, e_, e, 0xFFFFFFFFu, nullptr);
+                                else
+                                    (void)pair_wide_tails<POS>(A.spill, win_sel(hdr, k), 0u, s_, e_ - 1u, e, 0xFFFFFFFFu, a0, b0);
+                            } else {
+                                (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, sweep >> k & 1u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
+                            }
                             // (rare path, late in the round: leave no load of it in flight -- registers the compiler must treat as
                             //  "maybe still being loaded" at the top of the next round would turn the wait there into vmcnt(0) for
                             //  EVERY round, a drain of the counts store and of the reservation atomic)
@@ -766,6 +977,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 kp[1] = cnt[1] | cnt[2] << 16;
             }
         }
+        GFFX_WIN_STAMP(12);
         // ---- arrive: this wave's share of the round's segment; the last wave to arrive reserves the segment
         unsigned long long old = 0;
         if (lane == 0) old = atomicAdd(&s_arrive[par], (1ull << 56) | (unsigned long long)wtotal);
@@ -805,7 +1017,33 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             const unsigned long long seg = await_base(par, k_round + 1) + my_off;
             group_base(r, seg);
             if (OFFS) put_offsets(r, seg, lp0, cnt[0], cnt[1], cnt[2]);
-            if (out.fids) {
+            if (out.fids && WIDE) {
+                // the wide form writes what it holds: the kept entries of the line of qs, the run by position, then the list
+                // tail's / the sweep's words from a second walk -- nothing else is read again
+                unsigned long long o = seg + lp0;
+                auto put = [&](uint32_t word) {
+                    if (o < out.capacity) out.fids[o] = word;
+                    ++o;
+                };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (m[k] & 8u) put(wf[k].x);
+                    if (m[k] & 4u) put(wf[k].y);
+                    if (m[k] & 2u) put(wf[k].z);
+                    if (m[k] & 1u) put(wf[k].w);
+                    for (uint32_t t = 0; t < nr[k]; ++t) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
+                    if (deferred >> k & 1u) {
+                        uint32_t c_, s_, e_, a0 = 0, b0 = 0;
+                        pair_load_region(q, i0 + k, c_, s_, e_);
+                        uint32_t *e = out.fids + min(o, out.capacity);
+                        const uint32_t cap = (uint32_t)min(out.capacity - min(o, out.capacity), 0xFFFFFFFFull);
+                        if (sweep >> k & 1u)
+                            o += pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(c_, n_chr), s_, e_, e, cap, nullptr);
+                        else
+                            o += pair_wide_tails<POS>(A.spill, hdr[k], 0u, s_, e_ - 1u, e, cap, a0, b0);
+                    }
+                }
+            } else if (out.fids) {
                 unsigned long long o = seg + lp0;
                 for (uint32_t k = 0; k < 4; ++k) {
                     if (i0 + k >= nq) break;

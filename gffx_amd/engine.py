@@ -167,6 +167,11 @@ class QueryBatch:
         """threads per block of the last windows-strategy pair pass (512 or 1024; 0: none ran)"""
         return int(lib().gffx_hip_batch_block_threads(self._h))
 
+    @property
+    def wide_form(self) -> bool:
+        """the last run's pair passes took the wide form of the window kernel (regions of any width, overlap mode)"""
+        return bool(lib().gffx_hip_batch_wide_form(self._h))
+
     def wait(self) -> None:
         check(lib().gffx_hip_batch_wait(self._h))
 

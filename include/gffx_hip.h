@@ -263,6 +263,10 @@ int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, i
  * index has passes in flight, 512-thread blocks (two per CU: kernels of two batches share the CUs) otherwise;
  * GFFX_HIP_WIN_THREADS=512|1024 in the environment forces one. */
 uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *);
+/* 1 when the last run's pair passes took the WIDE form of the window kernel: regions of any width answered from two index lines
+ * and two rank words each (overlap mode).  AUTO chooses it for a batch whose previous pass sent most regions to the exact
+ * sweep (regions wider than the lines answer, 16 Ki bases by default); GFFX_HIP_WIN_WIDE=0 in the environment disables it. */
+int gffx_hip_batch_wide_form(const gffx_hip_batch *);
 
 /* One-shot drop-in for query_features (commands/intersect.rs:105-111): host regions in, host
  * triples out (malloc'd by the library, release with gffx_hip_free_host). */

@@ -70,6 +70,7 @@ extern "C" {
     pub fn gffx_hip_batch_wait(b: *mut gffx_hip_batch) -> c_int;
     pub fn gffx_hip_batch_sync(b: *mut gffx_hip_batch) -> c_int;
     pub fn gffx_hip_batch_block_threads(b: *const gffx_hip_batch) -> u32;
+    pub fn gffx_hip_batch_wide_form(b: *const gffx_hip_batch) -> c_int;
     // streaming BED ingestion through pinned staging buffers, several GPUs
     pub fn gffx_hip_regions_create(device: c_int, capacity_rows: u64, chunk_rows: u64, keep_all: c_int, out: *mut *mut gffx_hip_regions) -> c_int;
     pub fn gffx_hip_regions_destroy(r: *mut gffx_hip_regions);

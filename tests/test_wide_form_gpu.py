@@ -1,0 +1,205 @@
+"""The wide form of k_join_pairs (regions of any width, overlap mode) == oracle, bit for bit.
+
+A region [qs, qe) overlaps the roots over its first base and the roots that start inside it (gffx_device.hpp, "ranks"):
+the kernel reads the line of qs, the line of qe - 1 and a rank word for each.  Forced on every eligible pass of the windows
+strategy with GFFX_HIP_WIN_WIDE=2; AUTO's own choice (after a pass that sent most regions to the sweep) is covered at the end.
+Reference semantics: utils/tree.rs:110 (query_interval), commands/intersect.rs:145-161.
+"""
+import numpy as np
+import pytest
+
+from gffx_amd import engine, synth
+from gffx_amd.engine import OverlapMode
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+OV = int(OverlapMode.Overlap)
+
+
+def _rows(t):
+    t = np.asarray(t, dtype=np.uint32).reshape(-1, 3)
+    return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+
+def _pairs_of(regions, counts, offsets, words):
+    wc = counts.astype(np.int64)
+    qid = np.repeat(np.arange(len(regions), dtype=np.int64), wc)
+    within = np.arange(len(qid), dtype=np.int64) - np.repeat(np.cumsum(wc) - wc, wc)
+    p = np.stack([qid, words[offsets.astype(np.int64)[qid] + within].astype(np.int64)], axis=1)
+    return p[np.lexsort((p[:, 1], p[:, 0]))]
+
+
+def _want_pairs(regions, want_t, want_c):
+    wc = want_c.astype(np.int64)
+    by_chr = np.argsort(regions[:, 0], kind="stable")  # the oracle walks seqid after seqid, regions in input order
+    p = np.stack([np.repeat(by_chr, wc[by_chr]), want_t[:, 0].astype(np.int64)], axis=1)
+    return p[np.lexsort((p[:, 1], p[:, 0]))]
+
+
+def _check_wide(roots, regions, strategy=engine.STRATEGY_WINDOWS, soa=False):
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    want_t, want_c = oix.query_features(regions, OV, False)
+    want_p = _want_pairs(regions, want_t, want_c)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, max(len(regions), 1))
+    if soa:
+        b.set_regions_soa(regions[:, 0], regions[:, 1], regions[:, 2])
+    else:
+        b.set_regions(regions)
+    # root_fids + triples + u64 offsets (the position pass and k_expand_pairs)
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_OFFSETS, strategy)
+    b.wait()
+    assert b.total_hits == len(want_t)
+    assert np.array_equal(b.counts(), want_c)
+    got_t = b.triples()
+    assert np.array_equal(_rows(got_t), _rows(want_t))
+    assert np.array_equal(b.fids(), got_t[:, 0])
+    assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
+    # root_fids + one base per group of 256 regions (the pass bench.py times)
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_SEGBASE, strategy)
+    b.wait()
+    c3, f3 = b.counts(), b.fids()
+    assert np.array_equal(c3, want_c) and len(f3) == len(want_t)
+    assert np.array_equal(_pairs_of(regions, want_c, b.offsets_from_segbase(c3), f3), want_p)
+    # u32 offsets
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS32, strategy)
+    b.wait()
+    assert np.array_equal(b.counts(), want_c)
+    assert np.array_equal(_pairs_of(regions, want_c, b.offsets32(), b.fids()), want_p)
+    # counts alone
+    b.run(OV, False, 0, strategy)
+    b.wait()
+    assert np.array_equal(b.counts(), want_c) and b.total_hits == len(want_t)
+    assert b.wide_form
+    b.close()
+    ix.close()
+    return len(want_t)
+
+
+def _mixed_widths(rng, n, chroms, n_chr_extra=0):
+    """regions of every width class: a base, narrower than a line answers, a few windows, megabases, whole seqids, and the edge
+    rows the reference keeps as they are (empty, reversed, start 0, beyond the seqid's last root, unknown seqids)"""
+    clen = np.array([l for _, l in chroms], dtype=np.int64)
+    c = rng.integers(0, len(chroms) + n_chr_extra, n)
+    L = clen[np.minimum(c, len(chroms) - 1)]
+    cls = rng.integers(0, 8, n)
+    w = np.select([cls == 0, cls == 1, cls == 2, cls == 3, cls == 4, cls == 5],
+                  [np.ones(n, np.int64), rng.integers(1, 2000, n), rng.integers(2000, 40000, n), rng.integers(40000, 400000, n),
+                   rng.integers(400000, 5_000_000, n), L], rng.integers(1, 100000, n))
+    s = (rng.random(n) * L).astype(np.int64)
+    e = s + w
+    k = cls == 6  # empty / reversed
+    e[k] = s[k] - rng.integers(0, 3, int(k.sum()))
+    k = cls == 7  # from base 0 / far beyond the end of the seqid
+    half = rng.random(n) < 0.5
+    s[k & half] = 0
+    s[k & ~half] = L[k & ~half] + rng.integers(0, 1 << 20, int((k & ~half).sum()))
+    e[k & ~half] = s[k & ~half] + w[k & ~half]
+    e = np.clip(e, 0, 0xFFFFFFFF)
+    s = np.clip(s, 0, 0xFFFFFFFF)
+    out = np.empty((n, 3), dtype=np.uint32)
+    out[:, 0], out[:, 1], out[:, 2] = c, s, e
+    return out
+
+
+@pytest.fixture
+def wide_forced(monkeypatch):
+    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "2")
+
+
+def test_wide_form_gencode_like(wide_forced):
+    roots = synth.gencode_like_roots(63000, seed=42)
+    rng = np.random.default_rng(5)
+    regions = _mixed_widths(rng, 40_000, synth.GRCH38)
+    pairs = _check_wide(roots, regions)
+    assert pairs > 1_000_000
+    regions = synth.synth_bed(30_011, seed=77, width=(100, 200000), edge_frac=0.05, roots=roots)  # bench.py's wide_regions shape
+    _check_wide(roots, regions, soa=True)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_wide_form_small_indexes(wide_forced, seed):
+    """few roots per seqid, seqids without roots, dense stacks (lines whose lists continue elsewhere -> the sweep), split windows"""
+    rng = np.random.default_rng(100 + seed)
+    chroms = [("a", 3_000_000), ("b", 50_000), ("c", 800_000), ("d", 1000), ("e", 2_000_000)]
+    starts, ends, offs = [], [], [0]
+    for ci, (_, clen) in enumerate(chroms):
+        k = [int(rng.integers(200, 3000)), 0, int(rng.integers(1, 40)), 1, int(rng.integers(500, 1500))][ci] if seed % 2 == 0 else \
+            int(rng.integers(0, 1500))
+        st = np.sort(rng.integers(0, max(1, clen - 10), k))
+        ln = np.exp(rng.normal(np.log(3000.0), 1.8, size=k)).astype(np.int64) + 1
+        if ci == 4 and k:  # a stack of near-identical roots: long lists
+            st[: k // 3] = st[k // 3] + rng.integers(0, 50, k // 3)
+            st = np.sort(st)
+        if seed == 3 and k:
+            ln[rng.random(k) < 0.05] = 0  # empty intervals (end == start): kept when qs < start < qe
+        starts.append(st)
+        ends.append(np.minimum(st + ln, 0xFFFFFFF0))
+        offs.append(offs[-1] + k)
+    start = np.concatenate(starts).astype(np.uint32)
+    end = np.concatenate(ends).astype(np.uint32)
+    roots = {"chr_offsets": np.array(offs, dtype=np.uint32), "start": start, "end": end,
+             "fid": rng.permutation(len(start)).astype(np.uint32) * 3 + 1}
+    regions = _mixed_widths(rng, 6000 + 257 * seed, chroms, n_chr_extra=0)
+    _check_wide(roots, regions, soa=bool(seed & 1))
+
+
+def test_wide_form_is_autos_choice_for_wide_batches():
+    """AUTO: the first pass over wide regions runs the narrow form (most regions take the sweep), the batch's later overlap-mode
+    pair passes the wide form -- and a pass of another mode, or one that asks for the root bitmap, leaves it again."""
+    roots = synth.gencode_like_roots(20000, seed=3)
+    regions = synth.synth_bed(50_000, seed=9, width=(30000, 300000))
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    want_t, want_c = oix.query_features(regions, OV, False)
+    want_p = _want_pairs(regions, want_t, want_c)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)
+    for i in range(3):
+        b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_AUTO)
+        b.wait()
+        assert np.array_equal(b.counts(), want_c)
+        assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
+        assert b.wide_form == (i > 0)
+    for mode in (OverlapMode.Contained, OverlapMode.ContainsRegion):
+        wt, wc = oix.query_features(regions, int(mode), False)
+        b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_AUTO)
+        b.wait()
+        assert not b.wide_form and np.array_equal(b.counts(), wc)
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_ROOT_BITMAP, engine.STRATEGY_AUTO)
+    b.wait()
+    assert not b.wide_form and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_SEGBASE, engine.STRATEGY_AUTO)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.counts(), want_c)
+    b.close()
+    ix.close()
+
+
+def test_wide_form_full_size_properties(wide_forced):
+    """1 M regions of bench.py's wide shape: counts add up to the pairs, every region's run is what two binary searches over the
+    sorted roots say (start < qe, minus the roots that end at or before qs among those starting at or below it: checked through
+    the count), and the narrow form of the same pass agrees word for word after sorting each region's run."""
+    roots = synth.gencode_like_roots(63000, seed=42)
+    regions = synth.synth_bed(1_000_000, seed=1004, width=(100, 200000))
+    ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_WINDOWS)
+    b.wait()
+    assert b.wide_form
+    c, off, f = b.counts(), b.offsets(), b.fids()
+    assert int(c.sum()) == b.total_hits == len(f)
+    # counts from first principles (vectorised): per seqid, roots with start < qe minus roots with end <= qs -- exact when no
+    # root is nested so that it ends before an earlier one... use the oracle on a sample instead, and the identity on all
+    oix = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+    pick = np.random.default_rng(1).choice(len(regions), 20000, replace=False)
+    wt, wc = oix.query_features(regions[pick], OV, False)
+    assert np.array_equal(c[pick], wc)
+    got = _pairs_of(regions[pick], wc, off[:-1][pick], f)
+    assert np.array_equal(got, _want_pairs(regions[pick], wt, wc))
+    b.close()
+    ix.close()

@@ -12,7 +12,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 STRATS = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_WINDOWS]
 t0 = time.time()
-n_checks = 0
+n_checks = n_wide = 0
 for it in range(iters):
     n_chr = int(rng.choice([1, 2, 3, 7, 40, 300]))
     span = int(rng.choice([200, 5_000, 1_000_000, 250_000_000, 0xFFFFFF00]))
@@ -80,9 +80,20 @@ for it in range(iters):
                         os.environ["GFFX_HIP_WIN_THREADS"] = "1024"
                     else:
                         os.environ.pop("GFFX_HIP_WIN_THREADS", None)
-                for flags in flag_sets:
+                runs = [(fl, False) for fl in flag_sets]
+                if strat == engine.STRATEGY_WINDOWS and mode == 2 and not inv:
+                    # the wide form of the pair passes (regions of any width from two lines and two ranks; AUTO's choice for wide
+                    # batches), forced on these regions whatever their widths
+                    runs += [(fl, True) for fl in (engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_OFFSETS, 0,
+                                                   engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_FIDS | engine.OUT_SEGBASE)]
+                for flags, wide in runs:
+                    os.environ["GFFX_HIP_WIN_WIDE"] = "2" if wide else "1"
                     b.run(mode, inv, flags, strat)
                     b.wait()
+                    if b.wide_form and not wide:
+                        print("wide form taken unasked, iteration", it, "flags", flags, flush=True)
+                        sys.exit(1)
+                    n_wide += b.wide_form  # (an index without windows, or with an interval that ends before it starts, has no wide form)
                     c = b.counts()
                     ok = np.array_equal(c, want_c) and b.total_hits == len(want_t)
                     if flags == engine.OUT_ROOT_BITMAP:
@@ -90,10 +101,14 @@ for it in range(iters):
                         n_checks += 1
                         if ok:
                             continue
+                    if flags == 0:  # counts alone
+                        n_checks += 1
+                        if ok:
+                            continue
                     if flags & engine.OUT_SEGBASE:
                         off = np.concatenate([b.offsets_from_segbase(c), [np.uint64(b.total_hits)]]).astype(np.uint64) if ok else None
                     else:
-                        off = b.offsets() if ok or flags != engine.OUT_ROOT_BITMAP else None
+                        off = b.offsets() if ok or flags not in (0, engine.OUT_ROOT_BITMAP) else None
                     if ok and flags & engine.OUT_OFFSETS32:
                         ok = np.array_equal(off[:-1], b.offsets32().astype(np.uint64))
                     if ok and flags & engine.OUT_FIDS:
@@ -102,14 +117,15 @@ for it in range(iters):
                     if ok and flags & engine.OUT_TRIPLES:
                         t = b.triples()
                         srt = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]  # noqa: E731
-                        ok = np.array_equal(srt(t), srt(want_t)) and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+                        ok = np.array_equal(srt(t), srt(want_t)) and (not (flags & engine.OUT_ROOT_BITMAP) or
+                                                                       np.array_equal(b.unique_roots(), np.unique(want_t[:, 0])))
                     n_checks += 1
                     if not ok:
                         os.makedirs("gpurun_out", exist_ok=True)
                         np.savez("gpurun_out/fuzz_fail.npz", co=co, s=s, e=e, f=f, regions=regions)
-                        print("MISMATCH iteration", it, "strategy", strat, "mode", mode, "invert", inv, "flags", flags,
+                        print("MISMATCH iteration", it, "strategy", strat, "mode", mode, "invert", inv, "flags", flags, "wide form", wide,
                               "n_chr", n_chr, "R", R, "nq", nq, "shape", shape, "span", span, flush=True)
                         sys.exit(1)
     b.close()
     ix.close()
-print("fuzz ok: %d iterations, %d passes checked, %.0f s" % (iters, n_checks, time.time() - t0))
+print("fuzz ok: %d iterations, %d passes checked (%d of them wide-form pair passes), %.0f s" % (iters, n_checks, n_wide, time.time() - t0))

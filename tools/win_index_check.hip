@@ -2,7 +2,8 @@
 // line format of join_pairs_kernels.hpp): random indexes (seqids of 1 Kbp .. 4 Gbp, nested / empty / long roots), random regions that the
 // lines answer, all three modes.  Restates the kernel's use of a line on the CPU -- window of the region's last base,
 // 16-bit relative coordinates, the four inline tests, the list tail from win_spill -- and compares the kept root_fids with
-// a brute-force scan of the roots.  Runs without a GPU (tests/test_window_index_cpu.py); built by the Makefile of
+// a brute-force scan of the roots; then the WIDE form's reading (two lines and two rank words per region of any width, overlap
+// mode) against the same scan.  Runs without a GPU (tests/test_window_index_cpu.py); built by the Makefile of
 // gffx_amd/csrc into gffx_amd/bin/win_index_check.     usage: win_index_check [seed]
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -20,7 +21,7 @@ static bool keep(int mode, uint32_t s, uint32_t e, uint32_t qs, uint32_t qe) {
 }
 int main(int argc, char **argv) {
     uint64_t seed = argc > 1 ? atoll(argv[1]) : 1;
-    unsigned long long n_checked = 0, n_split_reads = 0;
+    unsigned long long n_checked = 0, n_split_reads = 0, n_wide = 0, n_wide_reads = 0, n_wide_tails = 0;
     std::mt19937_64 rng(seed);
     for (int iter = 0; iter < 200; iter++) {
         uint32_t n_chr = 1 + rng() % 4;
@@ -130,7 +131,78 @@ int main(int argc, char **argv) {
                 }
             }
         }
+        // ---- the wide form (gffx_device.hpp, "ranks"): regions of ANY width, overlap mode -- the roots over qs from the line of
+        // qs, the roots starting inside from two ranks, each a rank word + the entries of a line with start <= the base
+        std::vector<uint2> rank;
+        const bool range_ok = gffx::build_window_ranks(n_chr, co.data(), start, aux, meta, wpos, sbits, sub_at, sub_lines_pos, rank);
+        if (!range_ok && n_win) { printf("RANKS: end < start reported on an index without such a root (iter %d)\n", iter); return 1; }
+        for (int qi = 0; qi < 2000 && n_win; qi++) {
+            const uint32_t c = rng() % n_chr;
+            const uint4 m = meta[c];
+            if (co[c + 1] == co[c] || m.z > gffx::kWinMaxShift || m.w == 0 || m.y == 0) continue;
+            const uint32_t pick = co[c] + rng() % (co[c + 1] - co[c]);
+            const uint32_t qs = rng() % 8 == 0 ? (uint32_t)rng() : (uint32_t)std::max<int64_t>(0, (int64_t)start[pick] + (int64_t)(rng() % 40000) - 20000);
+            const uint32_t kind = rng() % 4;
+            const uint64_t wd = kind == 0 ? 1 + rng() % 3 : kind == 1 ? 1 + rng() % 50000 : kind == 2 ? 1 + rng() % 5000000 : 1 + rng() % 4000000000ull;
+            const uint32_t qe = (uint32_t)std::min<uint64_t>((uint64_t)qs + wd, 0xFFFFFFFFull);
+            if (qe <= qs) continue;
+            std::multiset<uint32_t> want, got;
+            for (uint32_t i = co[c]; i < co[c + 1]; i++)
+                if (keep(2, start[i], aux[i].x, qs, qe)) want.insert(aux[i].w);
+            bool marked = false;
+            uint32_t r[2];
+            for (int side = 0; side < 2; side++) {
+                uint32_t y = side ? qe - 1 : qs;
+                const bool past = (y >> m.z) >= m.y;
+                const uint32_t b = past ? m.y - 1 : y >> m.z;
+                if (past) y = 0xFFFFFFFFu;
+                const size_t w = (size_t)m.x + b;
+                const bool split = !sbits.empty() && (sbits[w >> 5] >> (w & 31) & 1u);
+                const uint32_t sh = m.z - (split ? gffx::kWinSplit : 0u);
+                static const uint32_t kZero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const uint32_t *l = ww + 8 * w;
+                size_t line = w;
+                if (split) {
+                    line = n_win + (w << gffx::kWinSplit) + ((y >> sh) & ((1u << gffx::kWinSplit) - 1));
+                    const auto it = sub_of.find((uint32_t)line);
+                    l = it == sub_of.end() ? kZero : (const uint32_t *)&sub_lines[2 * it->second];
+                }
+                n_wide_reads++;
+                const uint32_t rel = (y & ((1u << sh) - 1)) + m.w;
+                uint32_t le = 0;
+                for (int j = 0; j < 4; j++) le += (l[j] & 0xFFFFu) <= rel;
+                if (side == 0)
+                    for (int j = 0; j < 4; j++)
+                        if (keep(2, l[j] & 0xFFFF, l[j] >> 16, rel, rel + 1)) got.insert(l[4 + j]);
+                if (l[3] == 0xFFFFFFFFu) {  // the list continues in win_spill: the header comes with the rank record
+                    const uint32_t hdr = rank[line].y;
+                    if (hdr != l[7]) { printf("RANK HEADER MISMATCH iter %d line %zu\n", iter, line); return 1; }
+                    if ((hdr & 255u) == 255u) { marked = true; break; }  // dense: the sweep
+                    const uint32_t base = side ? qe - 1 : qs;  // (absolute coordinates: the real base, also beyond the windows)
+                    for (uint32_t j = 3; j < (hdr & 255u); j++) {
+                        const uint4 x = spill[(hdr >> 8) + j - 3];
+                        if (x.x <= base) {
+                            le++;
+                            if (side == 0 && x.y > base) got.insert(x.z);
+                        }
+                    }
+                    n_wide_tails++;
+                } else if (rank[line].y) { printf("RANK HEADER on an unmarked line, iter %d line %zu\n", iter, line); return 1; }
+                r[side] = rank[line].x + le;
+            }
+            if (marked) continue;  // a dense window: the kernel takes the sweep
+            if (r[1] < r[0] || r[1] > co[c + 1] || r[0] < co[c]) {
+                printf("RANK MISMATCH iter %d chr %u q [%u,%u): ranks %u %u outside [%u, %u]\n", iter, c, qs, qe, r[0], r[1], co[c], co[c + 1]);
+                return 1;
+            }
+            for (uint32_t i = r[0]; i < r[1]; i++) got.insert(aux[i].w);
+            n_wide++;
+            if (want != got) {
+                printf("WIDE MISMATCH iter %d chr %u q [%u,%u) want %zu got %zu (ranks %u %u) shift %u wmax %u\n", iter, c, qs, qe, want.size(), got.size(), r[0], r[1], m.z, m.w);
+                return 1;
+            }
+        }
     }
-    printf("ok (%llu line reads checked, %llu of them sub-lines of split windows)\n", n_checked, n_split_reads);
+    printf("ok (%llu line reads checked, %llu of them sub-lines of split windows; wide form: %llu regions, %llu line reads, %llu list tails)\n", n_checked, n_split_reads, n_wide, n_wide_reads, n_wide_tails);
     return 0;
 }
