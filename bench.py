@@ -20,7 +20,7 @@ The JSON line carries, next to the contract's fields:
                         takes 1024-thread blocks for such a pass (roofline inside), 512-thread blocks while two batches are in flight
   roofline              dominant kernel, HIP-event durations of serial back-to-back launches on the engine's stream
   roofline_10m          the same for a 10 M-region batch (seed 1002); roofline_10m_contained: --contained (configs[2]'s mode);
-                        wide_regions: 1 M regions of width U[100, 200000] (AUTO moves the batch to the sweep kernel);
+                        wide_regions: 1 M regions of width U[100, 200000] (AUTO runs the wide form of k_join_pairs);
                         sorted_bed: the 1 M batch sorted by (seqid, start) as BED files usually are
   cli_pass              the pass the CLI runs (root bitmap only) at 1 M and 10 M regions, next to the root_fid pass
   t_xfer                host regions in (pinned), counts + root_fids back on the host: two batches double-buffered
@@ -73,6 +73,8 @@ def parse_args():
                     help="N>1: weak = --queries-per-gpu regions per rank; strong = --strong-total regions (configs[3]: 100 M) "
                          "sharded over the ranks, the hit-count all-gather inside the timed region")
     ap.add_argument("--strong-total", type=int, default=100_000_000)
+    ap.add_argument("--region-width", type=int, nargs=2, default=None, metavar=("LO", "HI"),
+                    help="profiling aid: regions of width U[LO, HI] instead of the configuration's U[100, 10000] (the line says so)")
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
     ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused", "windows"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
@@ -285,6 +287,8 @@ def measure_traffic(args, block_threads=None):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "run", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--traffic-child", "--mode", args.mode, "--strategy", args.strategy,
                    "--out", args.out, "--offsets", args.offsets, "--queries-per-gpu", str(args.queries_per_gpu)]
+            if args.region_width:
+                cmd += ["--region-width", str(args.region_width[0]), str(args.region_width[1])]
             try:
                 env = dict(os.environ, TMPDIR="/tmp")
                 if block_threads:  # (the child's serial passes must run the kernel variant of the timed region)
@@ -536,7 +540,11 @@ def main():
         nq_global, seed, cfg = args.strong_total, 1003, "configs[3]"
     else:
         nq_global, seed, cfg = args.queries_per_gpu * world, 1001, "configs[1]"
-    regions_all = synth.synth_bed(nq_global, seed=seed)
+    if args.region_width:
+        regions_all = synth.synth_bed(nq_global, seed=seed, width=tuple(args.region_width))
+        cfg += " with region widths U[%d, %d] (NOT the configuration's: --region-width)" % tuple(args.region_width)
+    else:
+        regions_all = synth.synth_bed(nq_global, seed=seed)
     if world > 1:
         regions = np.ascontiguousarray(regions_all[shard.shard_rows(regions_all, n_chr, world, rank)])
     else:
@@ -738,15 +746,17 @@ def main():
         # ---- cold input: three distinct resident 12 M-region batches (432 MB of regions, more than the 256 MB Infinity Cache),
         # one QueryBatch pointed at them in turn, pass after pass on one stream: no pass finds its regions in any cache
         result["roofline_cold"] = cold_leg(engine, synth, torch, ix, dev, mode, out_flags, strategy, out_b)
-        # ---- regions the window lines cannot answer (wider than wmax = 16 Ki): AUTO moves the batch to the sweep kernel
+        # ---- regions wider than one window line answers (wmax = 16 Ki): after the first waited pass AUTO runs the batch's pair
+        # passes on the WIDE form of k_join_pairs (two lines and two rank records per region; round 3: the sweep kernel)
         regw = synth.synth_bed(nq, seed=1004, width=(100, 200000))
         colsw = to_dev(torch, regw, dev)
         pw = Pass(engine, ix, colsw, nq, 1, mode, out_flags & ~engine.OUT_SEGBASE | engine.OUT_OFFSETS, 0)
         pairsw = pw.size_and_warm(2)  # (the second waited pass is the one AUTO re-routes)
         kw = pw.kernel_us(10)
         result["wide_regions"] = roofline_obj(kw, nq, pairsw, out_b, "%d regions of width U[100, 200000] (seed 1004), AUTO, u64 offsets: "
-                                              "most regions are wider than the window lines serve, the batch's passes run on the "
-                                              "sweep kernel" % nq, None, pw.pass_us_one_event_pair, pw.block_threads)
+                                              "most regions are wider than one window line answers, the batch's passes run on the "
+                                              "wide form of k_join_pairs" % nq, None, pw.pass_us_one_event_pair, pw.block_threads)
+        result["wide_regions"]["wide_form"] = bool(pw.batches[0].wide_form)
         pw.close()
         del colsw, regw
         # ---- a BED file sorted by (seqid, start), as most are

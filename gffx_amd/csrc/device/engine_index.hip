@@ -451,9 +451,31 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     build_window_splits(n_chr, h_start, h_aux, win_meta, win, win_pos, win_spill, win_splittab, sub_at, sub_lines, sub_lines_pos);
     ix->win_swords = win_splittab.empty() ? 0u : (uint32_t)((ix->n_win + 31) / 32);
     std::vector<uint2> win_rank;
+    std::vector<uint32_t> wide_at;
+    std::vector<uint4> win_wide, wide_sub;
     std::vector<uint32_t> root_fids(ix->h_sorted_fids);
     root_fids.resize(root_fids.size() + 4, 0u);  // (runs are read 16 bytes at a time from any position)
     ix->win_range_ok = build_window_ranks(n_chr, chr_offsets, h_start, h_aux, win_meta, win_pos, win_splittab, sub_at, sub_lines_pos, win_rank);
+    // the wide form's line table (gffx_device.hpp): a line's coordinate half next to its rank record -- both in one 32-byte
+    // sector -- for the windows' lines and for ALL eight sub-lines of every split window (an empty sub-line has a rank too)
+    {
+        win_wide.resize(win.size());
+        for (size_t w = 0; w < ix->n_win; w++) {
+            win_wide[2 * w] = win[2 * w];
+            win_wide[2 * w + 1] = make_uint4(win_rank[w].x, win_rank[w].y, 0u, 0u);
+        }
+        std::vector<uint32_t> sub_of(win_splittab.empty() ? 0 : (size_t)ix->n_win << kWinSplit, 0xFFFFFFFFu);  // sub-line -> its place in sub_lines
+        for (size_t j = 0; j < sub_at.size(); j++) sub_of[sub_at[j] - ix->n_win] = (uint32_t)j;
+        for (size_t w = 0; w < ix->n_win && !win_splittab.empty(); w++) {
+            if (!(win_splittab[w >> 5] >> (w & 31) & 1u)) continue;
+            for (uint32_t j = 0; j < (1u << kWinSplit); j++) {
+                const size_t s = (w << kWinSplit) + j, line = ix->n_win + s;
+                wide_at.push_back((uint32_t)line);
+                wide_sub.push_back(sub_of[s] == 0xFFFFFFFFu ? make_uint4(0u, 0u, 0u, 0u) : sub_lines[2 * (size_t)sub_of[s]]);
+                wide_sub.push_back(make_uint4(win_rank[line].x, win_rank[line].y, 0u, 0u));
+            }
+        }
+    }
     std::vector<uint32_t> win_filter;
     std::vector<uint2> win_fmeta;
     build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);
@@ -556,13 +578,14 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     ix->cshift = cshift;
     ix->partition_ok = plan_ok && ix->n_tiles >= 1 && ix->n_tiles <= kMaxTiles;
     int rc;
-    size_t win_bytes = 0, win_pos_bytes = 0;
+    size_t win_bytes = 0, win_pos_bytes = 0, win_wide_bytes = 0;
     if ((rc = dev_upload(&ix->d_start, h_start)) || (rc = dev_upload(&ix->d_aux, h_aux)) ||
         (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
         (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = upload_line_table(&ix->d_win, win, ix->win_swords != 0, sub_at, sub_lines, &win_bytes)) ||
         (rc = upload_line_table(&ix->d_win_pos, win_pos, ix->win_swords != 0, sub_at, sub_lines_pos, &win_pos_bytes)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
         (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_splittab, win_splittab)) ||
-        (rc = dev_upload(&ix->d_win_rank, win_rank)) || (rc = dev_upload(&ix->d_root_fids, root_fids)) ||
+        (rc = upload_line_table(&ix->d_win_wide, win_wide, ix->win_swords != 0, wide_at, wide_sub, &win_wide_bytes)) ||
+        (rc = dev_upload(&ix->d_root_fids, root_fids)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -572,7 +595,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
     ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),
                        bytes(win_meta),  win_bytes,         win_pos_bytes,    bytes(win_spill), bytes(win_filter),
-                       bytes(win_splittab), bytes(win_rank), bytes(root_fids),
+                       bytes(win_splittab), win_wide_bytes, bytes(root_fids),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
     GFFX_HIP_TRY(hipDeviceSynchronize());
@@ -618,7 +641,7 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_win_spill);
     (void)hipFree(ix->d_win_filter);
     (void)hipFree(ix->d_win_splittab);
-    (void)hipFree(ix->d_win_rank);
+    (void)hipFree(ix->d_win_wide);
     (void)hipFree(ix->d_root_fids);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);

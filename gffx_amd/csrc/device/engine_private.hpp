@@ -83,7 +83,7 @@ struct gffx_hip_index {
     uint32_t win_fwords = 0, win_fshift = 0;
     uint32_t *d_win_splittab = nullptr;  // split windows (k_join_pairs): one bit per window; their sub-lines follow the lines in d_win / d_win_pos
     uint32_t win_swords = 0;
-    uint2 *d_win_rank = nullptr;
+    uint4 *d_win_wide = nullptr;  // the wide form's lines: {coordinates x 4 | rank, list-tail header, 0, 0}, both levels
     uint32_t *d_root_fids = nullptr;  // ranks per line, root_fids by position (the wide form of k_join_pairs)
     bool win_range_ok = false;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
@@ -103,7 +103,7 @@ struct gffx_hip_index {
     std::vector<void **> arrays() {
         return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_win_meta,   (void **)&d_win,
                 (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter,
-                (void **)&d_win_splittab, (void **)&d_win_rank,  (void **)&d_root_fids,
+                (void **)&d_win_splittab, (void **)&d_win_wide,  (void **)&d_root_fids,
                 (void **)&d_cell_base,
                 (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
     }
@@ -124,7 +124,7 @@ struct gffx_hip_index {
         v.win_fshift = win_fshift;
         v.win_splittab = d_win_splittab;
         v.win_swords = win_swords;
-        v.win_rank = d_win_rank;
+        v.win_wide = d_win_wide;
         v.root_fids = d_root_fids;
         v.win_range_ok = win_range_ok ? 1u : 0u;
         v.n_chr = n_chr;

@@ -171,7 +171,7 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     a.pv.meta = ix->d_win_meta;
     a.pv.filter = ix->d_win_filter;
     a.pv.splittab = ix->d_win_splittab;
-    a.pv.ranks = ix->d_win_rank;
+    a.pv.wide = ix->d_win_wide;
     a.pv.rfids = ix->d_root_fids;
     a.pv.n_roots = ix->n_roots;
     a.pv.n_win = ix->n_win;

@@ -97,13 +97,15 @@ struct IndexView {
     // the roots over its first base (what the line of qs answers for the one-base region [qs, qs + 1)) and the roots that start
     // inside it: positions rank(qs + 1) .. rank(qe) - 1 of the sorted arrays, rank(x) = the roots of the seqid and of the seqids
     // before it that start below x.  A line lists every root that starts in its (sub-)window, so
-    //   rank(x) = win_rank[line of x - 1].x + the entries of the line's list with start <= x - 1,
-    // win_rank[line] = {(roots starting below the line's right edge) - (entries of the list), the header n | spill << 8 of a list
-    // that continues in win_spill (else 0)}, one record per line of BOTH levels (for the zeroed sub-lines of a split window:
-    // - 4, the four zero words all compare "start <= x").  root_fids[] = the
+    //   rank(x) = rank word of the line of x - 1 + the entries of the line's list with start <= x - 1,
+    // rank word = (roots starting below the line's right edge) - (entries of the list).  win_wide is a line table of its own for
+    // this: per line of BOTH levels 32 bytes {the line's four coordinate words | rank word, the header n | spill << 8 of a list
+    // that continues in win_spill (else 0), 0, 0} -- coordinates and rank come from one 32-byte sector (a separate rank array
+    // cost a second L2 request per line: 37 -> see DESIGN 4.0b).  The eight sub-lines of a split window all exist here (an empty
+    // one: zero coordinates, rank word - 4: the four zero words all compare "start <= x").  root_fids[] = the
     // root_fid column of aux, 4 bytes per root (a region's run of kept roots is read 16 bytes at a time).  Only when
     // win_range_ok: an interval with end < start is listed by no line but counted by the ranks.
-    const uint2 *win_rank;
+    const uint4 *win_wide;
     const uint32_t *root_fids;
     uint32_t win_range_ok;
     uint32_t n_chr;

@@ -106,7 +106,7 @@ struct PairView {
     const uint4 *meta;         // IndexView::win_meta
     const uint32_t *filter;    // IndexView::win_filter
     const uint32_t *splittab;  // IndexView::win_splittab
-    const uint2 *ranks;        // IndexView::win_rank   } the wide form only
+    const uint4 *wide;         // IndexView::win_wide   } the wide form only
     const uint32_t *rfids;     // IndexView::root_fids  }
     uint32_t n_win, n_chr, fshift, n_roots;
 };
@@ -592,9 +592,10 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
     const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
     uint32_t n_slow = 0;
-    // (the wide form: {rank, list-tail header} per line; the root_fids by position, allocated 4 words beyond the last root)
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint2 *>(A.pv.ranks), 0, WIDE ? (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * 8u) : 0u, 0x00020000);
+    // (the wide form: its own line table {coordinates | rank, list-tail header}; the root_fids by position, allocated 4 words
+    //  beyond the last root)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(A.pv.wide), 0, WIDE ? (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes) : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rfd =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rfids), 0, WIDE ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
 
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         gffx_v4u wc[4], wf[4];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+        for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(WIDE ? rw : rs, off[k], 0, 0);
         if constexpr (!WIDE) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
@@ -749,11 +750,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             gffx_v4u wc1[4];
             gffx_v2u cu0[4], cu1[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wc1[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off1[k], 0, 0);
+            for (int k = 0; k < 4; ++k) cu0[k] = __builtin_amdgcn_raw_buffer_load_b64(rw, off[k] + 16, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cu0[k] = __builtin_amdgcn_raw_buffer_load_b64(rk, off[k] >> 2, 0, 0);
+            for (int k = 0; k < 4; ++k) wc1[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, off1[k], 0, 0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cu1[k] = __builtin_amdgcn_raw_buffer_load_b64(rk, off1[k] >> 2, 0, 0);
+            for (int k = 0; k < 4; ++k) cu1[k] = __builtin_amdgcn_raw_buffer_load_b64(rw, off1[k] + 16, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             uint32_t ra[4], rb[4], h1[4];
             bool any = false;
