@@ -36,6 +36,7 @@ pub const GFFX_OUT_OFFSETS: u32 = 16;
 pub const GFFX_OUT_OFFSETS32: u32 = 64;
 pub const GFFX_OUT_SEGBASE: u32 = 256; // one u64 segment base per group of 256 regions (include/gffx_hip.h)
 pub const GFFX_OUT_NO_COUNTS: u32 = 512; // with GFFX_OUT_ROOT_BITMAP alone: no per-region counts (the CLI wants the unique roots only)
+pub const GFFX_OUT_BITMAP_KEEP: u32 = 128; // with GFFX_OUT_ROOT_BITMAP: accumulate into the bitmap of the passes before (streamed chunks)
 pub const GFFX_STRATEGY_AUTO: c_int = 0;
 
 extern "C" {

@@ -448,7 +448,9 @@ def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert, st
         _check(roots2, regions, mode, invert, soa=bool(nq & 1), strategy=strategy)
 
 
-def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
+def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
+    """AUTO: a batch whose first waited pass sent most regions to the exact sweep runs its later passes on the wide form of the
+    window kernel (overlap mode, round 4) or on the sweep kernel (the other modes); a batch of narrow regions stays where it is."""
     roots = synth.gencode_like_roots(150, seed=5, chroms=synth.SMALL2)
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
     ix = engine.TreeIndexData.from_roots(co, s, e, f)
@@ -456,19 +458,26 @@ def test_auto_moves_a_batch_of_wide_regions_to_the_sweep_kernel():
     wide = synth.synth_bed(5000, seed=1, chroms=synth.SMALL2, width=(200_000, 900_000))
     narrow = synth.synth_bed(5000, seed=2, chroms=synth.SMALL2, width=(100, 5000))
     b = engine.QueryBatch(ix, 5000)
-    for regions, want_second in ((wide, "k_join_fused"), (narrow, "k_join_pairs")):
+
+    def one_pass(mode, want_c):
+        b.set_profiling(True)
+        b.reset_profile()
+        b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS)  # AUTO
+        b.wait()
+        b.set_profiling(False)
+        assert np.array_equal(b.counts(), want_c)
+        return [name for kid, name in engine.KERNEL_NAMES.items() if b.kernel_ms(kid)[1]], b.wide_form
+
+    for regions, is_wide in ((wide, True), (narrow, False)):
         b.set_regions(regions)
         _, want_c = oix.query_features(regions, 2, False)
-        used = []
-        for _ in range(2):
-            b.set_profiling(True)
-            b.reset_profile()
-            b.run(OverlapMode.Overlap, False, engine.OUT_FIDS | engine.OUT_OFFSETS)  # AUTO
-            b.wait()
-            b.set_profiling(False)
-            used.append([name for kid, name in engine.KERNEL_NAMES.items() if b.kernel_ms(kid)[1]])
-            assert np.array_equal(b.counts(), want_c)
-        assert used[0] == ["k_join_pairs"] and used[1] == [want_second]
+        assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], False)    # the narrow form finds out
+        assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)  # ... and the batch moves (or stays)
+        _, want_cc = oix.query_features(regions, 0, False)
+        assert one_pass(OverlapMode.Contained, want_cc) == (["k_join_fused" if is_wide else "k_join_pairs"], False)
+        assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)
+    b.close()
+    ix.close()
 
 
 def test_offsets32_and_bitmap_accumulation():
