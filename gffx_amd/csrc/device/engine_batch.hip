@@ -74,6 +74,22 @@ int gffx::batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who) {
     return GFFX_OK;
 }
 
+// AUTO's prior for regions the HOST hands over: a sample of the rows (4096 of them, evenly spaced) says whether most are wider
+// than a window line answers; then already the batch's FIRST pass takes the wide form of the window kernel, or the sweep kernel
+// (a one-shot caller -- gffx_hip_query_features -- has no second pass to learn for).  A speed matter only; the first waited pass
+// of the narrow form replaces the prior with its count.  GFFX_HIP_WIDTH_SAMPLE=0: no prior (tests of the learning path).
+static bool sample_mostly_wide(uint64_t nq, const uint32_t *start, const uint32_t *end, size_t stride) {
+    if (!nq || !env_long("GFFX_HIP_WIDTH_SAMPLE", 1, 0, 1)) return false;
+    const uint32_t wmax = (uint32_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
+    const uint64_t step = std::max<uint64_t>(1, nq / 4096);
+    uint64_t n = 0, wide = 0;
+    for (uint64_t i = 0; i < nq; i += step, ++n) {
+        const uint32_t s = start[i * stride], e = end[i * stride];
+        wide += (e > s && e - s > wmax) ? 1 : 0;
+    }
+    return 4 * wide > n;
+}
+
 extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t *regions,
                                                uint64_t nq) {
     int rc = batch_check_nq(b, nq, "gffx_hip_batch_set_regions_host");
@@ -86,7 +102,7 @@ extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t
     b->q = QueryView{b->d_regions, nullptr, nullptr, nullptr};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = false;
+    b->mostly_slow = sample_mostly_wide(nq, regions + 1, regions + 2, 3);
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -108,7 +124,7 @@ extern "C" int gffx_hip_batch_set_regions_soa_host(gffx_hip_batch *b, const uint
     b->q = QueryView{nullptr, dc, ds, de};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = false;
+    b->mostly_slow = sample_mostly_wide(nq, start, end, 1);
     b->ran = b->waited = false;
     return GFFX_OK;
 }

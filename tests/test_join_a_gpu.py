@@ -449,8 +449,9 @@ def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert, st
 
 
 def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
-    """AUTO: a batch whose first waited pass sent most regions to the exact sweep runs its later passes on the wide form of the
-    window kernel (overlap mode, round 4) or on the sweep kernel (the other modes); a batch of narrow regions stays where it is."""
+    """AUTO: a batch of mostly wide regions -- found by a sample of the rows the host hands over, or by a first waited pass that
+    sent most regions to the exact sweep (tests/test_wide_form_gpu.py) -- runs on the wide form of the window kernel (overlap mode,
+    round 4) or on the sweep kernel (the other modes); a batch of narrow regions stays where it is."""
     roots = synth.gencode_like_roots(150, seed=5, chroms=synth.SMALL2)
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
     ix = engine.TreeIndexData.from_roots(co, s, e, f)
@@ -471,8 +472,8 @@ def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
     for regions, is_wide in ((wide, True), (narrow, False)):
         b.set_regions(regions)
         _, want_c = oix.query_features(regions, 2, False)
-        assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], False)    # the narrow form finds out
-        assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)  # ... and the batch moves (or stays)
+        assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)  # (host regions: a sample of the widths decides at once)
+        assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)
         _, want_cc = oix.query_features(regions, 0, False)
         assert one_pass(OverlapMode.Contained, want_cc) == (["k_join_fused" if is_wide else "k_join_pairs"], False)
         assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)

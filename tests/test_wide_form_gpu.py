@@ -146,9 +146,11 @@ def test_wide_form_small_indexes(wide_forced, seed):
     _check_wide(roots, regions, soa=bool(seed & 1))
 
 
-def test_wide_form_is_autos_choice_for_wide_batches():
-    """AUTO: the first pass over wide regions runs the narrow form (most regions take the sweep), the batch's later overlap-mode
-    pair passes the wide form -- and a pass of another mode, or one that asks for the root bitmap, leaves it again."""
+def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
+    """AUTO without the prior from the host's rows (as for regions that are already on the device): the first pass over wide
+    regions runs the narrow form (most regions take the sweep), the batch's later overlap-mode pair passes the wide form -- and a
+    pass of another mode, or one that asks for the root bitmap, leaves it again.  With the prior the first pass is wide already."""
+    monkeypatch.setenv("GFFX_HIP_WIDTH_SAMPLE", "0")
     roots = synth.gencode_like_roots(20000, seed=3)
     regions = synth.synth_bed(50_000, seed=9, width=(30000, 300000))
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
@@ -175,6 +177,12 @@ def test_wide_form_is_autos_choice_for_wide_batches():
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_SEGBASE, engine.STRATEGY_AUTO)
     b.wait()
     assert b.wide_form and np.array_equal(b.counts(), want_c)
+    monkeypatch.delenv("GFFX_HIP_WIDTH_SAMPLE")
+    b.set_regions(regions)  # the host's rows again, sampled this time
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_AUTO)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.counts(), want_c)
+    assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
     b.close()
     ix.close()
 
