@@ -78,16 +78,18 @@ int gffx::batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who) {
 // than a window line answers; then already the batch's FIRST pass takes the wide form of the window kernel, or the sweep kernel
 // (a one-shot caller -- gffx_hip_query_features -- has no second pass to learn for).  A speed matter only; the first waited pass
 // of the narrow form replaces the prior with its count.  GFFX_HIP_WIDTH_SAMPLE=0: no prior (tests of the learning path).
-static bool sample_mostly_wide(uint64_t nq, const uint32_t *start, const uint32_t *end, size_t stride) {
-    if (!nq || !env_long("GFFX_HIP_WIDTH_SAMPLE", 1, 0, 1)) return false;
+void gffx::sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *start, const uint32_t *end, size_t stride) {
+    if (!rows || !env_long("GFFX_HIP_WIDTH_SAMPLE", 1, 0, 1)) return;
     const uint32_t wmax = (uint32_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
-    const uint64_t step = std::max<uint64_t>(1, nq / 4096);
-    uint64_t n = 0, wide = 0;
-    for (uint64_t i = 0; i < nq; i += step, ++n) {
+    for (uint64_t i = 0; i < rows; i += step, ++w.n) {
         const uint32_t s = start[i * stride], e = end[i * stride];
-        wide += (e > s && e - s > wmax) ? 1 : 0;
+        w.wide += (e > s && e - s > wmax) ? 1 : 0;
     }
-    return 4 * wide > n;
+}
+static bool sample_mostly_wide(uint64_t nq, const uint32_t *start, const uint32_t *end, size_t stride) {
+    WidthSample w;
+    sample_widths(w, nq, std::max<uint64_t>(1, nq / 4096), start, end, stride);
+    return w.mostly_wide();
 }
 
 extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t *regions,
@@ -446,12 +448,12 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
                        !(out_flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32 | GFFX_OUT_SEGBASE));
     b->flags = waive ? out_flags : ((out_flags & ~(uint32_t)GFFX_OUT_NO_COUNTS) | GFFX_OUT_COUNTS);
     b->strategy = pick_strategy(b, strategy);
-    // Wide batches (AUTO, after a pass that sent most regions to the sweep): overlap-mode pair passes take the wide form of the
-    // window kernel; the other modes and the root passes stay with the sweep kernel.  GFFX_HIP_WIN_WIDE: 0 = never, 2 = every
+    // Wide batches (AUTO: a sample of the host's rows, or a pass that sent most regions to the sweep): overlap-mode passes take
+    // the wide form of the window kernels; the other modes stay with the sweep kernel.  GFFX_HIP_WIN_WIDE: 0 = never, 2 = every
     // eligible pass of the windows strategy (tests).
     {
         const long ww = env_long("GFFX_HIP_WIN_WIDE", 1, 0, 2);
-        const bool eligible = mode == GFFX_MODE_OVERLAP && !invert && b->ix->win_range_ok && !(out_flags & GFFX_OUT_ROOT_BITMAP);
+        const bool eligible = mode == GFFX_MODE_OVERLAP && !invert && b->ix->win_range_ok;
         b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && b->strategy == GFFX_STRATEGY_FUSED && b->mostly_slow) ||
                                (ww == 2 && b->strategy == GFFX_STRATEGY_WINDOWS));
         if (b->wide) b->strategy = GFFX_STRATEGY_WINDOWS;

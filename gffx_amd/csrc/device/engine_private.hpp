@@ -209,6 +209,12 @@ void prof_begin(gffx_hip_batch *b, int kernel, ProfEvent *pe);  // engine_batch.
 void prof_end(gffx_hip_batch *b, ProfEvent *pe);
 void prof_resolve(gffx_hip_batch *b);
 uint32_t meta_bytes(const gffx_hip_index *ix);
+// AUTO's prior for regions the HOST hands over (engine_batch.hip): widths of a sample of the rows
+struct WidthSample {
+    uint64_t n = 0, wide = 0;
+    bool mostly_wide() const { return 4 * wide > n; }
+};
+void sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *start, const uint32_t *end, size_t stride);
 int run_windows(gffx_hip_batch *b);  // engine_windows.hip
 int windows_pack_roots(gffx_hip_batch *b);
 int batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who);  // engine_batch.hip

@@ -72,11 +72,16 @@ extern "C" int gffx_hip_regions_append_parts(gffx_hip_regions *R, int k, uint32_
     if (first + n_rows > R->cap_rows) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: the store is full (%llu rows)", (unsigned long long)R->cap_rows);
     GFFX_HIP_TRY(hipSetDevice(R->device));
     uint64_t at = first;
+    WidthSample ws;  // (the rows are still in the staging buffer: ~4096 of them say whether the chunk is mostly wide regions)
     for (uint32_t p = 0; p < n_parts; ++p) {
-        if (part_rows[p])
-            GFFX_HIP_TRY(hipMemcpyAsync(R->d + 3 * at, R->h_stage[k] + 3 * stage_first[p], part_rows[p] * 12, hipMemcpyHostToDevice, R->stream));
+        if (part_rows[p]) {
+            const uint32_t *rows = R->h_stage[k] + 3 * stage_first[p];
+            GFFX_HIP_TRY(hipMemcpyAsync(R->d + 3 * at, rows, part_rows[p] * 12, hipMemcpyHostToDevice, R->stream));
+            sample_widths(ws, part_rows[p], std::max<uint64_t>(1, n_rows / 4096), rows + 1, rows + 2, 3);
+        }
         at += part_rows[p];
     }
+    R->last_wide[k] = ws.mostly_wide();
     GFFX_HIP_TRY(hipEventRecord(R->copied[k], R->stream));
     R->pending[k] = true;
     R->last_first[k] = first;
@@ -96,7 +101,7 @@ extern "C" int gffx_hip_batch_set_regions_store(gffx_hip_batch *b, const gffx_hi
     b->q = QueryView{R->d + 3 * (R->last_first[k] + first), nullptr, nullptr, nullptr};
     b->nq = n_rows;
     b->have_regions = true;
-    b->mostly_slow = false;
+    b->mostly_slow = R->last_wide[k];
     b->ran = b->waited = false;
     return GFFX_OK;
 }

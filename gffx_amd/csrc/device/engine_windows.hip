@@ -60,16 +60,18 @@ static int launch_pairs(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uin
 
     return GFFX_OK;
 }
-template <int MODE, bool ML, int T>
+template <int MODE, bool ML, int T, bool WIDE>
 static int launch_roots3(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t lds) {
-    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_roots<MODE, ML, T>), b->ix->device, lds, T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
+    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_roots<MODE, ML, T, WIDE>), b->ix->device, lds, T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_join_roots<MODE, ML, T>), dim3(grid), dim3(T), lds, b->stream, a);
+    hipLaunchKernelGGL((k_join_roots<MODE, ML, T, WIDE>), dim3(grid), dim3(T), lds, b->stream, a);
     return GFFX_OK;
 }
 template <int MODE, bool ML>
-static int launch_roots(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, uint32_t lds) {
-    return threads == 1024 ? launch_roots3<MODE, ML, 1024>(b, grid, a, lds) : launch_roots3<MODE, ML, 512>(b, grid, a, lds);
+static int launch_roots(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool wide, uint32_t lds) {
+    if constexpr (MODE == GFFX_MODE_OVERLAP)
+        if (wide) return threads == 1024 ? launch_roots3<MODE, ML, 1024, true>(b, grid, a, lds) : launch_roots3<MODE, ML, 512, true>(b, grid, a, lds);
+    return threads == 1024 ? launch_roots3<MODE, ML, 1024, false>(b, grid, a, lds) : launch_roots3<MODE, ML, 512, false>(b, grid, a, lds);
 }
 
 // One launch of the windows strategy.  kind 1: pair pass (counts / root_fids / segment bases / offsets); 2: the same with
@@ -116,8 +118,8 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     const uint32_t threads = pair_threads(b);
     const bool offs = !roots && (o.offsets || o.offsets32);
     const uint32_t keep_words = offs ? 2u : 0u;
-    // the wide form (gffx_device.hpp, "ranks"): pair passes of a batch AUTO found mostly wider than the lines answer; it reads no filter
-    const bool wide = !roots && b->wide;
+    // the wide form (gffx_device.hpp, "ranks"): the passes of a batch AUTO found mostly wider than the lines answer; it reads no filter
+    const bool wide = b->wide;
     uint32_t fwords = wide ? 0u : (ix->win_fwords + 3) / 4 * 4, swords = ix->win_swords;
     if (fwords < 4) fwords = 0;
     // What does not fit the block's LDS goes in this order: the split bitmap (lists longer than 4 are then walked from
@@ -190,7 +192,7 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     prof_begin(b, roots ? GFFX_K_WINDOWS : GFFX_K_WAVE, &pe);
 #define GFFX_CASE(M, L)                                                                                                  \
     if (b->mode == M && ml == L)                                                                                         \
-        lrc = roots ? launch_roots<M, L>(b, grid, a, threads, lds) : launch_pairs<M, L>(b, grid, a, threads, offs, pos, wide, lds);
+        lrc = roots ? launch_roots<M, L>(b, grid, a, threads, wide, lds) : launch_pairs<M, L>(b, grid, a, threads, offs, pos, wide, lds);
     GFFX_CASE(0, true) GFFX_CASE(0, false) GFFX_CASE(1, true) GFFX_CASE(1, false) GFFX_CASE(2, true) GFFX_CASE(2, false)
 #undef GFFX_CASE
     prof_end(b, &pe);

@@ -421,10 +421,10 @@ __device__ __forceinline__ void pair_locate(const PairLds &L, uint32_t qc, uint3
 // The wide form's list tails: the entries 3 .. n - 1 of the two lines' lists, in win_spill (h = n | spill << 8 of a marked line,
 // else 0).  First line: an entry that starts at or below qs counts in le0, and is kept -- written to out[], at most `cap`
 // words -- if it ends beyond qs; second line: an entry that starts at or below qe1 = qe - 1 counts in le1.  Two records of
-// each list in flight.  Returns the kept entries.
+// each list in flight.  Returns the kept entries.  `bits` (root passes): a kept entry sets the bit of its position there instead.
 template <bool POS>
 __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t h0, uint32_t h1, uint32_t qs, uint32_t qe1, uint32_t *out,
-                                                    uint32_t cap, uint32_t &le0, uint32_t &le1) {
+                                                    uint32_t cap, uint32_t &le0, uint32_t &le1, uint32_t *bits = nullptr) {
     uint32_t c = 0;
     const uint32_t n0 = h0 ? (h0 & 255u) - kWinInlineTail : 0u, n1 = h1 ? (h1 & 255u) - kWinInlineTail : 0u;
     const uint4 *s0 = spill + (h0 >> 8), *s1 = spill + (h1 >> 8);
@@ -441,7 +441,10 @@ __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t
             if (x[t].x <= qs) {
                 ++le0;
                 if (x[t].y > qs) {
-                    if (c < cap) out[c] = POS ? x[t].w : x[t].z;
+                    if (bits)
+                        atomicOr(&bits[x[t].w >> 5], 1u << (x[t].w & 31));
+                    else if (c < cap)
+                        out[c] = POS ? x[t].w : x[t].z;
                     ++c;
                 }
             }
@@ -1081,8 +1084,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 // out.fids = the slabs (grid x bm_words words); out.capacity = bm_words (0: no LDS bitmap); out.segbase (as a number) = how many
 // slabs hold something to OR with (GFFX_OUT_BITMAP_KEEP), the others are overwritten.  out.block_sums[block] = the block's kept
 // pairs (summed on the host: one same-address device atomic per wave cost 43 us per 1 M regions, per block still 5).
-template <int MODE, bool META_LDS, int T>
+template <int MODE, bool META_LDS, int T, bool WIDE = false>
 __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
+    static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP, "the wide form answers overlap mode");
     constexpr uint32_t kChunk = 4u * T;
     const QueryView &q = A.q;
     const WaveOut &out = A.out;
@@ -1125,6 +1129,8 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4 *>(A.pv.wide), 0, WIDE ? (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes) : 0u, 0x00020000);
     const uint32_t bm = lds0 + (uint32_t)(reinterpret_cast<unsigned char *>(s_bm) - smem);  // the bitmap's LDS address
     uint32_t *g_bitmap = reinterpret_cast<uint32_t *>(out.root_flags);                       // ... or the batch's bitmap (no LDS bitmap)
     auto set_global = [&](uint32_t p) {
@@ -1139,25 +1145,87 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         const bool full = base + kChunk <= nq;
         uint32_t off[4], rqs[4], rqe1[4];
         bool swp[4];
+        uint32_t off1[4], r0[4], nr[4];  // (wide form, 4.0b) the line of qe - 1; the run of roots that start inside the region
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;
-            pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
+            if constexpr (WIDE) {
+                pair_locate_wide(L, qc[k], qs[k], qe[k], off[k], rqs[k], off1[k], rqe1[k], swp[k]);
+            } else {
+                pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
+                off1[k] = r0[k] = nr[k] = 0;
+            }
         }
         gffx_v4u wc[4], wf[4];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k], 0, 0);
+        for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(WIDE ? rw : rs, off[k], 0, 0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
         uint32_t m[4];
+        uint32_t tc[4] = {0, 0, 0, 0};
+        if constexpr (WIDE) {
+            // one trip: both lines' coordinates and rank records and the positions of the line of qs; the run of roots that start
+            // inside the region is a run of BITS -- nothing is read for it
+            gffx_v4u wc1[4];
+            gffx_v2u cu0[4], cu1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cu0[k] = __builtin_amdgcn_raw_buffer_load_b64(rw, off[k] + 16, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wc1[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, off1[k], 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cu1[k] = __builtin_amdgcn_raw_buffer_load_b64(rw, off1[k] + 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t ra[4], rb[4], h0[4], h1[4];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqs[k], false);
+                ra[k] = cu0[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);
+                rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rqe1[k]);
+                h0[k] = wc[k].w == kWinTailMark ? cu0[k].y : 0u;
+                h1[k] = wc1[k].w == kWinTailMark ? cu1[k].y : 0u;
+                swp[k] |= ((h0[k] & 255u) == 255u) | ((h1[k] & 255u) == 255u);
+                any |= swp[k] | ((h0[k] | h1[k]) != 0u);
+            }
+            if (__builtin_amdgcn_ballot_w64(any)) {  // list tails and sweeps set their bits themselves
+                uint32_t deferred = 0, sweep = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    deferred |= (swp[k] | ((h0[k] | h1[k]) != 0u)) ? 1u << k : 0u;
+                    sweep |= swp[k] ? 1u << k : 0u;
+                }
+                n_slow += __popc(sweep);
+                uint32_t d = deferred;
+                while (d) {
+                    const int k = __ffs(d) - 1;
+                    d &= d - 1;
+                    uint32_t c, a0 = 0, b0 = 0;
+                    if (sweep >> k & 1u)
+                        c = pair_sweep_call<MODE, true>(&pair_rare_ix(), 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), nullptr, 0u,
+                                                        bm_words ? s_bm : g_bitmap);
+                    else
+                        c = pair_wide_tails<true>(A.spill, win_sel(h0, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, nullptr, 0u, a0, b0,
+                                                  bm_words ? s_bm : g_bitmap);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tc[j] += k == j ? c : 0u, ra[j] += k == j ? a0 : 0u, rb[j] += k == j ? b0 : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                m[k] = swp[k] ? 0u : m[k];
+                r0[k] = ra[k];
+                nr[k] = swp[k] ? 0u : rb[k] - ra[k];
+                tc[k] += nr[k];
+                kept += __popc(m[k]) + tc[k];
+            }
+        } else {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
             kept += __popc(m[k]);
         }
-        uint32_t tc[4] = {0, 0, 0, 0};
         {  // the rare rest: list tails and sweeps set their bits themselves
             bool any = false;
             uint32_t deferred = 0, sweep = 0, hdr[4];
@@ -1186,6 +1254,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 }
             }
         }
+        }
         if (out.counts) {  // (uniform) per-region counts, unless the caller waived them (GFFX_OUT_NO_COUNTS); older than the prefetch below
             const unsigned long long left = nq - base;
             const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
@@ -1196,6 +1265,17 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         // the regions are done with: the next round's take their registers; then the flags (stores younger than every load
         // that is waited for)
         load_round(r + A.grid);
+        if constexpr (WIDE) {  // the runs: up to 32 bits per step
+            uint32_t *bits = bm_words ? s_bm : g_bitmap;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                for (uint32_t p = r0[k], left = nr[k]; left;) {
+                    const uint32_t b = p & 31u, n = min(32u - b, left);
+                    atomicOr(&bits[p >> 5], (n == 32u ? 0xFFFFFFFFu : (1u << n) - 1u) << b);
+                    p += n, left -= n;
+                }
+            }
+        }
         if (bm_words) {  // (uniform)
 #pragma unroll
             for (int k = 0; k < 4; ++k) pair_flag4(m[k] << 28, bm, wf[k].x, wf[k].y, wf[k].z, wf[k].w);

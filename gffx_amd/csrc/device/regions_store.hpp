@@ -11,5 +11,6 @@ struct gffx_hip_regions {
     hipEvent_t copied[2] = {nullptr, nullptr};    // the last append from staging buffer k has completed
     bool pending[2] = {false, false};
     uint64_t last_first[2] = {0, 0}, last_n[2] = {0, 0};  // where the last append from buffer k went
+    bool last_wide[2] = {false, false};                    // ... and whether a sample of its rows was mostly wide (AUTO's prior)
     hipStream_t stream = nullptr;                 // copies
 };

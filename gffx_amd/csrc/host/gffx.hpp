@@ -284,6 +284,7 @@ struct StreamResult {
     std::vector<uint32_t> roots;       // unique root fids, ascending
     std::vector<char> has_regions;     // per seqid: owns at least one region (query_ivmap's keys, intersect.rs:621-633)
     uint64_t n_regions = 0;
+    uint64_t wide_form_passes = 0;     // chunk passes that took the wide form of the root kernel (--stats-json)
     gffx_hip_regions *store = nullptr; // keep_store: all regions, on the first device (the caller destroys it)
 };
 StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &bed_path, OverlapMode mode, bool invert, bool verbose,

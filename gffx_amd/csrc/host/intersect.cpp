@@ -834,6 +834,7 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
             const uint32_t flags = static_cast<uint32_t>(GFFX_OUT_ROOT_BITMAP) | static_cast<uint32_t>(GFFX_OUT_NO_COUNTS) |
                                    (used[2 * d + k] ? static_cast<uint32_t>(GFFX_OUT_BITMAP_KEEP) : 0u);
             if (gffx_hip_batch_run(b, static_cast<int>(mode), invert ? 1 : 0, flags, GFFX_STRATEGY_AUTO) != GFFX_OK) hip_fail("batch_run");
+            res.wide_form_passes += gffx_hip_batch_wide_form(b) ? 1 : 0;
             used[2 * d + k] = 1;
             dev_rows[d] += n_dev[d];
         }
@@ -1244,6 +1245,7 @@ void run(const IntersectArgs &args) {
     const double total_ms = timer.total();
     g_run_stats.count("regions", args.bed ? (double)sr.n_regions : (double)regions.size());
     g_run_stats.count("unique_roots", (double)roots.size());
+    if (args.bed) g_run_stats.count("wide_form_passes", (double)sr.wide_form_passes);
     g_run_stats.count("blocks", (double)blocks.size());
     g_run_stats.count("threads", (double)args.common.effective_threads());
     g_run_stats.count("gpus", (double)args.gpus);

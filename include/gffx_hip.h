@@ -263,7 +263,7 @@ int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, i
  * index has passes in flight, 512-thread blocks (two per CU: kernels of two batches share the CUs) otherwise;
  * GFFX_HIP_WIN_THREADS=512|1024 in the environment forces one. */
 uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *);
-/* 1 when the last run's pair passes took the WIDE form of the window kernel: regions of any width answered from two index lines
+/* 1 when the last run's passes took the WIDE form of the window kernels: regions of any width answered from two index lines
  * and two rank words each (overlap mode).  AUTO chooses it for a batch of mostly wide regions (wider than the lines answer,
  * 16 Ki bases by default): found by a sample of the rows gffx_hip_batch_set_regions_host / _soa_host are given, or -- regions
  * already on the device -- by a previous waited pass that sent most regions to the exact sweep; the other modes of such a

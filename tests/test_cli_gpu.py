@@ -95,6 +95,35 @@ def test_all_flag_combinations_equal_the_oracle(tmp_path, seed, crlf):
     assert rc == 0 and r.returncode == 0 and r.stdout == open(want_p, "rb").read() and r.stdout
 
 
+def test_a_bed_file_of_wide_regions_takes_the_wide_form_and_equals_the_oracle(tmp_path):
+    """Most rows wider than a window line answers (16 Ki bases): the sample of a chunk's rows sends its overlap-mode root pass to
+    the wide form of k_join_roots (the other modes: the narrow form's exact sweeps) -- same bytes out either way."""
+    roots = synth.gencode_like_roots(3000, seed=21, chroms=synth.SMALL2)
+    gff = str(tmp_path / "w.gff")
+    synth.write_gff3(gff, roots, seed=21)
+    assert subprocess.run([GFFX, "index", "-i", gff]).returncode == 0
+    bed = str(tmp_path / "wide.bed")
+    rows = np.concatenate([synth.synth_bed(700, seed=22, chroms=synth.SMALL2, width=(20000, 600000)),
+                           synth.synth_bed(150, seed=23, chroms=synth.SMALL2, width=(1, 3000), edge_frac=0.3, roots=roots)])
+    rows = rows[np.random.default_rng(5).permutation(len(rows))]
+    synth.write_bed(bed, rows, ["chr1", "chr2"])
+    want_p, got_p = str(tmp_path / "want.gff"), str(tmp_path / "got.gff")
+    for mode in MODES:
+        for eg in (False, True):
+            rc, msg = ob.intersect_run(gff, want_p, bed=bed, mode=MODES[mode], entire_group=eg)
+            assert rc == 0, msg
+            want = open(want_p, "rb").read()
+            for env in (None, dict(os.environ, GFFX_HIP_WIN_WIDE="0")):  # with and without the wide form
+                r = _cli(gff, dict(bed=bed, mode=mode, entire_group=eg), out=got_p, env=env)
+                assert r.returncode == 0, r.stderr
+                assert open(got_p, "rb").read() == want and want, (mode, eg, env is None)
+    stats = str(tmp_path / "stats.json")
+    for env, wide in ((None, 1), (dict(os.environ, GFFX_HIP_WIN_WIDE="0"), 0)):
+        r = subprocess.run([GFFX, "intersect", "-i", gff, "-b", bed, "-e", "-o", got_p, "--stats-json", stats], capture_output=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert json.load(open(stats))["counts"]["wide_form_passes"] == wide  # (one chunk, one pass)
+
+
 def test_config1_10k_feature_gff_region_query(tmp_path):
     """BASELINE configs[0]: `gffx intersect --region chr1:1000000-2000000` on a ~10 k-feature GFF3."""
     roots = synth.gencode_like_roots(600, seed=1, chroms=synth.SMALL2)

@@ -1,4 +1,4 @@
-"""The wide form of k_join_pairs (regions of any width, overlap mode) == oracle, bit for bit.
+"""The wide form of k_join_pairs / k_join_roots (regions of any width, overlap mode) == oracle, bit for bit.
 
 A region [qs, qe) overlaps the roots over its first base and the roots that start inside it (gffx_device.hpp, "ranks"):
 the kernel reads the line of qs, the line of qe - 1 and a rank word for each.  Forced on every eligible pass of the windows
@@ -73,6 +73,18 @@ def _check_wide(roots, regions, strategy=engine.STRATEGY_WINDOWS, soa=False):
     b.wait()
     assert np.array_equal(b.counts(), want_c) and b.total_hits == len(want_t)
     assert b.wide_form
+    # the unique roots: a root pass of its own (with and without counts: what the CLI asks for), and behind a pair pass
+    want_u = np.unique(want_t[:, 0])
+    b.run(OV, False, engine.OUT_ROOT_BITMAP, strategy)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.unique_roots(), want_u) and np.array_equal(b.counts(), want_c) and b.total_hits == len(want_t)
+    b.run(OV, False, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, strategy)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.unique_roots(), want_u) and b.total_hits == len(want_t)
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_ROOT_BITMAP, strategy)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.unique_roots(), want_u) and np.array_equal(b.counts(), want_c)
+    assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
     b.close()
     ix.close()
     return len(want_t)
@@ -148,8 +160,8 @@ def test_wide_form_small_indexes(wide_forced, seed):
 
 def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
     """AUTO without the prior from the host's rows (as for regions that are already on the device): the first pass over wide
-    regions runs the narrow form (most regions take the sweep), the batch's later overlap-mode pair passes the wide form -- and a
-    pass of another mode, or one that asks for the root bitmap, leaves it again.  With the prior the first pass is wide already."""
+    regions runs the narrow form (most regions take the sweep), the batch's later overlap-mode passes the wide form -- and a pass of
+    another mode leaves it again.  With the prior the first pass is wide already."""
     monkeypatch.setenv("GFFX_HIP_WIDTH_SAMPLE", "0")
     roots = synth.gencode_like_roots(20000, seed=3)
     regions = synth.synth_bed(50_000, seed=9, width=(30000, 300000))
@@ -173,7 +185,7 @@ def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
         assert not b.wide_form and np.array_equal(b.counts(), wc)
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_ROOT_BITMAP, engine.STRATEGY_AUTO)
     b.wait()
-    assert not b.wide_form and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    assert b.wide_form and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_SEGBASE, engine.STRATEGY_AUTO)
     b.wait()
     assert b.wide_form and np.array_equal(b.counts(), want_c)

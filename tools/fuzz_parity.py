@@ -82,10 +82,11 @@ for it in range(iters):
                         os.environ.pop("GFFX_HIP_WIN_THREADS", None)
                 runs = [(fl, False) for fl in flag_sets]
                 if strat == engine.STRATEGY_WINDOWS and mode == 2 and not inv:
-                    # the wide form of the pair passes (regions of any width from two lines and two ranks; AUTO's choice for wide
+                    # the wide form of the pair and root passes (regions of any width from two lines and two ranks; AUTO's choice for wide
                     # batches), forced on these regions whatever their widths
                     runs += [(fl, True) for fl in (engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_OFFSETS, 0,
-                                                   engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_FIDS | engine.OUT_SEGBASE)]
+                                                   engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_FIDS | engine.OUT_SEGBASE,
+                                                   engine.OUT_ROOT_BITMAP, engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS)]
                 for flags, wide in runs:
                     os.environ["GFFX_HIP_WIN_WIDE"] = "2" if wide else "1"
                     b.run(mode, inv, flags, strat)
