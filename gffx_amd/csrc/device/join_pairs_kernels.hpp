@@ -23,6 +23,11 @@
 // What the line cannot answer -- the tail of a (sub-)list still longer than 4, dense windows, regions wider than wmax,
 // qs >= qe rows (the reference keeps them), seqids without windows -- is DEFERRED: list tails are walked in line (a few
 // 16-byte records), exact sweeps (join_a_kernels.hpp) through a function call.
+// The WIDE form of both kernels (template argument WIDE; overlap mode; pair_locate_wide below) answers regions of
+// ANY width from the same index: the roots over the region's first base -- the line of qs, asked about [qs, qs + 1) -- plus the
+// roots that start inside it, a run of positions between two ranks, each rank = a stored word of a line + the line's entries
+// that start at or below the base (win_wide: the line's coordinates and its rank record side by side).  AUTO takes it for
+// batches of mostly wide regions, which otherwise went to the sweep kernel.
 //
 // What bounds a pass, measured in round 4: the CU's vector memory path -- one line request per ~2.9 cycles and CU
 // for the gathers, ~10 B per cycle and CU for the region and result streams, and they add up -- and, next to it, instruction
@@ -1220,40 +1225,40 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 kept += __popc(m[k]) + tc[k];
             }
         } else {
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
-            kept += __popc(m[k]);
-        }
-        {  // the rare rest: list tails and sweeps set their bits themselves
-            bool any = false;
-            uint32_t deferred = 0, sweep = 0, hdr[4];
+            for (int k = 0; k < 4; ++k) {
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
+                kept += __popc(m[k]);
+            }
+            {  // the rare rest: list tails and sweeps set their bits themselves
+                bool any = false;
+                uint32_t deferred = 0, sweep = 0, hdr[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) any |= swp[k] || wc[k].w == kWinTailMark;
-            if (__builtin_amdgcn_ballot_w64(any)) {
+                for (int k = 0; k < 4; ++k) any |= swp[k] || wc[k].w == kWinTailMark;
+                if (__builtin_amdgcn_ballot_w64(any)) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool tail = wc[k].w == kWinTailMark;
-                    hdr[k] = tail ? wf[k].w : 0u;
-                    deferred |= (swp[k] || tail) ? 1u << k : 0u;
-                    sweep |= (swp[k] || (hdr[k] & 255u) == 255u) ? 1u << k : 0u;
-                }
-                n_slow += __popc(sweep);
-                uint32_t d = deferred;
-                while (d) {
-                    const int k = __ffs(d) - 1;
-                    d &= d - 1;
-                    const uint32_t c = pair_rest<MODE, true>(&pair_rare_ix(), A.spill, inv, sweep >> k & 1u, min(win_sel(qc, k), n_chr), win_sel(qs, k),
-                                                             win_sel(qe, k), win_sel(hdr, k), nullptr, 0u, bm_words ? s_bm : g_bitmap);
-                    kept += c;
-                    tc[0] += k == 0 ? c : 0u;
-                    tc[1] += k == 1 ? c : 0u;
-                    tc[2] += k == 2 ? c : 0u;
-                    tc[3] += k == 3 ? c : 0u;
+                    for (int k = 0; k < 4; ++k) {
+                        const bool tail = wc[k].w == kWinTailMark;
+                        hdr[k] = tail ? wf[k].w : 0u;
+                        deferred |= (swp[k] || tail) ? 1u << k : 0u;
+                        sweep |= (swp[k] || (hdr[k] & 255u) == 255u) ? 1u << k : 0u;
+                    }
+                    n_slow += __popc(sweep);
+                    uint32_t d = deferred;
+                    while (d) {
+                        const int k = __ffs(d) - 1;
+                        d &= d - 1;
+                        const uint32_t c = pair_rest<MODE, true>(&pair_rare_ix(), A.spill, inv, sweep >> k & 1u, min(win_sel(qc, k), n_chr), win_sel(qs, k),
+                                                                 win_sel(qe, k), win_sel(hdr, k), nullptr, 0u, bm_words ? s_bm : g_bitmap);
+                        kept += c;
+                        tc[0] += k == 0 ? c : 0u;
+                        tc[1] += k == 1 ? c : 0u;
+                        tc[2] += k == 2 ? c : 0u;
+                        tc[3] += k == 3 ? c : 0u;
+                    }
                 }
             }
-        }
         }
         if (out.counts) {  // (uniform) per-region counts, unless the caller waived them (GFFX_OUT_NO_COUNTS); older than the prefetch below
             const unsigned long long left = nq - base;
