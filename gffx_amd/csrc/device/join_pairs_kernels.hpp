@@ -97,10 +97,11 @@ constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequ
 constexpr uint32_t kWaveStash = 2;     // per thread: kept words of deferred regions wait here (LDS) for the parking
 // words a wave parks in LDS per round (a strip): 2 kept pairs per region at 1024 threads, 1.5 at 512 (two blocks share a CU's
 // LDS); a fuller round -- gene-dense stretches of a sorted BED file -- takes all kWaveDepth strips, beyond that the synchronous path
-// The wide form keeps several pairs per region (2.6 at bench.py's wide shape: 600 .. 800 a round): strips of ~4 pairs per region,
-// two of them per wave.
+// The wide form keeps several pairs per region (2.6 at bench.py's wide shape: 600 .. 800 a round): strips of 3.75 pairs per
+// region, two of them per wave (960 words: with per-region offsets parked next to them the split bitmap still fits a 1024-thread
+// block's LDS).
 __host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads, bool wide = false) {
-    return wide ? (threads == 1024 ? 1024u : 960u) : (threads == 1024 ? 512u : 384u);
+    return wide ? 960u : (threads == 1024 ? 512u : 384u);
 }
 __host__ __device__ constexpr uint32_t pair_depth(bool wide = false) { return wide ? 2u : kWaveDepth; }
 

@@ -34,7 +34,9 @@
  *                          of a group in input order; every query's segment start is given explicitly (GFFX_OUT_OFFSETS /
  *                          GFFX_OUT_OFFSETS32) or per group (GFFX_OUT_SEGBASE) and the segments tile [0, pairs) exactly.  Inside a segment:
  *                          WINDOWS ascending list order (start, ties in builder order) for regions answered from the
- *                          window's candidate list, descending for regions that took the exact sweep; FUSED descending
+ *                          window's candidate list (also in the wide form: the entries of the line of the region's first
+ *                          base, then the roots that start inside the region), descending for regions that took the exact
+ *                          sweep; FUSED descending
  *   SORTED (partitioned)   segments in the order genome tiles were served, offsets explicit, inside a segment descending
  *
  * Threading: an index is immutable after creation and may be shared by threads; a batch owns
@@ -43,6 +45,16 @@
  * last failure on the calling thread is in gffx_hip_last_error().  Nothing throws or aborts
  * across this boundary.  There is NO CPU fallback: without a HIP device every compute entry
  * point fails with GFFX_E_NO_DEVICE.
+ *
+ * Environment (tuning and tests; results never depend on any of them):
+ *   GFFX_HIP_WIN_THREADS=512|1024   block width of the window kernels (default: 1024 for a 0.5-2.5 M-region pass that runs alone)
+ *   GFFX_HIP_WIN_WIDE=0|1|2         the wide form of the window kernels: never / AUTO's choice for mostly wide batches (default) /
+ *                                   every eligible pass of the windows strategy
+ *   GFFX_HIP_WIDTH_SAMPLE=0         no width sample of the rows the host hands over (AUTO then learns from a first waited pass)
+ *   GFFX_HIP_AUTO_STRATEGY=n        what GFFX_STRATEGY_AUTO resolves to
+ *   index build (read by gffx_hip_index_create): GFFX_HIP_SLOT_WMAX (widest region a window line answers, 16384),
+ *   GFFX_HIP_WIN_PER_ENTRY, GFFX_HIP_WIN_SPLIT, GFFX_HIP_WIN_FILTER_KB, GFFX_HIP_WIN_MAX_LINES, GFFX_HIP_BINS_PER_ENTRY,
+ *   GFFX_HIP_PARTITION_BUDGET_MB; launch sizes: GFFX_HIP_FUSED_BLOCKS, GFFX_HIP_BITMAP_BLOCKS, GFFX_HIP_JOIN_BLOCKS
  */
 #ifndef GFFX_HIP_H
 #define GFFX_HIP_H

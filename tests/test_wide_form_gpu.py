@@ -199,11 +199,13 @@ def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
     ix.close()
 
 
-def test_wide_form_full_size_properties(wide_forced):
-    """1 M regions of bench.py's wide shape: counts add up to the pairs, every region's run is what two binary searches over the
-    sorted roots say (start < qe, minus the roots that end at or before qs among those starting at or below it: checked through
-    the count), and the narrow form of the same pass agrees word for word after sorting each region's run."""
+def test_wide_form_full_size_properties(wide_forced, monkeypatch):
+    """1 M regions of bench.py's wide shape.  EVERY count against first principles: a root with end >= start that ends at or
+    before qs also starts before qe, so the roots a region [qs, qe) overlaps are #{start < qe} - #{end <= qs} -- two binary
+    searches per region over the seqid's sorted starts and sorted ends.  The counts add up to the pairs; a 20 k-region sample
+    agrees with the oracle pair by pair; the sweep kernel's pass over the same batch keeps the same multiset of root_fids."""
     roots = synth.gencode_like_roots(63000, seed=42)
+    co, rs, re = roots["chr_offsets"], roots["start"].astype(np.int64), roots["end"].astype(np.int64)
     regions = synth.synth_bed(1_000_000, seed=1004, width=(100, 200000))
     ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
     b = engine.QueryBatch(ix, len(regions))
@@ -213,13 +215,41 @@ def test_wide_form_full_size_properties(wide_forced):
     assert b.wide_form
     c, off, f = b.counts(), b.offsets(), b.fids()
     assert int(c.sum()) == b.total_hits == len(f)
-    # counts from first principles (vectorised): per seqid, roots with start < qe minus roots with end <= qs -- exact when no
-    # root is nested so that it ends before an earlier one... use the oracle on a sample instead, and the identity on all
+    want = np.zeros(len(regions), dtype=np.int64)
+    for k in range(len(co) - 1):
+        sel = np.nonzero(regions[:, 0] == k)[0]
+        st, en = rs[co[k]:co[k + 1]], np.sort(re[co[k]:co[k + 1]])  # (starts are sorted per seqid)
+        want[sel] = np.searchsorted(st, regions[sel, 2].astype(np.int64), "left") - np.searchsorted(en, regions[sel, 1].astype(np.int64), "right")
+    assert np.array_equal(c.astype(np.int64), want)
     oix = ob.OracleIndex.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
     pick = np.random.default_rng(1).choice(len(regions), 20000, replace=False)
     wt, wc = oix.query_features(regions[pick], OV, False)
     assert np.array_equal(c[pick], wc)
-    got = _pairs_of(regions[pick], wc, off[:-1][pick], f)
-    assert np.array_equal(got, _want_pairs(regions[pick], wt, wc))
+    assert np.array_equal(_pairs_of(regions[pick], wc, off[:-1][pick], f), _want_pairs(regions[pick], wt, wc))
+    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "0")
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_FUSED)
+    b.wait()
+    assert not b.wide_form and np.array_equal(b.counts(), c) and np.array_equal(np.sort(b.fids()), np.sort(f))
+    b.close()
+    ix.close()
+
+
+def test_wide_form_on_a_cloned_index(wide_forced):
+    """gffx_hip_index_clone copies the wide form's line table and the root_fids by position with everything else."""
+    roots = synth.gencode_like_roots(20000, seed=11)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    regions = _mixed_widths(np.random.default_rng(12), 20_000, synth.GRCH38)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    want_t, want_c = oix.query_features(regions, OV, False)
+    ix0 = engine.TreeIndexData.from_roots(co, s, e, f)
+    ix = ix0.clone(0)
+    ix0.close()  # (the clone owns its device arrays)
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.counts(), want_c)
+    assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), _want_pairs(regions, want_t, want_c))
+    assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
     b.close()
     ix.close()
