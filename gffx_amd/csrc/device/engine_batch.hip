@@ -579,7 +579,9 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         const uint64_t passes = std::max<uint64_t>(b->win_passes, 1);
         // (a wide-form pass answers every width from the lines: it says nothing about the regions' widths -- the batch stays what
         //  the last narrow pass found it to be until its regions change)
-        if (!b->wide) b->mostly_slow = (h_slow_win - b->slow_seen_win) / passes > b->nq / 4;
+        //  Break-even, measured at 1 M regions: the narrow form costs 14.5 us + 120 us x the fraction of regions that take the
+        //  sweep, the wide form 28 + 8 x, the sweep kernel 25 + 40 x: an eighth.)
+        if (!b->wide) b->mostly_slow = (h_slow_win - b->slow_seen_win) / passes > b->nq / 8;
         b->slow_seen_win = h_slow_win;
         b->win_passes = 0;
     }

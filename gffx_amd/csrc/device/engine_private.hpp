@@ -181,8 +181,8 @@ struct gffx_hip_batch {
     int fused_word = 2;             // ... and the one the last fused pass used
     uint64_t slow_seen_win = 0;     // windows strategy: the device's exact-sweep counter at the last wait
     uint64_t win_passes = 0;        // ... and the windows passes enqueued since
-    bool wide = false;              // this run's pair passes take the wide form of k_join_pairs (AUTO, mostly_slow, overlap mode)
-    bool mostly_slow = false;       // ... > 1/4 of the regions took the slow lane: AUTO uses the sweep kernel
+    bool wide = false;              // this run's passes take the wide form of the window kernels (AUTO, mostly_slow, overlap mode)
+    bool mostly_slow = false;       // more than 1/8 of the regions are wide (a sample of the host's rows) or took the sweep in the last waited narrow pass
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
     uint32_t flags = 0;
@@ -212,7 +212,7 @@ uint32_t meta_bytes(const gffx_hip_index *ix);
 // AUTO's prior for regions the HOST hands over (engine_batch.hip): widths of a sample of the rows
 struct WidthSample {
     uint64_t n = 0, wide = 0;
-    bool mostly_wide() const { return 4 * wide > n; }
+    bool mostly_wide() const { return 8 * wide > n; }  // (the same eighth as the learned rule in gffx_hip_batch_wait)
 };
 void sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *start, const uint32_t *end, size_t stride);
 int run_windows(gffx_hip_batch *b);  // engine_windows.hip
