@@ -127,13 +127,15 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     // parked offsets, per-thread strips -- fits by construction; checked all the same: a launch over the limit would fail, or
     // silently run one block per CU.
     const uint32_t max_lds = threads == 1024 ? 2 * kWinMaxLds : kWinMaxLds;
-    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, 0, wide) > max_lds) swords = 0;
-    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, 0, wide) > max_lds) ml = false;
-    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, 0, wide) > max_lds) fwords = 0;
-    // a root pass keeps the block's root bitmap in LDS when it fits next to the tables (else: device atomics on the batch's bitmap)
+    // a root pass keeps the block's root bitmap in LDS (else: device atomics on the batch's bitmap); it is small and comes before
+    // the tables: only when nothing else is left to shed does it go
     uint32_t bm_words = roots ? ((ix->n_roots + 31) / 32 + 3) / 4 * 4 : 0;
-    if (pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, bm_words, wide) > max_lds) bm_words = 0;
-    const uint32_t lds = pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, bm_words, wide);
+    auto need = [&]() { return pairs_lds_bytes(ix, threads, roots, keep_words, fwords, swords, ml, bm_words, wide); };
+    if (need() > max_lds) swords = 0;
+    if (need() > max_lds) ml = false;
+    if (need() > max_lds) fwords = 0;
+    if (need() > max_lds) bm_words = 0;
+    const uint32_t lds = need();
     if (lds > max_lds) return fail(GFFX_E_INVALID, "windows pass: %u bytes of LDS per block exceed the limit of %u", lds, max_lds);
     if (!roots) b->win_threads = threads;
     const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
@@ -225,7 +227,7 @@ int gffx::run_windows(gffx_hip_batch *b) {
     const bool want_pairs = b->flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32 | GFFX_OUT_SEGBASE);
     if (want_bitmap && !(b->flags & GFFX_OUT_BITMAP_KEEP)) {
         // a new set of roots: no slab holds anything, and the bitmap itself starts empty (it is what a root pass without an LDS
-        // bitmap ORs into, and what the fold overwrites)
+        // bitmap ORs into, and what the fold ORs the slabs into)
         b->slab_valid = 0;
         b->root_flags_dirty = true;
         GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));

@@ -253,3 +253,49 @@ def test_wide_form_on_a_cloned_index(wide_forced):
     assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
     b.close()
     ix.close()
+
+
+def test_root_passes_of_both_forms_in_turn_on_an_index_with_many_windows(monkeypatch):
+    """Found by tools/fuzz_parity.py: 300 seqids of 250 Mbp with a few dozen roots each have 600 k windows -- a 76 KB split
+    bitmap.  The narrow root pass sheds it (the coverage filter is there too), the wide one kept it and had no room left for the
+    block's root bitmap: its bits went straight to the batch's bitmap, and the fold of the slabs of the EARLIER narrow pass then
+    wiped them.  The root bitmap now comes first in a block's LDS, and the fold ORs."""
+    rng = np.random.default_rng(1552)
+    n_chr, span = 300, 250_000_000
+    per = np.minimum(rng.choice([0, 1, 2, 10, 200, 3000], size=n_chr, p=[.1, .1, .1, .3, .3, .1]), 50)
+    co = np.concatenate([[0], np.cumsum(per)]).astype(np.uint32)
+    R = int(co[-1])
+    s = np.concatenate([np.sort(rng.integers(0, span, k)) for k in per]).astype(np.int64)
+    ln = np.where(rng.random(R) < 0.1, rng.integers(1, span // 2, R), rng.integers(1, span // 500, R))
+    e = np.minimum(s + ln, 0xFFFFFFFF)
+    roots = {"chr_offsets": co, "start": s.astype(np.uint32), "end": e.astype(np.uint32), "fid": (np.arange(R, dtype=np.uint32) * 3 + 1)}
+    nq = 63
+    qc = rng.integers(0, n_chr, nq)
+    qs = rng.integers(0, span, nq)
+    qe = np.minimum(qs + np.where(rng.random(nq) < 0.5, rng.integers(1, 80_000, nq), rng.integers(1, span, nq)), 0xFFFFFFFF)
+    regions = np.stack([qc, qs, qe], axis=1).astype(np.uint32)
+    oix = ob.OracleIndex.from_roots(co, roots["start"], roots["end"], roots["fid"])
+    want_t, want_c = oix.query_features(regions, OV, False)
+    want_u = np.unique(want_t[:, 0])
+    assert len(want_u) > 20
+    ix = engine.TreeIndexData.from_roots(co, roots["start"], roots["end"], roots["fid"])
+    b = engine.QueryBatch(ix, nq)
+    b.set_regions(regions)
+    for wide in ("1", "2", "1", "2", "2"):
+        monkeypatch.setenv("GFFX_HIP_WIN_WIDE", wide)
+        b.run(OV, False, engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)
+        b.wait()
+        assert b.wide_form == (wide == "2")
+        assert np.array_equal(b.unique_roots(), want_u) and np.array_equal(b.counts(), want_c), wide
+    # ... and accumulated over two halves of the regions (GFFX_OUT_BITMAP_KEEP), one half per form
+    half = nq // 2
+    b.set_regions(regions[:half])
+    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "1")
+    b.run(OV, False, engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)
+    b.set_regions(regions[half:])
+    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "2")
+    b.run(OV, False, engine.OUT_ROOT_BITMAP | engine.OUT_BITMAP_KEEP, engine.STRATEGY_WINDOWS)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.unique_roots(), want_u)
+    b.close()
+    ix.close()
