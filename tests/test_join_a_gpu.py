@@ -613,7 +613,7 @@ def test_warmup_reserve_hits_and_device_result_pointers():
 
 
 @pytest.mark.parametrize("n_roots", [300_000, 800_000])
-def test_many_roots_bitmap_beyond_the_default_lds(n_roots):
+def test_many_roots_bitmap_beyond_the_default_lds(n_roots, monkeypatch):
     """The root bitmap of a root-bitmap pass lives in LDS while it fits: 300 k roots need more than the default 64 KB of
     dynamic LDS (the kernel opts in), 800 k roots do not fit at all (test-before-set global atomics)."""
     rng = np.random.default_rng(n_roots)
@@ -639,6 +639,22 @@ def test_many_roots_bitmap_beyond_the_default_lds(n_roots):
         b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS32 | engine.OUT_ROOT_BITMAP)
         b.wait()
         assert np.array_equal(np.sort(b.fids()), np.sort(want_t[:, 0])) and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    # the wide form of the root pass (a region's run of roots is a run of bits: in LDS, or straight in the batch's bitmap), after
+    # the narrow passes above on the same batch, then accumulated over two halves
+    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "2")
+    wide = regions[:20_000].copy()
+    wide[:, 2] = wide[:, 1] + rng.integers(1, 150_000, len(wide)).astype(np.uint32)
+    want_t, want_c = oix.query_features(wide, int(OverlapMode.Overlap), False)
+    b.set_regions(wide)
+    b.run(OverlapMode.Overlap, False, engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.counts(), want_c) and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    b.set_regions(wide[:10_000])
+    b.run(OverlapMode.Overlap, False, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, engine.STRATEGY_WINDOWS)
+    b.set_regions(wide[10_000:])
+    b.run(OverlapMode.Overlap, False, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS | engine.OUT_BITMAP_KEEP, engine.STRATEGY_WINDOWS)
+    b.wait()
+    assert b.wide_form and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
     b.close()
     ix.close()
 
