@@ -273,23 +273,6 @@ __device__ __forceinline__ void pair_flag4(uint32_t x, uint32_t bm, uint32_t p0,
 // A parked run of `total` words leaves the wave's strip four trips at a time: a trip at word X is one LDS read and one buffer
 // store at immediate offsets from the run's own descriptor, whose range check drops the lanes -- and whole trips -- past the
 // run: no per-trip address or bounds arithmetic, one uniform compare per 256 words.
-// (16 bytes per lane and trip: one LDS read, one store -- a quarter of the vector memory instructions; the run starts at any
-//  word of the output, so the stores are 4-byte aligned only, and the one that straddles the end of the run relies on the range
-//  check dropping its dwords past the descriptor one by one: checked on gfx950 by tools/oob_test)
-template <uint32_t X, uint32_t END, bool DONE = (X >= END)>
-struct PairFlush4 {
-    static __device__ __forceinline__ void run(const gffx_v4u *st4 /* strip as quads + lane */, __amdgpu_buffer_rsrc_t rf, uint32_t lane16, uint32_t total) {
-        if (X < total) {
-            const gffx_v4u v = st4[X / 4];
-            __builtin_amdgcn_raw_buffer_store_b128(v, rf, lane16 + X * 4u, 0, 2 /* nt */);
-            PairFlush4<X + 256, END>::run(st4, rf, lane16, total);
-        }
-    }
-};
-template <uint32_t X, uint32_t END>
-struct PairFlush4<X, END, true> {
-    static __device__ __forceinline__ void run(const gffx_v4u *, __amdgpu_buffer_rsrc_t, uint32_t, uint32_t) {}
-};
 template <uint32_t X, uint32_t END, bool DONE = (X >= END)>
 struct PairFlush {
     static __device__ __forceinline__ void run(const uint32_t *st /* strip + lane */, __amdgpu_buffer_rsrc_t rf, uint32_t lane4, uint32_t total) {
@@ -711,11 +694,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(dst, 0, total * 4u, 0x00020000);
                 uint32_t l4 = lane4;
                 asm volatile("" : "+v"(l4));  // (made here: hoisted out of the round loop, lane4 + X would be a register per trip)
-#ifdef GFFX_PAIR_FLUSH4
-                PairFlush4<0, D * kStage>::run(reinterpret_cast<const gffx_v4u *>(s_stage + p_strip[i] * kStage) + lane, rf, 4u * l4, total);
-#else
                 PairFlush<0, D * kStage>::run(st, rf, l4, total);
-#endif
             } else {
                 for (uint32_t x = lane; x < total; x += 64)
                     if (seg + x < out.capacity) dst[x] = s_stage[p_strip[i] * kStage + x];
