@@ -129,4 +129,4 @@ for it in range(iters):
                         sys.exit(1)
     b.close()
     ix.close()
-print("fuzz ok: %d iterations, %d passes checked (%d of them wide-form pair passes), %.0f s" % (iters, n_checks, n_wide, time.time() - t0))
+print("fuzz ok: %d iterations, %d passes checked (%d of them in the wide form), %.0f s" % (iters, n_checks, n_wide, time.time() - t0))
