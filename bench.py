@@ -758,6 +758,13 @@ def main():
                                               "wide form of k_join_pairs" % nq, None, pw.pass_us_one_event_pair, pw.block_threads)
         result["wide_regions"]["wide_form"] = bool(pw.batches[0].wide_form)
         pw.close()
+        # ... and the root pass over them (what the CLI runs per chunk): the wide form of k_join_roots
+        bmw = Pass(engine, ix, colsw, nq, 1, mode, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, 0)
+        bmw.size_and_warm(2)
+        kbw = bmw.kernel_us(10)
+        result["wide_regions"]["root_pass"] = {"bitmap_pass_us": bmw.pass_us_one_event_pair, "kernels": kbw,
+                                               "wide_form": bool(bmw.batches[0].wide_form)}
+        bmw.close()
         del colsw, regw
         # ---- a BED file sorted by (seqid, start), as most are
         regs = np.ascontiguousarray(regions[np.lexsort((regions[:, 1], regions[:, 0]))])
