@@ -104,7 +104,7 @@ extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t
     b->q = QueryView{b->d_regions, nullptr, nullptr, nullptr};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = sample_mostly_wide(nq, regions + 1, regions + 2, 3);
+    b->mostly_slow = b->mostly_wide = sample_mostly_wide(nq, regions + 1, regions + 2, 3);
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -126,7 +126,7 @@ extern "C" int gffx_hip_batch_set_regions_soa_host(gffx_hip_batch *b, const uint
     b->q = QueryView{nullptr, dc, ds, de};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = sample_mostly_wide(nq, start, end, 1);
+    b->mostly_slow = b->mostly_wide = sample_mostly_wide(nq, start, end, 1);
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -141,7 +141,7 @@ extern "C" int gffx_hip_batch_set_regions_device(gffx_hip_batch *b, const uint32
     b->q = QueryView{nullptr, d_chr, d_start, d_end};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = false;
+    b->mostly_slow = b->mostly_wide = false;
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -454,7 +454,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     {
         const long ww = env_long("GFFX_HIP_WIN_WIDE", 1, 0, 2);
         const bool eligible = mode == GFFX_MODE_OVERLAP && !invert && b->ix->win_range_ok;
-        b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && b->strategy == GFFX_STRATEGY_FUSED && b->mostly_slow) ||
+        b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && b->strategy == GFFX_STRATEGY_FUSED && b->mostly_wide) ||
                                (ww == 2 && b->strategy == GFFX_STRATEGY_WINDOWS));
         if (b->wide) b->strategy = GFFX_STRATEGY_WINDOWS;
     }
@@ -580,8 +580,14 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
         // (a wide-form pass answers every width from the lines: it says nothing about the regions' widths -- the batch stays what
         //  the last narrow pass found it to be until its regions change)
         //  Break-even, measured at 1 M regions: the narrow form costs 14.5 us + 120 us x the fraction of regions that take the
-        //  sweep, the wide form 28 + 8 x, the sweep kernel 25 + 40 x: an eighth.)
-        if (!b->wide) b->mostly_slow = (h_slow_win - b->slow_seen_win) / passes > b->nq / 8;
+        //  sweep, the wide form 28 + 8 x, the sweep kernel 25 + 40 x: an eighth.  The word's halves are counters modulo 2^32:
+        //  all sweeps -> the sweep kernel; sweeps because of the region's width -> the wide form, which answers those and only those.)
+        if (!b->wide) {
+            const uint64_t all = (uint32_t)((uint32_t)h_slow_win - (uint32_t)b->slow_seen_win);
+            const uint64_t by_width = (uint32_t)((uint32_t)(h_slow_win >> 32) - (uint32_t)(b->slow_seen_win >> 32));
+            b->mostly_wide = by_width / passes > b->nq / 8;
+            b->mostly_slow = b->mostly_wide || all / passes > b->nq / 4;  // (sweeps for other reasons: the rule of rounds 2 and 3)
+        }
         b->slow_seen_win = h_slow_win;
         b->win_passes = 0;
     }

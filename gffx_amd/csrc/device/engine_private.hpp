@@ -183,6 +183,7 @@ struct gffx_hip_batch {
     uint64_t win_passes = 0;        // ... and the windows passes enqueued since
     bool wide = false;              // this run's passes take the wide form of the window kernels (AUTO, mostly_slow, overlap mode)
     bool mostly_slow = false;       // more than 1/8 of the regions are wide (a sample of the host's rows) or took the sweep in the last waited narrow pass
+    bool mostly_wide = false;       // ... because of their width (the wide form answers those; dense windows and seqids without windows it does not)
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
     uint32_t flags = 0;

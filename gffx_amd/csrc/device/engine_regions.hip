@@ -101,7 +101,7 @@ extern "C" int gffx_hip_batch_set_regions_store(gffx_hip_batch *b, const gffx_hi
     b->q = QueryView{R->d + 3 * (R->last_first[k] + first), nullptr, nullptr, nullptr};
     b->nq = n_rows;
     b->have_regions = true;
-    b->mostly_slow = R->last_wide[k];
+    b->mostly_slow = b->mostly_wide = R->last_wide[k];
     b->ran = b->waited = false;
     return GFFX_OK;
 }

@@ -125,7 +125,7 @@ struct WaveOut {
     uint32_t *fids;                 // pair segments: root_fids, or positions (or nullptr: counts only)
     uint8_t *root_flags;            // k_join_roots without an LDS bitmap: the batch's bitmap (device atomics)
     uint32_t *err;                  // bit0 = chr out of range, bit1 = internal (LDS base)
-    unsigned long long *slow;       // regions that took the exact sweep (AUTO's heuristic)
+    unsigned long long *slow;       // low half += regions that took the exact sweep, high half += ... because of their width (AUTO's census)
     unsigned long long *block_sums;        // k_join_roots: kept pairs per block (or nullptr)
     unsigned long long *pair_cursor;       // kept pairs of this pass (zero on entry)
     unsigned long long *pair_cursor_next;  // the other cursor word: zeroed here for the next pass
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
     const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
-    uint32_t n_slow = 0;
+    uint32_t n_slow = 0, n_wide = 0;  // regions that took the exact sweep; ... because the lines do not answer their width (AUTO's census)
     // (the wide form: its own line table {coordinates | rank, list-tail header}; the root_fids by position, allocated 4 words
     //  beyond the last root)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
@@ -852,6 +852,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 }
                 if (deferred) {
                     n_slow += __popc(sweep);
+                    if (sweep) {  // ... because of its width: a real row on a seqid that has windows (only the lanes with a sweep look)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            n_wide += (swp[k] && qe[k] > qs[k] && (cm[min(qc[k], n_chr)].z >> 8) != 0u) ? 1u : 0u;
+                    }
                     uint32_t d = deferred;
                     while (d) {
                         const int k = __ffs(d) - 1;
@@ -1074,8 +1079,8 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     for (int i = P - 1; i >= 0; --i) finish(i);
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64);
-    if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow);
+    for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64), n_wide += __shfl_xor(n_wide, o, 64);
+    if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow | ((unsigned long long)n_wide << 32));
 }
 
 // ---- root passes: which roots are in at least one kept pair.  The same regions, the same lines (the position copy of the
@@ -1143,7 +1148,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         if (!(__hip_atomic_load(&g_bitmap[p >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (p & 31) & 1u)) atomicOr(&g_bitmap[p >> 5], 1u << (p & 31));
     };
     const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
-    uint32_t n_slow = 0, kept = 0;
+    uint32_t n_slow = 0, n_wide = 0, kept = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(qc[k]), "+v"(qs[k]), "+v"(qe[k]));
     for (unsigned long long r = blockIdx.x; r < n_rounds; r += A.grid) {
@@ -1246,6 +1251,11 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                         sweep |= (swp[k] || (hdr[k] & 255u) == 255u) ? 1u << k : 0u;
                     }
                     n_slow += __popc(sweep);
+                    if (sweep) {  // ... because of its width: a real row on a seqid that has windows (only the lanes with a sweep look)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            n_wide += (swp[k] && qe[k] > qs[k] && (cm[min(qc[k], n_chr)].z >> 8) != 0u) ? 1u : 0u;
+                    }
                     uint32_t d = deferred;
                     while (d) {
                         const int k = __ffs(d) - 1;
@@ -1296,7 +1306,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64), kept += __shfl_xor(kept, o, 64);
+    for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64), n_wide += __shfl_xor(n_wide, o, 64), kept += __shfl_xor(kept, o, 64);
     if (lane == 0 && kept) atomicAdd(s_total, (unsigned long long)kept);
     win_barrier();
     if (bm_words) {  // the block's bitmap into the block's slab
@@ -1306,7 +1316,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     }
     if (tid == 0 && out.block_sums) out.block_sums[blockIdx.x] = s_total[0];
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);
-    if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow);
+    if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow | ((unsigned long long)n_wide << 32));
 }
 
 // the blocks' slabs -> ORed into the batch's root bitmap: block x takes 64 words, its 16 rows of threads a sixteenth of the slabs each
