@@ -26,3 +26,6 @@ for i in range(3):
 t0 = time.perf_counter(); bm = b.root_bitmap(); lap("copy_root_bitmap", t0)
 t0 = time.perf_counter(); b.run(2, False, engine.OUT_FIDS | engine.OUT_OFFSETS); b.wait(); lap("run+wait (fids, offsets) first", t0)
 t0 = time.perf_counter(); b.run(2, False, engine.OUT_FIDS | engine.OUT_OFFSETS); b.wait(); lap("run+wait (fids, offsets) again", t0)
+t0 = time.perf_counter()
+ix2 = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"])
+lap("index_create again (warm process)", t0)
