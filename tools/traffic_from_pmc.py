@@ -3,7 +3,7 @@
 (KiB per dispatch) -> HBM bytes per launch and per pass, corrected as MI355X_MICROARCH.md prescribes
 (separate --pmc passes; FETCH_SIZE doubled: gfx950 reports half the bytes of a wide read).
 
-    python tools/traffic_from_pmc.py gpurun_out/<tag>_pmc.txt k_join_win [k_other ...] > profiles/traffic_latest.json
+    python tools/traffic_from_pmc.py gpurun_out/<tag>_pmc.txt k_join_pairs [k_other ...] > profiles/traffic_latest.json
 
 The file is stamped with the commit it was measured at (GFFX_COMMIT, else `git rev-parse`): bench.py prints that stamp next
 to the number, so a stale figure is visible as such.
