@@ -600,7 +600,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
     const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
-    uint32_t n_slow = 0, n_wide = 0;  // regions that took the exact sweep; ... because the lines do not answer their width (AUTO's census)
+    uint32_t n_slow = 0;  // regions that took the exact sweep | << 16: ... because the lines do not answer their width (AUTO's census; per lane: < 2^16)
     // (the wide form: its own line table {coordinates | rank, list-tail header}; the root_fids by position, allocated 4 words
     //  beyond the last root)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
@@ -852,10 +852,10 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 }
                 if (deferred) {
                     n_slow += __popc(sweep);
-                    if (sweep) {  // ... because of its width: a real row on a seqid that has windows (only the lanes with a sweep look)
+                    if (sweep) {  // ... because of its width -- a real row on a seqid that has windows -- in the counter's upper half
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            n_wide += (swp[k] && qe[k] > qs[k] && (cm[min(qc[k], n_chr)].z >> 8) != 0u) ? 1u : 0u;
+                            n_slow += (swp[k] && qe[k] > qs[k] && (cm[min(qc[k], n_chr)].z >> 8) != 0u) ? 0x10000u : 0u;
                     }
                     uint32_t d = deferred;
                     while (d) {
@@ -1078,6 +1078,8 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 #pragma unroll
     for (int i = P - 1; i >= 0; --i) finish(i);
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);
+    uint32_t n_wide = n_slow >> 16;
+    n_slow &= 0xFFFFu;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64), n_wide += __shfl_xor(n_wide, o, 64);
     if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow | ((unsigned long long)n_wide << 32));
@@ -1148,7 +1150,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         if (!(__hip_atomic_load(&g_bitmap[p >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (p & 31) & 1u)) atomicOr(&g_bitmap[p >> 5], 1u << (p & 31));
     };
     const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
-    uint32_t n_slow = 0, n_wide = 0, kept = 0;
+    uint32_t n_slow = 0, kept = 0;  // (n_slow: as in k_join_pairs)
 #pragma unroll
     for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(qc[k]), "+v"(qs[k]), "+v"(qe[k]));
     for (unsigned long long r = blockIdx.x; r < n_rounds; r += A.grid) {
@@ -1251,10 +1253,10 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                         sweep |= (swp[k] || (hdr[k] & 255u) == 255u) ? 1u << k : 0u;
                     }
                     n_slow += __popc(sweep);
-                    if (sweep) {  // ... because of its width: a real row on a seqid that has windows (only the lanes with a sweep look)
+                    if (sweep) {  // ... because of its width -- a real row on a seqid that has windows -- in the counter's upper half
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            n_wide += (swp[k] && qe[k] > qs[k] && (cm[min(qc[k], n_chr)].z >> 8) != 0u) ? 1u : 0u;
+                            n_slow += (swp[k] && qe[k] > qs[k] && (cm[min(qc[k], n_chr)].z >> 8) != 0u) ? 0x10000u : 0u;
                     }
                     uint32_t d = deferred;
                     while (d) {
@@ -1305,6 +1307,8 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             }
         }
     }
+    uint32_t n_wide = n_slow >> 16;
+    n_slow &= 0xFFFFu;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_slow += __shfl_xor(n_slow, o, 64), n_wide += __shfl_xor(n_wide, o, 64), kept += __shfl_xor(kept, o, 64);
     if (lane == 0 && kept) atomicAdd(s_total, (unsigned long long)kept);
