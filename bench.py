@@ -94,6 +94,39 @@ def parse_args():
     return ap.parse_args()
 
 
+def rank_placement(env, n_devices):
+    """(rank, world, local_rank, device index) of this process: the driver launches one rank per GPU through
+    torch.distributed.run, so LOCAL_RANK r takes device r; with fewer devices than ranks (the 1-GPU box of the gloo tests) the
+    ranks wrap around the devices that exist."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    local_rank = int(env.get("LOCAL_RANK", "0"))
+    if n_devices < 1:
+        raise RuntimeError("no HIP device")
+    return rank, world, local_rank, local_rank % n_devices
+
+
+def bench_regions(synth, shard, n_chr, world, rank, scaling="weak", queries_per_gpu=1_000_000, strong_total=100_000_000, region_width=None):
+    """This rank's regions: weak scaling = its chromosome-bucket shard of an N x --queries-per-gpu batch of configs[1]'s seed,
+    strong scaling = its shard of configs[3]'s batch (seed 1003; commands/intersect.rs:114-120 buckets by seqid, the shards are
+    LPT-placed bucket slices).  Returns (regions, global region count, configuration name)."""
+    strong = scaling == "strong" and world > 1
+    if strong:
+        nq_global, seed, cfg = strong_total, 1003, "configs[3]"
+    else:
+        nq_global, seed, cfg = queries_per_gpu * world, 1001, "configs[1]"
+    if region_width:
+        regions_all = synth.synth_bed(nq_global, seed=seed, width=tuple(region_width))
+        cfg += " with region widths U[%d, %d] (NOT the configuration's: --region-width)" % tuple(region_width)
+    else:
+        regions_all = synth.synth_bed(nq_global, seed=seed)
+    if world > 1:
+        regions = np.ascontiguousarray(regions_all[shard.shard_rows(regions_all, n_chr, world, rank)])
+    else:
+        regions = regions_all
+    return regions, nq_global, cfg
+
+
 def host_info():
     model = "unknown"
     try:
@@ -481,9 +514,7 @@ def e2e_leg(synth, roots, regions, tmp):
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank, _ = rank_placement(os.environ, 1)
     if world != args.gpus:
         if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
             # invoked like the 1-GPU run: start the ranks as fresh child processes (this process has not touched the GPU and
@@ -499,6 +530,12 @@ def main():
         args.gpus = world
     if args.exchange is None:
         args.exchange = "final-timed" if (args.scaling == "strong" and world > 1) else "final"
+    # stdout carries ONE thing: rank 0's JSON line.  Everything else a rank prints -- gloo's and RCCL's C++ banners included,
+    # which go to file descriptor 1 behind Python's back -- is sent to stderr: fd 1 becomes a copy of fd 2 from here on, and the
+    # line is written to the descriptor that was stdout when the process started.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -511,7 +548,7 @@ def main():
     # GFFX_BENCH_BACKEND=gloo lets the N>1 plumbing be exercised on a 1-GPU box (all ranks share device 0); the driver's
     # runs use nccl (= RCCL over xGMI), one rank per GPU.
     backend = os.environ.get("GFFX_BENCH_BACKEND", "nccl")
-    dev_index = local_rank % torch.cuda.device_count()
+    dev_index = rank_placement(os.environ, torch.cuda.device_count())[3]
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -536,20 +573,8 @@ def main():
     roots = synth.gencode_like_roots(63000, seed=42)
     n_chr = len(roots["chr_offsets"]) - 1
     strong = args.scaling == "strong" and world > 1
-    if strong:
-        nq_global, seed, cfg = args.strong_total, 1003, "configs[3]"
-    else:
-        nq_global, seed, cfg = args.queries_per_gpu * world, 1001, "configs[1]"
-    if args.region_width:
-        regions_all = synth.synth_bed(nq_global, seed=seed, width=tuple(args.region_width))
-        cfg += " with region widths U[%d, %d] (NOT the configuration's: --region-width)" % tuple(args.region_width)
-    else:
-        regions_all = synth.synth_bed(nq_global, seed=seed)
-    if world > 1:
-        regions = np.ascontiguousarray(regions_all[shard.shard_rows(regions_all, n_chr, world, rank)])
-    else:
-        regions = regions_all
-    del regions_all
+    regions, nq_global, cfg = bench_regions(synth, shard, n_chr, world, rank, args.scaling, args.queries_per_gpu, args.strong_total,
+                                            args.region_width)
     if args.presort == "chr_end":
         regions = np.ascontiguousarray(regions[np.lexsort((regions[:, 2], regions[:, 0]))])
     nq = len(regions)
@@ -669,7 +694,7 @@ def main():
                 "workload": "BASELINE %s: %d synthetic BED regions %s (seed %d) x GENCODE/GRCh38-shaped index (25 seqids, %d root "
                             "genes, seed 42), --%s, regions resident in HBM as u32 SoA; one step = %d passes over the resident batch "
                             "(one kernel launch per pass)"
-                            % (cfg, nq_global if strong else args.queries_per_gpu, "in total" if strong else "per GPU", seed,
+                            % (cfg, nq_global if strong else args.queries_per_gpu, "in total" if strong else "per GPU", 1003 if strong else 1001,
                                ix.n_roots, args.mode, args.passes_per_step),
                 "regions_total": nq_total,
                 "kept_pairs_total": pairs_total,
@@ -797,7 +822,8 @@ def main():
     elif rank == 0:
         result["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

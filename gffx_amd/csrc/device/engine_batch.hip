@@ -486,6 +486,13 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         if ((rc = dev_alloc(&b->d_bitmap, ((size_t)b->ix->n_roots + 31) / 32 + 1))) return rc;
         GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));  // (GFFX_OUT_BITMAP_KEEP on a first pass)
     }
+    // A new set of roots (no GFFX_OUT_BITMAP_KEEP) starts from nothing WHATEVER strategy serves it: the slabs an earlier, unwaited
+    // root pass of the windows strategy left behind must not be folded into it at the wait (windows_pack_roots runs for every
+    // strategy).  run_windows marks the flags dirty again for its own passes.
+    if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !(b->flags & GFFX_OUT_BITMAP_KEEP)) {
+        b->slab_valid = 0;
+        b->root_flags_dirty = false;
+    }
     if (nq == 0) {
         if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !(b->flags & GFFX_OUT_BITMAP_KEEP))
             GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));

@@ -21,9 +21,10 @@ def _run_bench(extra):
                         "--passes-per-step", "10", "--repeats", "2", "--no-traffic", "--cpu-seconds", "1"] + extra,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    # stdout is the ONE JSON line and nothing else (gloo's / RCCL's banners go to stderr): a driver may json.loads() it whole
+    line = json.loads(r.stdout)
+    assert r.stdout.count("\n") == 1, r.stdout[-2000:]
+    return line
 
 
 def _oracle_pairs(n, seed):
@@ -47,6 +48,13 @@ def test_bench_two_ranks_weak_scaling_line():
     assert line["roofline"]["frac"] > 0 and line["roofline"]["traffic"]["hbm_bytes_per_launch"] is None  # (not copied from a file)
     cb = line["cpu_baseline"]
     assert cb and cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0  # a real baseline on the N > 1 line as well
+
+
+def test_committed_two_rank_line_is_valid_json():
+    """profiles/r05_bench_gpus2_gloo.json is what `bench.py --gpus 2` printed on stdout, as it was printed."""
+    with open(os.path.join(ROOT, "profiles", "r05_bench_gpus2_gloo.json")) as fh:
+        line = json.load(fh)
+    assert line["n_gpus"] == 2 and line["config"]["regions_total"] == 2_000_000
 
 
 def test_bench_two_ranks_strong_scaling_line():

@@ -528,6 +528,43 @@ def test_offsets32_and_bitmap_accumulation():
     ix.close()
 
 
+@pytest.mark.parametrize("second", [engine.STRATEGY_FUSED, engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, "empty"])
+def test_unwaited_windows_root_pass_does_not_leak_into_the_next_strategys_roots(second):
+    """A root pass of the windows strategy leaves its roots in per-block slabs that are folded at the wait.  A NEW set of roots
+    (no GFFX_OUT_BITMAP_KEEP) asked from another strategy -- or from an empty batch -- before anybody waited must not get the
+    earlier pass's slabs folded into it (round 4's advisor finding: the slab state was only reset inside run_windows)."""
+    roots = synth.gencode_like_roots(4000, seed=21)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    regions = synth.synth_bed(20000, seed=22, edge_frac=0.02, roots=roots)
+    first, rest = regions[:15000], regions[15000:15400]
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(first)
+    b.run(OverlapMode.Overlap, False, engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)  # not waited
+    if second == "empty":
+        b.set_regions(rest[:0])
+        b.run(OverlapMode.Contained, False, engine.OUT_ROOT_BITMAP)
+        b.wait()
+        assert len(b.unique_roots()) == 0
+    else:
+        b.set_regions(rest)
+        b.run(OverlapMode.Contained, False, engine.OUT_ROOT_BITMAP, second)
+        b.wait()
+        want_t, _ = oix.query_features(rest, int(OverlapMode.Contained), False)
+        assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    # ... and the windows strategy still accumulates across passes when asked to
+    b.set_regions(first)
+    b.run(OverlapMode.Overlap, False, engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)
+    b.set_regions(rest)
+    b.run(OverlapMode.Overlap, False, engine.OUT_ROOT_BITMAP | engine.OUT_BITMAP_KEEP, engine.STRATEGY_WINDOWS)
+    b.wait()
+    want_t, _ = oix.query_features(np.concatenate([first, rest]), int(OverlapMode.Overlap), False)
+    assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
+    b.close()
+    ix.close()
+
+
 @pytest.mark.parametrize("shift", [0, 1, 3])
 def test_device_resident_regions_aligned_and_unaligned(shift):
     """The zero-copy path of bench.py: three device-resident u32 columns borrowed by pointer (allocated here with

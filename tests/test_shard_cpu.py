@@ -145,3 +145,37 @@ def test_cpp_plan_of_the_cli_equals_the_python_plan():
             got[r].append((c, lo, hi))
         L.gffx_host_free(out)
         assert got == shard.plan_shards(sizes.tolist(), n_ranks), (sizes, n_ranks)
+
+
+def test_bench_rank_placement_and_strong_scaling_shards():
+    """What `bench.py --gpus 8` does with its environment, without a GPU: LOCAL_RANK r takes device r (wrapping only when the
+    box has fewer devices than ranks), and --scaling strong gives rank r exactly shard_rows(configs[3]'s batch, 8, r) -- the
+    partition tests/test_fullsize_gpu.py::test_config3_100m_regions_sharded_over_8_ranks runs through one GPU (here at 1/50 of
+    its size: the plan is a function of the bucket sizes only)."""
+    import bench
+
+    for r in range(8):
+        env = {"WORLD_SIZE": "8", "RANK": str(r), "LOCAL_RANK": str(r)}
+        assert bench.rank_placement(env, 8) == (r, 8, r, r)
+        assert bench.rank_placement(env, 1) == (r, 8, r, 0)
+        assert bench.rank_placement(env, 2)[3] == r % 2
+    assert bench.rank_placement({}, 4) == (0, 1, 0, 0)
+    with pytest.raises(RuntimeError):
+        bench.rank_placement({}, 0)
+    n_chr, total = 25, 2_000_000
+    ref = synth.synth_bed(total, seed=1003)
+    seen = np.zeros(total, dtype=np.int32)
+    sizes = []
+    for r in range(8):
+        part, nq_global, cfg = bench.bench_regions(synth, shard, n_chr, 8, r, "strong", strong_total=total)
+        rows = shard.shard_rows(ref, n_chr, 8, r)
+        assert nq_global == total and cfg == "configs[3]" and np.array_equal(part, ref[rows])
+        seen[rows] += 1
+        sizes.append(len(rows))
+    assert (seen == 1).all() and max(sizes) <= 1.03 * total / 8
+    # weak scaling: N x 1 M of configs[1]'s seed, sharded the same way; one rank: the batch itself
+    part, nq_global, cfg = bench.bench_regions(synth, shard, n_chr, 2, 1, "weak", queries_per_gpu=50_000)
+    ref = synth.synth_bed(100_000, seed=1001)
+    assert nq_global == 100_000 and cfg == "configs[1]" and np.array_equal(part, ref[shard.shard_rows(ref, n_chr, 2, 1)])
+    part, nq_global, _ = bench.bench_regions(synth, shard, n_chr, 1, 0, "strong", queries_per_gpu=30_000)
+    assert nq_global == 30_000 and np.array_equal(part, synth.synth_bed(30_000, seed=1001))
