@@ -252,16 +252,14 @@ class Pass:
         the measured passes must use (the engine takes 1024-thread blocks for a 0.5-2.5 M-region pass that runs ALONE and
         512-thread blocks while another batch is in flight: serial passes measured for a timed region with two batches in
         flight have to be told which kernel that region ran)."""
-        before = os.environ.get("GFFX_HIP_WIN_THREADS")
+        b0 = self.batches[0]
+        before = b0.options().get("GFFX_HIP_WIN_THREADS", 0)
         if block_threads:
-            os.environ["GFFX_HIP_WIN_THREADS"] = str(block_threads)
+            b0.set_option("WIN_THREADS", block_threads)
         try:
             return self._kernel_us(n_prof)
         finally:
-            if before is None:
-                os.environ.pop("GFFX_HIP_WIN_THREADS", None)
-            else:
-                os.environ["GFFX_HIP_WIN_THREADS"] = before
+            b0.set_option("WIN_THREADS", before)
 
     def _kernel_us(self, n_prof):
         b0 = self.batches[0]
@@ -712,6 +710,9 @@ def main():
                                 "final": "once per job, after the K timed steps (exchange_ms)"}[args.exchange])
                             if world > 1 else "none (1 GPU)",
                 "exchange_ms": exchange_ms,
+                # GFFX_HIP_* tuning knobs that were NOT at their defaults for this run ({}: all defaults), as the index / the timed
+                # batches read them when they were created
+                "knobs": {**ix.options(), **run.batches[0].options()},
             },
             "roofline": roofline_obj(kern, nq, pairs, out_b,
                                      "achieved = (12 B region + 4 B count + 4 B x pairs/region) x regions / summed HIP-event "

@@ -16,6 +16,7 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
     GFFX_HIP_TRY(hipSetDevice(ix->device));
     std::unique_ptr<gffx_hip_batch> b(new gffx_hip_batch);
     b->ix = ix;
+    b->knobs.read_env(kBatchKnobs);  // the one place the passes' environment is read (later changes: gffx_hip_batch_set_option)
     b->max_q = max_queries;
     int rc;
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
@@ -58,6 +59,7 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     (void)hipFree(b->d_offsets32);
     (void)hipFree(b->d_segbase);
     (void)hipFree(b->d_slabs);
+    (void)hipFree(b->d_lb_status);
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_cursor);
     (void)hipFree(b->d_q_rec);
@@ -78,17 +80,19 @@ int gffx::batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who) {
 // than a window line answers; then already the batch's FIRST pass takes the wide form of the window kernel, or the sweep kernel
 // (a one-shot caller -- gffx_hip_query_features -- has no second pass to learn for).  A speed matter only; the first waited pass
 // of the narrow form replaces the prior with its count.  GFFX_HIP_WIDTH_SAMPLE=0: no prior (tests of the learning path).
-void gffx::sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *start, const uint32_t *end, size_t stride) {
-    if (!rows || !env_long("GFFX_HIP_WIDTH_SAMPLE", 1, 0, 1)) return;
-    const uint32_t wmax = (uint32_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
+// A row is "wide" when the window lines of ITS seqid do not answer its width (h_wmax[chr]: 4 .. 32766 depending on the seqid's
+// window width, 0 when the seqid has no windows -- such rows take the sweep whatever their width and are not counted here).
+void gffx::sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride,
+                         const std::vector<uint32_t> &h_wmax) {
     for (uint64_t i = 0; i < rows; i += step, ++w.n) {
-        const uint32_t s = start[i * stride], e = end[i * stride];
-        w.wide += (e > s && e - s > wmax) ? 1 : 0;
+        const uint32_t c = chr[i * stride], s = start[i * stride], e = end[i * stride];
+        const uint32_t wmax = c < h_wmax.size() ? h_wmax[c] : 0u;
+        w.wide += (wmax && e > s && e - s > wmax) ? 1 : 0;
     }
 }
-static bool sample_mostly_wide(uint64_t nq, const uint32_t *start, const uint32_t *end, size_t stride) {
+static bool sample_mostly_wide(const gffx_hip_batch *b, uint64_t nq, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride) {
     WidthSample w;
-    sample_widths(w, nq, std::max<uint64_t>(1, nq / 4096), start, end, stride);
+    if (nq && b->knobs.v[BK_WIDTH_SAMPLE]) sample_widths(w, nq, std::max<uint64_t>(1, nq / 4096), chr, start, end, stride, b->ix->h_win_wmax);
     return w.mostly_wide();
 }
 
@@ -104,7 +108,7 @@ extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t
     b->q = QueryView{b->d_regions, nullptr, nullptr, nullptr};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = b->mostly_wide = sample_mostly_wide(nq, regions + 1, regions + 2, 3);
+    b->mostly_slow = b->mostly_wide = sample_mostly_wide(b, nq, regions, regions + 1, regions + 2, 3);
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -126,7 +130,7 @@ extern "C" int gffx_hip_batch_set_regions_soa_host(gffx_hip_batch *b, const uint
     b->q = QueryView{nullptr, dc, ds, de};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = b->mostly_wide = sample_mostly_wide(nq, start, end, 1);
+    b->mostly_slow = b->mostly_wide = sample_mostly_wide(b, nq, chr, start, end, 1);
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -146,6 +150,15 @@ extern "C" int gffx_hip_batch_set_regions_device(gffx_hip_batch *b, const uint32
     return GFFX_OK;
 }
 
+
+extern "C" int gffx_hip_batch_set_option(gffx_hip_batch *b, const char *name, long value) {
+    if (!b || !name) return fail(GFFX_E_INVALID, "gffx_hip_batch_set_option: NULL argument");
+    if (!b->knobs.set(kBatchKnobs, name, value)) return fail(GFFX_E_INVALID, "gffx_hip_batch_set_option: no knob '%s', or %ld is outside its range", name, value);
+    return GFFX_OK;
+}
+extern "C" int gffx_hip_batch_options(const gffx_hip_batch *b, char *buf, size_t cap) {
+    return copy_out(b ? b->knobs.json(kBatchKnobs) : std::string("{}"), buf, cap);
+}
 
 extern "C" int gffx_hip_batch_reserve_hits(gffx_hip_batch *b, uint64_t n_pairs) {
     if (!b) return fail(GFFX_E_INVALID, "reserve_hits: batch is NULL");
@@ -257,7 +270,7 @@ static int enqueue_emit(gffx_hip_batch *b) {
 static int partition_prepare(gffx_hip_batch *b) {
     if (b->d_rec) return GFFX_OK;
     const gffx_hip_index *ix = b->ix;
-    const uint64_t budget = (uint64_t)env_long("GFFX_HIP_PARTITION_BUDGET_MB", 12 * 1024, 1, 256 * 1024) << 20;
+    const uint64_t budget = (uint64_t)b->knobs.v[BK_PARTITION_BUDGET_MB] << 20;
     uint64_t cap = std::max<uint64_t>(b->max_q, 1);
     const uint64_t fit = budget / (16ull * ix->n_tiles);
     if (cap > fit) cap = std::max<uint64_t>(fit / kPartChunk * kPartChunk, kPartChunk);
@@ -318,7 +331,7 @@ static int run_partitioned(gffx_hip_batch *b) {
     ja.cap = b->sub_cap;
     // every block takes an equal share of the batch; 2 blocks of 512 threads per CU keep the whole
     // grid resident and the pair cursor at <= 512 same-line atomics per round
-    const uint32_t join_blocks = (uint32_t)env_long("GFFX_HIP_JOIN_BLOCKS", 512, 1, 65535);
+    const uint32_t join_blocks = (uint32_t)b->knobs.v[BK_JOIN_BLOCKS];
     for (uint64_t q0 = 0; q0 < b->nq; q0 += b->sub_cap) {
         ja.q0 = q0;
         const uint32_t n = (uint32_t)std::min<uint64_t>(b->sub_cap, b->nq - q0);
@@ -394,7 +407,7 @@ static int run_fused(gffx_hip_batch *b) {
     if (o.triples) cap = std::min(cap, b->cap_triples);
     o.capacity = cap;
     const uint64_t rounds = (b->nq + kFusedChunk - 1) / kFusedChunk;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)env_long("GFFX_HIP_FUSED_BLOCKS", 1024, 1, 65535));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)(b->knobs.v[BK_FUSED_BLOCKS] ? b->knobs.v[BK_FUSED_BLOCKS] : 1024));
     const bool aos = b->q.aos != nullptr;
     const bool ml = meta_bytes(b->ix) <= kMetaLdsBytes;
     ProfEvent pe;
@@ -423,7 +436,7 @@ static int pick_strategy(const gffx_hip_batch *b, int strategy) {
     if (strategy == GFFX_STRATEGY_SORTED) return part_ok ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_DIRECT;
     if (strategy != GFFX_STRATEGY_AUTO) return strategy;
     // GFFX_HIP_AUTO_STRATEGY overrides for experiments
-    const long forced = env_long("GFFX_HIP_AUTO_STRATEGY", 0, 1, 5);
+    const long forced = b->knobs.v[BK_AUTO_STRATEGY] == 4 ? 0 : b->knobs.v[BK_AUTO_STRATEGY];  // (4: the retired slots strategy)
     if (forced == GFFX_STRATEGY_SORTED) return part_ok ? GFFX_STRATEGY_SORTED : GFFX_STRATEGY_FUSED;
     if (forced) return (int)forced;
     return b->mostly_slow ? GFFX_STRATEGY_FUSED : GFFX_STRATEGY_WINDOWS;
@@ -452,7 +465,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     // the wide form of the window kernels; the other modes stay with the sweep kernel.  GFFX_HIP_WIN_WIDE: 0 = never, 2 = every
     // eligible pass of the windows strategy (tests).
     {
-        const long ww = env_long("GFFX_HIP_WIN_WIDE", 1, 0, 2);
+        const long ww = b->knobs.v[BK_WIN_WIDE];
         const bool eligible = mode == GFFX_MODE_OVERLAP && !invert && b->ix->win_range_ok;
         b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && b->strategy == GFFX_STRATEGY_FUSED && b->mostly_wide) ||
                                (ww == 2 && b->strategy == GFFX_STRATEGY_WINDOWS));
@@ -510,11 +523,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     }
     // contiguous chunk of queries per block, a multiple of the block size; <= 2048 blocks
     const uint64_t tiles = (nq + kJoinThreads - 1) / kJoinThreads;
-    uint64_t max_blocks = 2048;  // 8 resident 256-thread blocks per CU
-    if (const char *e = getenv("GFFX_HIP_MAX_BLOCKS")) {  // experiments only
-        const long v = strtol(e, nullptr, 10);
-        if (v >= 1 && v <= (long)gffx_hip_batch::kMaxBlocks) max_blocks = (uint64_t)v;
-    }
+    const uint64_t max_blocks = (uint64_t)b->knobs.v[BK_MAX_BLOCKS];  // default 2048: 8 resident 256-thread blocks per CU
     const uint64_t tiles_per_block = (tiles + max_blocks - 1) / max_blocks;
     b->chunk = tiles_per_block * kJoinThreads;
     b->n_blocks = (uint32_t)((nq + b->chunk - 1) / b->chunk);
@@ -573,6 +582,10 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     if (b->h_status[0] & 2ull) {
         GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
         return fail(GFFX_E_HIP, "internal: the dynamic LDS of a windows pass does not start at LDS address 0");
+    }
+    if (b->h_status[0] & 4ull) {
+        GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
+        return fail(GFFX_E_HIP, "internal: a windows pass gave up waiting for the pair counts of the blocks before it (look-back)");
     }
     if (b->h_status[0] & 1ull) {
         // the flag is sticky on the device (kernels only ever set it): clear it for the next pass

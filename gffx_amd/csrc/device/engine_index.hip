@@ -34,11 +34,12 @@ int fail(int code, const char *fmt, ...) {
 // Returns 1 when the directory does not fit at this coarseness.
 static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
                                  const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
-                                 std::vector<uint4> &win_pos, std::vector<uint4> &spill, uint32_t coarsen, uint64_t max_lines) {
+                                 std::vector<uint4> &win_pos, std::vector<uint4> &spill, uint32_t coarsen, uint64_t max_lines,
+                                 const Knobs<IK__COUNT> &K) {
     meta.assign(n_chr + 1, make_uint4(0, 0, 0, 0));  // (+ one zero entry: a kernel may read one past the end)
     win.clear(), win_pos.clear(), spill.clear();
-    const uint64_t per_entry = (uint64_t)env_long("GFFX_HIP_WIN_PER_ENTRY", 2, 1, 16);
-    const uint64_t wmax_min = (uint64_t)env_long("GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30);
+    const uint64_t per_entry = (uint64_t)K.v[IK_WIN_PER_ENTRY];
+    const uint64_t wmax_min = (uint64_t)K.v[IK_SLOT_WMAX];
     auto win_wmax = [&](uint32_t shift) {  // widest region the lines answer: 16 Ki, but between 1/4 and 4 windows,
         const uint64_t w = 1ull << shift;  // and W + wmax + 1 <= 65535 (16-bit relative coordinates)
         return std::min<uint64_t>(std::max<uint64_t>(w >> 2, std::min<uint64_t>(wmax_min, w << 2)), 65534 - w);
@@ -128,11 +129,11 @@ static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, co
 
 static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
                               const std::vector<uint4> &h_aux, std::vector<uint4> &meta, std::vector<uint4> &win,
-                              std::vector<uint4> &win_pos, std::vector<uint4> &spill) {
+                              std::vector<uint4> &win_pos, std::vector<uint4> &spill, const Knobs<IK__COUNT> &K) {
     // (GFFX_HIP_WIN_MAX_LINES: tests shrink the limit to reach the coarsening path with small indexes)
-    const uint64_t max_lines = (uint64_t)env_long("GFFX_HIP_WIN_MAX_LINES", 1l << 25, 64, 1l << 25);
+    const uint64_t max_lines = (uint64_t)K.v[IK_WIN_MAX_LINES];
     for (uint32_t coarsen = 0; coarsen < 40; ++coarsen) {
-        const int rc = build_window_index_at(n_chr, chr_offsets, h_start, h_aux, meta, win, win_pos, spill, coarsen, max_lines);
+        const int rc = build_window_index_at(n_chr, chr_offsets, h_start, h_aux, meta, win, win_pos, spill, coarsen, max_lines, K);
         if (rc <= 0) return rc;
     }
     return fail(GFFX_E_INVALID, "index too large for the window directory (%u seqids need more than 2^25 lines)", n_chr);
@@ -148,10 +149,10 @@ static int build_window_index(uint32_t n_chr, const uint32_t *chr_offsets, const
 static void build_window_splits(uint32_t n_chr, const std::vector<uint32_t> &h_start, const std::vector<uint4> &h_aux,
                                 const std::vector<uint4> &meta, const std::vector<uint4> &win, const std::vector<uint4> &win_pos,
                                 std::vector<uint4> &spill, std::vector<uint32_t> &bits, std::vector<uint32_t> &sub_at,
-                                std::vector<uint4> &sub_lines, std::vector<uint4> &sub_lines_pos) {
+                                std::vector<uint4> &sub_lines, std::vector<uint4> &sub_lines_pos, const Knobs<IK__COUNT> &K) {
     bits.clear(), sub_at.clear(), sub_lines.clear(), sub_lines_pos.clear();
     const size_t n_win = win.size() / 2;
-    if (!n_win || !env_long("GFFX_HIP_WIN_SPLIT", 1, 0, 1)) return;
+    if (!n_win || !K.v[IK_WIN_SPLIT]) return;
     if ((uint64_t)n_win * ((1u << kWinSplit) + 1) * kWinLineBytes >= (1ull << 31)) return;
     const size_t nw = (n_win + 31) / 32;
     bits.assign((nw + 4) / 4 * 4, 0u);
@@ -261,11 +262,11 @@ static bool build_window_ranks(uint32_t n_chr, const uint32_t *chr_offsets, cons
 // (default 24 KB of LDS per block; 48 KB measured 1.5 % faster at 10 M regions, 1.5 % slower at 1 M), but never so small that a region the lines answer (width <= wmax) spans more than 32 cells.
 static void build_window_filter(uint32_t n_chr, const uint32_t *chr_offsets, const std::vector<uint32_t> &h_start,
                                 const std::vector<uint4> &h_aux, const std::vector<uint4> &win_meta, std::vector<uint32_t> &bits,
-                                std::vector<uint2> &fmeta, uint32_t &fshift) {
+                                std::vector<uint2> &fmeta, uint32_t &fshift, const Knobs<IK__COUNT> &K) {
     fmeta.assign(n_chr + 1, make_uint2(0, 0));
     bits.clear();
     fshift = 0;
-    const uint64_t budget_bits = (uint64_t)env_long("GFFX_HIP_WIN_FILTER_KB", 24, 0, 120) * 1024 * 8;
+    const uint64_t budget_bits = (uint64_t)K.v[IK_WIN_FILTER_KB] * 1024 * 8;
     if (!budget_bits) return;
     auto cells_of = [&](uint32_t c, uint32_t sh) -> uint64_t {
         const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
@@ -396,6 +397,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     std::vector<uint4> bins;
     std::vector<uint32_t> order, stack;
     std::unique_ptr<gffx_hip_index> ix(new gffx_hip_index);
+    ix->knobs.read_env(kIndexKnobs);  // the one place the index builders' environment is read
     ix->h_sorted_fids.resize(R);
     for (uint32_t c = 0; c < n_chr; c++) {
         const uint32_t lo = chr_offsets[c], hi = chr_offsets[c + 1];
@@ -421,7 +423,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
             continue;
         }
         const uint32_t max_start = h_start[hi - 1];
-        const uint64_t budget = std::max<uint64_t>((uint64_t)env_long("GFFX_HIP_BINS_PER_ENTRY", 2, 1, 64) * (hi - lo), 64);
+        const uint64_t budget = std::max<uint64_t>((uint64_t)ix->knobs.v[IK_BINS_PER_ENTRY] * (hi - lo), 64);
         uint32_t shift = 0;
         while ((((uint64_t)max_start >> shift) + 1) > budget) shift++;
         const uint32_t nb = (max_start >> shift) + 1;
@@ -442,13 +444,16 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
 
     chr_meta[n_chr] = make_uint4(R, R, (uint32_t)bins.size(), 0u);
     std::vector<uint4> win_meta, win, win_pos, win_spill;
-    if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill)) return wrc;
+    if (int wrc = build_window_index(n_chr, chr_offsets, h_start, h_aux, win_meta, win, win_pos, win_spill, ix->knobs)) return wrc;
+    // (AUTO's width sample measures a row against ITS seqid's limit: win_meta[c].w is still the plain wmax here; 0 = no windows)
+    ix->h_win_wmax.assign(n_chr, 0u);
+    for (uint32_t c = 0; c < n_chr; c++) ix->h_win_wmax[c] = chr_offsets[c + 1] == chr_offsets[c] ? 0xFFFFFFu : win_meta[c].w;
     ix->n_win = (uint32_t)(win.size() / 2);
     // split windows (gffx_device.hpp): their sub-lines, compact on the host ({line number, line} pairs), scattered into the
     // zeroed second level on the device
     std::vector<uint32_t> win_splittab, sub_at;
     std::vector<uint4> sub_lines, sub_lines_pos;
-    build_window_splits(n_chr, h_start, h_aux, win_meta, win, win_pos, win_spill, win_splittab, sub_at, sub_lines, sub_lines_pos);
+    build_window_splits(n_chr, h_start, h_aux, win_meta, win, win_pos, win_spill, win_splittab, sub_at, sub_lines, sub_lines_pos, ix->knobs);
     ix->win_swords = win_splittab.empty() ? 0u : (uint32_t)((ix->n_win + 31) / 32);
     std::vector<uint2> win_rank;
     std::vector<uint32_t> wide_at;
@@ -478,7 +483,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     }
     std::vector<uint32_t> win_filter;
     std::vector<uint2> win_fmeta;
-    build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift);
+    build_window_filter(n_chr, chr_offsets, h_start, h_aux, win_meta, win_filter, win_fmeta, ix->win_fshift, ix->knobs);
     // the kernel's seqid record: {first window, windows, shift | wmax << 8, first filter bit}
     // (a seqid without windows AND without roots -- and the extra record -- answers "fits, but beyond my last window" for every
     //  sane row: wmax = 2^24 - 1, no windows; only its empty / reversed / absurdly wide rows reach the sweep, which returns at once)
@@ -653,6 +658,9 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
 }
 
 extern "C" uint32_t gffx_hip_index_n_chr(const gffx_hip_index *ix) { return ix ? ix->n_chr : 0; }
+extern "C" int gffx_hip_index_options(const gffx_hip_index *ix, char *buf, size_t cap) {
+    return copy_out(ix ? ix->knobs.json(kIndexKnobs) : std::string("{}"), buf, cap);
+}
 extern "C" uint64_t gffx_hip_index_n_roots(const gffx_hip_index *ix) { return ix ? ix->n_roots : 0; }
 extern "C" int gffx_hip_index_device(const gffx_hip_index *ix) { return ix ? ix->device : -1; }
 extern "C" const uint32_t *gffx_hip_index_sorted_fids(const gffx_hip_index *ix) {

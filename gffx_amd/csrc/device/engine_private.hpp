@@ -10,6 +10,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
@@ -38,6 +39,66 @@ inline long env_long(const char *name, long dflt, long lo, long hi) {
         if (v >= lo && v <= hi) return v;
     }
     return dflt;
+}
+
+// ---- tuning knobs (GFFX_HIP_*) -----------------------------------------------------------------------------------------
+// Read from the environment ONCE per object: an index's when it is created (a clone inherits them), a batch's when it is
+// created; afterwards a batch's knobs change only through gffx_hip_batch_set_option.  No launch reads the environment.
+// Values that differ from the defaults are reported (gffx_hip_index_options / gffx_hip_batch_options: `gffx ... --stats-json`,
+// bench.py's config).  Default 0 in a *_BLOCKS knob means "the engine's choice for that kernel".
+struct KnobDef {
+    const char *name;
+    long dflt, lo, hi;
+};
+enum IndexKnob { IK_WIN_PER_ENTRY, IK_SLOT_WMAX, IK_WIN_MAX_LINES, IK_WIN_SPLIT, IK_WIN_FILTER_KB, IK_BINS_PER_ENTRY, IK__COUNT };
+constexpr KnobDef kIndexKnobs[IK__COUNT] = {{"GFFX_HIP_WIN_PER_ENTRY", 2, 1, 16},         {"GFFX_HIP_SLOT_WMAX", 16384, 1, 1 << 30},
+                                            {"GFFX_HIP_WIN_MAX_LINES", 1l << 25, 64, 1l << 25}, {"GFFX_HIP_WIN_SPLIT", 1, 0, 1},
+                                            {"GFFX_HIP_WIN_FILTER_KB", 24, 0, 120},         {"GFFX_HIP_BINS_PER_ENTRY", 2, 1, 64}};
+enum BatchKnob {
+    BK_AUTO_STRATEGY, BK_FUSED_BLOCKS, BK_BITMAP_BLOCKS, BK_JOIN_BLOCKS, BK_MAX_BLOCKS, BK_PARTITION_BUDGET_MB, BK_WIDTH_SAMPLE, BK_WIN_THREADS,
+    BK_WIN_WIDE, BK_LOOKBACK, BK__COUNT
+};
+constexpr KnobDef kBatchKnobs[BK__COUNT] = {{"GFFX_HIP_AUTO_STRATEGY", 0, 0, 5},   {"GFFX_HIP_FUSED_BLOCKS", 0, 0, 65535},
+                                            {"GFFX_HIP_BITMAP_BLOCKS", 0, 0, 8192}, {"GFFX_HIP_JOIN_BLOCKS", 512, 1, 65535},
+                                            {"GFFX_HIP_MAX_BLOCKS", 2048, 1, 8192}, {"GFFX_HIP_PARTITION_BUDGET_MB", 12 * 1024, 1, 256 * 1024},
+                                            {"GFFX_HIP_WIDTH_SAMPLE", 1, 0, 1},     {"GFFX_HIP_WIN_THREADS", 0, 0, 1024},
+                                            {"GFFX_HIP_WIN_WIDE", 1, 0, 2},         {"GFFX_HIP_LOOKBACK", 1, 0, 1}};
+template <int N>
+struct Knobs {
+    long v[N];
+    void read_env(const KnobDef (&defs)[N]) {
+        for (int i = 0; i < N; ++i) v[i] = env_long(defs[i].name, defs[i].dflt, defs[i].lo, defs[i].hi);
+    }
+    // name: the variable's, with or without the GFFX_HIP_ prefix, any case.  false: no such knob, or a value out of its range.
+    bool set(const KnobDef (&defs)[N], const char *name, long value) {
+        auto same = [](const char *a, const char *b) {
+            for (; *a && *b; ++a, ++b)
+                if (toupper((unsigned char)*a) != toupper((unsigned char)*b)) return false;
+            return !*a && !*b;
+        };
+        for (int i = 0; i < N; ++i)
+            if (same(name, defs[i].name) || same(name, defs[i].name + 9)) {
+                if (value < defs[i].lo || value > defs[i].hi) return false;
+                v[i] = value;
+                return true;
+            }
+        return false;
+    }
+    // {"GFFX_HIP_X": value, ...} of the knobs that are not at their defaults
+    std::string json(const KnobDef (&defs)[N]) const {
+        std::string s = "{";
+        for (int i = 0; i < N; ++i)
+            if (v[i] != defs[i].dflt) s += std::string(s.size() > 1 ? ", " : "") + "\"" + defs[i].name + "\": " + std::to_string(v[i]);
+        return s + "}";
+    }
+};
+inline int copy_out(const std::string &s, char *buf, size_t cap) {  // snprintf's contract: the length needed, at most cap - 1 bytes + NUL written
+    if (buf && cap) {
+        const size_t n = std::min(s.size(), cap - 1);
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int)s.size();
 }
 
 template <typename T>
@@ -71,6 +132,8 @@ struct BusyCount {
 
 struct gffx_hip_index {
     int device = 0;
+    Knobs<IK__COUNT> knobs{};            // GFFX_HIP_* of the index builders, as read when the index was created
+    std::vector<uint32_t> h_win_wmax;    // per seqid: the widest region its window lines answer (0: no windows) -- AUTO's width sample
     uint32_t n_chr = 0;
     uint32_t n_roots = 0;
     uint32_t *d_start = nullptr;
@@ -143,6 +206,7 @@ struct ProfEvent {
 
 struct gffx_hip_batch {
     const gffx_hip_index *ix = nullptr;
+    Knobs<BK__COUNT> knobs{};  // GFFX_HIP_* of the passes, as read when the batch was created (gffx_hip_batch_set_option changes them)
     hipStream_t stream = nullptr;
     uint64_t max_q = 0, nq = 0;
     // inputs
@@ -168,6 +232,9 @@ struct gffx_hip_batch {
     uint32_t slab_valid = 0;                    // ... slabs that hold something since the last clear
     bool root_flags_dirty = false;              // ... newer than d_bitmap (windows_pack_roots)
     uint32_t roots_blocks = 0;                  // last pass was a root pass of its own: its blocks (their pair counts are in d_block_sums)
+    unsigned long long *d_lb_status = nullptr;  // windows strategy, pair passes of one round per block: the look-back's status words (PairArgs::lb_status)
+    uint32_t lb_tag = 0;                        // ... the tag of the last such pass (1 .. 65535; the words are cleared when it wraps)
+    static constexpr uint32_t kLbWords = 512;   // ... rounds of the largest such launch
     uint64_t cap_fids = 0, cap_triples = 0;
     uint64_t reserve = 0;
     // partitioned strategy workspace (allocated on first use)
@@ -215,7 +282,9 @@ struct WidthSample {
     uint64_t n = 0, wide = 0;
     bool mostly_wide() const { return 8 * wide > n; }  // (the same eighth as the learned rule in gffx_hip_batch_wait)
 };
-void sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *start, const uint32_t *end, size_t stride);
+// (chr may be nullptr: then every row is measured against `wmax_all`; with chr, against its seqid's own limit h_wmax[chr])
+void sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride,
+                   const std::vector<uint32_t> &h_wmax);
 int run_windows(gffx_hip_batch *b);  // engine_windows.hip
 int windows_pack_roots(gffx_hip_batch *b);
 int batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who);  // engine_batch.hip

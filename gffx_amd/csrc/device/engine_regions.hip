@@ -72,16 +72,19 @@ extern "C" int gffx_hip_regions_append_parts(gffx_hip_regions *R, int k, uint32_
     if (first + n_rows > R->cap_rows) return fail(GFFX_E_INVALID, "gffx_hip_regions_append: the store is full (%llu rows)", (unsigned long long)R->cap_rows);
     GFFX_HIP_TRY(hipSetDevice(R->device));
     uint64_t at = first;
-    WidthSample ws;  // (the rows are still in the staging buffer: ~4096 of them say whether the chunk is mostly wide regions)
+    // (the rows are still in the staging buffer: ~4096 of them will say whether the chunk is mostly wide regions)
+    std::vector<std::pair<uint32_t, uint32_t>> &sample = R->last_sample[k];
+    sample.clear();
+    const uint64_t step = std::max<uint64_t>(1, n_rows / 4096);
     for (uint32_t p = 0; p < n_parts; ++p) {
         if (part_rows[p]) {
             const uint32_t *rows = R->h_stage[k] + 3 * stage_first[p];
             GFFX_HIP_TRY(hipMemcpyAsync(R->d + 3 * at, rows, part_rows[p] * 12, hipMemcpyHostToDevice, R->stream));
-            sample_widths(ws, part_rows[p], std::max<uint64_t>(1, n_rows / 4096), rows + 1, rows + 2, 3);
+            for (uint64_t i = 0; i < part_rows[p]; i += step)
+                sample.emplace_back(rows[3 * i], rows[3 * i + 2] > rows[3 * i + 1] ? rows[3 * i + 2] - rows[3 * i + 1] : 0u);
         }
         at += part_rows[p];
     }
-    R->last_wide[k] = ws.mostly_wide();
     GFFX_HIP_TRY(hipEventRecord(R->copied[k], R->stream));
     R->pending[k] = true;
     R->last_first[k] = first;
@@ -101,7 +104,15 @@ extern "C" int gffx_hip_batch_set_regions_store(gffx_hip_batch *b, const gffx_hi
     b->q = QueryView{R->d + 3 * (R->last_first[k] + first), nullptr, nullptr, nullptr};
     b->nq = n_rows;
     b->have_regions = true;
-    b->mostly_slow = b->mostly_wide = R->last_wide[k];
+    {
+        WidthSample ws;
+        if (b->knobs.v[BK_WIDTH_SAMPLE])
+            for (const auto &row : R->last_sample[k]) {
+                const uint32_t wmax = row.first < b->ix->h_win_wmax.size() ? b->ix->h_win_wmax[row.first] : 0u;
+                ws.n++, ws.wide += (wmax && row.second > wmax) ? 1 : 0;
+            }
+        b->mostly_slow = b->mostly_wide = ws.mostly_wide();
+    }
     b->ran = b->waited = false;
     return GFFX_OK;
 }

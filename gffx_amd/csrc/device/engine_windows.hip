@@ -33,7 +33,7 @@ static uint32_t pairs_lds_bytes(const gffx_hip_index *ix, uint32_t threads, bool
 // reservation atomic (2048 or 4096) and whether two kernels can share a CU: 1024-thread blocks (one per CU) for a pass that
 // runs alone, 512 (two per CU) while another batch of the index has passes in flight.  GFFX_HIP_WIN_THREADS forces one.
 static uint32_t pair_threads(const gffx_hip_batch *b) {
-    const long forced = env_long("GFFX_HIP_WIN_THREADS", 0, 0, 1024);
+    const long forced = b->knobs.v[BK_WIN_THREADS];
     if (forced == 512 || forced == 1024) return (uint32_t)forced;
     return (!b->others_busy && b->nq >= 500000) ? 1024u : 512u;
 }
@@ -139,9 +139,8 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     if (lds > max_lds) return fail(GFFX_E_INVALID, "windows pass: %u bytes of LDS per block exceed the limit of %u", lds, max_lds);
     if (!roots) b->win_threads = threads;
     const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(
-        rounds, (uint64_t)env_long(roots ? "GFFX_HIP_BITMAP_BLOCKS" : "GFFX_HIP_FUSED_BLOCKS", threads == 1024 ? 256 : 512, 1,
-                                   roots ? (long)gffx_hip_batch::kMaxBlocks : 65535));
+    const long blocks_knob = b->knobs.v[roots ? BK_BITMAP_BLOCKS : BK_FUSED_BLOCKS];
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)(blocks_knob ? blocks_knob : (threads == 1024 ? 256 : 512)));
     if (roots && !second) b->roots_blocks = grid;
     if (roots && bm_words) {
         // one slab per block; the blocks below slab_valid OR into what their slab holds (passes since the last clear), the
@@ -188,6 +187,22 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     a.swords = swords;
     a.spill = ix->d_win_spill;
     a.grid = grid;
+    // Look-back instead of the reservation atomic (join_pairs_kernels.hpp, PairArgs::lb_status): pair passes whose blocks run one
+    // round each -- round = block number, so a block only waits for blocks with lower numbers.  GFFX_HIP_LOOKBACK=0: never.
+    if (!roots && rounds == grid && rounds >= 2 && rounds <= (threads == 1024 ? 256u : 512u) && b->knobs.v[BK_LOOKBACK]) {
+        if (!b->d_lb_status) {
+            int rc = dev_alloc(&b->d_lb_status, gffx_hip_batch::kLbWords);
+            if (rc) return rc;
+            b->lb_tag = 0;
+            GFFX_HIP_TRY(hipMemsetAsync(b->d_lb_status, 0, gffx_hip_batch::kLbWords * sizeof(unsigned long long), b->stream));
+        }
+        if (++b->lb_tag > 65535u) {  // the tags start over: no word of an earlier pass may look like one of a later pass
+            b->lb_tag = 1;
+            GFFX_HIP_TRY(hipMemsetAsync(b->d_lb_status, 0, gffx_hip_batch::kLbWords * sizeof(unsigned long long), b->stream));
+        }
+        a.lb_status = b->d_lb_status;
+        a.lb_tag = b->lb_tag;
+    }
     a.ix = ix->view();
     ProfEvent pe;
     int lrc = GFFX_OK;

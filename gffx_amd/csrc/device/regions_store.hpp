@@ -1,5 +1,7 @@
 // regions_store.hpp -- device-resident store of BED regions filled chunk by chunk (include/gffx_hip.h "region stores").
 #pragma once
+#include <utility>
+
 #include "gffx_device.hpp"
 
 struct gffx_hip_regions {
@@ -11,6 +13,7 @@ struct gffx_hip_regions {
     hipEvent_t copied[2] = {nullptr, nullptr};    // the last append from staging buffer k has completed
     bool pending[2] = {false, false};
     uint64_t last_first[2] = {0, 0}, last_n[2] = {0, 0};  // where the last append from buffer k went
-    bool last_wide[2] = {false, false};                    // ... and whether a sample of its rows was mostly wide (AUTO's prior)
+    std::vector<std::pair<uint32_t, uint32_t>> last_sample[2];  // ... and {seqid, width} of ~4096 of its rows (AUTO's prior: judged against the
+                                                                // index's per-seqid line widths when a batch takes the rows: the store knows no index)
     hipStream_t stream = nullptr;                 // copies
 };

@@ -41,6 +41,16 @@ KERNEL_NAMES = {K_JOIN_COUNT: "k_join_count", K_JOIN_EMIT: "k_join_emit", K_SORT
                 K_WINDOWS: "k_join_roots", K_BITMAP_OR: "k_bitmap_fold", K_WAVE: "k_join_pairs"}
 
 
+def _options(fn, handle) -> dict:
+    import json
+    buf = C.create_string_buffer(1024)
+    n = fn(handle, buf, len(buf))
+    if n >= len(buf):
+        buf = C.create_string_buffer(n + 1)
+        fn(handle, buf, len(buf))
+    return json.loads(buf.value.decode())
+
+
 def device_count() -> int:
     return lib().gffx_hip_device_count()
 
@@ -103,6 +113,10 @@ class TreeIndexData:
     def device(self) -> int:
         return lib().gffx_hip_index_device(self._h)
 
+    def options(self) -> dict:
+        """The index builders' GFFX_HIP_* knobs that were not at their defaults when the index was created."""
+        return _options(lib().gffx_hip_index_options, self._h)
+
     def sorted_fids(self) -> np.ndarray:
         n = self.n_roots
         if n == 0:  # (an index without roots has no array behind the pointer)
@@ -147,6 +161,14 @@ class QueryBatch:
         """Borrow three device arrays (raw pointers, e.g. torch.Tensor.data_ptr())."""
         self._keep = keep
         check(lib().gffx_hip_batch_set_regions_device(self._h, d_chr, d_start, d_end, int(nq)))
+
+    def set_option(self, name: str, value: int) -> None:
+        """A tuning knob of this batch's passes (include/gffx_hip.h "Tuning knobs"), e.g. ("WIN_THREADS", 512)."""
+        check(lib().gffx_hip_batch_set_option(self._h, name.encode(), int(value)))
+
+    def options(self) -> dict:
+        """The knobs of this batch that are not at their defaults (environment at creation + set_option)."""
+        return _options(lib().gffx_hip_batch_options, self._h)
 
     def reserve_hits(self, n_pairs: int) -> None:
         check(lib().gffx_hip_batch_reserve_hits(self._h, int(n_pairs)))

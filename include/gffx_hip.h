@@ -46,15 +46,24 @@
  * across this boundary.  There is NO CPU fallback: without a HIP device every compute entry
  * point fails with GFFX_E_NO_DEVICE.
  *
- * Environment (tuning and tests; results never depend on any of them):
- *   GFFX_HIP_WIN_THREADS=512|1024   block width of the window kernels (default: 1024 for a 0.5-2.5 M-region pass that runs alone)
+ * Tuning knobs (results never depend on any of them).  Each is an environment variable that is read ONCE per object -- the
+ * index builders' when gffx_hip_index_create runs (a clone inherits them), the passes' when gffx_hip_batch_create runs -- and a
+ * batch's can be changed afterwards with gffx_hip_batch_set_option(batch, "WIN_THREADS", 512).  No launch reads the environment.
+ * gffx_hip_index_options / gffx_hip_batch_options report the values that differ from the defaults as a JSON object
+ * (`gffx ... --stats-json` and bench.py's `config.knobs` carry it).
+ *   passes (batch):
+ *   GFFX_HIP_WIN_THREADS=0|512|1024 block width of the window kernels (0 = the engine's choice: 1024 for a pass of >= 500 000 regions
+ *                                   that runs alone, 512 otherwise)
  *   GFFX_HIP_WIN_WIDE=0|1|2         the wide form of the window kernels: never / AUTO's choice for mostly wide batches (default) /
  *                                   every eligible pass of the windows strategy
  *   GFFX_HIP_WIDTH_SAMPLE=0         no width sample of the rows the host hands over (AUTO then learns from a first waited pass)
- *   GFFX_HIP_AUTO_STRATEGY=n        what GFFX_STRATEGY_AUTO resolves to
- *   index build (read by gffx_hip_index_create): GFFX_HIP_SLOT_WMAX (widest region a window line answers, 16384),
- *   GFFX_HIP_WIN_PER_ENTRY, GFFX_HIP_WIN_SPLIT, GFFX_HIP_WIN_FILTER_KB, GFFX_HIP_WIN_MAX_LINES, GFFX_HIP_BINS_PER_ENTRY,
- *   GFFX_HIP_PARTITION_BUDGET_MB; launch sizes: GFFX_HIP_FUSED_BLOCKS, GFFX_HIP_BITMAP_BLOCKS, GFFX_HIP_JOIN_BLOCKS
+ *   GFFX_HIP_AUTO_STRATEGY=n        what GFFX_STRATEGY_AUTO resolves to (0: the engine's choice)
+ *   GFFX_HIP_LOOKBACK=0             pair passes of one round per block reserve their segments with a device atomic like larger ones
+ *                                   (default 1: look-back over per-block status words, segments in input order)
+ *   launch sizes (0 = the engine's choice): GFFX_HIP_FUSED_BLOCKS, GFFX_HIP_BITMAP_BLOCKS; GFFX_HIP_JOIN_BLOCKS, GFFX_HIP_MAX_BLOCKS;
+ *   GFFX_HIP_PARTITION_BUDGET_MB (record buffers of the partitioned strategy)
+ *   index build: GFFX_HIP_SLOT_WMAX (widest region a window line answers, 16384), GFFX_HIP_WIN_PER_ENTRY, GFFX_HIP_WIN_SPLIT,
+ *   GFFX_HIP_WIN_FILTER_KB, GFFX_HIP_WIN_MAX_LINES, GFFX_HIP_BINS_PER_ENTRY
  */
 #ifndef GFFX_HIP_H
 #define GFFX_HIP_H
@@ -173,6 +182,9 @@ int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets, const uin
                           gffx_hip_index **out);
 void gffx_hip_index_destroy(gffx_hip_index *);
 uint32_t gffx_hip_index_n_chr(const gffx_hip_index *);
+/* the index builders' knobs that are not at their defaults, as a JSON object ("{}": all defaults).  snprintf's contract: returns the
+ * length the text needs; at most cap - 1 bytes and a NUL are written (buf may be NULL with cap 0). */
+int gffx_hip_index_options(const gffx_hip_index *, char *buf, size_t cap);
 uint64_t gffx_hip_index_n_roots(const gffx_hip_index *);
 int gffx_hip_index_device(const gffx_hip_index *);
 /* root_fid of the i-th bit of the root bitmap (i < n_roots), host array owned by the index */
@@ -255,6 +267,10 @@ const uint32_t *gffx_hip_batch_device_triples(const gffx_hip_batch *);
 const uint32_t *gffx_hip_batch_device_regions(const gffx_hip_batch *);
 /* pre-size the pair buffers (pairs); avoids the capacity replay on the first run */
 int gffx_hip_batch_reserve_hits(gffx_hip_batch *, uint64_t n_pairs);
+/* Tuning knobs of the batch's passes ("Tuning knobs" above): set one by its name (with or without the GFFX_HIP_ prefix, any
+ * case); GFFX_E_INVALID for an unknown name or a value outside the knob's range.  _options: the non-default ones as JSON. */
+int gffx_hip_batch_set_option(gffx_hip_batch *, const char *name, long value);
+int gffx_hip_batch_options(const gffx_hip_batch *, char *buf, size_t cap);
 
 /* HIP-event timing of the kernels on the batch's own stream.  While enabled every launch is
  * bracketed by events; _kernel_ms returns the accumulated milliseconds and launch count of

@@ -226,7 +226,7 @@ def test_wide_form_full_size_properties(wide_forced, monkeypatch):
     wt, wc = oix.query_features(regions[pick], OV, False)
     assert np.array_equal(c[pick], wc)
     assert np.array_equal(_pairs_of(regions[pick], wc, off[:-1][pick], f), _want_pairs(regions[pick], wt, wc))
-    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "0")
+    b.set_option("WIN_WIDE", 0)  # (a batch reads its knobs from the environment once, when it is created; later: set_option)
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_FUSED)
     b.wait()
     assert not b.wide_form and np.array_equal(b.counts(), c) and np.array_equal(np.sort(b.fids()), np.sort(f))
@@ -282,7 +282,7 @@ def test_root_passes_of_both_forms_in_turn_on_an_index_with_many_windows(monkeyp
     b = engine.QueryBatch(ix, nq)
     b.set_regions(regions)
     for wide in ("1", "2", "1", "2", "2"):
-        monkeypatch.setenv("GFFX_HIP_WIN_WIDE", wide)
+        b.set_option("GFFX_HIP_WIN_WIDE", int(wide))
         b.run(OV, False, engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)
         b.wait()
         assert b.wide_form == (wide == "2")
@@ -290,10 +290,10 @@ def test_root_passes_of_both_forms_in_turn_on_an_index_with_many_windows(monkeyp
     # ... and accumulated over two halves of the regions (GFFX_OUT_BITMAP_KEEP), one half per form
     half = nq // 2
     b.set_regions(regions[:half])
-    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "1")
+    b.set_option("win_wide", 1)
     b.run(OV, False, engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)
     b.set_regions(regions[half:])
-    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "2")
+    b.set_option("win_wide", 2)
     b.run(OV, False, engine.OUT_ROOT_BITMAP | engine.OUT_BITMAP_KEEP, engine.STRATEGY_WINDOWS)
     b.wait()
     assert b.wide_form and np.array_equal(b.unique_roots(), want_u)

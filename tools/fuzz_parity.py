@@ -77,9 +77,9 @@ for it in range(iters):
                     flag_sets += [engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_ROOT_BITMAP,
                                   engine.OUT_FIDS | engine.OUT_SEGBASE]  # (the pass bench.py times: one base per 256 regions)
                     if it % 3 == 0:  # the 1024-thread variant of the pair pass (the engine takes it for 0.5-2.5 M regions alone)
-                        os.environ["GFFX_HIP_WIN_THREADS"] = "1024"
+                        b.set_option("WIN_THREADS", 1024)
                     else:
-                        os.environ.pop("GFFX_HIP_WIN_THREADS", None)
+                        b.set_option("WIN_THREADS", 0)
                 runs = [(fl, False) for fl in flag_sets]
                 if strat == engine.STRATEGY_WINDOWS and mode == 2 and not inv:
                     # the wide form of the pair and root passes (regions of any width from two lines and two ranks; AUTO's choice for wide
@@ -88,7 +88,7 @@ for it in range(iters):
                                                    engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_FIDS | engine.OUT_SEGBASE,
                                                    engine.OUT_ROOT_BITMAP, engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS)]
                 for flags, wide in runs:
-                    os.environ["GFFX_HIP_WIN_WIDE"] = "2" if wide else "1"
+                    b.set_option("WIN_WIDE", 2 if wide else 1)
                     b.run(mode, inv, flags, strat)
                     b.wait()
                     if b.wide_form and not wide:

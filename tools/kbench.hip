@@ -20,6 +20,10 @@ __device__ int g_stamp_sel;
     } while (0)
 #endif
 
+#if GFFX_STAMPS
+#define GFFX_WIN_STAMP(slot) GFFX_STAMP(4, slot)  // the pair kernel's phase stamps (slots 13 / 14 / 15: entry, loop done, end)
+#endif
+
 #if GFFX_CLKCHECK  // shader clocks (clock64) against the 100 MHz wall clock over a block's life: the CU's effective frequency
 __device__ unsigned long long g_clk[8192 * 4];
 #define GFFX_CLK(which)                                                          \
@@ -170,6 +174,16 @@ int main(int argc, char **argv) {
                (double)(t1 - t0) * 0.01, first_start_spread);
         for (int k = 1; k < 16; k++)
             if (sum[k] > 0) printf(" [%d]%.2f", k, sum[k] / nb);
+        printf("\n");
+        // the same as a timeline: per slot the mean and the latest time since the first stamp of the launch
+        printf("  timeline (mean / max us since the launch's first stamp):");
+        for (int k = 0; k < 16; k++) {
+            double m = 0, mx = 0;
+            int n = 0;
+            for (int blk = 0; blk < 8192; blk++)
+                if (z[blk * 16 + k]) m += (double)(z[blk * 16 + k] - t0) * 0.01, mx = std::max(mx, (double)(z[blk * 16 + k] - t0) * 0.01), n++;
+            if (n) printf(" [%d]%.2f/%.2f", k, m / n, mx);
+        }
         printf("\n");
     }
 #endif

@@ -48,19 +48,21 @@ int main(int argc, char **argv) {
             co.push_back((uint32_t)start.size());
         }
         std::vector<uint4> meta, win, wpos, spill;
-        int rc = gffx::build_window_index_at(n_chr, co.data(), start, aux, meta, win, wpos, spill, iter % 3 == 0 ? 1 : 0, 1 << 25);
+        Knobs<IK__COUNT> knobs;
+        knobs.read_env(kIndexKnobs);
+        int rc = gffx::build_window_index_at(n_chr, co.data(), start, aux, meta, win, wpos, spill, iter % 3 == 0 ? 1 : 0, 1 << 25, knobs);
         if (rc) { printf("rc %d\n", rc); return 1; }
         const uint32_t *ww = (const uint32_t *)win.data();
         // the coverage filter as the kernel tests it: 32 bits from the region's first cell on, no clamp to the seqid's cells
         std::vector<uint32_t> fbits;
         std::vector<uint2> fmeta;
         uint32_t fshift = 0;
-        gffx::build_window_filter(n_chr, co.data(), start, aux, meta, fbits, fmeta, fshift);
+        gffx::build_window_filter(n_chr, co.data(), start, aux, meta, fbits, fmeta, fshift, knobs);
         const uint32_t fwords = (uint32_t)fbits.size();
         // the split windows (round 4): the sub-lines as the builder hands them to the device, by line number
         std::vector<uint32_t> sbits, sub_at;
         std::vector<uint4> sub_lines, sub_lines_pos;
-        gffx::build_window_splits(n_chr, start, aux, meta, win, wpos, spill, sbits, sub_at, sub_lines, sub_lines_pos);
+        gffx::build_window_splits(n_chr, start, aux, meta, win, wpos, spill, sbits, sub_at, sub_lines, sub_lines_pos, knobs);
         std::map<uint32_t, size_t> sub_of;  // line number -> index into sub_lines / 2
         for (size_t i = 0; i < sub_at.size(); i++) sub_of[sub_at[i]] = i;
         const size_t n_win = win.size() / 2;
