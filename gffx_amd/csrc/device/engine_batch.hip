@@ -59,7 +59,6 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     (void)hipFree(b->d_offsets32);
     (void)hipFree(b->d_segbase);
     (void)hipFree(b->d_slabs);
-    (void)hipFree(b->d_lb_status);
     (void)hipFree(b->d_rec);
     (void)hipFree(b->d_cursor);
     (void)hipFree(b->d_q_rec);
@@ -582,10 +581,6 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     if (b->h_status[0] & 2ull) {
         GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
         return fail(GFFX_E_HIP, "internal: the dynamic LDS of a windows pass does not start at LDS address 0");
-    }
-    if (b->h_status[0] & 4ull) {
-        GFFX_HIP_TRY(hipMemset(b->d_status, 0, sizeof(unsigned long long)));
-        return fail(GFFX_E_HIP, "internal: a windows pass gave up waiting for the pair counts of the blocks before it (look-back)");
     }
     if (b->h_status[0] & 1ull) {
         // the flag is sticky on the device (kernels only ever set it): clear it for the next pass

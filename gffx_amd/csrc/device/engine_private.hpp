@@ -56,13 +56,13 @@ constexpr KnobDef kIndexKnobs[IK__COUNT] = {{"GFFX_HIP_WIN_PER_ENTRY", 2, 1, 16}
                                             {"GFFX_HIP_WIN_FILTER_KB", 24, 0, 120},         {"GFFX_HIP_BINS_PER_ENTRY", 2, 1, 64}};
 enum BatchKnob {
     BK_AUTO_STRATEGY, BK_FUSED_BLOCKS, BK_BITMAP_BLOCKS, BK_JOIN_BLOCKS, BK_MAX_BLOCKS, BK_PARTITION_BUDGET_MB, BK_WIDTH_SAMPLE, BK_WIN_THREADS,
-    BK_WIN_WIDE, BK_LOOKBACK, BK__COUNT
+    BK_WIN_WIDE, BK__COUNT
 };
 constexpr KnobDef kBatchKnobs[BK__COUNT] = {{"GFFX_HIP_AUTO_STRATEGY", 0, 0, 5},   {"GFFX_HIP_FUSED_BLOCKS", 0, 0, 65535},
                                             {"GFFX_HIP_BITMAP_BLOCKS", 0, 0, 8192}, {"GFFX_HIP_JOIN_BLOCKS", 512, 1, 65535},
                                             {"GFFX_HIP_MAX_BLOCKS", 2048, 1, 8192}, {"GFFX_HIP_PARTITION_BUDGET_MB", 12 * 1024, 1, 256 * 1024},
                                             {"GFFX_HIP_WIDTH_SAMPLE", 1, 0, 1},     {"GFFX_HIP_WIN_THREADS", 0, 0, 1024},
-                                            {"GFFX_HIP_WIN_WIDE", 1, 0, 2},         {"GFFX_HIP_LOOKBACK", 1, 0, 1}};
+                                            {"GFFX_HIP_WIN_WIDE", 1, 0, 2}};
 template <int N>
 struct Knobs {
     long v[N];
@@ -232,9 +232,6 @@ struct gffx_hip_batch {
     uint32_t slab_valid = 0;                    // ... slabs that hold something since the last clear
     bool root_flags_dirty = false;              // ... newer than d_bitmap (windows_pack_roots)
     uint32_t roots_blocks = 0;                  // last pass was a root pass of its own: its blocks (their pair counts are in d_block_sums)
-    unsigned long long *d_lb_status = nullptr;  // windows strategy, pair passes of one round per block: the look-back's status words (PairArgs::lb_status)
-    uint32_t lb_tag = 0;                        // ... the tag of the last such pass (1 .. 65535; the words are cleared when it wraps)
-    static constexpr uint32_t kLbWords = 512;   // ... rounds of the largest such launch
     uint64_t cap_fids = 0, cap_triples = 0;
     uint64_t reserve = 0;
     // partitioned strategy workspace (allocated on first use)

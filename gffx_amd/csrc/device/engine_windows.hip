@@ -187,22 +187,6 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     a.swords = swords;
     a.spill = ix->d_win_spill;
     a.grid = grid;
-    // Look-back instead of the reservation atomic (join_pairs_kernels.hpp, PairArgs::lb_status): pair passes whose blocks run one
-    // round each -- round = block number, so a block only waits for blocks with lower numbers.  GFFX_HIP_LOOKBACK=0: never.
-    if (!roots && rounds == grid && rounds >= 2 && rounds <= (threads == 1024 ? 256u : 512u) && b->knobs.v[BK_LOOKBACK]) {
-        if (!b->d_lb_status) {
-            int rc = dev_alloc(&b->d_lb_status, gffx_hip_batch::kLbWords);
-            if (rc) return rc;
-            b->lb_tag = 0;
-            GFFX_HIP_TRY(hipMemsetAsync(b->d_lb_status, 0, gffx_hip_batch::kLbWords * sizeof(unsigned long long), b->stream));
-        }
-        if (++b->lb_tag > 65535u) {  // the tags start over: no word of an earlier pass may look like one of a later pass
-            b->lb_tag = 1;
-            GFFX_HIP_TRY(hipMemsetAsync(b->d_lb_status, 0, gffx_hip_batch::kLbWords * sizeof(unsigned long long), b->stream));
-        }
-        a.lb_status = b->d_lb_status;
-        a.lb_tag = b->lb_tag;
-    }
     a.ix = ix->view();
     ProfEvent pe;
     int lrc = GFFX_OK;

@@ -145,68 +145,9 @@ struct PairArgs {
     uint32_t fwords, swords;  // filter / split-bitmap words staged in LDS (0: that table did not fit, or does not exist)
     const uint4 *spill;       // IndexView::win_spill (list tails: the one rare path that is walked in line)
     uint32_t grid;            // blocks of the launch (read from the dispatch packet it would be a scalar load per round)
-    // LOOK-BACK (round 5): a launch whose blocks run ONE round each (round = block number: batches of up to ~1 M regions) reserves
-    // no segment with a device atomic -- 245 / 489 same-address atomics arrive within a microsecond or two of each other and
-    // serialise at ~90 per us, on the critical path of every block's flush.  Instead the round's last wave publishes the round's
-    // kept pairs as lb_status[round] = lb_tag << 48 | pairs (one plain store that carries its own flag; the tag tells this pass's
-    // words from an earlier pass's: no clearing), and the block's segment starts at the sum over the rounds before it, read by
-    // one wave, 64 status words per load.  A block only ever waits for blocks with LOWER numbers.  Segments in input order.
-    unsigned long long *lb_status;
-    uint32_t lb_tag;          // 1 .. 65535; 0: the reservation atomic
     IndexView ix;
 };
 
-constexpr uint32_t kLbSpinLimit = 1u << 22;  // polls of the status words before a look-back gives up (error bit 2: the pass fails, the GPU does not hang)
-
-// The start of round r's segment = the kept pairs of the rounds before it (look-back mode, PairArgs::lb_status).  One wave; every
-// lane holds up to NV status words (rounds r - 1 - lane - 64 i), all in flight together, re-read until every one carries this
-// pass's tag.  The launch's last round also leaves the pass's total in *cursor.
-template <int NV>
-__device__ __attribute__((noinline)) unsigned long long pair_lookback(const unsigned long long *status, uint32_t tag, uint32_t r, uint32_t n_rounds,
-                                                                      unsigned long long btotal, unsigned long long *cursor, uint32_t *err) {
-    const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long v[NV];
-    bool need[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        need[i] = lane + 64u * i < r;
-        v[i] = 0;
-    }
-    for (uint32_t spins = 0;; ++spins) {
-        bool missing = false;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (need[i]) v[i] = __hip_atomic_load(&status[r - 1u - lane - 64u * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            need[i] = need[i] && (uint32_t)(v[i] >> 48) != tag;
-            missing |= need[i];
-        }
-        if (!__builtin_amdgcn_ballot_w64(missing)) break;
-        if (spins > kLbSpinLimit) {
-            if (lane == 0) atomicOr(err, 4u);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    unsigned long long sum = 0;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) sum += (lane + 64u * i < r) ? (v[i] & ((1ull << 48) - 1)) : 0ull;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-    const unsigned long long base =
-        ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(sum >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sum);
-    if (r + 1u == n_rounds && lane == 0) *cursor = base + btotal;  // (zero on entry; the host reads the pass's total here)
-    return base;
-}
-
-// the whole argument, read where it lies (for fields only rare paths need: kept in registers they are spilled across the loop)
-__device__ __forceinline__ const PairArgs &pair_args_in_place() {
-    typedef const unsigned char __attribute__((address_space(4))) * KernargBytes;
-    KernargBytes p = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return *(const PairArgs *)p;
-}
 __device__ __forceinline__ const IndexView &pair_rare_ix() {
     typedef const unsigned char __attribute__((address_space(4))) * KernargBytes;
     KernargBytes p = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
@@ -738,13 +679,6 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             p_poster[0] = false;
         }
     };
-    // look-back mode: the round's segment base from the status words of the rounds before it (a block runs one round: this is
-    // called behind the loop, or on the synchronous path of an overfull round)
-    constexpr int kLbWords = T == 1024 ? 4 : 8;  // status words per lane: rounds (= blocks) of a look-back launch <= 64 x this
-    auto lb_base = [&](unsigned long long round, unsigned long long btotal) {
-        const PairArgs &K = pair_args_in_place();
-        return pair_lookback<kLbWords>(K.lb_status, K.lb_tag, (uint32_t)round, (uint32_t)((K.nq + kChunk - 1) / kChunk), btotal, K.out.pair_cursor, K.out.err);
-    };
     const uint32_t lane4 = 4u * (uint32_t)lane;
     auto finish = [&](int i) {  // (i: compile-time after unrolling)
         if (!p_valid[i]) return;
@@ -1072,11 +1006,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             const unsigned long long btotal = my_off + wtotal;
             if (lane == 0) {
                 __hip_atomic_store(&s_arrive[par], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const PairArgs &K = pair_args_in_place();
-                if (K.lb_tag)  // (uniform) look-back: the round's pairs, for the blocks behind this one
-                    __hip_atomic_store(&K.lb_status[r], ((unsigned long long)K.lb_tag << 48) | btotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else if (btotal)
-                    p_got = atomicAdd(out.pair_cursor, btotal);
+                if (btotal) p_got = atomicAdd(out.pair_cursor, btotal);
             }
         }
 #pragma unroll
@@ -1099,7 +1029,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         } else {
             // more pairs than the strips hold: wait for the base now and write them from a second walk of the regions
             // (the rounds before were posted above, right after this round's gathers: nobody waits for THIS wave while it waits)
-            if (last) post(par, k_round + 1, pair_args_in_place().lb_tag ? lb_base(r, my_off + wtotal) : p_got);
+            if (last) post(par, k_round + 1, p_got);
             const unsigned long long seg = await_base(par, k_round + 1) + my_off;
             group_base(r, seg);
             if (OFFS) put_offsets(r, seg, lp0, cnt[0], cnt[1], cnt[2]);
@@ -1146,14 +1076,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         slot_now = slot_now + 1 == D ? 0u : slot_now + 1;
     }
     GFFX_WIN_STAMP(14);
-    if (pair_args_in_place().lb_tag) {  // (uniform) the block's one round: its poster looks back, everybody else waits for the base in finish()
-        if (p_valid[0] && p_poster[0]) {
-            post(p_slot[0], p_seq[0], lb_base(p_round[0], p_off[0] + p_total[0]));  // (the poster arrived last: its offset + its pairs = the round's)
-            p_poster[0] = false;
-        }
-    } else {
-        post_pending();
-    }
+    post_pending();
 #pragma unroll
     for (int i = P - 1; i >= 0; --i) finish(i);
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);

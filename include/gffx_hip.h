@@ -58,8 +58,6 @@
  *                                   every eligible pass of the windows strategy
  *   GFFX_HIP_WIDTH_SAMPLE=0         no width sample of the rows the host hands over (AUTO then learns from a first waited pass)
  *   GFFX_HIP_AUTO_STRATEGY=n        what GFFX_STRATEGY_AUTO resolves to (0: the engine's choice)
- *   GFFX_HIP_LOOKBACK=0             pair passes of one round per block reserve their segments with a device atomic like larger ones
- *                                   (default 1: look-back over per-block status words, segments in input order)
  *   launch sizes (0 = the engine's choice): GFFX_HIP_FUSED_BLOCKS, GFFX_HIP_BITMAP_BLOCKS; GFFX_HIP_JOIN_BLOCKS, GFFX_HIP_MAX_BLOCKS;
  *   GFFX_HIP_PARTITION_BUDGET_MB (record buffers of the partitioned strategy)
  *   index build: GFFX_HIP_SLOT_WMAX (widest region a window line answers, 16384), GFFX_HIP_WIN_PER_ENTRY, GFFX_HIP_WIN_SPLIT,
