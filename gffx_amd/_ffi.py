@@ -65,6 +65,7 @@ SIGNATURES = {
     "gffx_hip_batch_device_offsets32": (vp, [vp]),
     "gffx_hip_batch_device_segbase": (vp, [vp]),
     "gffx_hip_batch_reserve_hits": (C.c_int, [vp, C.c_uint64]),
+    "gffx_hip_batch_kept_pairs_accumulated": (C.c_int, [vp, u64p]),
     "gffx_hip_batch_set_option": (C.c_int, [vp, C.c_char_p, C.c_long]),
     "gffx_hip_batch_options": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "gffx_hip_index_options": (C.c_int, [vp, C.c_char_p, C.c_size_t]),

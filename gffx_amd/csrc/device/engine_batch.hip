@@ -21,7 +21,7 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
     int rc;
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(GFFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
-    if ((rc = dev_alloc(&b->d_counts, max_queries)) || (rc = dev_alloc(&b->d_block_sums, gffx_hip_batch::kMaxBlocks)) ||
+    if ((rc = dev_alloc(&b->d_counts, max_queries)) || (rc = dev_alloc(&b->d_block_sums, 2 * gffx_hip_batch::kMaxBlocks)) ||
         (rc = dev_alloc(&b->d_status, gffx_hip_batch::kStatusWords))) {
         gffx_hip_batch_destroy(b.release());
         return rc;
@@ -503,6 +503,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     // strategy).  run_windows marks the flags dirty again for its own passes.
     if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !(b->flags & GFFX_OUT_BITMAP_KEEP)) {
         b->slab_valid = 0;
+        b->sums_valid = 0;
         b->root_flags_dirty = false;
     }
     if (nq == 0) {
@@ -653,6 +654,20 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
 }
 
 extern "C" uint64_t gffx_hip_batch_n_queries(const gffx_hip_batch *b) { return b ? b->nq : 0; }
+extern "C" int gffx_hip_batch_kept_pairs_accumulated(gffx_hip_batch *b, uint64_t *out) {
+    if (!b || !out) return fail(GFFX_E_INVALID, "gffx_hip_batch_kept_pairs_accumulated: NULL argument");
+    if (!b->waited) return fail(GFFX_E_STATE, "gffx_hip_batch_kept_pairs_accumulated: call gffx_hip_batch_wait first");
+    *out = b->total;
+    if (b->strategy != GFFX_STRATEGY_WINDOWS || !b->roots_blocks || !b->sums_valid) return GFFX_OK;
+    static_assert(kPairSumsStride == gffx_hip_batch::kMaxBlocks, "the accumulated sums follow the pass's sums");
+    GFFX_HIP_TRY(hipSetDevice(b->ix->device));
+    std::vector<unsigned long long> sums(b->sums_valid);
+    GFFX_HIP_TRY(hipMemcpy(sums.data(), b->d_block_sums + gffx_hip_batch::kMaxBlocks, sums.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *out = 0;
+    for (unsigned long long x : sums) *out += x;
+    return GFFX_OK;
+}
+
 extern "C" uint64_t gffx_hip_batch_total_hits(const gffx_hip_batch *b) {
     return (b && b->waited) ? b->total : 0;
 }

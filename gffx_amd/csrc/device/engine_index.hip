@@ -209,6 +209,9 @@ static void build_window_splits(uint32_t n_chr, const std::vector<uint32_t> &h_s
             }
         }
     }
+    // no window was split: no second level at all (the caller then allocates the line tables at 1x, not 9x, their size, and
+    // no block stages an all-zero bitmap)
+    if (sub_at.empty()) bits.clear();
 }
 
 // Ranks (gffx_device.hpp): one record {rank, list-tail header} per line of both levels.  `meta` = {first window, windows, shift,

@@ -232,6 +232,7 @@ struct gffx_hip_batch {
     uint32_t slab_valid = 0;                    // ... slabs that hold something since the last clear
     bool root_flags_dirty = false;              // ... newer than d_bitmap (windows_pack_roots)
     uint32_t roots_blocks = 0;                  // last pass was a root pass of its own: its blocks (their pair counts are in d_block_sums)
+    uint32_t sums_valid = 0;                    // ... blocks whose ACCUMULATED pair count (d_block_sums + kMaxBlocks) holds something since the last clear
     uint64_t cap_fids = 0, cap_triples = 0;
     uint64_t reserve = 0;
     // partitioned strategy workspace (allocated on first use)

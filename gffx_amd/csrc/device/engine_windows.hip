@@ -141,7 +141,11 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
     const long blocks_knob = b->knobs.v[roots ? BK_BITMAP_BLOCKS : BK_FUSED_BLOCKS];
     const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)(blocks_knob ? blocks_knob : (threads == 1024 ? 256 : 512)));
-    if (roots && !second) b->roots_blocks = grid;
+    if (roots && !second) {
+        b->roots_blocks = grid;
+        o.sums_valid = b->sums_valid;  // (the kept pairs of a run of GFFX_OUT_BITMAP_KEEP passes add up per block: gffx_hip_batch_kept_pairs_accumulated)
+        b->sums_valid = std::max(b->sums_valid, grid);
+    }
     if (roots && bm_words) {
         // one slab per block; the blocks below slab_valid OR into what their slab holds (passes since the last clear), the
         // others overwrite theirs; folded into the bitmap by windows_pack_roots
@@ -228,6 +232,7 @@ int gffx::run_windows(gffx_hip_batch *b) {
         // a new set of roots: no slab holds anything, and the bitmap itself starts empty (it is what a root pass without an LDS
         // bitmap ORs into, and what the fold ORs the slabs into)
         b->slab_valid = 0;
+        b->sums_valid = 0;
         b->root_flags_dirty = true;
         GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));
     }

@@ -121,6 +121,7 @@ constexpr uint32_t kWinAbsent = 0x0000FFFFu;     // coordinate word of an absent
 constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (n = 255)
 constexpr uint32_t kWinSplit = 3;                // a split window has 2^kWinSplit sub-windows (round 4)
 constexpr uint32_t kWaveGroup = 256;             // regions per GFFX_OUT_SEGBASE entry: 64 lanes x 4 regions, one wave's share of a round
+constexpr uint32_t kPairSumsStride = 8192;       // (= gffx_hip_batch::kMaxBlocks) k_join_roots: from a block's pair count of the pass to its accumulated one
 constexpr uint32_t kPosBits = 27;
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1;
 constexpr uint32_t kCntSat = 31;

@@ -99,9 +99,10 @@ constexpr uint32_t kWaveStash = 2;     // per thread: kept words of deferred reg
 // LDS); a fuller round -- gene-dense stretches of a sorted BED file -- takes all kWaveDepth strips, beyond that the synchronous path
 // The wide form keeps several pairs per region (2.6 at bench.py's wide shape: 600 .. 800 a round): strips of 3.75 pairs per
 // region, two of them per wave (960 words: with per-region offsets parked next to them the split bitmap still fits a 1024-thread
-// block's LDS).
+// block's LDS; 768 at 512 threads, where two blocks share the CU's LDS: with 960 the ~12-16 KB bitmap was always shed there and
+// every list longer than 4 fell to the deferred walk -- the variant that runs while two batches are in flight).
 __host__ __device__ constexpr uint32_t pair_stage_words(uint32_t threads, bool wide = false) {
-    return wide ? 960u : (threads == 1024 ? 512u : 384u);
+    return wide ? (threads == 1024 ? 960u : 768u) : (threads == 1024 ? 512u : 384u);
 }
 __host__ __device__ constexpr uint32_t pair_depth(bool wide = false) { return wide ? 2u : kWaveDepth; }
 
@@ -126,7 +127,9 @@ struct WaveOut {
     uint8_t *root_flags;            // k_join_roots without an LDS bitmap: the batch's bitmap (device atomics)
     uint32_t *err;                  // bit0 = chr out of range, bit1 = internal (LDS base)
     unsigned long long *slow;       // low half += regions that took the exact sweep, high half += ... because of their width (AUTO's census)
-    unsigned long long *block_sums;        // k_join_roots: kept pairs per block (or nullptr)
+    unsigned long long *block_sums;        // k_join_roots: kept pairs per block (or nullptr); kPairSumsStride words further on: the same,
+                                           // ACCUMULATED over the passes since the last clear (blocks below sums_valid add, the others start over)
+    uint32_t sums_valid;
     unsigned long long *pair_cursor;       // kept pairs of this pass (zero on entry)
     unsigned long long *pair_cursor_next;  // the other cursor word: zeroed here for the next pass
     unsigned long long capacity;
@@ -1321,7 +1324,11 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         const bool merge = blockIdx.x < (uint32_t)(uintptr_t)out.segbase;
         for (uint32_t x = tid; x < bm_words; x += T) slab[x] = merge ? (slab[x] | s_bm[x]) : s_bm[x];
     }
-    if (tid == 0 && out.block_sums) out.block_sums[blockIdx.x] = s_total[0];
+    if (tid == 0 && out.block_sums) {
+        out.block_sums[blockIdx.x] = s_total[0];
+        unsigned long long *acc = out.block_sums + kPairSumsStride + blockIdx.x;  // (this block's own word: plain load and store)
+        *acc = (blockIdx.x < out.sums_valid ? *acc : 0ull) + s_total[0];
+    }
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);
     if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow | ((unsigned long long)n_wide << 32));
 }

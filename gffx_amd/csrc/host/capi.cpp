@@ -82,6 +82,20 @@ extern "C" int gffx_host_parse_bed_file_chunked(const char *gff, const char *bed
     });
 }
 
+extern "C" int gffx_host_shard_bed_file(const char *gff, const char *bed, uint32_t threads, uint64_t chunk_bytes, uint32_t n_dev, int keep_all,
+                                        uint32_t **rows, uint64_t *dev_rows, char *err, size_t errlen) {
+    return guard(err, errlen, [&] {
+        const auto sqs = index_loader::load_sqs(gff);
+        const auto parts = commands::intersect::shard_bed_file_host(bed, sqs.second, threads, chunk_bytes, n_dev, keep_all != 0);
+        std::vector<uint32_t> flat;
+        for (uint32_t d = 0; d < n_dev; ++d) {
+            dev_rows[d] = parts[d].size() / 3;
+            flat.insert(flat.end(), parts[d].begin(), parts[d].end());
+        }
+        *rows = dup_vec(flat);
+    });
+}
+
 extern "C" int gffx_host_parse_region(const char *gff, const char *region, uint32_t out[3], char *err,
                                       size_t errlen) {
     return guard(err, errlen, [&] {

@@ -243,7 +243,8 @@ void write_gff_output(const std::string &gff_path, const std::vector<Block> &blo
     if (verbose) std::fprintf(stderr, "Wrote %zu merged GFF block(s) with vectored I/O\n", merged.size());
 }
 
-// --stats-json: one object {"command", "total_ms", "stages_ms": [[name, ms], ...] in the order they ended, "counts": {...}}
+// --stats-json: one object {"command", "total_ms", "stages_ms": [[name, ms], ...] in the order they ended, "counts": {...}, and
+// whatever a command adds: intersect's "devices" (per device {regions, kept pairs}, through the RCCL exchange) and "knobs"}
 void RunStats::write(const char *command, double total_ms) {
     if (!on()) return;
     std::lock_guard<std::mutex> lock(mu);
@@ -260,7 +261,9 @@ void RunStats::write(const char *command, double total_ms) {
         j += std::string(i ? ", " : "") + "[\"" + esc(stages_ms[i].first) + "\", " + std::to_string(stages_ms[i].second) + "]";
     j += "], \"counts\": {";
     for (size_t i = 0; i < counts.size(); ++i) j += std::string(i ? ", " : "") + "\"" + esc(counts[i].first) + "\": " + std::to_string(counts[i].second);
-    j += "}}\n";
+    j += "}";
+    for (const auto &e : extras) j += ", \"" + esc(e.first) + "\": " + e.second;
+    j += "}\n";
     FILE *f = std::fopen(path.c_str(), "w");
     if (!f) throw Error("Cannot write --stats-json file " + path);
     std::fwrite(j.data(), 1, j.size(), f);

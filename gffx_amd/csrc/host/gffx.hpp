@@ -51,6 +51,12 @@ struct RunStats {
         std::lock_guard<std::mutex> lock(mu);
         counts.emplace_back(what, v);
     }
+    std::vector<std::pair<std::string, std::string>> extras;  // further members of the object: name -> JSON text
+    void extra(const char *what, const std::string &json) {
+        if (!on()) return;
+        std::lock_guard<std::mutex> lock(mu);
+        extras.emplace_back(what, json);
+    }
     void write(const char *command, double total_ms);  // common.cpp
 };
 inline RunStats g_run_stats;
@@ -277,6 +283,10 @@ struct ShardSlice {
     uint64_t lo, hi;
 };
 std::vector<std::vector<ShardSlice>> plan_shards(const std::vector<uint64_t> &bucket_sizes, size_t n_ranks, double tolerance = 0.02);
+void scatter_chunk_by_bucket(const std::vector<std::vector<uint32_t>> &piece, uint32_t n_seq, bool keep_all, const std::vector<uint32_t *> &stage,
+                             std::vector<uint64_t> &n_dev, std::vector<char> &has_regions);
+std::vector<std::vector<uint32_t>> shard_bed_file_host(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                                                       size_t threads, size_t chunk_bytes, size_t n_dev, bool keep_all);
 
 // parse_bed_file + query_features + the unique-root collection (intersect.rs:586-615) over a whole BED file, streamed
 // chunk by chunk through pinned staging buffers to n_gpus devices
@@ -285,6 +295,9 @@ struct StreamResult {
     std::vector<char> has_regions;     // per seqid: owns at least one region (query_ivmap's keys, intersect.rs:621-633)
     uint64_t n_regions = 0;
     uint64_t wide_form_passes = 0;     // chunk passes that took the wide form of the root kernel (--stats-json)
+    std::vector<uint64_t> per_device;  // {regions, kept pairs} per logical device: with --gpus N on N distinct devices what the RCCL
+    bool exchanged = false;            // all-gather RETURNED (exchanged), otherwise the host's own counts
+    std::string knobs = "{}";          // GFFX_HIP_* knobs of the index / the batches that were not at their defaults
     gffx_hip_regions *store = nullptr; // keep_store: all regions, on the first device (the caller destroys it)
 };
 StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &bed_path, OverlapMode mode, bool invert, bool verbose,

@@ -586,6 +586,115 @@ constexpr size_t kMinRowBytes = 6;
 
 }  // namespace
 
+// One parsed chunk of a `--gpus N` run -> the devices' staging buffers: bucket sizes of the chunk, the plan (plan_shards:
+// chromosome buckets placed by LPT, a bucket that overshoots is split; commands/intersect.rs:114-120 buckets by seqid), then the
+// rows are scattered.  W <= 16 workers take CONTIGUOUS runs of the parser's pieces (file order), so a row's rank inside its
+// seqid's bucket is (rows of the seqid in earlier workers) + (rows seen so far by this worker): one exclusive prefix over the
+// workers, O(n_seq x W) work and memory per chunk whatever the number of pieces (a draft assembly has 10^5 seqids).
+// stage[d]: room for the chunk's rows; n_dev[d] (zero on entry) = rows that went to device d; keep_all: device 0 also gets EVERY
+// row, as [share 0 | share 1 | ...] (Join B needs all regions on one device).  No HIP call in here: tests/test_sanitizers_cpu.py
+// drives it under ThreadSanitizer through gffx_host_shard_bed_file.
+void scatter_chunk_by_bucket(const std::vector<std::vector<uint32_t>> &piece, uint32_t n_seq, bool keep_all, const std::vector<uint32_t *> &stage,
+                             std::vector<uint64_t> &n_dev, std::vector<char> &has_regions) {
+    const size_t D = stage.size(), T = piece.size();
+    if (!T || !D) return;
+    const size_t W = std::min<size_t>(T, 16);
+    auto first_piece = [&](size_t w) { return T * w / W; };
+    std::vector<std::vector<uint64_t>> cnt(W, std::vector<uint64_t>(n_seq, 0));
+    {
+        auto work = [&](size_t w) {
+            for (size_t t = first_piece(w); t < first_piece(w + 1); ++t)
+                for (size_t i = 0; i < piece[t].size(); i += 3) cnt[w][piece[t][i]]++;
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < W; ++w) pool.emplace_back(work, w);
+        work(0);
+        for (auto &th : pool) th.join();
+    }
+    std::vector<uint64_t> size(n_seq, 0);
+    for (uint32_t c = 0; c < n_seq; ++c) {
+        uint64_t acc = 0;
+        for (size_t w = 0; w < W; ++w) {  // cnt[w][c] becomes the rank of worker w's first row of seqid c
+            const uint64_t n = cnt[w][c];
+            cnt[w][c] = acc;
+            acc += n;
+        }
+        size[c] = acc;
+        has_regions[c] |= acc != 0;
+    }
+    const auto plan = plan_shards(size, D);
+    // per seqid: its slices as (lo, hi, device, offset inside the device's share)
+    struct Dest {
+        uint64_t lo, hi, off;
+        uint32_t d;
+    };
+    std::vector<std::vector<Dest>> dest(n_seq);
+    for (size_t d = 0; d < D; ++d)
+        for (const ShardSlice &sl : plan[d]) {
+            dest[sl.chr].push_back({sl.lo, sl.hi, n_dev[d], static_cast<uint32_t>(d)});
+            n_dev[d] += sl.hi - sl.lo;
+        }
+    for (auto &v : dest) std::sort(v.begin(), v.end(), [](const Dest &x, const Dest &y) { return x.lo < y.lo; });
+    // device 0's store keeps everything when Join B follows: its chunk is [share 0 | share 1 | ...]
+    std::vector<uint64_t> all_base(D + 1, 0);
+    for (size_t d = 0; d < D; ++d) all_base[d + 1] = all_base[d] + n_dev[d];
+    auto work = [&](size_t w) {
+        std::vector<uint64_t> &rank = cnt[w];  // bucket rank of this worker's next row of the seqid (file order)
+        for (size_t t = first_piece(w); t < first_piece(w + 1); ++t)
+            for (size_t i = 0; i < piece[t].size(); i += 3) {
+                const uint32_t c = piece[t][i];
+                const uint64_t p = rank[c]++;
+                const std::vector<Dest> &v = dest[c];
+                size_t j = 0;
+                while (j + 1 < v.size() && p >= v[j].hi) ++j;
+                const uint64_t at = v[j].off + (p - v[j].lo);
+                const uint32_t d = v[j].d;
+                if (d != 0 || !keep_all) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[d] + 3 * at);
+                if (keep_all) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[0] + 3 * (all_base[d] + at));
+            }
+    };
+    std::vector<std::thread> pool;
+    for (size_t w = 1; w < W; ++w) pool.emplace_back(work, w);
+    work(0);
+    for (auto &th : pool) th.join();
+}
+
+// The host half of `gffx intersect --gpus N` without a device: the BED file parsed chunk by chunk on the worker pool, every
+// chunk scattered by chromosome bucket into plain memory; per device the rows it would have received, chunk after chunk
+// (device 0 with keep_all: every row, each chunk as [share 0 | share 1 | ...]).
+std::vector<std::vector<uint32_t>> shard_bed_file_host(const std::string &bed_path, const std::unordered_map<std::string, uint32_t> &seqid_map,
+                                                       size_t threads, size_t chunk_bytes, size_t n_dev, bool keep_all) {
+    MappedFile f(bed_path);
+    const std::string_view text = f.view();
+    const SeqidTable seqids(seqid_map);
+    uint32_t n_seq = 0;
+    for (const auto &kv : seqid_map) n_seq = std::max(n_seq, kv.second + 1);
+    WorkerPool workers(std::min<size_t>(std::max<size_t>(threads, 1), 64) - 1);
+    std::vector<std::vector<uint32_t>> piece, out(n_dev);
+    std::vector<char> has(n_seq, 0);
+    chunk_bytes = std::max<size_t>(chunk_bytes, 1);
+    size_t pos = 0;
+    for (bool first = true; pos < text.size() || first; first = false) {
+        size_t z = std::min(text.size(), pos + chunk_bytes);
+        if (z < text.size()) {
+            const size_t nl = text.find('\n', z);
+            z = nl == std::string_view::npos ? text.size() : nl + 1;
+        }
+        parse_bed_pieces(text, pos, z, z == text.size(), seqids, threads, piece, &workers);
+        size_t rows = 0;
+        for (const auto &v : piece) rows += v.size() / 3;
+        std::vector<std::vector<uint32_t>> buf(n_dev, std::vector<uint32_t>(3 * rows));
+        std::vector<uint32_t *> stage(n_dev);
+        for (size_t d = 0; d < n_dev; ++d) stage[d] = buf[d].data();
+        std::vector<uint64_t> got(n_dev, 0);
+        scatter_chunk_by_bucket(piece, n_seq, keep_all, stage, got, has);
+        for (size_t d = 0; d < n_dev; ++d) out[d].insert(out[d].end(), buf[d].begin(), buf[d].begin() + 3 * ((d == 0 && keep_all) ? rows : got[d]));
+        pos = z;
+        if (pos >= text.size()) break;
+    }
+    return out;
+}
+
 // Join A over a whole BED file, streamed: the text is parsed chunk by chunk on the host threads straight into pinned
 // staging buffers, every chunk goes to the device(s) while the next one is parsed (two staging buffers / two batches per
 // device), the root bitmap accumulates on the device across chunks (GFFX_OUT_BITMAP_KEEP).  With n_gpus > 1 every chunk is
@@ -705,6 +814,13 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
             if (gffx_hip_batch_create(ix[d], chunk_rows, &batch[2 * d + k].h) != GFFX_OK) hip_fail("batch_create");
     }
     sub.lap("  region stores + batches");
+    {  // the tuning knobs this run did not leave at their defaults (--stats-json "knobs")
+        char ik[512] = "{}", bk[512] = "{}";
+        gffx_hip_index_options(ix[0], ik, sizeof ik);
+        gffx_hip_batch_options(batch[0].h, bk, sizeof bk);
+        std::string a(ik), b(bk);
+        res.knobs = a.size() <= 2 ? b : b.size() <= 2 ? a : a.substr(0, a.size() - 1) + ", " + b.substr(1);
+    }
     res.has_regions.assign(n_seq, 0);
     std::vector<uint64_t> dev_rows(D, 0);
     std::vector<char> used(2 * D, 0);
@@ -753,71 +869,9 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
                 for (uint32_t c = 0; c < n_seq; ++c) res.has_regions[c] |= seen[w][c];
             n_dev[0] = off[T];
         } else {
-            // bucket sizes of the chunk, the plan, then the rows are scattered to their device's staging buffer.  W <= 16
-            // workers take CONTIGUOUS runs of the parser's pieces (file order), so a row's rank inside its seqid's bucket is
-            // (rows of the seqid in earlier workers) + (rows seen so far by this worker): one exclusive prefix over the
-            // workers, O(n_seq x W) work and memory per chunk whatever the number of pieces (a draft assembly has 10^5 seqids).
-            const size_t W = std::min<size_t>(T, 16);
-            auto first_piece = [&](size_t w) { return T * w / W; };
-            std::vector<std::vector<uint64_t>> cnt(W, std::vector<uint64_t>(n_seq, 0));
-            {
-                auto work = [&](size_t w) {
-                    for (size_t t = first_piece(w); t < first_piece(w + 1); ++t)
-                        for (size_t i = 0; i < piece[t].size(); i += 3) cnt[w][piece[t][i]]++;
-                };
-                std::vector<std::thread> pool;
-                for (size_t w = 1; w < W; ++w) pool.emplace_back(work, w);
-                work(0);
-                for (auto &th : pool) th.join();
-            }
-            std::vector<uint64_t> size(n_seq, 0);
-            for (uint32_t c = 0; c < n_seq; ++c) {
-                uint64_t acc = 0;
-                for (size_t w = 0; w < W; ++w) {  // cnt[w][c] becomes the rank of worker w's first row of seqid c
-                    const uint64_t n = cnt[w][c];
-                    cnt[w][c] = acc;
-                    acc += n;
-                }
-                size[c] = acc;
-                res.has_regions[c] |= acc != 0;
-            }
-            const auto plan = plan_shards(size, D);
-            // per seqid: its slices as (lo, hi, device, offset inside the device's share)
-            struct Dest {
-                uint64_t lo, hi, off;
-                uint32_t d;
-            };
-            std::vector<std::vector<Dest>> dest(n_seq);
-            for (size_t d = 0; d < D; ++d)
-                for (const ShardSlice &sl : plan[d]) {
-                    dest[sl.chr].push_back({sl.lo, sl.hi, n_dev[d], static_cast<uint32_t>(d)});
-                    n_dev[d] += sl.hi - sl.lo;
-                }
-            for (auto &v : dest) std::sort(v.begin(), v.end(), [](const Dest &x, const Dest &y) { return x.lo < y.lo; });
-            // device 0's store keeps everything when Join B follows: its chunk is [share 0 | share 1 | ...]
-            std::vector<uint64_t> all_base(D + 1, 0);
-            for (size_t d = 0; d < D; ++d) all_base[d + 1] = all_base[d] + n_dev[d];
             std::vector<uint32_t *> stage(D);
             for (size_t d = 0; d < D; ++d) stage[d] = gffx_hip_regions_staging(store[d].h, k);
-            auto work = [&](size_t w) {
-                std::vector<uint64_t> &rank = cnt[w];  // bucket rank of this worker's next row of the seqid (file order)
-                for (size_t t = first_piece(w); t < first_piece(w + 1); ++t)
-                    for (size_t i = 0; i < piece[t].size(); i += 3) {
-                        const uint32_t c = piece[t][i];
-                        const uint64_t p = rank[c]++;
-                        const std::vector<Dest> &v = dest[c];
-                        size_t j = 0;
-                        while (j + 1 < v.size() && p >= v[j].hi) ++j;
-                        const uint64_t at = v[j].off + (p - v[j].lo);
-                        const uint32_t d = v[j].d;
-                        if (d != 0 || !keep_store) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[d] + 3 * at);
-                        if (keep_store) std::copy(piece[t].begin() + i, piece[t].begin() + i + 3, stage[0] + 3 * (all_base[d] + at));
-                    }
-            };
-            std::vector<std::thread> pool;
-            for (size_t w = 1; w < W; ++w) pool.emplace_back(work, w);
-            work(0);
-            for (auto &th : pool) th.join();
+            scatter_chunk_by_bucket(piece, n_seq, keep_store, stage, n_dev, res.has_regions);
         }
         t_fill += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
         {  // the rows are in the staging buffers: the parser may fill these vectors again
@@ -857,13 +911,16 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
             if (gffx_hip_batch_wait(b) != GFFX_OK) hip_fail("query_features");
             if (gffx_hip_batch_copy_root_bitmap(b, tmp.data(), tmp.size()) != GFFX_OK) hip_fail("copy_root_bitmap");
             for (size_t w = 0; w < words.size(); ++w) words[w] |= tmp[w];
+            uint64_t kept = 0;  // the kept pairs of every chunk this batch served (the root passes count them per block)
+            if (gffx_hip_batch_kept_pairs_accumulated(b, &kept) != GFFX_OK) hip_fail("kept_pairs_accumulated");
+            counts[2 * d + 1] += kept;
         }
     sub.lap("  streaming the BED file through Join A");
     for (size_t d = 0; d < D; ++d) counts[2 * d] = dev_rows[d];
+    res.per_device.assign(counts.begin(), counts.end());  // {regions, kept pairs} per logical device, as counted here ...
     if (D > 1) {
-        // the exchange step: every device learns every device's {regions, unique roots so far is host-side; kept pairs are
-        // not materialised by a bitmap pass} -- the per-device region counts and bitmap population
-        for (size_t d = 0; d < D; ++d) counts[2 * d + 1] = 0;
+        // the exchange step: every device learns every device's {regions, kept pairs} -- 16 bytes per device over RCCL;
+        // what the run REPORTS per device (--stats-json "devices", -v) is what came back from the exchange
         std::vector<uint64_t> gathered(2 * D * D, 0);
         // (every result of the run already sits on the host: the exchange is the job's reported hit-count step, and a node
         //  without a usable librccl must not lose a finished run to it -- a failure is a warning)
@@ -875,12 +932,14 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
                 exchanged = true;
                 for (size_t d = 0; d < D; ++d)
                     if (gathered[2 * d] != counts[2 * d]) throw Error("the RCCL all-gather returned different region counts");
+                res.per_device.assign(gathered.begin(), gathered.begin() + 2 * D);  // ... and as device 0 received them
+                res.exchanged = true;
             }
         }
         if (verbose)
             for (size_t d = 0; d < D; ++d)
-                std::fprintf(stderr, "[INFO] device %d: %llu regions%s\n", dev[d], (unsigned long long)dev_rows[d],
-                             exchanged ? " (all-gathered over RCCL)" : "");
+                std::fprintf(stderr, "[INFO] device %d: %llu regions, %llu kept pairs%s\n", dev[d], (unsigned long long)res.per_device[2 * d],
+                             (unsigned long long)res.per_device[2 * d + 1], exchanged ? " (all-gathered over RCCL)" : "");
         sub.lap("  hit-count exchange");
     }
     const uint32_t *fids = gffx_hip_index_sorted_fids(index_data.device_index);
@@ -1249,6 +1308,15 @@ void run(const IntersectArgs &args) {
     g_run_stats.count("blocks", (double)blocks.size());
     g_run_stats.count("threads", (double)args.common.effective_threads());
     g_run_stats.count("gpus", (double)args.gpus);
+    if (args.bed) {
+        std::string devs = "[";
+        for (size_t d = 0; 2 * d + 1 < sr.per_device.size(); ++d)
+            devs += std::string(d ? ", " : "") + "{\"regions\": " + std::to_string(sr.per_device[2 * d]) + ", \"kept_pairs\": " +
+                    std::to_string(sr.per_device[2 * d + 1]) + "}";
+        g_run_stats.extra("devices", devs + "]");
+        g_run_stats.extra("devices_from_rccl_exchange", sr.exchanged ? "true" : "false");
+        g_run_stats.extra("knobs", sr.knobs);
+    }
     g_run_stats.write("intersect", total_ms);
 }
 

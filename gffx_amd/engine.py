@@ -170,6 +170,13 @@ class QueryBatch:
         """The knobs of this batch that are not at their defaults (environment at creation + set_option)."""
         return _options(lib().gffx_hip_batch_options, self._h)
 
+    @property
+    def kept_pairs_accumulated(self) -> int:
+        """Kept pairs of all root passes since the last one without OUT_BITMAP_KEEP (after wait)."""
+        out = C.c_uint64(0)
+        check(lib().gffx_hip_batch_kept_pairs_accumulated(self._h, C.byref(out)))
+        return int(out.value)
+
     def reserve_hits(self, n_pairs: int) -> None:
         check(lib().gffx_hip_batch_reserve_hits(self._h, int(n_pairs)))
 

@@ -34,9 +34,10 @@
  *                          of a group in input order; every query's segment start is given explicitly (GFFX_OUT_OFFSETS /
  *                          GFFX_OUT_OFFSETS32) or per group (GFFX_OUT_SEGBASE) and the segments tile [0, pairs) exactly.  Inside a segment:
  *                          WINDOWS ascending list order (start, ties in builder order) for regions answered from the
- *                          window's candidate list (also in the wide form: the entries of the line of the region's first
- *                          base, then the roots that start inside the region), descending for regions that took the exact
- *                          sweep; FUSED descending
+ *                          window's candidate list (the wide form: the inline entries of the line of the region's first
+ *                          base, then the run of roots that start inside the region, then the entries of that line's
+ *                          list that continue in the spill records -- these start at or before the region, so a wide-form
+ *                          segment is NOT ascending by start), descending for regions that took the exact sweep; FUSED descending
  *   SORTED (partitioned)   segments in the order genome tiles were served, offsets explicit, inside a segment descending
  *
  * Threading: an index is immutable after creation and may be shared by threads; a batch owns
@@ -243,6 +244,11 @@ int gffx_hip_batch_sync(gffx_hip_batch *);
 uint64_t gffx_hip_batch_n_queries(const gffx_hip_batch *);
 /* valid after _wait */
 uint64_t gffx_hip_batch_total_hits(const gffx_hip_batch *);
+/* After _wait: the kept pairs of ALL root passes (GFFX_OUT_ROOT_BITMAP alone, windows strategy) since the batch's last pass without
+ * GFFX_OUT_BITMAP_KEEP -- what a caller that streams a BED file chunk by chunk through one batch reports per device
+ * (commands/intersect.rs:105-169 returns the pairs of the whole file; the hit-count exchange of `gffx intersect --gpus N` carries
+ * this number).  For any other last pass: the pass's own total (= gffx_hip_batch_total_hits). */
+int gffx_hip_batch_kept_pairs_accumulated(gffx_hip_batch *, uint64_t *out);
 int gffx_hip_batch_copy_counts(gffx_hip_batch *, uint32_t *host /* nq */);
 int gffx_hip_batch_copy_offsets(gffx_hip_batch *, uint64_t *host /* nq+1 */);
 int gffx_hip_batch_copy_offsets32(gffx_hip_batch *, uint32_t *host /* nq */); /* GFFX_OUT_OFFSETS32 */

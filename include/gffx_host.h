@@ -27,6 +27,10 @@ int gffx_host_parse_bed_file(const char *gff, const char *bed, uint32_t **region
  * thread on persistent workers, recycled row buffers): host/intersect.cpp::stream_unique_roots' producer, without a device */
 int gffx_host_parse_bed_file_chunked(const char *gff, const char *bed, uint32_t threads, uint64_t chunk_bytes, uint32_t **regions,
                                      uint64_t *n_regions, char *err, size_t errlen);
+/* The host half of `gffx intersect --gpus n_dev` without a device (stream_unique_roots' parser pool + per-chunk bucket scatter):
+ * rows = device 0's rows, then device 1's, ... (dev_rows[d] rows of 3 words each); keep_all: device 0 receives every row. */
+int gffx_host_shard_bed_file(const char *gff, const char *bed, uint32_t threads, uint64_t chunk_bytes, uint32_t n_dev, int keep_all,
+                             uint32_t **rows, uint64_t *dev_rows /* n_dev */, char *err, size_t errlen);
 int gffx_host_parse_region(const char *gff, const char *region, uint32_t out[3], char *err, size_t errlen);
 /* index_loader/gof.rs:54-128: offsets[2*i], offsets[2*i+1] = block of roots[i] (UINT64_MAX = missing) */
 int gffx_host_roots_to_offsets(const char *gff, const uint32_t *roots, uint64_t n, uint64_t *offsets,

@@ -153,13 +153,22 @@ def test_multi_gpu_cli_is_byte_identical_and_streams_in_chunks(tmp_path):
     for flags, kw in ((["-c"], dict(mode=0)), (["-e"], dict(mode=2, entire_group=True)), (["-C", "-I"], dict(mode=1, invert=True))):
         want = str(tmp_path / "want.gff")
         rc, msg = ob.intersect_run(gff, want, bed=bed, **kw) if kw.get("entire_group") else (None, None)
-        outs = []
+        outs, kept = [], []
         for n in (1, 2, 3):
-            out = str(tmp_path / ("got%d.gff" % n))
-            r = subprocess.run([GFFX, "intersect", "-v", "-i", gff, "-b", bed, "-o", out, "--gpus", str(n)] + flags, capture_output=True)
+            out, sj = str(tmp_path / ("got%d.gff" % n)), str(tmp_path / ("stats%d.json" % n))
+            r = subprocess.run([GFFX, "intersect", "-v", "-i", gff, "-b", bed, "-o", out, "--gpus", str(n), "--stats-json", sj] + flags,
+                               capture_output=True)
             assert r.returncode == 0, r.stderr[-400:]
             outs.append(open(out, "rb").read())
+            # per device {regions, kept pairs}: the hit counts of the job's exchange step (here the host's own: the logical devices
+            # share one GPU, so no RCCL communicator exists); the devices' shares add up to the run's totals whatever N is
+            st = json.load(open(sj))
+            assert len(st["devices"]) == n and st["devices_from_rccl_exchange"] is False and st["knobs"] == {}
+            assert sum(d["regions"] for d in st["devices"]) == st["counts"]["regions"] == len(regions)
+            assert n == 1 or min(d["regions"] for d in st["devices"]) > 0.2 * len(regions) / n
+            kept.append(sum(d["kept_pairs"] for d in st["devices"]))
         assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 0, flags
+        assert kept[0] == kept[1] == kept[2] and kept[0] > 0, (flags, kept)
         if rc is not None:
             assert rc == 0 and outs[0] == open(want, "rb").read(), (flags, msg)
     # per-line mode against the oracle needs the literal scan: a 20 k-row BED keeps it fast

@@ -513,6 +513,45 @@ def test_streaming_parser_chunks_pool_and_recycled_buffers(host, tmp_path, monke
     assert b"12x" in e.value
 
 
+def test_multi_device_scatter_of_bed_chunks_equals_the_shard_plan(host, tmp_path, monkeypatch):
+    """The host half of `gffx intersect --gpus N` without a device (gffx_host_shard_bed_file = the parser pool + scatter_chunk_by_bucket,
+    the code stream_unique_roots runs per chunk): one chunk -> device d receives exactly regions[shard_rows(regions, N, d)]
+    (gffx_amd.shard: the plan the bench's ranks and the reference's seqid buckets, intersect.rs:114-120, share); several chunks ->
+    every row exactly once, balanced shares; keep_all -> device 0 holds every row."""
+    from gffx_amd import shard
+
+    monkeypatch.setenv("GFFX_TREE_INDEX", "gof")
+    gff, roots = _make_gff(tmp_path, 6)
+    assert _build(host, gff)[0] == 0
+    rows = synth.synth_bed(150_000, seed=8, chroms=synth.SMALL2, width=(1, 50000), edge_frac=0.05, roots=roots)
+    bed = str(tmp_path / "shard.bed")
+    with open(bed, "w") as f:
+        for c, s, e in rows.tolist():
+            f.write("%s\t%d\t%d\n" % (("chr1", "chr2")[c], s, e))
+    host.gffx_host_shard_bed_file.restype = C.c_int
+    host.gffx_host_shard_bed_file.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_int, C.POINTER(u32p), u64p, C.c_char_p, C.c_size_t]
+
+    def run(threads, chunk, n_dev, keep_all):
+        e, pr, dn = _err(), u32p(), (C.c_uint64 * n_dev)()
+        assert host.gffx_host_shard_bed_file(gff.encode(), bed.encode(), threads, chunk, n_dev, keep_all, C.byref(pr), dn, e, len(e)) == 0, e.value
+        n = [int(x) for x in dn]
+        flat = np.ctypeslib.as_array(pr, shape=(max(sum(n), 1), 3))[: sum(n)].copy()
+        host.gffx_host_free(pr)
+        return [flat[sum(n[:d]): sum(n[:d + 1])] for d in range(n_dev)]
+
+    key = lambda a: np.sort(a[:, 0].astype(np.uint64) << 40 | a[:, 1].astype(np.uint64) << 20 ^ a[:, 2].astype(np.uint64))  # noqa: E731
+    for n_dev in (2, 3, 8):
+        parts = run(8, 1 << 30, n_dev, 0)  # one chunk
+        for d in range(n_dev):
+            assert np.array_equal(parts[d], rows[shard.shard_rows(rows, 2, n_dev, d)]), (n_dev, d)
+    for threads, chunk, n_dev in ((5, 1 << 19, 2), (16, 3 << 18, 4), (1, 1 << 20, 3)):
+        parts = run(threads, chunk, n_dev, 0)
+        assert np.array_equal(key(np.concatenate(parts)), key(rows))
+        assert max(len(p) for p in parts) < 1.1 * len(rows) / n_dev + 64
+        kept = run(threads, chunk, n_dev, 1)
+        assert np.array_equal(key(kept[0]), key(rows)) and all(np.array_equal(kept[d], parts[d]) for d in range(1, n_dev))
+
+
 @pytest.mark.parametrize("crlf", [False, True])
 def test_all_line_table_image_equals_the_text_walk_of_every_block(host, tmp_path, crlf):
     """`gffx index` writes `<gff>.lall` (line_index.cpp): for every block of the index it lists exactly the lines, raw

@@ -521,9 +521,43 @@ def test_offsets32_and_bitmap_accumulation():
         b.wait()
         assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
         assert b.total_hits == len(oix.query_features(halves[1], int(mode), False)[0])
+        assert b.kept_pairs_accumulated == len(want_t)  # ... and the kept pairs of BOTH passes, summed per block on the device
         with pytest.raises(Exception):
             b.counts()  # (not requested)
         b.set_regions(regions)
+    b.close()
+    ix.close()
+
+
+def test_knobs_are_read_once_and_set_through_the_api(monkeypatch):
+    """GFFX_HIP_* are read when an index / a batch is created, never by a launch; a batch's change through set_option; the values that
+    are not defaults are reported (bench.py's config.knobs, the CLI's --stats-json)."""
+    roots = synth.gencode_like_roots(3000, seed=5)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    regions = synth.synth_bed(600_000, seed=6)
+    monkeypatch.setenv("GFFX_HIP_WIN_FILTER_KB", "8")
+    monkeypatch.setenv("GFFX_HIP_WIN_THREADS", "512")
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, len(regions))
+    monkeypatch.delenv("GFFX_HIP_WIN_FILTER_KB")
+    monkeypatch.setenv("GFFX_HIP_WIN_THREADS", "1024")  # (too late for `b`)
+    assert ix.options() == {"GFFX_HIP_WIN_FILTER_KB": 8} and b.options() == {"GFFX_HIP_WIN_THREADS": 512}
+    b.set_regions(regions)
+    b.run(OverlapMode.Overlap, False, engine.OUT_FIDS | engine.OUT_SEGBASE)
+    b.wait()
+    assert b.block_threads == 512
+    pairs = b.total_hits
+    b.set_option("win_threads", 1024)
+    b.run(OverlapMode.Overlap, False, engine.OUT_FIDS | engine.OUT_SEGBASE)
+    b.wait()
+    assert b.block_threads == 1024 and b.total_hits == pairs and b.options() == {"GFFX_HIP_WIN_THREADS": 1024}
+    b.set_option("GFFX_HIP_WIN_THREADS", 0)
+    b.run(OverlapMode.Overlap, False, engine.OUT_FIDS | engine.OUT_SEGBASE)
+    b.wait()
+    assert b.block_threads == 1024 and b.options() == {}  # the engine's choice for 600 k regions alone
+    for name, value in (("no_such_knob", 1), ("WIN_THREADS", 4096), ("WIN_WIDE", 3)):
+        with pytest.raises(Exception):
+            b.set_option(name, value)
     b.close()
     ix.close()
 
