@@ -20,7 +20,8 @@ The JSON line carries, next to the contract's fields:
                         takes 1024-thread blocks for such a pass (roofline inside), 512-thread blocks while two batches are in flight
   roofline              dominant kernel, HIP-event durations of serial back-to-back launches on the engine's stream
   roofline_10m          the same for a 10 M-region batch (seed 1002); roofline_10m_contained: --contained (configs[2]'s mode);
-                        wide_regions: 1 M regions of width U[100, 200000] (AUTO runs the wide form of k_join_pairs);
+                        wide_regions: 1 M regions of width U[100, 200000] (AUTO runs the mixed form of k_join_pairs, every lane the
+                        wide way); mixed_widths: the headline's batch with every tenth row SV-sized (the mixed form, lane by lane);
                         sorted_bed: the 1 M batch sorted by (seqid, start) as BED files usually are
   cli_pass              the pass the CLI runs (root bitmap only) at 1 M and 10 M regions, next to the root_fid pass
   t_xfer                host regions in (pinned), counts + root_fids back on the host: two batches double-buffered
@@ -792,6 +793,32 @@ def main():
                                                "wide_form": bool(bmw.batches[0].wide_form)}
         bmw.close()
         del colsw, regw
+        # ---- a MIXED batch: the headline's regions with every tenth row replaced by an SV-sized one (width U[20 000, 2 000 000])
+        # -- below the eighth at which AUTO used to leave the narrow form: the mixed form serves every region its own way
+        regm = regions.copy()
+        rng_m = np.random.default_rng(1005)
+        pick_m = rng_m.choice(nq, nq // 10, replace=False)
+        wid_m = rng_m.integers(20_000, 2_000_000, len(pick_m), dtype=np.int64)
+        regm[pick_m, 2] = np.minimum(regm[pick_m, 1].astype(np.int64) + wid_m, 0xFFFFFFF0).astype(np.uint32)
+        colsm = to_dev(torch, regm, dev)
+        pm = Pass(engine, ix, colsm, nq, 1, mode, out_flags, 0)
+        pairsm = pm.size_and_warm(2)  # (regions on the device carry no width sample: the first waited pass tells AUTO)
+        km = pm.kernel_us(10)
+        result["mixed_widths"] = roofline_obj(km, nq, pairsm, out_b, "the headline's %d regions, every tenth one widened to U[20000, 2000000] bases "
+                                              "(seed 1005), AUTO: the mixed form of k_join_pairs -- a lane per region, narrow regions from one "
+                                              "line, wide ones from two lines and two ranks" % nq, None, pm.pass_us_one_event_pair, pm.block_threads)
+        result["mixed_widths"]["mixed_form"] = bool(pm.batches[0].wide_form)
+        result["mixed_widths"]["narrow_pass_us"] = result["serial"]["roofline"]["pass_kernel_us"] if "serial" in result else None
+        pm.batches[0].set_option("WIN_WIDE", 0)  # the same batch on the narrow form (every wide row an out-of-line sweep): round 4's answer
+        pm.kernel_us(10)
+        result["mixed_widths"]["narrow_form_pass_us"] = pm.pass_us_one_event_pair
+        pm.close()
+        bmm = Pass(engine, ix, colsm, nq, 1, mode, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, 0)
+        bmm.size_and_warm(2)
+        kbm = bmm.kernel_us(10)
+        result["mixed_widths"]["root_pass"] = {"bitmap_pass_us": bmm.pass_us_one_event_pair, "kernels": kbm, "mixed_form": bool(bmm.batches[0].wide_form)}
+        bmm.close()
+        del colsm, regm
         # ---- a BED file sorted by (seqid, start), as most are
         regs = np.ascontiguousarray(regions[np.lexsort((regions[:, 1], regions[:, 0]))])
         colss = to_dev(torch, regs, dev)

@@ -89,10 +89,11 @@ void gffx::sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uin
         w.wide += (wmax && e > s && e - s > wmax) ? 1 : 0;
     }
 }
-static bool sample_mostly_wide(const gffx_hip_batch *b, uint64_t nq, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride) {
+static void sample_host_rows(gffx_hip_batch *b, uint64_t nq, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride) {
     WidthSample w;
     if (nq && b->knobs.v[BK_WIDTH_SAMPLE]) sample_widths(w, nq, std::max<uint64_t>(1, nq / 4096), chr, start, end, stride, b->ix->h_win_wmax);
-    return w.mostly_wide();
+    b->mostly_slow = b->mostly_wide = w.mostly_wide();
+    b->some_wide = w.some_wide();
 }
 
 extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t *regions,
@@ -107,7 +108,7 @@ extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t
     b->q = QueryView{b->d_regions, nullptr, nullptr, nullptr};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = b->mostly_wide = sample_mostly_wide(b, nq, regions, regions + 1, regions + 2, 3);
+    sample_host_rows(b, nq, regions, regions + 1, regions + 2, 3);
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -129,7 +130,7 @@ extern "C" int gffx_hip_batch_set_regions_soa_host(gffx_hip_batch *b, const uint
     b->q = QueryView{nullptr, dc, ds, de};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = b->mostly_wide = sample_mostly_wide(b, nq, chr, start, end, 1);
+    sample_host_rows(b, nq, chr, start, end, 1);
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -144,7 +145,7 @@ extern "C" int gffx_hip_batch_set_regions_device(gffx_hip_batch *b, const uint32
     b->q = QueryView{nullptr, d_chr, d_start, d_end};
     b->nq = nq;
     b->have_regions = true;
-    b->mostly_slow = b->mostly_wide = false;
+    b->mostly_slow = b->mostly_wide = b->some_wide = false;
     b->ran = b->waited = false;
     return GFFX_OK;
 }
@@ -466,7 +467,9 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     {
         const long ww = b->knobs.v[BK_WIN_WIDE];
         const bool eligible = mode == GFFX_MODE_OVERLAP && !invert && b->ix->win_range_ok;
-        b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && b->strategy == GFFX_STRATEGY_FUSED && b->mostly_wide) ||
+        // (AUTO: some wide rows -- more than 1/32 -- and no other reason for most regions to sweep: the mixed form, which serves every
+        //  region its own way; mostly wide: the same kernel, every lane the wide way)
+        b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && (b->mostly_wide || (b->some_wide && !b->mostly_slow))) ||
                                (ww == 2 && b->strategy == GFFX_STRATEGY_WINDOWS));
         if (b->wide) b->strategy = GFFX_STRATEGY_WINDOWS;
     }
@@ -602,6 +605,7 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
             const uint64_t all = (uint32_t)((uint32_t)h_slow_win - (uint32_t)b->slow_seen_win);
             const uint64_t by_width = (uint32_t)((uint32_t)(h_slow_win >> 32) - (uint32_t)(b->slow_seen_win >> 32));
             b->mostly_wide = by_width / passes > b->nq / 8;
+            b->some_wide = by_width / passes > b->nq / 32;
             b->mostly_slow = b->mostly_wide || all / passes > b->nq / 4;  // (sweeps for other reasons: the rule of rounds 2 and 3)
         }
         b->slow_seen_win = h_slow_win;

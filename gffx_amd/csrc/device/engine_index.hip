@@ -344,28 +344,44 @@ __global__ void k_scatter_lines(uint4 *table, const uint32_t *at, const uint4 *l
 // A line table = the windows' lines, followed -- when the index has split windows -- by 2^kWinSplit sub-lines per window, zero but
 // for the sub-lines of the split ones (gffx_device.hpp).  The second level is zeroed and filled on the device: only the
 // compact list of sub-lines crosses the bus.  *bytes = the array's size (gffx_hip_index_clone).
-static int upload_line_table(uint4 **dst, const std::vector<uint4> &lines, bool split, const std::vector<uint32_t> &sub_at,
-                             const std::vector<uint4> &sub_lines, size_t *bytes) {
+static int fill_line_table(uint4 *dst, const std::vector<uint4> &lines, bool split, const std::vector<uint32_t> &sub_at,
+                           const std::vector<uint4> &sub_lines) {
     const size_t n_win = lines.size() / 2, total = 2 * n_win * (split ? (1u << kWinSplit) + 1 : 1);
-    int rc = dev_alloc(dst, total);
-    if (rc) return rc;
-    *bytes = std::max<size_t>(total, 1) * sizeof(uint4);
-    if (!lines.empty()) GFFX_HIP_TRY(hipMemcpy(*dst, lines.data(), lines.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!lines.empty()) GFFX_HIP_TRY(hipMemcpy(dst, lines.data(), lines.size() * sizeof(uint4), hipMemcpyHostToDevice));
     if (!split) return GFFX_OK;
-    GFFX_HIP_TRY(hipMemset(*dst + lines.size(), 0, (total - lines.size()) * sizeof(uint4)));
+    GFFX_HIP_TRY(hipMemset(dst + lines.size(), 0, (total - lines.size()) * sizeof(uint4)));
     if (sub_at.empty()) return GFFX_OK;
     uint32_t *d_at = nullptr;
     uint4 *d_sub = nullptr;
+    int rc;
     if ((rc = dev_upload(&d_at, sub_at)) || (rc = dev_upload(&d_sub, sub_lines))) {
         (void)hipFree(d_at), (void)hipFree(d_sub);
         return rc;
     }
     const uint32_t n_halves = (uint32_t)sub_lines.size();
-    hipLaunchKernelGGL(k_scatter_lines, dim3((n_halves + 255) / 256), dim3(256), 0, 0, *dst, d_at, d_sub, n_halves);
+    hipLaunchKernelGGL(k_scatter_lines, dim3((n_halves + 255) / 256), dim3(256), 0, 0, dst, d_at, d_sub, n_halves);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(d_at), (void)hipFree(d_sub);
     if (e != hipSuccess) return fail(GFFX_E_HIP, "k_scatter_lines failed: %s", hipGetErrorString(e));
+    return GFFX_OK;
+}
+// The three line tables (root_fids, positions, the wide form's) live in ONE allocation, one behind the other, each
+// win_table_bytes long: the kernels that serve narrow and wide regions side by side (the mixed form, round 5) address all of
+// them through one buffer descriptor.
+static int upload_line_tables(gffx_hip_index *ix, const std::vector<uint4> &win, const std::vector<uint4> &win_pos, const std::vector<uint4> &win_wide,
+                              const std::vector<uint32_t> &sub_at, const std::vector<uint4> &sub_lines, const std::vector<uint4> &sub_lines_pos,
+                              const std::vector<uint32_t> &wide_at, const std::vector<uint4> &wide_sub, size_t *bytes) {
+    const bool split = ix->win_swords != 0;
+    const size_t n_win = win.size() / 2, per_table = std::max<size_t>(2 * n_win * (split ? (1u << kWinSplit) + 1 : 1), 2);  // uint4 units
+    int rc = dev_alloc(&ix->d_win_all, 3 * per_table);
+    if (rc) return rc;
+    *bytes = 3 * per_table * sizeof(uint4);
+    ix->win_table_bytes = per_table * sizeof(uint4);
+    ix->fix_win_pointers();
+    if ((rc = fill_line_table(ix->d_win, win, split, sub_at, sub_lines)) || (rc = fill_line_table(ix->d_win_pos, win_pos, split, sub_at, sub_lines_pos)) ||
+        (rc = fill_line_table(ix->d_win_wide, win_wide, split, wide_at, wide_sub)))
+        return rc;
     return GFFX_OK;
 }
 
@@ -586,13 +602,13 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     ix->cshift = cshift;
     ix->partition_ok = plan_ok && ix->n_tiles >= 1 && ix->n_tiles <= kMaxTiles;
     int rc;
-    size_t win_bytes = 0, win_pos_bytes = 0, win_wide_bytes = 0;
+    size_t win_all_bytes = 0;
     if ((rc = dev_upload(&ix->d_start, h_start)) || (rc = dev_upload(&ix->d_aux, h_aux)) ||
         (rc = dev_upload(&ix->d_chr_meta, chr_meta)) || (rc = dev_upload(&ix->d_bins, bins)) ||
-        (rc = dev_upload(&ix->d_win_meta, win_meta)) || (rc = upload_line_table(&ix->d_win, win, ix->win_swords != 0, sub_at, sub_lines, &win_bytes)) ||
-        (rc = upload_line_table(&ix->d_win_pos, win_pos, ix->win_swords != 0, sub_at, sub_lines_pos, &win_pos_bytes)) || (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
+        (rc = dev_upload(&ix->d_win_meta, win_meta)) ||
+        (rc = upload_line_tables(ix.get(), win, win_pos, win_wide, sub_at, sub_lines, sub_lines_pos, wide_at, wide_sub, &win_all_bytes)) ||
+        (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
         (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_splittab, win_splittab)) ||
-        (rc = upload_line_table(&ix->d_win_wide, win_wide, ix->win_swords != 0, wide_at, wide_sub, &win_wide_bytes)) ||
         (rc = dev_upload(&ix->d_root_fids, root_fids)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
@@ -602,9 +618,10 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     }
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
     ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),
-                       bytes(win_meta),  win_bytes,         win_pos_bytes,    bytes(win_spill), bytes(win_filter),
-                       bytes(win_splittab), win_wide_bytes, bytes(root_fids),
+                       bytes(win_meta),  win_all_bytes,     bytes(win_spill), bytes(win_filter),
+                       bytes(win_splittab), bytes(root_fids),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
+    ix->win_range_ok = ix->win_range_ok && ix->win_all_ok();  // (the mixed form addresses the three line tables through one descriptor)
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
     GFFX_HIP_TRY(hipDeviceSynchronize());
     *out = ix.release();
@@ -631,6 +648,7 @@ extern "C" int gffx_hip_index_clone(const gffx_hip_index *src, int device, gffx_
             return fail(e == hipErrorOutOfMemory ? GFFX_E_OOM : GFFX_E_HIP, "gffx_hip_index_clone: %s", hipGetErrorString(e));
         }
     }
+    ix->fix_win_pointers();
     GFFX_HIP_TRY(hipDeviceSynchronize());
     *out = ix.release();
     return GFFX_OK;
@@ -644,12 +662,10 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_chr_meta);
     (void)hipFree(ix->d_bins);
     (void)hipFree(ix->d_win_meta);
-    (void)hipFree(ix->d_win);
-    (void)hipFree(ix->d_win_pos);
+    (void)hipFree(ix->d_win_all);  // (d_win, d_win_pos, d_win_wide point into it)
     (void)hipFree(ix->d_win_spill);
     (void)hipFree(ix->d_win_filter);
     (void)hipFree(ix->d_win_splittab);
-    (void)hipFree(ix->d_win_wide);
     (void)hipFree(ix->d_root_fids);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);

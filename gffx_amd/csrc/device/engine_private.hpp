@@ -140,13 +140,16 @@ struct gffx_hip_index {
     uint4 *d_aux = nullptr;
     uint4 *d_chr_meta = nullptr;
     uint4 *d_bins = nullptr;
-    uint4 *d_win_meta = nullptr, *d_win = nullptr, *d_win_pos = nullptr, *d_win_spill = nullptr;  // window index (join_pairs_kernels.hpp)
+    uint4 *d_win_meta = nullptr, *d_win_spill = nullptr;  // window index (join_pairs_kernels.hpp)
+    uint4 *d_win_all = nullptr;  // the three line tables in one allocation: [win | win_pos | win_wide], win_table_bytes each
+    uint4 *d_win = nullptr, *d_win_pos = nullptr;  // ... (pointers into d_win_all: fix_win_pointers)
+    size_t win_table_bytes = 0;
     uint32_t n_win = 0;
     uint32_t *d_win_filter = nullptr;
     uint32_t win_fwords = 0, win_fshift = 0;
     uint32_t *d_win_splittab = nullptr;  // split windows (k_join_pairs): one bit per window; their sub-lines follow the lines in d_win / d_win_pos
     uint32_t win_swords = 0;
-    uint4 *d_win_wide = nullptr;  // the wide form's lines: {coordinates x 4 | rank, list-tail header, 0, 0}, both levels
+    uint4 *d_win_wide = nullptr;  // the wide form's lines: {coordinates x 4 | rank, list-tail header, 0, 0}, both levels (into d_win_all)
     uint32_t *d_root_fids = nullptr;  // ranks per line, root_fids by position (the wide form of k_join_pairs)
     bool win_range_ok = false;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
@@ -164,12 +167,20 @@ struct gffx_hip_index {
 
     // every device array of the index, in a fixed order
     std::vector<void **> arrays() {
-        return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_win_meta,   (void **)&d_win,
-                (void **)&d_win_pos,   (void **)&d_win_spill, (void **)&d_win_filter,
-                (void **)&d_win_splittab, (void **)&d_win_wide,  (void **)&d_root_fids,
+        return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_win_meta,   (void **)&d_win_all,
+                (void **)&d_win_spill, (void **)&d_win_filter,
+                (void **)&d_win_splittab, (void **)&d_root_fids,
                 (void **)&d_cell_base,
                 (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
     }
+
+    void fix_win_pointers() {  // after d_win_all was allocated or copied
+        d_win = d_win_all;
+        d_win_pos = d_win_all ? d_win_all + win_table_bytes / sizeof(uint4) : nullptr;
+        d_win_wide = d_win_all ? d_win_all + 2 * (win_table_bytes / sizeof(uint4)) : nullptr;
+    }
+    // the mixed form's one descriptor covers all three tables with 31-bit byte offsets
+    bool win_all_ok() const { return d_win_all && 3 * (uint64_t)win_table_bytes < (1ull << 31); }
 
     IndexView view() const {
         IndexView v;
@@ -249,6 +260,7 @@ struct gffx_hip_batch {
     bool wide = false;              // this run's passes take the wide form of the window kernels (AUTO, mostly_slow, overlap mode)
     bool mostly_slow = false;       // more than 1/8 of the regions are wide (a sample of the host's rows) or took the sweep in the last waited narrow pass
     bool mostly_wide = false;       // ... because of their width (the wide form answers those; dense windows and seqids without windows it does not)
+    bool some_wide = false;         // more than 1/32 of the regions are wider than their seqid's lines answer: AUTO's overlap-mode passes take the MIXED form
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
     uint32_t flags = 0;
@@ -279,6 +291,9 @@ uint32_t meta_bytes(const gffx_hip_index *ix);
 struct WidthSample {
     uint64_t n = 0, wide = 0;
     bool mostly_wide() const { return 8 * wide > n; }  // (the same eighth as the learned rule in gffx_hip_batch_wait)
+    // Break-even of the narrow form (every wide row an out-of-line sweep: ~14.5 us + 120 us x the wide fraction per 1 M regions)
+    // against the mixed form (~19 us + ~20 x): about 1/25; a thirty-second of the sample (128 of 4096 rows)
+    bool some_wide() const { return 32 * wide > n; }
 };
 // (chr may be nullptr: then every row is measured against `wmax_all`; with chr, against its seqid's own limit h_wmax[chr])
 void sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride,

@@ -112,6 +112,7 @@ extern "C" int gffx_hip_batch_set_regions_store(gffx_hip_batch *b, const gffx_hi
                 ws.n++, ws.wide += (wmax && row.second > wmax) ? 1 : 0;
             }
         b->mostly_slow = b->mostly_wide = ws.mostly_wide();
+        b->some_wide = ws.some_wide();
     }
     b->ran = b->waited = false;
     return GFFX_OK;

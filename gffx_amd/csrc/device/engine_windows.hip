@@ -179,6 +179,8 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     a.pv.filter = ix->d_win_filter;
     a.pv.splittab = ix->d_win_splittab;
     a.pv.wide = ix->d_win_wide;
+    a.pv.all = ix->d_win_all;
+    a.pv.table_bytes = (uint32_t)ix->win_table_bytes;
     a.pv.rfids = ix->d_root_fids;
     a.pv.n_roots = ix->n_roots;
     a.pv.n_win = ix->n_win;

@@ -23,7 +23,7 @@
 // What the line cannot answer -- the tail of a (sub-)list still longer than 4, dense windows, regions wider than wmax,
 // qs >= qe rows (the reference keeps them), seqids without windows -- is DEFERRED: list tails are walked in line (a few
 // 16-byte records), exact sweeps (join_a_kernels.hpp) through a function call.
-// The WIDE form of both kernels (template argument WIDE; overlap mode; pair_locate_wide below) answers regions of
+// The WIDE form of both kernels (template argument WIDE; overlap mode; pair_locate_mixed below) answers regions of
 // ANY width from the same index: the roots over the region's first base -- the line of qs, asked about [qs, qs + 1) -- plus the
 // roots that start inside it, a run of positions between two ranks, each rank = a stored word of a line + the line's entries
 // that start at or below the base (win_wide: the line's coordinates and its rank record side by side).  AUTO takes it for
@@ -113,8 +113,10 @@ struct PairView {
     const uint4 *meta;         // IndexView::win_meta
     const uint32_t *filter;    // IndexView::win_filter
     const uint32_t *splittab;  // IndexView::win_splittab
-    const uint4 *wide;         // IndexView::win_wide   } the wide form only
+    const uint4 *wide;         // IndexView::win_wide   } the mixed form only
     const uint32_t *rfids;     // IndexView::root_fids  }
+    const uint4 *all;          // the three line tables in one allocation: [win | win_pos | win_wide], table_bytes each (the mixed form's
+    uint32_t table_bytes;      //   one descriptor; 3 x table_bytes < 2^31)
     uint32_t n_win, n_chr, fshift, n_roots;
 };
 
@@ -463,31 +465,44 @@ __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t
     return c;
 }
 
-// The WIDE form (gffx_device.hpp, "ranks"; overlap mode): a region of ANY width is its first base -- the roots over it are in
-// the line of qs -- and the roots that start inside it, a run of positions between two ranks, each read off a line and its
-// rank word: the line of qs again, and the line of qe - 1.  off0 / rel0: the line of qs and qs in its coordinates; off1 / rel1:
-// the same for qe - 1.  A base beyond the seqid's windows stands for the last base of the last window (nothing overlaps it,
-// every root starts at or below it).  A row on a seqid without roots reads nothing; a seqid without windows, an empty and a
-// reversed row take the sweep.
-__device__ __forceinline__ void pair_locate_wide(const PairLds &L, uint32_t qc, uint32_t qs, uint32_t qe, uint32_t &off0, uint32_t &rel0,
-                                                 uint32_t &off1, uint32_t &rel1, bool &swp) {
+// The MIXED form (round 5; template argument WIDE; overlap mode): narrow and wide regions side by side, each lane its own way.
+//   * A region the lines answer (0 < qe - qs <= wmax) is served as in the narrow form: ONE line -- the line of its last base, both
+//     halves (coordinates | root_fids or positions) -- tested against [rqs, rqe1].  No coverage filter (the strips leave no room).
+//   * A wider region is its first base -- the roots over it are in the line of qs, asked about [qs, qs + 1) -- and the roots that
+//     start inside it, a run of positions between two ranks (gffx_device.hpp, "ranks"), each read off a line of the wide table and
+//     its rank word: the line of qs again, and the line of qe - 1.
+// All three line tables are one buffer; off = byte offset of the lane's first line in it (narrow: in the pass's own table at
+// lines_base; wide: in the wide table at wide_base), ta / tb = the test's region in that line's coordinates, off1 / rel1 = the line of
+// qe - 1 and qe - 1 in its coordinates (wide lanes only).  A base beyond the seqid's windows stands for the last base of the last
+// window (nothing overlaps it, every root starts at or below it); a narrow region whose last base lies there reads nothing.  A row
+// on a seqid without roots reads nothing; a seqid without windows, an empty and a reversed row take the sweep.
+__device__ __forceinline__ void pair_locate_mixed(const PairLds &L, uint32_t lines_base, uint32_t wide_base, uint32_t qc, uint32_t qs, uint32_t qe,
+                                                  uint32_t &off, uint32_t &ta, uint32_t &tb, uint32_t &off1, uint32_t &rel1, bool &wide, bool &swp) {
     const uint4 m = L.cm[min(qc, L.n_chr)];
-    const uint32_t wmax = m.z >> 8, shift = m.z & 31u;
+    const uint32_t wmax = m.z >> 8, shift = m.z & 31u, e1 = qe - 1u, wd1 = e1 - qs;
+    const bool fits = wd1 < wmax;  // 0 < qe - qs <= wmax (unsigned: an empty or reversed row wraps)
     const bool live = (qs < qe) & (m.y != 0u);
     swp = (m.y != 0u) & ((wmax == 0u) | (qs >= qe));  // (an empty or reversed row keeps the roots that reach over both its ends: rare, the sweep)
     const bool lines = live & (wmax != 0u);
-    auto point = [&](uint32_t y, uint32_t &off, uint32_t &rel) {
-        const bool past = (y >> shift) >= m.y;
+    wide = lines & !fits;
+    auto point = [&](uint32_t y, uint32_t &line, uint32_t &rel, bool &past) {
+        past = (y >> shift) >= m.y;
         const uint32_t b = past ? m.y - 1u : y >> shift, yy = past ? 0xFFFFFFFFu : y;
         const uint32_t w = m.x + b;
         const bool split = (__builtin_amdgcn_ubfe(L.sbits[min(w >> 5, L.swords)], w, 1) != 0) & L.split_on;
         const uint32_t sh = shift - (split ? kWinSplit : 0u);
-        const uint32_t line = split ? L.n_win + (w << kWinSplit) + __builtin_amdgcn_ubfe(yy, sh, kWinSplit) : w;
-        off = lines ? line * kWinLineBytes : kWinNoLine;
+        line = split ? L.n_win + (w << kWinSplit) + __builtin_amdgcn_ubfe(yy, sh, kWinSplit) : w;
         rel = __builtin_amdgcn_ubfe(yy, 0, sh) + wmax;
     };
-    point(qs, off0, rel0);
-    point(qe - 1u, off1, rel1);
+    uint32_t l0, r0, l1, r1;
+    bool p0, p1;
+    point(qs, l0, r0, p0);
+    point(e1, l1, r1, p1);
+    off = !lines ? kWinNoLine : fits ? (p1 ? kWinNoLine : lines_base + l1 * kWinLineBytes) : wide_base + l0 * kWinLineBytes;
+    ta = fits ? r1 - wd1 : r0;  // narrow: qs relative to the line of its last base; wide: the one-base region [qs, qs + 1)
+    tb = fits ? r1 : r0;
+    off1 = wide ? wide_base + l1 * kWinLineBytes : kWinNoLine;
+    rel1 = r1;
 }
 
 // a round's regions: buffer loads from a descriptor of exactly the round's rows (scalar work), 16 bytes per thread and column
@@ -539,7 +554,8 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 // T: threads per block (512: two blocks per CU; 1024: one, half the reservation atomics)
 // OFFS: per-region offsets are written (GFFX_OUT_OFFSETS / _OFFSETS32): each lane parks its place inside the round's segment
 // POS: the words a pass emits are index positions (table win_pos), not root_fids
-// WIDE: the wide form (pair_locate_wide; overlap mode, not inverted): batches AUTO found mostly wider than the lines answer
+// WIDE: the mixed form (pair_locate_mixed; overlap mode, not inverted): a batch in which AUTO found wide regions -- every lane serves its
+//       region the narrow way (one line) or the wide way (two lines, two ranks) as the region's width asks
 template <int MODE, bool META_LDS, int T, bool OFFS, bool POS, bool WIDE = false>
 __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP, "the wide form answers overlap mode");
@@ -605,10 +621,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
     const PairLds L{cm, s_sbits, n_chr, A.pv.n_win, A.pv.fshift, swords, fwords == 0, swords != 0};
     uint32_t n_slow = 0;  // regions that took the exact sweep | << 16: ... because the lines do not answer their width (AUTO's census; per lane: < 2^16)
-    // (the wide form: its own line table {coordinates | rank, list-tail header}; the root_fids by position, allocated 4 words
-    //  beyond the last root)
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(A.pv.wide), 0, WIDE ? (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes) : 0u, 0x00020000);
+    // (the mixed form: ONE descriptor over the three line tables [win | win_pos | win_wide] -- a narrow lane reads its line in the
+    //  pass's own table, a wide lane the wide table {coordinates | rank, list-tail header} --; the root_fids by position, allocated
+    //  4 words beyond the last root)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(A.pv.all), 0, WIDE ? 3u * A.pv.table_bytes : 0u, 0x00020000);
+    const uint32_t lines_base = POS ? A.pv.table_bytes : 0u, wide_base = 2u * A.pv.table_bytes;
     const __amdgpu_buffer_rsrc_t rfd =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rfids), 0, WIDE ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
 
@@ -725,26 +742,28 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
         uint32_t off[4], rqs[4], rqe1[4];  // the line's byte offset; the region in the line's coordinates (rqe1 = its last base)
         bool swp[4];  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
-        uint32_t off1[4], r0[4], nr[4];  // (wide form) the line of qe - 1 (rqe1[] = qe - 1 in ITS coordinates); the run of roots starting inside
+        uint32_t off1[4], rel1[4], r0[4], nr[4];  // (mixed form, wide lanes) the line of qe - 1 and qe - 1 in its coordinates; the run of roots starting inside
+        bool isw[4];                              // (mixed form) the lane serves this region the wide way
+        uint32_t iswm = 0;                        // ... as a bit per region
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;  // (a partial round's rows were checked when they were loaded)
             if constexpr (WIDE) {
-                pair_locate_wide(L, qc[k], qs[k], qe[k], off[k], rqs[k], off1[k], rqe1[k], swp[k]);
+                pair_locate_mixed(L, lines_base, wide_base, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k]);
+                iswm |= isw[k] ? 1u << k : 0u;
             } else {
                 pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
-                off1[k] = r0[k] = nr[k] = 0;
+                off1[k] = rel1[k] = r0[k] = nr[k] = 0;
+                isw[k] = false;
             }
         }
         GFFX_WIN_STAMP(1);
-        gffx_v4u wc[4], wf[4];
+        gffx_v4u wc[4], wf[4];  // the line's halves: coordinates | root_fids (or positions); a wide lane's second half: {rank, list-tail header, 0, 0}
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(WIDE ? rw : rs, off[k], 0, 0);
-        if constexpr (!WIDE) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
-        }
+        for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(WIDE ? rw : rs, off[k] + 16, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         GFFX_WIN_STAMP(2);
         // (Nothing that MAY issue a vector memory operation stands between these loads and their use: a conditional store there
@@ -757,13 +776,12 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         uint32_t tc[4] = {0, 0, 0, 0}, hdr[4] = {0, 0, 0, 0};
         uint32_t deferred = 0, sweep = 0, n_rest = 0;
         if constexpr (WIDE) {
-            // the second line's coordinates and the two rank records (in flight with the first line's), then: the roots over qs
-            // (the one-base region) and the two ranks.  A line whose list continues in win_spill has the list's header in its rank
-            // record: the tail is walked below (a dense window: the sweep).
+            // wide lanes: the second line's coordinates and rank record (in flight with the first line's halves), then the roots over qs
+            // (the one-base region) and the two ranks; narrow lanes: the line's four tests.  A line whose list continues in win_spill
+            // carries the list's header -- a wide lane's in its rank record, a narrow lane's in word 7 --: the tail is walked below
+            // (a dense window: the sweep).
             gffx_v4u wc1[4];
-            gffx_v2u cu0[4], cu1[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cu0[k] = __builtin_amdgcn_raw_buffer_load_b64(rw, off[k] + 16, 0, 0);
+            gffx_v2u cu1[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) wc1[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, off1[k], 0, 0);
 #pragma unroll
@@ -773,23 +791,26 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqs[k], false);
-                ra[k] = cu0[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);
-                rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rqe1[k]);
-                hdr[k] = wc[k].w == kWinTailMark ? cu0[k].y : 0u;
-                h1[k] = wc1[k].w == kWinTailMark ? cu1[k].y : 0u;
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false);
+                ra[k] = wf[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);  // (a narrow lane's: unused)
+                rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rel1[k]);
+                hdr[k] = wc[k].w == kWinTailMark ? (isw[k] ? wf[k].y : wf[k].w) : 0u;
+                h1[k] = (isw[k] && wc1[k].w == kWinTailMark) ? cu1[k].y : 0u;
                 swp[k] |= ((hdr[k] & 255u) == 255u) | ((h1[k] & 255u) == 255u);
                 any |= swp[k] | ((hdr[k] | h1[k]) != 0u);
             }
             GFFX_WIN_STAMP(8);
-            // second trip, issued BEFORE the tails are walked: the kept entries' words and the head of the run (positions need no
-            // read) -- a region whose rank a tail entry moves reads its head again below
+            // second trip of the wide lanes, issued BEFORE the tails are walked: the kept entries' words (the other half of the line of
+            // qs, in the pass's own table) and the head of the run (positions need no read) -- a region whose rank a tail entry moves
+            // reads its head again below
+            // (the wide lanes' rank records have been used: their registers take the words; a narrow lane keeps its line's half)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (m[k] && !swp[k]) ? off[k] + 16 : kWinNoLine, 0, 0);
+            for (int k = 0; k < 4; ++k)
+                if (isw[k]) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, (m[k] && !swp[k]) ? lines_base + (off[k] - wide_base) + 16 : kWinNoLine, 0, 0);
             if (!POS) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, (rb[k] != ra[k] && !swp[k]) ? 4u * ra[k] : kWinNoLine, 0, 0);
+                    rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, (isw[k] && rb[k] != ra[k] && !swp[k]) ? 4u * ra[k] : kWinNoLine, 0, 0);
             }
             if (__builtin_amdgcn_ballot_w64(any)) {  // (uniform: some lane of the wave has a list tail to walk, or a sweep)
 #pragma unroll
@@ -808,8 +829,10 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                         const uint32_t cap = kWaveStash - min(n_rest, kWaveStash);
                         if (sweep >> k & 1u)
                             c = pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), st, cap, nullptr);
-                        else
+                        else if (iswm >> k & 1u)
                             c = pair_wide_tails<POS>(A.spill, win_sel(hdr, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, st, cap, a0, b0);
+                        else  // a narrow lane's list tail
+                            c = pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k), st, cap);
                         n_rest += c;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) tc[j] += k == j ? c : 0u, ra[j] += k == j ? a0 : 0u, rb[j] += k == j ? b0 : 0u;
@@ -827,7 +850,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             for (int k = 0; k < 4; ++k) {
                 m[k] = swp[k] ? 0u : m[k];
                 r0[k] = ra[k];
-                nr[k] = swp[k] ? 0u : rb[k] - ra[k];
+                nr[k] = (swp[k] || !isw[k]) ? 0u : rb[k] - ra[k];
                 if (POS) rg[k].x = r0[k], rg[k].y = r0[k] + 1u, rg[k].z = r0[k] + 2u, rg[k].w = r0[k] + 3u;
             }
         } else {
@@ -977,8 +1000,10 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                                 uint32_t a0 = 0, b0 = 0;
                                 if (sweep >> k & 1u)
                                     (void)pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(c_, n_chr), s_, e_, e, 0xFFFFFFFFu, nullptr);
-                                else
+                                else if (iswm >> k & 1u)
                                     (void)pair_wide_tails<POS>(A.spill, win_sel(hdr, k), 0u, s_, e_ - 1u, e, 0xFFFFFFFFu, a0, b0);
+                                else
+                                    (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
                             } else {
                                 (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, sweep >> k & 1u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
                             }
@@ -1058,8 +1083,10 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                         const uint32_t cap = (uint32_t)min(out.capacity - min(o, out.capacity), 0xFFFFFFFFull);
                         if (sweep >> k & 1u)
                             o += pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(c_, n_chr), s_, e_, e, cap, nullptr);
-                        else
+                        else if (iswm >> k & 1u)
                             o += pair_wide_tails<POS>(A.spill, hdr[k], 0u, s_, e_ - 1u, e, cap, a0, b0);
+                        else
+                            o += pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(c_, n_chr), s_, e_, hdr[k], e, cap);
                     }
                 }
             } else if (out.fids) {
@@ -1148,8 +1175,9 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4 *>(A.pv.lines), 0, (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4 *>(A.pv.wide), 0, WIDE ? (uint32_t)(A.pv.n_win * (swords ? (1u << kWinSplit) + 1u : 1u) * kWinLineBytes) : 0u, 0x00020000);
+    // (the mixed form: one descriptor over [win | win_pos | win_wide]; a root pass reads positions: its own table is win_pos)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(A.pv.all), 0, WIDE ? 3u * A.pv.table_bytes : 0u, 0x00020000);
+    const uint32_t lines_base = A.pv.table_bytes, wide_base = 2u * A.pv.table_bytes;
     const uint32_t bm = lds0 + (uint32_t)(reinterpret_cast<unsigned char *>(s_bm) - smem);  // the bitmap's LDS address
     uint32_t *g_bitmap = reinterpret_cast<uint32_t *>(out.root_flags);                       // ... or the batch's bitmap (no LDS bitmap)
     auto set_global = [&](uint32_t p) {
@@ -1164,15 +1192,17 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         const bool full = base + kChunk <= nq;
         uint32_t off[4], rqs[4], rqe1[4];
         bool swp[4];
-        uint32_t off1[4], r0[4], nr[4];  // (wide form, 4.0b) the line of qe - 1; the run of roots that start inside the region
+        uint32_t off1[4], rel1[4], r0[4], nr[4];  // (mixed form, wide lanes) the line of qe - 1, qe - 1 in its coordinates; the run of roots that start inside the region
+        bool isw[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;
             if constexpr (WIDE) {
-                pair_locate_wide(L, qc[k], qs[k], qe[k], off[k], rqs[k], off1[k], rqe1[k], swp[k]);
+                pair_locate_mixed(L, lines_base, wide_base, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k]);
             } else {
                 pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
-                off1[k] = r0[k] = nr[k] = 0;
+                off1[k] = rel1[k] = r0[k] = nr[k] = 0;
+                isw[k] = false;
             }
         }
         gffx_v4u wc[4], wf[4];
@@ -1180,16 +1210,17 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) wc[k] = __builtin_amdgcn_raw_buffer_load_b128(WIDE ? rw : rs, off[k], 0, 0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[k] + 16, 0, 0);
+        for (int k = 0; k < 4; ++k) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(WIDE ? rw : rs, off[k] + 16, 0, 0);
         uint32_t m[4];
         uint32_t tc[4] = {0, 0, 0, 0};
         if constexpr (WIDE) {
-            // one trip: both lines' coordinates and rank records and the positions of the line of qs; the run of roots that start
-            // inside the region is a run of BITS -- nothing is read for it
-            gffx_v4u wc1[4];
-            gffx_v2u cu0[4], cu1[4];
+            // one trip: a narrow lane's line (coordinates | positions); a wide lane's two lines of the wide table (coordinates | rank
+            // record) and the positions of the line of qs; the run of roots that start inside a wide region is a run of BITS --
+            // nothing is read for it
+            gffx_v4u wc1[4], wp[4];
+            gffx_v2u cu1[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cu0[k] = __builtin_amdgcn_raw_buffer_load_b64(rw, off[k] + 16, 0, 0);
+            for (int k = 0; k < 4; ++k) wp[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, isw[k] ? lines_base + (off[k] - wide_base) + 16 : kWinNoLine, 0, 0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) wc1[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, off1[k], 0, 0);
 #pragma unroll
@@ -1197,15 +1228,20 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             __builtin_amdgcn_sched_barrier(0);
             uint32_t ra[4], rb[4], h0[4], h1[4];
             bool any = false;
+            uint32_t iswm = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqs[k], false);
-                ra[k] = cu0[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);
-                rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rqe1[k]);
-                h0[k] = wc[k].w == kWinTailMark ? cu0[k].y : 0u;
-                h1[k] = wc1[k].w == kWinTailMark ? cu1[k].y : 0u;
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false);
+                ra[k] = wf[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);  // (a narrow lane's: unused)
+                rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rel1[k]);
+                h0[k] = wc[k].w == kWinTailMark ? (isw[k] ? wf[k].y : wf[k].w) : 0u;
+                h1[k] = (isw[k] && wc1[k].w == kWinTailMark) ? cu1[k].y : 0u;
                 swp[k] |= ((h0[k] & 255u) == 255u) | ((h1[k] & 255u) == 255u);
                 any |= swp[k] | ((h0[k] | h1[k]) != 0u);
+                iswm |= isw[k] ? 1u << k : 0u;
+                // the positions of the line's entries: a wide lane's come from the position table
+                wf[k].x = isw[k] ? wp[k].x : wf[k].x, wf[k].y = isw[k] ? wp[k].y : wf[k].y;
+                wf[k].z = isw[k] ? wp[k].z : wf[k].z, wf[k].w = isw[k] ? wp[k].w : wf[k].w;
             }
             if (__builtin_amdgcn_ballot_w64(any)) {  // list tails and sweeps set their bits themselves
                 uint32_t deferred = 0, sweep = 0;
@@ -1223,9 +1259,12 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                     if (sweep >> k & 1u)
                         c = pair_sweep_call<MODE, true>(&pair_rare_ix(), 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), nullptr, 0u,
                                                         bm_words ? s_bm : g_bitmap);
-                    else
+                    else if (iswm >> k & 1u)
                         c = pair_wide_tails<true>(A.spill, win_sel(h0, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, nullptr, 0u, a0, b0,
                                                   bm_words ? s_bm : g_bitmap);
+                    else  // a narrow lane's list tail
+                        c = pair_rest<MODE, true>(&pair_rare_ix(), A.spill, false, 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k),
+                                                  win_sel(h0, k), nullptr, 0u, bm_words ? s_bm : g_bitmap);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) tc[j] += k == j ? c : 0u, ra[j] += k == j ? a0 : 0u, rb[j] += k == j ? b0 : 0u;
                 }
@@ -1234,7 +1273,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             for (int k = 0; k < 4; ++k) {
                 m[k] = swp[k] ? 0u : m[k];
                 r0[k] = ra[k];
-                nr[k] = swp[k] ? 0u : rb[k] - ra[k];
+                nr[k] = (swp[k] || !isw[k]) ? 0u : rb[k] - ra[k];
                 tc[k] += nr[k];
                 kept += __popc(m[k]) + tc[k];
             }

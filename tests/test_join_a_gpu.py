@@ -712,7 +712,7 @@ def test_many_roots_bitmap_beyond_the_default_lds(n_roots, monkeypatch):
         assert np.array_equal(np.sort(b.fids()), np.sort(want_t[:, 0])) and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
     # the wide form of the root pass (a region's run of roots is a run of bits: in LDS, or straight in the batch's bitmap), after
     # the narrow passes above on the same batch, then accumulated over two halves
-    monkeypatch.setenv("GFFX_HIP_WIN_WIDE", "2")
+    b.set_option("WIN_WIDE", 2)  # (a batch reads its knobs when it is created; later changes go through set_option)
     wide = regions[:20_000].copy()
     wide[:, 2] = wide[:, 1] + rng.integers(1, 150_000, len(wide)).astype(np.uint32)
     want_t, want_c = oix.query_features(wide, int(OverlapMode.Overlap), False)

@@ -189,12 +189,57 @@ def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_SEGBASE, engine.STRATEGY_AUTO)
     b.wait()
     assert b.wide_form and np.array_equal(b.counts(), want_c)
-    monkeypatch.delenv("GFFX_HIP_WIDTH_SAMPLE")
+    b.set_option("WIDTH_SAMPLE", 1)
     b.set_regions(regions)  # the host's rows again, sampled this time
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_AUTO)
     b.wait()
     assert b.wide_form and np.array_equal(b.counts(), want_c)
     assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
+    b.close()
+    ix.close()
+
+
+@pytest.mark.parametrize("frac,mixed", [(0.10, True), (0.05, True), (0.01, False), (0.0, False)])
+def test_mixed_batches_take_the_mixed_form(frac, mixed, monkeypatch):
+    """A BED file with SOME SV-sized rows (round 5): more than a thirty-second of the rows wider than their seqid's lines answer and
+    AUTO's overlap-mode passes -- pair passes, triples, the CLI's root pass -- run the MIXED form of the window kernels, in which every
+    lane serves its region the narrow way (one line) or the wide way (two lines, two ranks); fewer, and the narrow form keeps the batch
+    (its few wide rows sweep).  Either way every region's pairs equal the oracle's.  Host rows are judged from a sample, device-resident
+    ones from the first waited pass; the other modes are not touched by any of this."""
+    roots = synth.gencode_like_roots(30000, seed=4)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    regions = synth.synth_bed(300_000, seed=12, edge_frac=0.01, roots=roots)
+    rng = np.random.default_rng(13)
+    pick = rng.choice(len(regions), int(frac * len(regions)), replace=False)
+    regions[pick, 2] = np.minimum(regions[pick, 1].astype(np.int64) + rng.integers(20_000, 2_000_000, len(pick)), 0xFFFFFFF0).astype(np.uint32)
+    want_t, want_c = oix.query_features(regions, OV, False)
+    want_p = _want_pairs(regions, want_t, want_c)
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    b = engine.QueryBatch(ix, len(regions))
+    b.set_regions(regions)  # (host rows: sampled)
+    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS)
+    b.wait()
+    assert b.wide_form == mixed and np.array_equal(b.counts(), want_c)
+    assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
+    b.run(OV, False, engine.OUT_TRIPLES | engine.OUT_OFFSETS)
+    b.wait()
+    assert b.wide_form == mixed and np.array_equal(_rows(b.triples()), _rows(want_t))
+    b.run(OV, False, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS)
+    b.wait()
+    assert b.wide_form == mixed and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0])) and b.total_hits == len(want_t)
+    wt, wc = oix.query_features(regions, int(OverlapMode.Contained), False)
+    b.run(OverlapMode.Contained, False, engine.OUT_FIDS | engine.OUT_OFFSETS)
+    b.wait()
+    assert not b.wide_form and np.array_equal(b.counts(), wc)
+    # the same regions resident on the device: no sample, the first waited pass (narrow form) counts the rows its lines did not answer
+    b.set_option("WIDTH_SAMPLE", 0)
+    b.set_regions(regions)
+    for i in range(2):
+        b.run(OV, False, engine.OUT_FIDS | engine.OUT_SEGBASE)
+        b.wait()
+        assert b.wide_form == (mixed and i > 0) and np.array_equal(b.counts(), want_c)
+        assert np.array_equal(_pairs_of(regions, want_c, b.offsets_from_segbase(b.counts()), b.fids()), want_p)
     b.close()
     ix.close()
 

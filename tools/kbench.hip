@@ -2,7 +2,7 @@
 // Includes the engine source so compile-time knobs (-DGFFX_...) can be varied per binary, and records
 // optional in-kernel phase stamps (wall_clock64, 100 MHz) to see where a block's time goes.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGFFX_STAMPS=1 tools/kbench.hip -o tools/_kb/kbench
-//   tools/_kb/kbench [nq] [strategy 1|2] [flags] [iters] [presort] [max region width]
+//   tools/_kb/kbench [nq] [strategy 0..5] [flags] [iters] [presort] [max region width] [every n-th region SV-sized]
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -51,6 +51,7 @@ int main(int argc, char **argv) {
     const int iters = argc > 4 ? atoi(argv[4]) : 50;
     const int presort = argc > 5 ? atoi(argv[5]) : 0;  // 1: queries sorted by (chr, end) on the host (experiment)
     const uint32_t max_width = argc > 6 ? (uint32_t)atoi(argv[6]) : 10000;  // regions of width U[100, max_width)
+    const uint32_t wide_every = argc > 7 ? (uint32_t)atoi(argv[7]) : 0;     // every wide_every-th region: width U[20000, 2000000) instead (0: none)
     const int n_chr = sizeof(kChroms) / sizeof(kChroms[0]);
     std::mt19937_64 rng(42);
     double total_len = 0;
@@ -83,6 +84,7 @@ int main(int argc, char **argv) {
         int c = (int)(std::lower_bound(cum.begin(), cum.end(), u) - cum.begin());
         if (c >= n_chr) c = n_chr - 1;
         uint32_t w = 100 + (uint32_t)(uni(rng) * (max_width - 100));
+        if (wide_every && i % wide_every == 0) w = 20000 + (uint32_t)(uni(rng) * 1980000);
         w = std::min<uint32_t>(w, std::max<uint32_t>(1, kChroms[c].len - 1));
         const uint32_t st = (uint32_t)(uni(rng) * std::max<uint32_t>(1, kChroms[c].len - w));
         qc[i] = c;

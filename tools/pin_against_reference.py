@@ -17,6 +17,11 @@ oracle's restatement of the same commands on the same inputs, and byte-diffs
   * every intersect output (byte for byte: blocks in file order, lines in file order),
   * the depth / coverage rows (compared as sorted row sets: the reference's row order is hash order).
 
+With --product (default when gffx_amd/bin/gffx exists and a HIP device is visible) every intersect case also runs THIS repository's
+CLI on the same inputs and byte-diffs it against the reference directly; the wide BED of every synthetic annotation (region
+widths up to 2 Mbp) sends the product down the wide form of the window kernels (round 4), which its --stats-json must confirm
+(`wide_form_passes` >= 1) -- so the day a real binary exists the kit pins the GPU paths themselves, not only the oracle.
+
 Exit status: 0 = everything equal, or no toolchain (prints "no toolchain: nothing pinned"); 1 = at least one difference
 (the differing case, file and first differing byte are printed); 2 = usage / build failure.
 Nothing here is imported by the product or by the tests; it only uses oracle/ as the thing being checked.
@@ -80,6 +85,12 @@ def make_cases(work: str):
         synth.write_bed(dbed, ok, [c for c, _ in synth.SMALL2])
         c0 = synth.SMALL2[0][0]
         cases.append((name, gff, bed, dbed, ["%s:1000-200000" % c0, "%s:1-2" % c0]))
+        # the same annotation against WIDE regions (SV-sized: 20 kbp .. 2 Mbp): the product answers these from two lines and two
+        # ranks per region (the wide form) instead of a sweep
+        wide = synth.synth_bed(3000, seed=seed + 200, chroms=synth.SMALL2, width=(20_000, 2_000_000), edge_frac=0.05, roots=roots)
+        wbed = os.path.join(work, name + ".wide.bed")
+        synth.write_bed(wbed, wide, [c for c, _ in synth.SMALL2])
+        cases.append((name + "_wide", gff, wbed, None, []))
     return cases
 
 
@@ -93,6 +104,8 @@ def main() -> int:
     ap.add_argument("--cargo", action="store_true", help="build the reference with cargo first")
     ap.add_argument("--reference", default="/root/reference", help="the reference's source tree (for --cargo)")
     ap.add_argument("--keep", action="store_true", help="keep the work directory")
+    ap.add_argument("--product", choices=["auto", "yes", "no"], default="auto",
+                    help="also diff this repository's CLI (gffx_amd/bin/gffx, needs an MI355X) against the reference")
     args = ap.parse_args()
     work = tempfile.mkdtemp(prefix="gffx_pin_")
     exe = args.gffx
@@ -108,6 +121,19 @@ def main() -> int:
         return 2
     from oracle import binding as ob
 
+    product = os.path.join(ROOT, "gffx_amd", "bin", "gffx")
+    have_product = False
+    if args.product != "no" and os.path.exists(product):
+        try:
+            from gffx_amd import engine
+            have_product = engine.device_count() >= 1
+        except Exception:
+            have_product = False
+    if args.product == "yes" and not have_product:
+        print("--product yes: no built CLI or no HIP device", file=sys.stderr)
+        return 2
+    print("[pin] product CLI %s" % ("is compared too: " + product if have_product else "not compared (no build / no device)"))
+    indexed_for_product = set()
     bad = 0
     checked = 0
 
@@ -124,6 +150,13 @@ def main() -> int:
     for name, gff, bed, dbed, regions in make_cases(work):
         # ---- index: the reference's side-cars, then the oracle's over a copy of the same GFF
         ogff = os.path.join(work, "oracle_" + os.path.basename(gff))
+        pgff = os.path.join(work, "product_" + os.path.basename(gff))
+        if have_product and pgff not in indexed_for_product:
+            shutil.copy(gff, pgff)
+            if run([product, "index", "-i", pgff]).returncode != 0:
+                print("[DIFF] %s: this repository's `gffx index` failed" % name)
+                bad += 1
+            indexed_for_product.add(pgff)
         shutil.copy(gff, ogff)
         r = run([exe, "index", "-i", gff])
         if r.returncode != 0:
@@ -162,6 +195,22 @@ def main() -> int:
                 checked += 1
                 print("[DIFF] %s: exit %d (reference: %s) vs oracle %d (%s)" % (what, r.returncode, r.stderr.decode(errors="replace")[-200:].strip(), rc_o, msg))
                 continue
+            if have_product and r.returncode == 0:
+                out_p, sj = os.path.join(work, "prod.out"), os.path.join(work, "prod.json")
+                pcmd = [product, "intersect", "-i", pgff, sflag, sval, mflag, "-o", out_p, "--stats-json", sj] + cmd[9:]
+                rp = run(pcmd)
+                if rp.returncode != 0:
+                    bad += 1
+                    checked += 1
+                    print("[DIFF] %s: the product CLI failed: %s" % (what, rp.stderr.decode(errors="replace")[-200:].strip()))
+                else:
+                    compare(what + " [product vs reference]", open(out_r, "rb").read(), open(out_p, "rb").read())
+                    if name.endswith("_wide") and sflag == "-b" and mode == 2 and not invert:
+                        import json
+                        checked += 1
+                        if json.load(open(sj))["counts"].get("wide_form_passes", 0) < 1:
+                            bad += 1
+                            print("[DIFF] %s: the product did not take the wide form on the wide BED (stats: %s)" % (what, open(sj).read()[:300]))
             if r.returncode == 0:
                 compare(what, open(out_r, "rb").read(), open(out_o, "rb").read())
             else:  # both failed: the message after "Error: " should agree
@@ -171,7 +220,7 @@ def main() -> int:
                     bad += 1
                     print("[DIFF] %s: error text %r vs oracle %r" % (what, ref_msg[0], msg))
         # ---- depth / coverage with a BED source: row sets
-        for cmd_name, fn in (("depth", ob.depth_run), ("coverage", ob.coverage_run)):
+        for cmd_name, fn in ((("depth", ob.depth_run), ("coverage", ob.coverage_run)) if dbed else ()):
             out_r, out_o = os.path.join(work, "ref.%s" % cmd_name), os.path.join(work, "ora.%s" % cmd_name)
             r = run([exe, cmd_name, "-i", gff, "-s", dbed, "-o", out_r])
             rc_o, msg = fn(ogff, dbed, out_o)
