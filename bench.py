@@ -76,6 +76,8 @@ def parse_args():
     ap.add_argument("--strong-total", type=int, default=100_000_000)
     ap.add_argument("--region-width", type=int, nargs=2, default=None, metavar=("LO", "HI"),
                     help="profiling aid: regions of width U[LO, HI] instead of the configuration's U[100, 10000] (the line says so)")
+    ap.add_argument("--wide-every", type=int, default=0, metavar="N",
+                    help="profiling aid: every N-th region SV-sized (width U[20000, 2000000]): the mixed_widths leg as a run of its own")
     ap.add_argument("--mode", default="overlap", choices=["overlap", "contained", "contains_region"])
     ap.add_argument("--strategy", default="auto", choices=["auto", "direct", "sorted", "fused", "windows"])
     ap.add_argument("--out", default="fids", choices=["counts", "fids", "triples"])
@@ -107,7 +109,18 @@ def rank_placement(env, n_devices):
     return rank, world, local_rank, local_rank % n_devices
 
 
-def bench_regions(synth, shard, n_chr, world, rank, scaling="weak", queries_per_gpu=1_000_000, strong_total=100_000_000, region_width=None):
+def widen_every(regions, every, seed=1005):
+    """Every `every`-th row (a random tenth for every = 10, ...) becomes SV-sized: width U[20 000, 2 000 000] (the mixed_widths leg)."""
+    out = regions.copy()
+    rng = np.random.default_rng(seed)
+    pick = rng.choice(len(out), len(out) // every, replace=False)
+    wid = rng.integers(20_000, 2_000_000, len(pick), dtype=np.int64)
+    out[pick, 2] = np.minimum(out[pick, 1].astype(np.int64) + wid, 0xFFFFFFF0).astype(np.uint32)
+    return out
+
+
+def bench_regions(synth, shard, n_chr, world, rank, scaling="weak", queries_per_gpu=1_000_000, strong_total=100_000_000, region_width=None,
+                  wide_every=0):
     """This rank's regions: weak scaling = its chromosome-bucket shard of an N x --queries-per-gpu batch of configs[1]'s seed,
     strong scaling = its shard of configs[3]'s batch (seed 1003; commands/intersect.rs:114-120 buckets by seqid, the shards are
     LPT-placed bucket slices).  Returns (regions, global region count, configuration name)."""
@@ -121,6 +134,9 @@ def bench_regions(synth, shard, n_chr, world, rank, scaling="weak", queries_per_
         cfg += " with region widths U[%d, %d] (NOT the configuration's: --region-width)" % tuple(region_width)
     else:
         regions_all = synth.synth_bed(nq_global, seed=seed)
+    if wide_every:
+        regions_all = widen_every(regions_all, wide_every)
+        cfg += " with every %d-th row widened to U[20000, 2000000] (NOT the configuration's: --wide-every)" % wide_every
     if world > 1:
         regions = np.ascontiguousarray(regions_all[shard.shard_rows(regions_all, n_chr, world, rank)])
     else:
@@ -573,7 +589,7 @@ def main():
     n_chr = len(roots["chr_offsets"]) - 1
     strong = args.scaling == "strong" and world > 1
     regions, nq_global, cfg = bench_regions(synth, shard, n_chr, world, rank, args.scaling, args.queries_per_gpu, args.strong_total,
-                                            args.region_width)
+                                            args.region_width, args.wide_every)
     if args.presort == "chr_end":
         regions = np.ascontiguousarray(regions[np.lexsort((regions[:, 2], regions[:, 0]))])
     nq = len(regions)
@@ -795,11 +811,7 @@ def main():
         del colsw, regw
         # ---- a MIXED batch: the headline's regions with every tenth row replaced by an SV-sized one (width U[20 000, 2 000 000])
         # -- below the eighth at which AUTO used to leave the narrow form: the mixed form serves every region its own way
-        regm = regions.copy()
-        rng_m = np.random.default_rng(1005)
-        pick_m = rng_m.choice(nq, nq // 10, replace=False)
-        wid_m = rng_m.integers(20_000, 2_000_000, len(pick_m), dtype=np.int64)
-        regm[pick_m, 2] = np.minimum(regm[pick_m, 1].astype(np.int64) + wid_m, 0xFFFFFFF0).astype(np.uint32)
+        regm = widen_every(regions, 10)
         colsm = to_dev(torch, regm, dev)
         pm = Pass(engine, ix, colsm, nq, 1, mode, out_flags, 0)
         pairsm = pm.size_and_warm(2)  # (regions on the device carry no width sample: the first waited pass tells AUTO)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "gffx_hip_lines_test_device": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_int, u8p]),
     "gffx_hip_lines_last_kernel_ms": (C.c_double, [vp]),
     "gffx_hip_lines_last_prep_ms": (C.c_double, [vp]),
+    "gffx_hip_lines_last_sort_passes": (C.c_int, [vp]),
     "gffx_hip_lines_copy_tables": (C.c_int, [vp, u64p, u32p, u32p, u32p, u32p]),
     "gffx_hip_lines_copy_dirs": (C.c_int, [vp, u64p, u32p, u32p]),
     "gffx_hip_lines_copy_degenerate": (C.c_int, [vp, u64p, u64p, u32p]),

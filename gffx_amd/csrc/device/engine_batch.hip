@@ -467,7 +467,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     {
         const long ww = b->knobs.v[BK_WIN_WIDE];
         const bool eligible = mode == GFFX_MODE_OVERLAP && !invert && b->ix->win_range_ok;
-        // (AUTO: some wide rows -- more than 1/32 -- and no other reason for most regions to sweep: the mixed form, which serves every
+        // (AUTO: some wide rows -- more than 1/128 -- and no other reason for most regions to sweep: the mixed form, which serves every
         //  region its own way; mostly wide: the same kernel, every lane the wide way)
         b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && (b->mostly_wide || (b->some_wide && !b->mostly_slow))) ||
                                (ww == 2 && b->strategy == GFFX_STRATEGY_WINDOWS));
@@ -605,7 +605,7 @@ extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
             const uint64_t all = (uint32_t)((uint32_t)h_slow_win - (uint32_t)b->slow_seen_win);
             const uint64_t by_width = (uint32_t)((uint32_t)(h_slow_win >> 32) - (uint32_t)(b->slow_seen_win >> 32));
             b->mostly_wide = by_width / passes > b->nq / 8;
-            b->some_wide = by_width / passes > b->nq / 32;
+            b->some_wide = by_width / passes > b->nq / 128;
             b->mostly_slow = b->mostly_wide || all / passes > b->nq / 4;  // (sweeps for other reasons: the rule of rounds 2 and 3)
         }
         b->slow_seen_win = h_slow_win;

@@ -260,7 +260,7 @@ struct gffx_hip_batch {
     bool wide = false;              // this run's passes take the wide form of the window kernels (AUTO, mostly_slow, overlap mode)
     bool mostly_slow = false;       // more than 1/8 of the regions are wide (a sample of the host's rows) or took the sweep in the last waited narrow pass
     bool mostly_wide = false;       // ... because of their width (the wide form answers those; dense windows and seqids without windows it does not)
-    bool some_wide = false;         // more than 1/32 of the regions are wider than their seqid's lines answer: AUTO's overlap-mode passes take the MIXED form
+    bool some_wide = false;         // more than 1/128 of the regions are wider than their seqid's lines answer: AUTO's overlap-mode passes take the MIXED form
     // last run
     int mode = GFFX_MODE_OVERLAP, invert = 0, strategy = GFFX_STRATEGY_DIRECT;
     uint32_t flags = 0;
@@ -291,9 +291,10 @@ uint32_t meta_bytes(const gffx_hip_index *ix);
 struct WidthSample {
     uint64_t n = 0, wide = 0;
     bool mostly_wide() const { return 8 * wide > n; }  // (the same eighth as the learned rule in gffx_hip_batch_wait)
-    // Break-even of the narrow form (every wide row an out-of-line sweep: ~14.5 us + 120 us x the wide fraction per 1 M regions)
-    // against the mixed form (~19 us + ~20 x): about 1/25; a thirty-second of the sample (128 of 4096 rows)
-    bool some_wide() const { return 32 * wide > n; }
+    // Break-even of the narrow form (every wide row an out-of-line sweep) against the mixed form, measured with SV-sized rows
+    // (width U[20 k, 2 M]; us per 1 M regions at 1 M / 10 M): narrow 14.6 + 8.8 per % of wide rows / 8.2 + 5.8 per %, mixed
+    // 19.1 + 1.0 per % / 12.5 + 1.0 per %: 0.6 % / 0.9 % -- one row in 128 (32 of the sample's 4096)
+    bool some_wide() const { return 128 * wide > n; }
 };
 // (chr may be nullptr: then every row is measured against `wmax_all`; with chr, against its seqid's own limit h_wmax[chr])
 void sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride,

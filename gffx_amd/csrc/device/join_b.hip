@@ -667,6 +667,7 @@ struct gffx_hip_lines {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;  // bracket k_lines_exists of the last _test
     hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;  // ... and the device preparation of the region tables
     uint32_t note_seq = 0;                        // h_cnt = {degenerate regions, note_seq}, posted by the sort's histogram kernel
+    int last_sort_passes = 0;                     // radix passes of the last run's region sort (4 with the top digit, else 4 + seqid bytes)
     double last_kernel_ms = 0.0, last_prep_ms = 0.0;
     // region tables of the last _test (grow-only device buffers)
     uint64_t cap_q = 0, cap_seq = 0, cap_work = 0, cap_dir = 0, cap_blocks = 0;
@@ -741,7 +742,7 @@ extern "C" int gffx_hip_lines_create(int device, uint64_t n_lines, const uint32_
     L->cap_work = kWorkFront;
     L->d_err = L->d_work, L->d_cnt = L->d_work + 4;
     GFFX_HIP_TRY(hipHostMalloc((void **)&L->h_cnt, 64, hipHostMallocCoherent | hipHostMallocMapped));
-    L->h_cnt[0] = L->h_cnt[1] = 0;
+    L->h_cnt[0] = L->h_cnt[1] = L->h_cnt[2] = L->h_cnt[3] = 0;
     GFFX_HIP_TRY(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
     for (hipEvent_t *e : {&L->ev_a, &L->ev_b, &L->ev_p0, &L->ev_p1}) GFFX_HIP_TRY(hipEventCreate(e));
     if (n_lines) {
@@ -834,8 +835,11 @@ static int lines_run(gffx_hip_lines *L, uint64_t nq, uint32_t n_seq, int mode, u
         // after the table kernels: the histogram kernel counts them, and the host reads the count while the passes run.
         const bool want_deg = mode == GFFX_MODE_OVERLAP;
         const uint32_t note_seq = ++L->note_seq;
+        // (h_cnt + 2: the sort's own note -- does the mixed-radix top digit of (seqid, start >> 24) fit 256 values?  Then the sort is
+        //  four passes instead of five: radix_sort.hpp)
         int rc = DeviceSort::run<3>(L->stream, L->d_rec_a, L->d_rec_b, n, p1, n_seq, L->d_work + kWorkFront, L->d_err, &s1,
-                                    want_deg ? SortNote{L->d_cnt + 2, L->h_cnt, note_seq} : SortNote{nullptr, nullptr, 0}, true);
+                                    want_deg ? SortNote{L->d_cnt + 2, L->h_cnt, note_seq} : SortNote{nullptr, nullptr, 0}, true, L->h_cnt + 2, note_seq,
+                                    &L->last_sort_passes);
         if (rc) return rc;
         uint32_t *other = s1 == L->d_rec_a ? L->d_rec_b : L->d_rec_a;
         hipLaunchKernelGGL(k_b_local, dim3(n_blocks), dim3(kLocalThreads), 0, L->stream, s1, n, n_seq, L->d_T, L->d_qoff, C);
@@ -1009,5 +1013,6 @@ extern "C" int gffx_hip_lines_copy_degenerate(gffx_hip_lines *L, uint64_t *n_deg
     return GFFX_OK;
 }
 extern "C" double gffx_hip_lines_last_prep_ms(const gffx_hip_lines *L) { return L ? L->last_prep_ms : 0.0; }
+extern "C" int gffx_hip_lines_last_sort_passes(const gffx_hip_lines *L) { return L ? L->last_sort_passes : 0; }
 
 extern "C" double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *L) { return L ? L->last_kernel_ms : 0.0; }

@@ -17,9 +17,21 @@
 //                  their own flag (one granule: nothing to order); every spin is bounded and a timeout sets the error
 //                  word instead of hanging the GPU.  A pass whose byte is the same in ALL records (high bytes of small
 //                  coordinates, the seqid of a one-chromosome BED; k_radix_scan flags it) is a straight copy.
+// THE TOP DIGIT (round 5; W = 3 sorts by (word 0, word 1) with <= 256 values of word 0: Join B's (seqid, start)).  The keys of a
+// GRCh38-scale BED are 33 bits -- 28 of start, 5 of seqid --, one bit more than four 8-bit passes hold; but the last two passes'
+// digits are far from full: start >> 24 takes <= 15 values per seqid, the seqid 25.  k_radix_hist therefore also takes the
+// per-seqid maximum of start >> 24, k_radix_scan turns the maxima into lut[seqid] = sum over the earlier seqids of (max + 1), and
+// when the total fits 256 the sort's LAST pass sorts by the mixed-radix digit lut[seqid] + (start >> 24) -- the order of
+// (seqid, start's top byte) -- in place of the two passes "byte 3 of start" and "seqid": four passes instead of five (GRCh38:
+// 196 values).  The histogram of that digit is taken by the pass before it (the records are in registers there); its bin
+// starts are a 256-thread scan at the start of the pass.  Whether the total fits is known on the device only: k_radix_scan posts
+// {fits, sequence number} to pinned host memory, and the host -- three passes of enqueueing later -- reads it and enqueues either
+// the one pass or the two (no stream synchronisation: the note is written ~20 us after the first kernel starts).
 // Stability: wave w of a tile ranks records [1024 w, 1024 w + 1024) in order (step j holds records j*64 + lane), waves and
 // tiles are prefix-summed in order; the LDS reorder keeps the rank order inside a byte's run.  Roofline bound: HBM, 8 W bytes per record and pass.
 #pragma once
+#include <chrono>
+#include <thread>
 #include <type_traits>
 
 #include "gffx_device.hpp"
@@ -35,9 +47,6 @@ constexpr int kSortThreads = 256;
 #endif
 #ifndef GFFX_SORT_LOOKBACK
 #define GFFX_SORT_LOOKBACK 4
-#endif
-#ifndef GFFX_SORT_ABL
-#define GFFX_SORT_ABL 0  // timing ablations (wrong results): 1 no look-back, 2 no ranking, 3 no global stores, 4 no global loads
 #endif
 constexpr int kSortItems = GFFX_SORT_ITEMS;
 constexpr int kHistThreads = 1024;
@@ -59,10 +68,27 @@ struct SortNote {
     uint32_t *inverted, *note;
     uint32_t note_seq;
 };
+// the top digit (header comment): device words {maxhi1[256]: per value of word 0 the largest (word 1 >> 24) + 1, 0 = no record;
+// lut[256]; hist[256]: the digit's histogram; ok}, and where the host learns `ok`: note = pinned {ok, seq}
+struct SortTop {
+    uint32_t *words;  // 3 x 256 + 4 device words (nullptr: no top digit)
+    uint32_t *note;
+    uint32_t seq;
+    __host__ __device__ uint32_t *maxhi1() const { return words; }
+    __host__ __device__ uint32_t *lut() const { return words + 256; }
+    __host__ __device__ uint32_t *hist() const { return words + 512; }
+    __host__ __device__ uint32_t *ok() const { return words + 768; }
+};
+constexpr size_t kSortTopWords = 3 * 256 + 4;
 template <int W>
 __global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec, unsigned long long n, SortPlan plan, uint32_t *hist,
-                                                    uint32_t limit0, uint32_t *err, SortNote note, uint32_t *zero, unsigned long long zero_words) {
+                                                    uint32_t limit0, uint32_t *err, SortNote note, uint32_t *zero, unsigned long long zero_words,
+                                                    SortTop top) {
     __shared__ uint32_t s_h[kSortMaxPasses * 256];
+    __shared__ uint32_t s_mx[256];  // (top digit) per value of word 0: the largest (word 1 >> 24) + 1 seen by this block
+    if (W == 3 && top.words)
+        for (int i = threadIdx.x; i < 256; i += kHistThreads) s_mx[i] = 0;
+    uint32_t my_seq = 0xFFFFFFFFu, my_max = 0;  // the thread's run of equal word 0: one LDS atomic per run, not per record
     for (unsigned long long i = (unsigned long long)blockIdx.x * kHistThreads + threadIdx.x; i < zero_words; i += (unsigned long long)gridDim.x * kHistThreads)
         zero[i] = 0u;
     uint32_t *inverted = note.inverted;
@@ -76,6 +102,13 @@ __global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec
         for (int k = 0; k < W; ++k) w[k] = rec[W * i + k];
         bad |= w[0] >= limit0;
         if (W == 3 && w[1] > w[W - 1]) n_inv++;
+        if (W == 3 && top.words) {
+            if (w[0] != my_seq) {
+                if (my_seq < 256u) atomicMax(&s_mx[my_seq], my_max);
+                my_seq = w[0], my_max = 0;
+            }
+            my_max = max(my_max, (w[1] >> 24) + 1u);
+        }
         for (int p = 0; p < plan.n_passes; ++p) {
             const uint32_t d = (w[plan.word[p]] >> plan.shift[p]) & 255u;
             // a byte that is the same in the whole wave (high bytes of coordinates, seqids of a sorted BED) is one add
@@ -88,9 +121,13 @@ __global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec
             }
         }
     }
+    if (W == 3 && top.words && my_seq < 256u) atomicMax(&s_mx[my_seq], my_max);
     __syncthreads();
     for (int i = threadIdx.x; i < plan.n_passes * 256; i += kHistThreads)
         if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+    if (W == 3 && top.words)
+        for (int i = threadIdx.x; i < 256; i += kHistThreads)
+            if (s_mx[i]) atomicMax(&top.maxhi1()[i], s_mx[i]);
     if (bad) atomicOr(err, 2u);
     if (W == 3 && inverted) {
 #pragma unroll
@@ -100,8 +137,32 @@ __global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec
 }
 
 // exclusive scan of each pass's 256 bins (block p = pass p); same_byte[p] = 1 when one bin holds all n records
-__global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned long long n, uint32_t *same_byte, SortNote note) {
+// block n_passes (launched only with a top digit): lut[] = exclusive scan of the per-seqid digit counts, ok = they fit 256
+__global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned long long n, uint32_t *same_byte, SortNote note, SortTop top, uint32_t n_passes,
+                                                    uint32_t limit0) {
     __shared__ uint32_t s_w[4];
+    if (blockIdx.x == n_passes) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t v = threadIdx.x < limit0 ? top.maxhi1()[threadIdx.x] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int x = 0; x < wave; ++x) base += s_w[x];
+        top.lut()[threadIdx.x] = base + inc - v;
+        if (threadIdx.x == 255) {
+            const uint32_t ok = (limit0 <= 256u && base + inc <= 256u) ? 1u : 0u;
+            *top.ok() = ok;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(top.note), (unsigned long long)ok | ((unsigned long long)top.seq << 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (note.note && blockIdx.x == 0 && threadIdx.x == 0) {
         // ONE relaxed 8-byte store {count, seq}: both values come from registers (the count was complete when the histogram
         // kernel ended), so nothing has to be released -- a fence here would write the L2 back
@@ -129,28 +190,67 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned lon
 // one LSD pass: in -> out, stable by byte (word, shift).  status: n_tiles x 256 words, zero on entry; ticket: zero on entry.
 // The tile is reordered in LDS first (digit by digit, stable), so that a wave's 64 consecutive stores cover a few runs of
 // consecutive global records instead of 64 scattered 8- or 12-byte writes.
+// TOP (W = 3; the header comment's top digit): 0 a plain pass; 1 a plain pass that ALSO takes the histogram of the top digit
+// (when top.ok says the digit fits); 2 the pass that sorts by the top digit (word / shift unused; its bin starts are scanned here).
 constexpr int kSortLookBack = GFFX_SORT_LOOKBACK;
-template <int W, int WORD>
+template <int W, int WORD, int TOP = 0>
 __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in, uint32_t *out, unsigned long long n,
                                                              int shift, const uint32_t *bin_start, const uint32_t *same_byte,
-                                                             uint32_t *status, uint32_t *ticket, uint32_t *err) {
+                                                             uint32_t *status, uint32_t *ticket, uint32_t *err, SortTop top) {
+    static_assert(TOP == 0 || W == 3, "the top digit is a digit of {word 0, word 1} of three-word records");
     __shared__ uint32_t s_cnt[kSortThreads / 64][256];  // per wave: records of the byte so far; then: first rank of the wave's run
     __shared__ uint32_t s_base[256];                     // where the tile's run of the byte starts in `out`
     __shared__ uint32_t s_dstart[256];                   // ... and inside the tile (exclusive scan of the tile's byte counts)
     __shared__ uint32_t s_wsum[kSortThreads / 64];
     __shared__ uint32_t s_rec[kSortTile * W];            // the tile, byte-sorted
     __shared__ uint32_t s_tile;
-    if (*same_byte) {  // every record has the same byte here: the stable order is the input order
-        const unsigned long long w0 = (unsigned long long)blockIdx.x * kSortTile * W;
-        const unsigned long long w1 = min(w0 + (unsigned long long)kSortTile * W, n * W);
-        for (unsigned long long x = w0 + threadIdx.x; x < w1; x += kSortThreads) out[x] = in[x];
+    __shared__ uint32_t s_lut[TOP ? 256 : 1];            // (top digit) lut[word 0]
+    __shared__ uint32_t s_top[TOP ? 256 : 1];            // TOP 1: the tile's histogram of the top digit; TOP 2: the digit's bin starts
+    __shared__ uint32_t s_same;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool top_on = TOP != 0 && *top.ok() != 0u;     // (uniform; TOP 2 is only launched when it holds)
+    auto top_digit = [&](uint32_t w0, uint32_t w1) { return s_lut[min(w0, 255u)] + (w1 >> 24); };
+    if (TOP) {
+        s_lut[threadIdx.x] = top.lut()[threadIdx.x];
+        if (TOP == 1) s_top[threadIdx.x] = 0;
+        if (threadIdx.x == 0) s_same = 0;
+    }
+    bool same = TOP == 2 ? false : *same_byte != 0u;
+    if (TOP == 2) {
+        if (!top_on) return;
+        // the digit's bin starts: exclusive scan of its histogram (complete: the pass before this one took it)
+        const uint32_t v = top.hist()[threadIdx.x];
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        if (v == n) s_same = 1;  // (every record has the same digit)
+        uint32_t base = 0;
+        for (int w = 0; w < wave; ++w) base += s_wsum[w];
+        s_top[threadIdx.x] = base + inc - v;
+        __syncthreads();
+        same = s_same != 0u;
+    } else if (TOP == 1) {
+        __syncthreads();
+    }
+    if (same) {  // every record has the same byte here: the stable order is the input order
+        const unsigned long long r0 = (unsigned long long)blockIdx.x * kSortTile, r1 = min(r0 + (unsigned long long)kSortTile, n);
+        for (unsigned long long x = r0 * W + threadIdx.x; x < r1 * W; x += kSortThreads) out[x] = in[x];
+        if (TOP == 1 && top_on) {  // (the top digit's histogram is still wanted)
+            for (unsigned long long i = r0 + threadIdx.x; i < r1; i += kSortThreads) atomicAdd(&s_top[top_digit(in[W * i], in[W * i + 1])], 1u);
+            __syncthreads();
+            if (s_top[threadIdx.x]) atomicAdd(&top.hist()[threadIdx.x], s_top[threadIdx.x]);
+        }
         return;
     }
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     for (int i = threadIdx.x; i < (kSortThreads / 64) * 256; i += kSortThreads) (&s_cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long tile_i = (unsigned long long)tile * kSortTile;
     const unsigned long long base_i = tile_i + (unsigned long long)wave * (64 * kSortItems);
     const uint32_t n_tile = (uint32_t)min((unsigned long long)kSortTile, n - tile_i);
@@ -161,18 +261,16 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     for (int j = 0; j < kSortItems; ++j) {
         const unsigned long long i = base_i + j * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < W; ++k) r[k][j] = GFFX_SORT_ABL == 4 ? (uint32_t)(i * 2654435761u + k) : (i < n ? in[W * i + k] : 0u);
-        dig[j / 4] |= ((r[WORD][j] >> shift) & 255u) << (8 * (j % 4));
+        for (int k = 0; k < W; ++k) r[k][j] = i < n ? in[W * i + k] : 0u;
+        const uint32_t d = TOP == 2 ? (i < n ? top_digit(r[0][j], r[W > 1 ? 1 : 0][j]) & 255u : 0u) : (r[WORD][j] >> shift) & 255u;
+        dig[j / 4] |= d << (8 * (j % 4));
+        if (TOP == 1 && top_on && i < n) atomicAdd(&s_top[top_digit(r[0][j], r[W > 1 ? 1 : 0][j]) & 255u], 1u);
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
         const bool valid = base_i + j * 64 + lane < n;
         const uint32_t d = (dig[j / 4] >> (8 * (j % 4))) & 255u;
-#if GFFX_SORT_ABL == 2
-        rank[j] = 0;
-        continue;
-#endif
         unsigned long long peers = __ballot(valid);  // lanes of this step with my byte
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -198,6 +296,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     {  // thread = byte value: runs of the waves inside the tile, the tile's place among the tiles (look-back), the byte's
        // place inside the tile (block scan of the counts)
         const uint32_t d = threadIdx.x;
+        if (TOP == 1 && top_on && s_top[d]) atomicAdd(&top.hist()[d], s_top[d]);  // (complete after the barrier above)
         uint32_t total = 0;
 #pragma unroll
         for (int w = 0; w < kSortThreads / 64; ++w) {
@@ -215,7 +314,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         uint32_t *st = status + (size_t)tile * 256 + d;
         __hip_atomic_store(st, total | (tile == 0 ? kSortFlagPrefix : kSortFlagAgg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
-        bool done = tile == 0 || GFFX_SORT_ABL == 1;
+        bool done = tile == 0;
         for (uint32_t t = tile; !done;) {  // t = the nearest tile not yet summed + 1
             uint32_t v[kSortLookBack];
 #pragma unroll
@@ -238,7 +337,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
             t -= done ? 0 : kSortLookBack;
         }
         if (tile) __hip_atomic_store(st, ((excl + total) & kSortValueMask) | kSortFlagPrefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_base[d] = bin_start[d] + excl;
+        s_base[d] = (TOP == 2 ? s_top[d] : bin_start[d]) + excl;
         __syncthreads();
         uint32_t wbase = 0;
         for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
@@ -249,8 +348,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     for (int j = 0; j < kSortItems; ++j) {  // into LDS at the record's place inside the byte-sorted tile
         if (base_i + j * 64 + lane >= n) continue;
         const uint32_t d = (dig[j / 4] >> (8 * (j % 4))) & 255u;
-        uint32_t lp = s_dstart[d] + s_cnt[wave][d] + rank[j];
-        if (GFFX_SORT_ABL) lp = min(lp, kSortTile - 1);
+        const uint32_t lp = s_dstart[d] + s_cnt[wave][d] + rank[j];
 #pragma unroll
         for (int k = 0; k < W; ++k) s_rec[W * lp + k] = r[k][j];
     }
@@ -259,10 +357,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         uint32_t w[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) w[k] = s_rec[W * x + k];
-        const uint32_t d = (w[WORD] >> shift) & 255u;
-        unsigned long long pos = (unsigned long long)s_base[d] + (x - s_dstart[d]);
-        if (GFFX_SORT_ABL) pos = min(pos, n - 1);
-        if (GFFX_SORT_ABL == 3 && w[0] != 0xFFFFFFF0u) continue;
+        const uint32_t d = TOP == 2 ? top_digit(w[0], w[W > 1 ? 1 : 0]) & 255u : (w[WORD] >> shift) & 255u;
+        const unsigned long long pos = (unsigned long long)s_base[d] + (x - s_dstart[d]);
 #pragma unroll
         for (int k = 0; k < W; ++k) out[W * pos + k] = w[k];
     }
@@ -273,37 +369,88 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
 // memset (or by the caller: head_is_clear), the status words by the histogram kernel.  Everything is enqueued on `stream`.
 struct DeviceSort {
     // (a multiple of 64 words: one fill kernel, no unaligned tail)
-    static size_t head_words(int n_passes) { return ((size_t)n_passes * 256 + 2 * (size_t)n_passes + 16 + 63) / 64 * 64; }
+    static size_t head_words(int n_passes) { return ((size_t)n_passes * 256 + 2 * (size_t)n_passes + 16 + kSortTopWords + 63) / 64 * 64; }
     static size_t work_words(unsigned long long n, int n_passes) {
         const size_t tiles = (size_t)((n + kSortTile - 1) / kSortTile);
         return head_words(n_passes) + tiles * (size_t)n_passes * 256;
     }
-    // note: {device counter of the records with word 1 > word 2, pinned host words {count, seq}, seq} or all NULL
+    // note: {device counter of the records with word 1 > word 2, pinned host words {count, seq}, seq} or all NULL.
+    // top_note (W = 3, a plan whose last two passes are {word 1, byte 3} and {word 0, byte 0}, limit0 <= 256): pinned host words
+    // {ok, seq}; the sort then tries the top digit (header comment) and the host waits for the note before it enqueues the last
+    // pass(es) -- *passes_run says how many ran (the result is in buf_a after an even number, in buf_b after an odd one).
     template <int W>
     static int run(hipStream_t stream, uint32_t *buf_a, uint32_t *buf_b, unsigned long long n, const SortPlan &plan, uint32_t limit0,
                    uint32_t *work, uint32_t *err, uint32_t **sorted, SortNote note = SortNote{nullptr, nullptr, 0},
-                   bool head_is_clear = false) {
+                   bool head_is_clear = false, uint32_t *top_note = nullptr, uint32_t top_seq = 0, int *passes_run = nullptr) {
         *sorted = buf_a;
+        if (passes_run) *passes_run = 0;
         if (n == 0) return GFFX_OK;
         if (n >= (1ull << 30)) return fail(GFFX_E_INVALID, "device sort: %llu records exceed the limit of 2^30 - 1", n);
         const size_t tiles = (size_t)((n + kSortTile - 1) / kSortTile);
         if (!head_is_clear) GFFX_HIP_TRY(hipMemsetAsync(work, 0, head_words(plan.n_passes) * 4, stream));
         uint32_t *hist = work, *tickets = work + (size_t)plan.n_passes * 256, *same = tickets + plan.n_passes,
                  *status = work + head_words(plan.n_passes);
+        const int P = plan.n_passes;
+        const bool try_top = W == 3 && top_note && limit0 <= 256 && P >= 2 && plan.word[P - 2] == 1 && plan.shift[P - 2] == 24 && plan.word[P - 1] == 0 &&
+                             plan.shift[P - 1] == 0;
+        const SortTop top{try_top ? same + plan.n_passes + 8 : nullptr, top_note, top_seq};  // (behind the flags, inside the cleared head)
         // (few blocks: every block ends with one global atomic per non-empty bin and pass)
         const uint32_t hgrid = (uint32_t)std::max<unsigned long long>(1, std::min<unsigned long long>((n + 4095) / 4096, 256));
         hipLaunchKernelGGL(k_radix_hist<W>, dim3(hgrid), dim3(kHistThreads), 0, stream, buf_a, n, plan, hist, limit0, err, note, status,
-                           (unsigned long long)(tiles * (size_t)plan.n_passes * 256));
-        hipLaunchKernelGGL(k_radix_scan, dim3(plan.n_passes), dim3(256), 0, stream, hist, n, same, note);
+                           (unsigned long long)(tiles * (size_t)plan.n_passes * 256), top);
+        hipLaunchKernelGGL(k_radix_scan, dim3(plan.n_passes + (try_top ? 1 : 0)), dim3(256), 0, stream, hist, n, same, note, top, (uint32_t)plan.n_passes, limit0);
         uint32_t *src = buf_a, *dst = buf_b;
-        for (int p = 0; p < plan.n_passes; ++p) {
-            auto *pass = plan.word[p] == 0 ? k_radix_pass<W, 0> : plan.word[p] == 1 ? k_radix_pass<W, 1> : k_radix_pass<W, W - 1>;
+        int ran = 0;
+        auto plain = [&](int p, bool take_top_hist) {
+            if constexpr (W == 3) {
+                if (take_top_hist) {  // (the pass before the top digit's: word 1, byte 2)
+                    hipLaunchKernelGGL((k_radix_pass<3, 1, 1>), dim3((uint32_t)tiles), dim3(kSortThreads), 0, stream, src, dst, n, (int)plan.shift[p],
+                                       hist + (size_t)p * 256, same + p, status + (size_t)p * tiles * 256, tickets + p, err, top);
+                    std::swap(src, dst);
+                    ++ran;
+                    return;
+                }
+            }
+            auto *pass = plan.word[p] == 0 ? k_radix_pass<W, 0, 0> : plan.word[p] == 1 ? k_radix_pass<W, 1, 0> : k_radix_pass<W, W - 1, 0>;
             hipLaunchKernelGGL(pass, dim3((uint32_t)tiles), dim3(kSortThreads), 0, stream, src, dst, n, (int)plan.shift[p],
-                               hist + (size_t)p * 256, same + p, status + (size_t)p * tiles * 256, tickets + p, err);
+                               hist + (size_t)p * 256, same + p, status + (size_t)p * tiles * 256, tickets + p, err, SortTop{nullptr, nullptr, 0});
             std::swap(src, dst);
+            ++ran;
+        };
+        for (int p = 0; p < P - (try_top ? 2 : 0); ++p) plain(p, try_top && p == P - 3 && plan.word[p] == 1);
+        if (try_top) {
+            // does the digit fit?  k_radix_scan posted the answer long ago (it ran before the first pass); should the note never
+            // arrive the stream itself is the clock
+            bool ok = false, posted = false;
+            if (P >= 3 && plan.word[P - 3] == 1) {  // (the histogram of the digit was taken by the pass just enqueued)
+                const auto t0 = std::chrono::steady_clock::now();
+                unsigned long long word = 0;
+                while (!(posted = (uint32_t)((word = __atomic_load_n(reinterpret_cast<unsigned long long *>(top_note), __ATOMIC_ACQUIRE)) >> 32) == top_seq) &&
+                       std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2))
+                    std::this_thread::yield();
+                ok = posted && (uint32_t)word != 0u;
+                if (!posted) {
+                    uint32_t h_ok = 0;
+                    GFFX_HIP_TRY(hipStreamSynchronize(stream));
+                    GFFX_HIP_TRY(hipMemcpy(&h_ok, top.ok(), 4, hipMemcpyDeviceToHost));
+                    ok = h_ok != 0;
+                }
+            }
+            if (ok) {
+                if constexpr (W == 3) {
+                    hipLaunchKernelGGL((k_radix_pass<3, 1, 2>), dim3((uint32_t)tiles), dim3(kSortThreads), 0, stream, src, dst, n, 0, hist, same,
+                                       status + (size_t)(P - 2) * tiles * 256, tickets + (P - 2), err, top);
+                    std::swap(src, dst);
+                    ++ran;
+                }
+            } else {
+                plain(P - 2, false);
+                plain(P - 1, false);
+            }
         }
         GFFX_HIP_TRY(hipGetLastError());
         *sorted = src;
+        if (passes_run) *passes_run = ran;
         return GFFX_OK;
     }
 };

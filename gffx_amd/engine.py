@@ -355,6 +355,11 @@ class LineTable:
         return lib().gffx_hip_lines_last_kernel_ms(self._h)
 
     @property
+    def last_sort_passes(self) -> int:
+        """Radix passes of the last call's region sort (4 with the mixed-radix top digit, else 4 + seqid bytes)."""
+        return lib().gffx_hip_lines_last_sort_passes(self._h)
+
+    @property
     def last_prep_ms(self) -> float:
         """HIP-event duration of the device preparation of the region tables (radix sorts, scans, directories)."""
         return lib().gffx_hip_lines_last_prep_ms(self._h)

@@ -55,7 +55,7 @@
  *   passes (batch):
  *   GFFX_HIP_WIN_THREADS=0|512|1024 block width of the window kernels (0 = the engine's choice: 1024 for a pass of >= 500 000 regions
  *                                   that runs alone, 512 otherwise)
- *   GFFX_HIP_WIN_WIDE=0|1|2         the wide form of the window kernels: never / AUTO's choice for mostly wide batches (default) /
+ *   GFFX_HIP_WIN_WIDE=0|1|2         the mixed form of the window kernels: never / AUTO's choice for batches with wide rows (default) /
  *                                   every eligible pass of the windows strategy
  *   GFFX_HIP_WIDTH_SAMPLE=0         no width sample of the rows the host hands over (AUTO then learns from a first waited pass)
  *   GFFX_HIP_AUTO_STRATEGY=n        what GFFX_STRATEGY_AUTO resolves to (0: the engine's choice)
@@ -293,13 +293,15 @@ int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, i
 /* Threads per block of the last windows-strategy pair pass of this batch (512 or 1024; 0: none ran).  The engine takes
  * 1024-thread blocks (one per CU, rounds of 4096 regions) for a batch of 0.5-2.5 M regions while NO other batch of the
  * index has passes in flight, 512-thread blocks (two per CU: kernels of two batches share the CUs) otherwise;
- * GFFX_HIP_WIN_THREADS=512|1024 in the environment forces one. */
+ * The knob GFFX_HIP_WIN_THREADS (512 / 1024) forces one. */
 uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *);
-/* 1 when the last run's passes took the WIDE form of the window kernels: regions of any width answered from two index lines
- * and two rank words each (overlap mode).  AUTO chooses it for a batch of mostly wide regions (wider than the lines answer,
- * 16 Ki bases by default): found by a sample of the rows gffx_hip_batch_set_regions_host / _soa_host are given, or -- regions
- * already on the device -- by a previous waited pass that sent most regions to the exact sweep; the other modes of such a
- * batch run on the sweep kernel.  GFFX_HIP_WIN_WIDE=0 in the environment disables the form. */
+/* 1 when the last run's passes took the MIXED form of the window kernels (overlap mode; round 4's "wide form" is its all-wide
+ * case): every region is served its own way in one launch -- a region the index lines answer (up to 16 Ki bases by default) from ONE
+ * line as in the narrow form, a wider one from two index lines and two rank words, no sweep.  AUTO chooses it for a batch with
+ * more than one wide row in 128: found by a sample of the rows gffx_hip_batch_set_regions_host / _soa_host are given (each judged
+ * against its own seqid's line width), or -- regions already on the device -- by a previous waited pass of the narrow form, which
+ * counts the rows its lines did not answer; the other modes of a MOSTLY wide batch run on the sweep kernel.  The knob
+ * GFFX_HIP_WIN_WIDE (0 never / 1 AUTO / 2 every eligible pass of the windows strategy) steers it. */
 int gffx_hip_batch_wide_form(const gffx_hip_batch *);
 
 /* One-shot drop-in for query_features (commands/intersect.rs:105-111): host regions in, host
@@ -333,6 +335,9 @@ double gffx_hip_lines_last_kernel_ms(const gffx_hip_lines *);
  * ends, the bin directory and -- Overlap mode, when the run has regions with start > end -- the sort of those regions' ends
  * (the reference builds `query_ivmap` on the CPU: intersect.rs:621-633) */
 double gffx_hip_lines_last_prep_ms(const gffx_hip_lines *);
+/* radix passes of the last call's region sort by (seqid, start): 4 when the mixed-radix top digit (seqid, start >> 24) fits 256 values
+ * (GRCh38-scale BED files), else 4 + one per byte of the seqid count */
+int gffx_hip_lines_last_sort_passes(const gffx_hip_lines *);
 /* The region tables of the last _test, for parity checks: q_off (n_seq + 1 entries), then per region in (seqid, start)
  * order (stable: equal starts keep the order of `regions`): QS = start, PM = running max of `end` inside the seqid, SM =
  * running min of `end` from the seqid's last region backwards, CD = regions with start > end before this position (all

@@ -72,7 +72,13 @@ extern "C" {
     pub fn gffx_hip_batch_wait(b: *mut gffx_hip_batch) -> c_int;
     pub fn gffx_hip_batch_sync(b: *mut gffx_hip_batch) -> c_int;
     pub fn gffx_hip_batch_block_threads(b: *const gffx_hip_batch) -> u32;
-    pub fn gffx_hip_batch_wide_form(b: *const gffx_hip_batch) -> c_int;
+    pub fn gffx_hip_batch_wide_form(b: *const gffx_hip_batch) -> c_int; // (round 5: the MIXED form -- narrow and wide regions lane by lane)
+    // round 5: tuning knobs (read from the environment once per object; changed through set_option), the non-default ones as JSON;
+    // the kept pairs of all root passes since the last pass without GFFX_OUT_BITMAP_KEEP (a streaming caller's per-device hit count)
+    pub fn gffx_hip_batch_set_option(b: *mut gffx_hip_batch, name: *const std::os::raw::c_char, value: std::os::raw::c_long) -> c_int;
+    pub fn gffx_hip_batch_options(b: *const gffx_hip_batch, buf: *mut std::os::raw::c_char, cap: usize) -> c_int;
+    pub fn gffx_hip_index_options(ix: *const gffx_hip_index, buf: *mut std::os::raw::c_char, cap: usize) -> c_int;
+    pub fn gffx_hip_batch_kept_pairs_accumulated(b: *mut gffx_hip_batch, out: *mut u64) -> c_int;
     // streaming BED ingestion through pinned staging buffers, several GPUs
     pub fn gffx_hip_regions_create(device: c_int, capacity_rows: u64, chunk_rows: u64, keep_all: c_int, out: *mut *mut gffx_hip_regions) -> c_int;
     pub fn gffx_hip_regions_destroy(r: *mut gffx_hip_regions);

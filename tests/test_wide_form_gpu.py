@@ -199,9 +199,9 @@ def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
     ix.close()
 
 
-@pytest.mark.parametrize("frac,mixed", [(0.10, True), (0.05, True), (0.01, False), (0.0, False)])
+@pytest.mark.parametrize("frac,mixed", [(0.10, True), (0.02, True), (0.002, False), (0.0, False)])
 def test_mixed_batches_take_the_mixed_form(frac, mixed, monkeypatch):
-    """A BED file with SOME SV-sized rows (round 5): more than a thirty-second of the rows wider than their seqid's lines answer and
+    """A BED file with SOME SV-sized rows (round 5): more than one row in 128 wider than their seqid's lines answer and
     AUTO's overlap-mode passes -- pair passes, triples, the CLI's root pass -- run the MIXED form of the window kernels, in which every
     lane serves its region the narrow way (one line) or the wide way (two lines, two ranks); fewer, and the narrow form keeps the batch
     (its few wide rows sweep).  Either way every region's pairs equal the oracle's.  Host rows are judged from a sample, device-resident

@@ -38,7 +38,7 @@ def main():
                     prep.append(1e3 * lt.last_prep_ms)
                 k = float(np.median(us))
                 print(json.dumps({"regions": nq, "input": name, "mode": mode.name, "lines": int(lt.n), "kernel_us": round(k, 2),
-                                  "prep_us": round(float(np.median(prep)), 1), "prep_us_per_1m": round(float(np.median(prep)) * 1e6 / nq, 1),
+                                  "prep_us": round(float(np.median(prep)), 1), "sort_passes": lt.last_sort_passes, "prep_us_per_1m": round(float(np.median(prep)) * 1e6 / nq, 1),
                                   "GBps": round(13.0 * lt.n / (k * 1e-6) / 1e9, 1), "frac_of_8TBps": round(13.0 * lt.n / (k * 1e-6) / 8e12, 3),
                                   "kept": int(kept.sum())}), flush=True)
     lt.close()
