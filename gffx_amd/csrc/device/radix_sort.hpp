@@ -19,14 +19,15 @@
 //                  coordinates, the seqid of a one-chromosome BED; k_radix_scan flags it) is a straight copy.
 // THE TOP DIGIT (round 5; W = 3 sorts by (word 0, word 1) with <= 256 values of word 0: Join B's (seqid, start)).  The keys of a
 // GRCh38-scale BED are 33 bits -- 28 of start, 5 of seqid --, one bit more than four 8-bit passes hold; but the last two passes'
-// digits are far from full: start >> 24 takes <= 15 values per seqid, the seqid 25.  k_radix_hist therefore also takes the
-// per-seqid maximum of start >> 24, k_radix_scan turns the maxima into lut[seqid] = sum over the earlier seqids of (max + 1), and
-// when the total fits 256 the sort's LAST pass sorts by the mixed-radix digit lut[seqid] + (start >> 24) -- the order of
-// (seqid, start's top byte) -- in place of the two passes "byte 3 of start" and "seqid": four passes instead of five (GRCh38:
-// 196 values).  The histogram of that digit is taken by the pass before it (the records are in registers there); its bin
-// starts are a 256-thread scan at the start of the pass.  Whether the total fits is known on the device only: k_radix_scan posts
-// {fits, sequence number} to pinned host memory, and the host -- three passes of enqueueing later -- reads it and enqueues either
-// the one pass or the two (no stream synchronisation: the note is written ~20 us after the first kernel starts).
+// digits are far from full: start >> 24 takes <= 15 values per seqid, the seqid 25.  k_radix_hist therefore also counts the records
+// per (seqid, start >> 24) -- a 256 x 16 table in LDS; a top byte of 16 or more switches the whole thing off --, k_radix_scan turns the
+// counts into lut[seqid] = sum over the earlier seqids of (largest top byte + 1) and, when the total fits 256, into the bin starts of
+// the mixed-radix digit lut[seqid] + (start >> 24) -- the order of (seqid, start's top byte) -- by which the sort's LAST pass then
+// sorts in place of the two passes "byte 3 of start" and "seqid": four passes instead of five (GRCh38: 196 values).  Whether the
+// total fits is known on the device only: k_radix_scan posts {fits, sequence number} to pinned host memory, and the host -- three
+// passes of enqueueing later -- reads it and enqueues either the one pass or the two (no stream synchronisation: the note is written
+// ~20 us after the first kernel starts).  (First version: per-seqid maxima in the histogram kernel, the digit's histogram taken by
+// the pass before the last: that pass +7 us, the last +5 -- the joint table costs the histogram kernel ~3.)
 // Stability: wave w of a tile ranks records [1024 w, 1024 w + 1024) in order (step j holds records j*64 + lane), waves and
 // tiles are prefix-summed in order; the LDS reorder keeps the rank order inside a byte's run.  Roofline bound: HBM, 8 W bytes per record and pass.
 #pragma once
@@ -68,27 +69,29 @@ struct SortNote {
     uint32_t *inverted, *note;
     uint32_t note_seq;
 };
-// the top digit (header comment): device words {maxhi1[256]: per value of word 0 the largest (word 1 >> 24) + 1, 0 = no record;
-// lut[256]; hist[256]: the digit's histogram; ok}, and where the host learns `ok`: note = pinned {ok, seq}
+// the top digit (header comment): device words {joint[256 x 16]: records per (word 0, word 1 >> 24); lut[256]; bins[256]: the digit's
+// bin starts; flags: [0] a record outside the table, [1] ok, [2] one bin holds every record}, and where the host learns `ok`:
+// note = pinned {ok, seq}
+constexpr uint32_t kSortTopHi = 16;  // top bytes 0 .. 15 (starts below 2^28)
 struct SortTop {
-    uint32_t *words;  // 3 x 256 + 4 device words (nullptr: no top digit)
+    uint32_t *words;  // kSortTopWords device words, zero on entry (nullptr: no top digit)
     uint32_t *note;
     uint32_t seq;
-    __host__ __device__ uint32_t *maxhi1() const { return words; }
-    __host__ __device__ uint32_t *lut() const { return words + 256; }
-    __host__ __device__ uint32_t *hist() const { return words + 512; }
-    __host__ __device__ uint32_t *ok() const { return words + 768; }
+    __host__ __device__ uint32_t *joint() const { return words; }
+    __host__ __device__ uint32_t *lut() const { return words + 256 * kSortTopHi; }
+    __host__ __device__ uint32_t *bins() const { return words + 256 * kSortTopHi + 256; }
+    __host__ __device__ uint32_t *flags() const { return words + 256 * kSortTopHi + 512; }
 };
-constexpr size_t kSortTopWords = 3 * 256 + 4;
+constexpr size_t kSortTopWords = 256 * kSortTopHi + 512 + 4;
 template <int W>
 __global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec, unsigned long long n, SortPlan plan, uint32_t *hist,
                                                     uint32_t limit0, uint32_t *err, SortNote note, uint32_t *zero, unsigned long long zero_words,
                                                     SortTop top) {
     __shared__ uint32_t s_h[kSortMaxPasses * 256];
-    __shared__ uint32_t s_mx[256];  // (top digit) per value of word 0: the largest (word 1 >> 24) + 1 seen by this block
+    __shared__ uint32_t s_joint[W == 3 ? 256 * kSortTopHi : 1];  // (top digit) records per (word 0, word 1 >> 24) seen by this block
+    bool top_out = false;                                        // ... a record outside that table
     if (W == 3 && top.words)
-        for (int i = threadIdx.x; i < 256; i += kHistThreads) s_mx[i] = 0;
-    uint32_t my_seq = 0xFFFFFFFFu, my_max = 0;  // the thread's run of equal word 0: one LDS atomic per run, not per record
+        for (int i = threadIdx.x; i < (int)(256 * kSortTopHi); i += kHistThreads) s_joint[i] = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kHistThreads + threadIdx.x; i < zero_words; i += (unsigned long long)gridDim.x * kHistThreads)
         zero[i] = 0u;
     uint32_t *inverted = note.inverted;
@@ -103,11 +106,11 @@ __global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec
         bad |= w[0] >= limit0;
         if (W == 3 && w[1] > w[W - 1]) n_inv++;
         if (W == 3 && top.words) {
-            if (w[0] != my_seq) {
-                if (my_seq < 256u) atomicMax(&s_mx[my_seq], my_max);
-                my_seq = w[0], my_max = 0;
-            }
-            my_max = max(my_max, (w[1] >> 24) + 1u);
+            const uint32_t hi = w[1] >> 24;
+            if (w[0] < 256u && hi < kSortTopHi)
+                atomicAdd(&s_joint[w[0] * kSortTopHi + hi], 1u);
+            else
+                top_out = true;
         }
         for (int p = 0; p < plan.n_passes; ++p) {
             const uint32_t d = (w[plan.word[p]] >> plan.shift[p]) & 255u;
@@ -121,13 +124,14 @@ __global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec
             }
         }
     }
-    if (W == 3 && top.words && my_seq < 256u) atomicMax(&s_mx[my_seq], my_max);
     __syncthreads();
     for (int i = threadIdx.x; i < plan.n_passes * 256; i += kHistThreads)
         if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
-    if (W == 3 && top.words)
-        for (int i = threadIdx.x; i < 256; i += kHistThreads)
-            if (s_mx[i]) atomicMax(&top.maxhi1()[i], s_mx[i]);
+    if (W == 3 && top.words) {
+        for (int i = threadIdx.x; i < (int)(256 * kSortTopHi); i += kHistThreads)
+            if (s_joint[i]) atomicAdd(&top.joint()[i], s_joint[i]);
+        if (top_out) atomicOr(&top.flags()[0], 1u);
+    }
     if (bad) atomicOr(err, 2u);
     if (W == 3 && inverted) {
 #pragma unroll
@@ -141,25 +145,41 @@ __global__ __launch_bounds__(kHistThreads) void k_radix_hist(const uint32_t *rec
 __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned long long n, uint32_t *same_byte, SortNote note, SortTop top, uint32_t n_passes,
                                                     uint32_t limit0) {
     __shared__ uint32_t s_w[4];
-    if (blockIdx.x == n_passes) {
+    if (blockIdx.x == n_passes) {  // thread c = value c of word 0
+        __shared__ uint32_t s_w2[4];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const uint32_t v = threadIdx.x < limit0 ? top.maxhi1()[threadIdx.x] : 0u;
-        uint32_t inc = v;
+        uint32_t cnt[kSortTopHi], width = 0, total = 0;
+#pragma unroll
+        for (uint32_t h = 0; h < kSortTopHi; ++h) {
+            cnt[h] = threadIdx.x < limit0 ? top.joint()[threadIdx.x * kSortTopHi + h] : 0u;
+            if (cnt[h]) width = h + 1;
+            total += cnt[h];
+        }
+        uint32_t inc = width, inc2 = total;  // two scans over the values of word 0: the digits before mine, the records before mine
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
+            const uint32_t t = __shfl_up(inc, o, 64), t2 = __shfl_up(inc2, o, 64);
+            if (lane >= o) inc += t, inc2 += t2;
         }
-        if (lane == 63) s_w[wave] = inc;
+        if (lane == 63) s_w[wave] = inc, s_w2[wave] = inc2;
         __syncthreads();
-        uint32_t base = 0;
-        for (int x = 0; x < wave; ++x) base += s_w[x];
-        top.lut()[threadIdx.x] = base + inc - v;
-        if (threadIdx.x == 255) {
-            const uint32_t ok = (limit0 <= 256u && base + inc <= 256u) ? 1u : 0u;
-            *top.ok() = ok;
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(top.note), (unsigned long long)ok | ((unsigned long long)top.seq << 32), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t base = 0, base2 = 0;
+        for (int x = 0; x < wave; ++x) base += s_w[x], base2 += s_w2[x];
+        const uint32_t first = base + inc - width;  // lut: my first digit
+        top.lut()[threadIdx.x] = first;
+        const bool ok = limit0 <= 256u && s_w[0] + s_w[1] + s_w[2] + s_w[3] <= 256u && top.flags()[0] == 0u;  // (uniform)
+        if (ok) {
+            uint32_t at = base2 + inc2 - total;  // records before my first digit
+            for (uint32_t h = 0; h < width; ++h) {
+                top.bins()[first + h] = at;
+                if (cnt[h] == n) top.flags()[2] = 1u;
+                at += cnt[h];
+            }
+        }
+        if (threadIdx.x == 0) {
+            top.flags()[1] = ok ? 1u : 0u;
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(top.note), (unsigned long long)(ok ? 1u : 0u) | ((unsigned long long)top.seq << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
@@ -190,8 +210,8 @@ __global__ __launch_bounds__(256) void k_radix_scan(uint32_t *hist, unsigned lon
 // one LSD pass: in -> out, stable by byte (word, shift).  status: n_tiles x 256 words, zero on entry; ticket: zero on entry.
 // The tile is reordered in LDS first (digit by digit, stable), so that a wave's 64 consecutive stores cover a few runs of
 // consecutive global records instead of 64 scattered 8- or 12-byte writes.
-// TOP (W = 3; the header comment's top digit): 0 a plain pass; 1 a plain pass that ALSO takes the histogram of the top digit
-// (when top.ok says the digit fits); 2 the pass that sorts by the top digit (word / shift unused; its bin starts are scanned here).
+// TOP (W = 3; the header comment's top digit): 0 a plain pass; 2 the pass that sorts by the top digit (word / shift / bin_start /
+// same_byte unused: the digit's bin starts and its "one bin holds everything" flag are k_radix_scan's, in `top`).
 constexpr int kSortLookBack = GFFX_SORT_LOOKBACK;
 template <int W, int WORD, int TOP = 0>
 __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in, uint32_t *out, unsigned long long n,
@@ -205,46 +225,20 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     __shared__ uint32_t s_rec[kSortTile * W];            // the tile, byte-sorted
     __shared__ uint32_t s_tile;
     __shared__ uint32_t s_lut[TOP ? 256 : 1];            // (top digit) lut[word 0]
-    __shared__ uint32_t s_top[TOP ? 256 : 1];            // TOP 1: the tile's histogram of the top digit; TOP 2: the digit's bin starts
-    __shared__ uint32_t s_same;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool top_on = TOP != 0 && *top.ok() != 0u;     // (uniform; TOP 2 is only launched when it holds)
-    auto top_digit = [&](uint32_t w0, uint32_t w1) { return s_lut[min(w0, 255u)] + (w1 >> 24); };
-    if (TOP) {
-        s_lut[threadIdx.x] = top.lut()[threadIdx.x];
-        if (TOP == 1) s_top[threadIdx.x] = 0;
-        if (threadIdx.x == 0) s_same = 0;
-    }
-    bool same = TOP == 2 ? false : *same_byte != 0u;
+    auto top_digit = [&](uint32_t w0, uint32_t w1) { return (s_lut[min(w0, 255u)] + (w1 >> 24)) & 255u; };
+    bool same;
     if (TOP == 2) {
-        if (!top_on) return;
-        // the digit's bin starts: exclusive scan of its histogram (complete: the pass before this one took it)
-        const uint32_t v = top.hist()[threadIdx.x];
-        uint32_t inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) s_wsum[wave] = inc;
-        __syncthreads();
-        if (v == n) s_same = 1;  // (every record has the same digit)
-        uint32_t base = 0;
-        for (int w = 0; w < wave; ++w) base += s_wsum[w];
-        s_top[threadIdx.x] = base + inc - v;
-        __syncthreads();
-        same = s_same != 0u;
-    } else if (TOP == 1) {
-        __syncthreads();
+        if (top.flags()[1] == 0u) return;  // (only launched when the digit fits)
+        s_lut[threadIdx.x] = top.lut()[threadIdx.x];
+        same = top.flags()[2] != 0u;
+    } else {
+        same = *same_byte != 0u;
     }
     if (same) {  // every record has the same byte here: the stable order is the input order
-        const unsigned long long r0 = (unsigned long long)blockIdx.x * kSortTile, r1 = min(r0 + (unsigned long long)kSortTile, n);
-        for (unsigned long long x = r0 * W + threadIdx.x; x < r1 * W; x += kSortThreads) out[x] = in[x];
-        if (TOP == 1 && top_on) {  // (the top digit's histogram is still wanted)
-            for (unsigned long long i = r0 + threadIdx.x; i < r1; i += kSortThreads) atomicAdd(&s_top[top_digit(in[W * i], in[W * i + 1])], 1u);
-            __syncthreads();
-            if (s_top[threadIdx.x]) atomicAdd(&top.hist()[threadIdx.x], s_top[threadIdx.x]);
-        }
+        const unsigned long long w0 = (unsigned long long)blockIdx.x * kSortTile * W;
+        const unsigned long long w1 = min(w0 + (unsigned long long)kSortTile * W, n * W);
+        for (unsigned long long x = w0 + threadIdx.x; x < w1; x += kSortThreads) out[x] = in[x];
         return;
     }
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
@@ -262,9 +256,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         const unsigned long long i = base_i + j * 64 + lane;
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k][j] = i < n ? in[W * i + k] : 0u;
-        const uint32_t d = TOP == 2 ? (i < n ? top_digit(r[0][j], r[W > 1 ? 1 : 0][j]) & 255u : 0u) : (r[WORD][j] >> shift) & 255u;
+        const uint32_t d = TOP == 2 ? (i < n ? top_digit(r[0][j], r[W > 1 ? 1 : 0][j]) : 0u) : (r[WORD][j] >> shift) & 255u;
         dig[j / 4] |= d << (8 * (j % 4));
-        if (TOP == 1 && top_on && i < n) atomicAdd(&s_top[top_digit(r[0][j], r[W > 1 ? 1 : 0][j]) & 255u], 1u);
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -296,7 +289,6 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     {  // thread = byte value: runs of the waves inside the tile, the tile's place among the tiles (look-back), the byte's
        // place inside the tile (block scan of the counts)
         const uint32_t d = threadIdx.x;
-        if (TOP == 1 && top_on && s_top[d]) atomicAdd(&top.hist()[d], s_top[d]);  // (complete after the barrier above)
         uint32_t total = 0;
 #pragma unroll
         for (int w = 0; w < kSortThreads / 64; ++w) {
@@ -337,7 +329,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
             t -= done ? 0 : kSortLookBack;
         }
         if (tile) __hip_atomic_store(st, ((excl + total) & kSortValueMask) | kSortFlagPrefix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_base[d] = (TOP == 2 ? s_top[d] : bin_start[d]) + excl;
+        s_base[d] = (TOP == 2 ? top.bins()[d] : bin_start[d]) + excl;
         __syncthreads();
         uint32_t wbase = 0;
         for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
@@ -357,7 +349,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
         uint32_t w[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) w[k] = s_rec[W * x + k];
-        const uint32_t d = TOP == 2 ? top_digit(w[0], w[W > 1 ? 1 : 0]) & 255u : (w[WORD] >> shift) & 255u;
+        const uint32_t d = TOP == 2 ? top_digit(w[0], w[W > 1 ? 1 : 0]) : (w[WORD] >> shift) & 255u;
         const unsigned long long pos = (unsigned long long)s_base[d] + (x - s_dstart[d]);
 #pragma unroll
         for (int k = 0; k < W; ++k) out[W * pos + k] = w[k];
@@ -401,28 +393,19 @@ struct DeviceSort {
         hipLaunchKernelGGL(k_radix_scan, dim3(plan.n_passes + (try_top ? 1 : 0)), dim3(256), 0, stream, hist, n, same, note, top, (uint32_t)plan.n_passes, limit0);
         uint32_t *src = buf_a, *dst = buf_b;
         int ran = 0;
-        auto plain = [&](int p, bool take_top_hist) {
-            if constexpr (W == 3) {
-                if (take_top_hist) {  // (the pass before the top digit's: word 1, byte 2)
-                    hipLaunchKernelGGL((k_radix_pass<3, 1, 1>), dim3((uint32_t)tiles), dim3(kSortThreads), 0, stream, src, dst, n, (int)plan.shift[p],
-                                       hist + (size_t)p * 256, same + p, status + (size_t)p * tiles * 256, tickets + p, err, top);
-                    std::swap(src, dst);
-                    ++ran;
-                    return;
-                }
-            }
+        auto plain = [&](int p) {
             auto *pass = plan.word[p] == 0 ? k_radix_pass<W, 0, 0> : plan.word[p] == 1 ? k_radix_pass<W, 1, 0> : k_radix_pass<W, W - 1, 0>;
             hipLaunchKernelGGL(pass, dim3((uint32_t)tiles), dim3(kSortThreads), 0, stream, src, dst, n, (int)plan.shift[p],
                                hist + (size_t)p * 256, same + p, status + (size_t)p * tiles * 256, tickets + p, err, SortTop{nullptr, nullptr, 0});
             std::swap(src, dst);
             ++ran;
         };
-        for (int p = 0; p < P - (try_top ? 2 : 0); ++p) plain(p, try_top && p == P - 3 && plan.word[p] == 1);
+        for (int p = 0; p < P - (try_top ? 2 : 0); ++p) plain(p);
         if (try_top) {
             // does the digit fit?  k_radix_scan posted the answer long ago (it ran before the first pass); should the note never
             // arrive the stream itself is the clock
             bool ok = false, posted = false;
-            if (P >= 3 && plan.word[P - 3] == 1) {  // (the histogram of the digit was taken by the pass just enqueued)
+            {
                 const auto t0 = std::chrono::steady_clock::now();
                 unsigned long long word = 0;
                 while (!(posted = (uint32_t)((word = __atomic_load_n(reinterpret_cast<unsigned long long *>(top_note), __ATOMIC_ACQUIRE)) >> 32) == top_seq) &&
@@ -432,7 +415,7 @@ struct DeviceSort {
                 if (!posted) {
                     uint32_t h_ok = 0;
                     GFFX_HIP_TRY(hipStreamSynchronize(stream));
-                    GFFX_HIP_TRY(hipMemcpy(&h_ok, top.ok(), 4, hipMemcpyDeviceToHost));
+                    GFFX_HIP_TRY(hipMemcpy(&h_ok, top.flags() + 1, 4, hipMemcpyDeviceToHost));
                     ok = h_ok != 0;
                 }
             }
@@ -444,8 +427,8 @@ struct DeviceSort {
                     ++ran;
                 }
             } else {
-                plain(P - 2, false);
-                plain(P - 1, false);
+                plain(P - 2);
+                plain(P - 1);
             }
         }
         GFFX_HIP_TRY(hipGetLastError());
