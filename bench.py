@@ -953,11 +953,13 @@ def join_b_leg(engine, synth, roots, regions, mode):
         us.append(1e3 * lt.last_kernel_ms)
         prep.append(1e3 * lt.last_prep_ms)
     avg = float(np.mean(us))
-    out = {"kernel": "k_lines_exists2", "avg_us": avg, "prep_us": float(np.mean(prep)), "lines": int(lt.n), "regions": int(len(regions)),
+    out = {"kernel": "k_lines_exists2", "avg_us": avg, "prep_us": float(np.mean(prep)), "sort_passes": lt.last_sort_passes, "lines": int(lt.n),
+           "regions": int(len(regions)),
            "lines_per_s": lt.n / (avg * 1e-6), "achieved_GBps": 13.0 * lt.n / (avg * 1e-6) / 1e9,
            "frac_of_hbm_peak": 13.0 * lt.n / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, "kept_lines": int(kept.sum()),
            "note": "13 B per line (seq, start, end in; keep flag out); prep_us = the region tables built on the device per call "
-                   "(one stable radix sort by (seqid, start): k_radix_hist + 5 x k_radix_pass, then k_b_local / _carry / _finish)"}
+                   "(one stable radix sort by (seqid, start): k_radix_hist + sort_passes x k_radix_pass -- 4 at GRCh38 scale since round 5: "
+                   "the last pass sorts by the mixed-radix digit of (seqid, top byte of start) --, then k_b_local / _carry / _finish)"}
     lt.close()
     return out
 

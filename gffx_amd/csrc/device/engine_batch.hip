@@ -466,7 +466,8 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     // eligible pass of the windows strategy (tests).
     {
         const long ww = b->knobs.v[BK_WIN_WIDE];
-        const bool eligible = mode == GFFX_MODE_OVERLAP && !invert && b->ix->win_range_ok;
+        // (Overlap and -- round 5 -- Contained, not inverted: a wide lane's Contained answer is its run of roots filtered by their ends)
+        const bool eligible = (mode == GFFX_MODE_OVERLAP || mode == GFFX_MODE_CONTAINED) && !invert && b->ix->win_range_ok;
         // (AUTO: some wide rows -- more than 1/128 -- and no other reason for most regions to sweep: the mixed form, which serves every
         //  region its own way; mostly wide: the same kernel, every lane the wide way)
         b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && (b->mostly_wide || (b->some_wide && !b->mostly_slow))) ||

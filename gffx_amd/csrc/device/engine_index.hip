@@ -479,6 +479,8 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     std::vector<uint4> win_wide, wide_sub;
     std::vector<uint32_t> root_fids(ix->h_sorted_fids);
     root_fids.resize(root_fids.size() + 4, 0u);  // (runs are read 16 bytes at a time from any position)
+    std::vector<uint32_t> root_ends(R + 4, 0u);  // the `end` column by position: the mixed form's Contained test of a wide region's run
+    for (uint32_t i = 0; i < R; i++) root_ends[i] = h_aux[i].x;
     ix->win_range_ok = build_window_ranks(n_chr, chr_offsets, h_start, h_aux, win_meta, win_pos, win_splittab, sub_at, sub_lines_pos, win_rank);
     // the wide form's line table (gffx_device.hpp): a line's coordinate half next to its rank record -- both in one 32-byte
     // sector -- for the windows' lines and for ALL eight sub-lines of every split window (an empty sub-line has a rank too)
@@ -609,7 +611,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
         (rc = upload_line_tables(ix.get(), win, win_pos, win_wide, sub_at, sub_lines, sub_lines_pos, wide_at, wide_sub, &win_all_bytes)) ||
         (rc = dev_upload(&ix->d_win_spill, win_spill)) ||
         (rc = dev_upload(&ix->d_win_filter, win_filter)) || (rc = dev_upload(&ix->d_win_splittab, win_splittab)) ||
-        (rc = dev_upload(&ix->d_root_fids, root_fids)) ||
+        (rc = dev_upload(&ix->d_root_fids, root_fids)) || (rc = dev_upload(&ix->d_root_ends, root_ends)) ||
         (rc = dev_upload(&ix->d_cell_base, cell_base)) || (rc = dev_upload(&ix->d_cell_tile, cell_tile)) ||
         (rc = dev_upload(&ix->d_tile_meta, tile_meta)) || (rc = dev_upload(&ix->d_tile_aux, tile_aux)) ||
         (rc = dev_upload(&ix->d_tile_bins, tile_bins)) || (rc = dev_upload(&ix->d_tile_desc, tile_desc))) {
@@ -619,7 +621,7 @@ extern "C" int gffx_hip_index_create(uint32_t n_chr, const uint32_t *chr_offsets
     auto bytes = [](const auto &v) { return std::max<size_t>(v.size(), 1) * sizeof(v[0]); };
     ix->array_bytes = {bytes(h_start),   bytes(h_aux),     bytes(chr_meta),   bytes(bins),
                        bytes(win_meta),  win_all_bytes,     bytes(win_spill), bytes(win_filter),
-                       bytes(win_splittab), bytes(root_fids),
+                       bytes(win_splittab), bytes(root_fids), bytes(root_ends),
                        bytes(cell_base), bytes(cell_tile), bytes(tile_meta),  bytes(tile_aux),  bytes(tile_bins), bytes(tile_desc)};
     ix->win_range_ok = ix->win_range_ok && ix->win_all_ok();  // (the mixed form addresses the three line tables through one descriptor)
     // the uploads ran on the NULL stream; batches use non-blocking streams, which do not order against it
@@ -667,6 +669,7 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     (void)hipFree(ix->d_win_filter);
     (void)hipFree(ix->d_win_splittab);
     (void)hipFree(ix->d_root_fids);
+    (void)hipFree(ix->d_root_ends);
     (void)hipFree(ix->d_cell_base);
     (void)hipFree(ix->d_cell_tile);
     (void)hipFree(ix->d_tile_meta);

@@ -151,6 +151,7 @@ struct gffx_hip_index {
     uint32_t win_swords = 0;
     uint4 *d_win_wide = nullptr;  // the wide form's lines: {coordinates x 4 | rank, list-tail header, 0, 0}, both levels (into d_win_all)
     uint32_t *d_root_fids = nullptr;  // ranks per line, root_fids by position (the wide form of k_join_pairs)
+    uint32_t *d_root_ends = nullptr;  // ... and the ends by position (Contained over a wide region's run of roots)
     bool win_range_ok = false;
     // partitioned strategy: genome-window tiles (gffx_device.hpp)
     uint32_t *d_cell_base = nullptr;
@@ -169,7 +170,7 @@ struct gffx_hip_index {
     std::vector<void **> arrays() {
         return {(void **)&d_start,     (void **)&d_aux,       (void **)&d_chr_meta,   (void **)&d_bins,       (void **)&d_win_meta,   (void **)&d_win_all,
                 (void **)&d_win_spill, (void **)&d_win_filter,
-                (void **)&d_win_splittab, (void **)&d_root_fids,
+                (void **)&d_win_splittab, (void **)&d_root_fids, (void **)&d_root_ends,
                 (void **)&d_cell_base,
                 (void **)&d_cell_tile, (void **)&d_tile_meta, (void **)&d_tile_aux,   (void **)&d_tile_bins,  (void **)&d_tile_desc};
     }

@@ -50,7 +50,7 @@ template <int MODE, bool ML>
 static int launch_pairs(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, bool pos, bool wide, uint32_t lds) {
 #define GFFX_P(T, O, P)                                                                                          \
     if (threads == T && offs == O && pos == P) {                                                                 \
-        if constexpr (MODE == GFFX_MODE_OVERLAP)                                                                 \
+        if constexpr (MODE == GFFX_MODE_OVERLAP || MODE == GFFX_MODE_CONTAINED)                                  \
             if (wide) return launch_pairs4<MODE, ML, T, O, P, true>(b, grid, a, lds);                            \
         return launch_pairs4<MODE, ML, T, O, P, false>(b, grid, a, lds);                                         \
     }
@@ -69,7 +69,7 @@ static int launch_roots3(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, ui
 }
 template <int MODE, bool ML>
 static int launch_roots(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool wide, uint32_t lds) {
-    if constexpr (MODE == GFFX_MODE_OVERLAP)
+    if constexpr (MODE == GFFX_MODE_OVERLAP || MODE == GFFX_MODE_CONTAINED)
         if (wide) return threads == 1024 ? launch_roots3<MODE, ML, 1024, true>(b, grid, a, lds) : launch_roots3<MODE, ML, 512, true>(b, grid, a, lds);
     return threads == 1024 ? launch_roots3<MODE, ML, 1024, false>(b, grid, a, lds) : launch_roots3<MODE, ML, 512, false>(b, grid, a, lds);
 }
@@ -182,6 +182,7 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     a.pv.all = ix->d_win_all;
     a.pv.table_bytes = (uint32_t)ix->win_table_bytes;
     a.pv.rfids = ix->d_root_fids;
+    a.pv.rends = ix->d_root_ends;
     a.pv.n_roots = ix->n_roots;
     a.pv.n_win = ix->n_win;
     a.pv.n_chr = ix->n_chr;

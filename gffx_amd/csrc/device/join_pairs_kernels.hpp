@@ -115,6 +115,7 @@ struct PairView {
     const uint32_t *splittab;  // IndexView::win_splittab
     const uint4 *wide;         // IndexView::win_wide   } the mixed form only
     const uint32_t *rfids;     // IndexView::root_fids  }
+    const uint32_t *rends;     // the `end` column by position (R + 4 words): the mixed form's Contained test of a wide region's run
     const uint4 *all;          // the three line tables in one allocation: [win | win_pos | win_wide], table_bytes each (the mixed form's
     uint32_t table_bytes;      //   one descriptor; 3 x table_bytes < 2^31)
     uint32_t n_win, n_chr, fshift, n_roots;
@@ -433,7 +434,9 @@ __device__ __forceinline__ void pair_locate(const PairLds &L, uint32_t qc, uint3
 // else 0).  First line: an entry that starts at or below qs counts in le0, and is kept -- written to out[], at most `cap`
 // words -- if it ends beyond qs; second line: an entry that starts at or below qe1 = qe - 1 counts in le1.  Two records of
 // each list in flight.  Returns the kept entries.  `bits` (root passes): a kept entry sets the bit of its position there instead.
-template <bool POS>
+// CONT (Contained over a wide region: the kept roots are a subset of the RUN [rank(qs), rank(qe)) -- start >= qs -- and nothing of the
+// first line's list): the first line's entries only count, those that start BELOW qs.
+template <bool POS, bool CONT = false>
 __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t h0, uint32_t h1, uint32_t qs, uint32_t qe1, uint32_t *out,
                                                     uint32_t cap, uint32_t &le0, uint32_t &le1, uint32_t *bits = nullptr) {
     uint32_t c = 0;
@@ -449,9 +452,9 @@ __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t
         }
 #pragma unroll
         for (uint32_t t = 0; t < 2; ++t) {
-            if (x[t].x <= qs) {
+            if (CONT ? x[t].x < qs : x[t].x <= qs) {
                 ++le0;
-                if (x[t].y > qs) {
+                if (!CONT && x[t].y > qs) {
                     if (bits)
                         atomicOr(&bits[x[t].w >> 5], 1u << (x[t].w & 31));
                     else if (c < cap)
@@ -476,6 +479,9 @@ __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t
 // qe - 1 and qe - 1 in its coordinates (wide lanes only).  A base beyond the seqid's windows stands for the last base of the last
 // window (nothing overlaps it, every root starts at or below it); a narrow region whose last base lies there reads nothing.  A row
 // on a seqid without roots reads nothing; a seqid without windows, an empty and a reversed row take the sweep.
+// CONT (Contained): a wide lane's first rank is rank(qs) -- the roots that start BELOW qs --, so its ta is one less (unless qs lies
+// beyond the seqid's windows, where every root starts below it).
+template <bool CONT = false>
 __device__ __forceinline__ void pair_locate_mixed(const PairLds &L, uint32_t lines_base, uint32_t wide_base, uint32_t qc, uint32_t qs, uint32_t qe,
                                                   uint32_t &off, uint32_t &ta, uint32_t &tb, uint32_t &off1, uint32_t &rel1, bool &wide, bool &swp) {
     const uint4 m = L.cm[min(qc, L.n_chr)];
@@ -499,7 +505,7 @@ __device__ __forceinline__ void pair_locate_mixed(const PairLds &L, uint32_t lin
     point(qs, l0, r0, p0);
     point(e1, l1, r1, p1);
     off = !lines ? kWinNoLine : fits ? (p1 ? kWinNoLine : lines_base + l1 * kWinLineBytes) : wide_base + l0 * kWinLineBytes;
-    ta = fits ? r1 - wd1 : r0;  // narrow: qs relative to the line of its last base; wide: the one-base region [qs, qs + 1)
+    ta = fits ? r1 - wd1 : (CONT && !p0) ? r0 - 1u : r0;  // narrow: qs relative to the line of its last base; wide: the one-base region [qs, qs + 1)
     tb = fits ? r1 : r0;
     off1 = wide ? wide_base + l1 * kWinLineBytes : kWinNoLine;
     rel1 = r1;
@@ -558,7 +564,8 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 //       region the narrow way (one line) or the wide way (two lines, two ranks) as the region's width asks
 template <int MODE, bool META_LDS, int T, bool OFFS, bool POS, bool WIDE = false>
 __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
-    static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP, "the wide form answers overlap mode");
+    static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP || MODE == GFFX_MODE_CONTAINED, "the mixed form answers Overlap and Contained");
+    constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED;  // a wide lane keeps the roots of its run that end inside the region
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     constexpr uint32_t kWaves = T / 64;
     constexpr uint32_t D = pair_depth(WIDE);
@@ -628,6 +635,14 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     const uint32_t lines_base = POS ? A.pv.table_bytes : 0u, wide_base = 2u * A.pv.table_bytes;
     const __amdgpu_buffer_rsrc_t rfd =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rfids), 0, WIDE ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rde =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rends), 0, CONT ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
+    // (Contained, a wide lane) which of up to four roots of the run, ends e, are kept: end <= qe and end > qs (start >= qs holds for
+    // the whole run; an empty interval AT qs does not overlap: tree.rs:110) -- a bit per root, the first one bit 3
+    auto run_mask = [](const gffx_v4u &e, uint32_t n4, uint32_t qs_, uint32_t qe_) {
+        return ((n4 > 0 && e.x <= qe_ && e.x > qs_) ? 8u : 0u) | ((n4 > 1 && e.y <= qe_ && e.y > qs_) ? 4u : 0u) |
+               ((n4 > 2 && e.z <= qe_ && e.z > qs_) ? 2u : 0u) | ((n4 > 3 && e.w <= qe_ && e.w > qs_) ? 1u : 0u);
+    };
 
     // ---- what is left to do for the wave's previous D - 1 rounds once their segment bases are known (all wave-uniform;
     // entry 0 = the latest round)
@@ -743,13 +758,14 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         uint32_t off[4], rqs[4], rqe1[4];  // the line's byte offset; the region in the line's coordinates (rqe1 = its last base)
         bool swp[4];  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
         uint32_t off1[4], rel1[4], r0[4], nr[4];  // (mixed form, wide lanes) the line of qe - 1 and qe - 1 in its coordinates; the run of roots starting inside
+        uint32_t nra[4] = {0, 0, 0, 0}, em0[4] = {0, 0, 0, 0};  // (Contained) the run's length before the test of the ends (nr: the kept ones); the first four's kept bits
         bool isw[4];                              // (mixed form) the lane serves this region the wide way
         uint32_t iswm = 0;                        // ... as a bit per region
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;  // (a partial round's rows were checked when they were loaded)
             if constexpr (WIDE) {
-                pair_locate_mixed(L, lines_base, wide_base, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k]);
+                pair_locate_mixed<CONT>(L, lines_base, wide_base, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k]);
                 iswm |= isw[k] ? 1u << k : 0u;
             } else {
                 pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
@@ -792,6 +808,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false);
+                if (CONT) m[k] = isw[k] ? 0u : m[k];  // (Contained: a wide lane keeps nothing of the roots that start before its region)
                 ra[k] = wf[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);  // (a narrow lane's: unused)
                 rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rel1[k]);
                 hdr[k] = wc[k].w == kWinTailMark ? (isw[k] ? wf[k].y : wf[k].w) : 0u;
@@ -830,7 +847,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                         if (sweep >> k & 1u)
                             c = pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), st, cap, nullptr);
                         else if (iswm >> k & 1u)
-                            c = pair_wide_tails<POS>(A.spill, win_sel(hdr, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, st, cap, a0, b0);
+                            c = pair_wide_tails<POS, CONT>(A.spill, win_sel(hdr, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, st, cap, a0, b0);
                         else  // a narrow lane's list tail
                             c = pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k), st, cap);
                         n_rest += c;
@@ -852,6 +869,25 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 r0[k] = ra[k];
                 nr[k] = (swp[k] || !isw[k]) ? 0u : rb[k] - ra[k];
                 if (POS) rg[k].x = r0[k], rg[k].y = r0[k] + 1u, rg[k].z = r0[k] + 2u, rg[k].w = r0[k] + 3u;
+            }
+            if constexpr (CONT) {
+                // Contained: the run [rank(qs), rank(qe)) holds the roots that START inside the region; kept are those that also END
+                // inside it -- the ends by position, sixteen bytes a trip, the four regions in step: counted here (the reservation
+                // needs the number), read again when the words are parked
+                uint32_t longest = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nra[k] = nr[k], nr[k] = 0u, longest = max(longest, nra[k]);
+                for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < longest); t += 4) {
+                    gffx_v4u ev[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ev[k] = __builtin_amdgcn_raw_buffer_load_b128(rde, t < nra[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t msk = run_mask(ev[k], t < nra[k] ? min(nra[k] - t, 4u) : 0u, qs[k], qe[k]);
+                        nr[k] += __popc(msk);
+                        em0[k] = t == 0 ? msk : em0[k];
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -926,6 +962,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(6);
         finish(P - 1);
         GFFX_WIN_STAMP(7);
+        uint32_t cqs[4], cqe[4];  // (Contained, mixed form: the parking of long runs tests ends against THIS round's regions)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cqs[k] = CONT ? qs[k] : 0u, cqe[k] = CONT ? qe[k] : 0u;
         load_round(r + A.grid);
         const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         const uint32_t inc = win_wave_scan(mine);
@@ -956,7 +995,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 for (int k = 0; k < 4; ++k) {
                     uint32_t pos = pb;
                     pair_park4(m[k] << 28, pos, wf[k].x, wf[k].y, wf[k].z, wf[k].w);
-                    if constexpr (WIDE) {
+                    if constexpr (CONT) {
+                        pair_park4(em0[k] << 28, pos, rg[k].x, rg[k].y, rg[k].z, rg[k].w);
+                    } else if constexpr (WIDE) {
                         const uint32_t n4 = min(nr[k], 4u);
                         pair_park4(n4 ? 0xFFFFFFFFu << (32u - n4) : 0u, pos, rg[k].x, rg[k].y, rg[k].z, rg[k].w);
                     }
@@ -967,20 +1008,26 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 if constexpr (WIDE) {
                     // runs longer than four roots: four more words of every region's run per trip, the four regions in step,
                     // until no lane of the wave has a word left (the cursors pd[] move on: a list tail's words follow the run)
-                    const uint32_t longest = max(max(nr[0], nr[1]), max(nr[2], nr[3]));
+                    // (Contained: the run's length is nra[], its kept roots are picked by their ends again)
+                    uint32_t len[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) len[k] = CONT ? nra[k] : nr[k];
+                    const uint32_t longest = max(max(len[0], len[1]), max(len[2], len[3]));
                     for (uint32_t t = 4; __builtin_amdgcn_ballot_w64(t < longest); t += 4) {
-                        gffx_v4u v[4];
+                        gffx_v4u v[4], ev[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             if (POS)
                                 v[k].x = r0[k] + t, v[k].y = r0[k] + t + 1u, v[k].z = r0[k] + t + 2u, v[k].w = r0[k] + t + 3u;
                             else
-                                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, t < nr[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
+                                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, t < len[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
+                            if (CONT) ev[k] = __builtin_amdgcn_raw_buffer_load_b128(rde, t < len[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
                         }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const uint32_t n4 = t < nr[k] ? min(nr[k] - t, 4u) : 0u;
-                            pair_park4(n4 ? 0xFFFFFFFFu << (32u - n4) : 0u, pd[k], v[k].x, v[k].y, v[k].z, v[k].w);
+                            const uint32_t n4 = t < len[k] ? min(len[k] - t, 4u) : 0u;
+                            const uint32_t bits = CONT ? run_mask(ev[k], n4, cqs[k], cqe[k]) << 28 : (n4 ? 0xFFFFFFFFu << (32u - n4) : 0u);
+                            pair_park4(bits, pd[k], v[k].x, v[k].y, v[k].z, v[k].w);
                         }
                     }
                 }
@@ -1001,7 +1048,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                                 if (sweep >> k & 1u)
                                     (void)pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(c_, n_chr), s_, e_, e, 0xFFFFFFFFu, nullptr);
                                 else if (iswm >> k & 1u)
-                                    (void)pair_wide_tails<POS>(A.spill, win_sel(hdr, k), 0u, s_, e_ - 1u, e, 0xFFFFFFFFu, a0, b0);
+                                    (void)pair_wide_tails<POS, CONT>(A.spill, win_sel(hdr, k), 0u, s_, e_ - 1u, e, 0xFFFFFFFFu, a0, b0);
                                 else
                                     (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
                             } else {
@@ -1075,7 +1122,14 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                     if (m[k] & 4u) put(wf[k].y);
                     if (m[k] & 2u) put(wf[k].z);
                     if (m[k] & 1u) put(wf[k].w);
-                    for (uint32_t t = 0; t < nr[k]; ++t) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
+                    if constexpr (CONT) {
+                        for (uint32_t t = 0; t < nra[k]; ++t) {
+                            const uint32_t e_ = A.pv.rends[r0[k] + t];
+                            if (e_ <= cqe[k] && e_ > cqs[k]) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
+                        }
+                    } else {
+                        for (uint32_t t = 0; t < nr[k]; ++t) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
+                    }
                     if (deferred >> k & 1u) {
                         uint32_t c_, s_, e_, a0 = 0, b0 = 0;
                         pair_load_region(q, i0 + k, c_, s_, e_);
@@ -1084,7 +1138,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                         if (sweep >> k & 1u)
                             o += pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(c_, n_chr), s_, e_, e, cap, nullptr);
                         else if (iswm >> k & 1u)
-                            o += pair_wide_tails<POS>(A.spill, hdr[k], 0u, s_, e_ - 1u, e, cap, a0, b0);
+                            o += pair_wide_tails<POS, CONT>(A.spill, hdr[k], 0u, s_, e_ - 1u, e, cap, a0, b0);
                         else
                             o += pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(c_, n_chr), s_, e_, hdr[k], e, cap);
                     }
@@ -1132,7 +1186,8 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 // pairs (summed on the host: one same-address device atomic per wave cost 43 us per 1 M regions, per block still 5).
 template <int MODE, bool META_LDS, int T, bool WIDE = false>
 __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
-    static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP, "the wide form answers overlap mode");
+    static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP || MODE == GFFX_MODE_CONTAINED, "the mixed form answers Overlap and Contained");
+    constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED;
     constexpr uint32_t kChunk = 4u * T;
     const QueryView &q = A.q;
     const WaveOut &out = A.out;
@@ -1178,6 +1233,8 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     // (the mixed form: one descriptor over [win | win_pos | win_wide]; a root pass reads positions: its own table is win_pos)
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(A.pv.all), 0, WIDE ? 3u * A.pv.table_bytes : 0u, 0x00020000);
     const uint32_t lines_base = A.pv.table_bytes, wide_base = 2u * A.pv.table_bytes;
+    const __amdgpu_buffer_rsrc_t rde =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rends), 0, CONT ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
     const uint32_t bm = lds0 + (uint32_t)(reinterpret_cast<unsigned char *>(s_bm) - smem);  // the bitmap's LDS address
     uint32_t *g_bitmap = reinterpret_cast<uint32_t *>(out.root_flags);                       // ... or the batch's bitmap (no LDS bitmap)
     auto set_global = [&](uint32_t p) {
@@ -1198,7 +1255,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;
             if constexpr (WIDE) {
-                pair_locate_mixed(L, lines_base, wide_base, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k]);
+                pair_locate_mixed<CONT>(L, lines_base, wide_base, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k]);
             } else {
                 pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
                 off1[k] = rel1[k] = r0[k] = nr[k] = 0;
@@ -1232,6 +1289,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false);
+                if (CONT) m[k] = isw[k] ? 0u : m[k];  // (Contained: a wide lane keeps nothing of the roots that start before its region)
                 ra[k] = wf[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);  // (a narrow lane's: unused)
                 rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rel1[k]);
                 h0[k] = wc[k].w == kWinTailMark ? (isw[k] ? wf[k].y : wf[k].w) : 0u;
@@ -1260,7 +1318,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                         c = pair_sweep_call<MODE, true>(&pair_rare_ix(), 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), nullptr, 0u,
                                                         bm_words ? s_bm : g_bitmap);
                     else if (iswm >> k & 1u)
-                        c = pair_wide_tails<true>(A.spill, win_sel(h0, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, nullptr, 0u, a0, b0,
+                        c = pair_wide_tails<true, CONT>(A.spill, win_sel(h0, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, nullptr, 0u, a0, b0,
                                                   bm_words ? s_bm : g_bitmap);
                     else  // a narrow lane's list tail
                         c = pair_rest<MODE, true>(&pair_rare_ix(), A.spill, false, 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k),
@@ -1274,9 +1332,37 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 m[k] = swp[k] ? 0u : m[k];
                 r0[k] = ra[k];
                 nr[k] = (swp[k] || !isw[k]) ? 0u : rb[k] - ra[k];
-                tc[k] += nr[k];
-                kept += __popc(m[k]) + tc[k];
             }
+            if constexpr (CONT) {
+                // Contained: of the run of roots that start inside the region those that also end inside it (the ends by position,
+                // sixteen bytes a trip, the four regions in step): their bits are set here, one by one
+                uint32_t *bits = bm_words ? s_bm : g_bitmap;
+                const uint32_t longest = max(max(nr[0], nr[1]), max(nr[2], nr[3]));
+                uint32_t keptr[4] = {0, 0, 0, 0};
+                for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < longest); t += 4) {
+                    gffx_v4u ev[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ev[k] = __builtin_amdgcn_raw_buffer_load_b128(rde, t < nr[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t n4 = t < nr[k] ? min(nr[k] - t, 4u) : 0u, e4[4] = {ev[k].x, ev[k].y, ev[k].z, ev[k].w};
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; ++j)
+                            if (j < n4 && e4[j] <= qe[k] && e4[j] > qs[k]) {
+                                const uint32_t p = r0[k] + t + j;
+                                atomicOr(&bits[p >> 5], 1u << (p & 31));
+                                ++keptr[k];
+                            }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nr[k] = 0u, tc[k] += keptr[k];  // (nothing is left for the range-OR below)
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tc[k] += nr[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) kept += __popc(m[k]) + tc[k];
         } else {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -37,10 +37,10 @@ def _want_pairs(regions, want_t, want_c):
     return p[np.lexsort((p[:, 1], p[:, 0]))]
 
 
-def _check_wide(roots, regions, strategy=engine.STRATEGY_WINDOWS, soa=False):
+def _check_wide(roots, regions, strategy=engine.STRATEGY_WINDOWS, soa=False, OV=OV):
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
     oix = ob.OracleIndex.from_roots(co, s, e, f)
-    want_t, want_c = oix.query_features(regions, OV, False)
+    want_t, want_c = oix.query_features(regions, int(OV), False)
     want_p = _want_pairs(regions, want_t, want_c)
     ix = engine.TreeIndexData.from_roots(co, s, e, f)
     b = engine.QueryBatch(ix, max(len(regions), 1))
@@ -127,8 +127,10 @@ def test_wide_form_gencode_like(wide_forced):
     regions = _mixed_widths(rng, 40_000, synth.GRCH38)
     pairs = _check_wide(roots, regions)
     assert pairs > 1_000_000
+    assert _check_wide(roots, regions, OV=OverlapMode.Contained) > 100_000  # (round 5: a wide lane's run filtered by the roots' ends)
     regions = synth.synth_bed(30_011, seed=77, width=(100, 200000), edge_frac=0.05, roots=roots)  # bench.py's wide_regions shape
     _check_wide(roots, regions, soa=True)
+    _check_wide(roots, regions, OV=OverlapMode.Contained)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -156,6 +158,7 @@ def test_wide_form_small_indexes(wide_forced, seed):
              "fid": rng.permutation(len(start)).astype(np.uint32) * 3 + 1}
     regions = _mixed_widths(rng, 6000 + 257 * seed, chroms, n_chr_extra=0)
     _check_wide(roots, regions, soa=bool(seed & 1))
+    _check_wide(roots, regions, soa=not (seed & 1), OV=OverlapMode.Contained)
 
 
 def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
@@ -178,11 +181,13 @@ def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
         assert np.array_equal(b.counts(), want_c)
         assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
         assert b.wide_form == (i > 0)
-    for mode in (OverlapMode.Contained, OverlapMode.ContainsRegion):
-        wt, wc = oix.query_features(regions, int(mode), False)
-        b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_AUTO)
+    for mode, inv in ((OverlapMode.Contained, False), (OverlapMode.ContainsRegion, False), (OverlapMode.Contained, True)):
+        wt, wc = oix.query_features(regions, int(mode), inv)
+        b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_AUTO)
         b.wait()
-        assert not b.wide_form and np.array_equal(b.counts(), wc)
+        # (Contained takes the mixed form since round 5; ContainsRegion and inverted passes stay with the sweep kernel)
+        assert b.wide_form == (mode == OverlapMode.Contained and not inv) and np.array_equal(b.counts(), wc)
+        assert np.array_equal(_pairs_of(regions, wc, b.offsets()[:-1], b.fids()), _want_pairs(regions, wt, wc))
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_ROOT_BITMAP, engine.STRATEGY_AUTO)
     b.wait()
     assert b.wide_form and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
@@ -229,9 +234,19 @@ def test_mixed_batches_take_the_mixed_form(frac, mixed, monkeypatch):
     b.wait()
     assert b.wide_form == mixed and np.array_equal(b.unique_roots(), np.unique(want_t[:, 0])) and b.total_hits == len(want_t)
     wt, wc = oix.query_features(regions, int(OverlapMode.Contained), False)
-    b.run(OverlapMode.Contained, False, engine.OUT_FIDS | engine.OUT_OFFSETS)
+    for flags in (engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_OFFSETS32):
+        b.run(OverlapMode.Contained, False, flags)
+        b.wait()
+        assert b.wide_form == mixed and np.array_equal(b.counts(), wc) and b.total_hits == len(wt)
+    assert np.array_equal(_rows(b.triples()), _rows(wt))
+    b.run(OverlapMode.Contained, False, engine.OUT_ROOT_BITMAP)
     b.wait()
-    assert not b.wide_form and np.array_equal(b.counts(), wc)
+    assert b.wide_form == mixed and np.array_equal(b.unique_roots(), np.unique(wt[:, 0])) and np.array_equal(b.counts(), wc)
+    for mode, inv in ((OverlapMode.ContainsRegion, False), (OverlapMode.Contained, True)):
+        wt, wc = oix.query_features(regions, int(mode), inv)
+        b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS)
+        b.wait()
+        assert not b.wide_form and np.array_equal(b.counts(), wc)
     # the same regions resident on the device: no sample, the first waited pass (narrow form) counts the rows its lines did not answer
     b.set_option("WIDTH_SAMPLE", 0)
     b.set_regions(regions)
