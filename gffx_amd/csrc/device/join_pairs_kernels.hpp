@@ -962,9 +962,6 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(6);
         finish(P - 1);
         GFFX_WIN_STAMP(7);
-        uint32_t cqs[4], cqe[4];  // (Contained, mixed form: the parking of long runs tests ends against THIS round's regions)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cqs[k] = CONT ? qs[k] : 0u, cqe[k] = CONT ? qe[k] : 0u;
         load_round(r + A.grid);
         const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         const uint32_t inc = win_wave_scan(mine);
@@ -1013,6 +1010,17 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) len[k] = CONT ? nra[k] : nr[k];
                     const uint32_t longest = max(max(len[0], len[1]), max(len[2], len[3]));
+                    uint32_t cqs[4] = {0, 0, 0, 0}, cqe[4] = {0, 0, 0, 0};
+                    if (CONT && __builtin_amdgcn_ballot_w64(longest > 4)) {
+                        // (Contained: a long run's ends are tested against THIS round's regions, whose registers the next round's have
+                        //  taken: read them again -- runs of more than four roots are the SV-sized rows' business)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (i0 + k < nq) {
+                                uint32_t c_;
+                                pair_load_region(q, i0 + k, c_, cqs[k], cqe[k]);
+                            }
+                    }
                     for (uint32_t t = 4; __builtin_amdgcn_ballot_w64(t < longest); t += 4) {
                         gffx_v4u v[4], ev[4];
 #pragma unroll
@@ -1123,9 +1131,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                     if (m[k] & 2u) put(wf[k].z);
                     if (m[k] & 1u) put(wf[k].w);
                     if constexpr (CONT) {
+                        uint32_t c_ = 0, s_ = 0, q_ = 0;
+                        if (nra[k] && i0 + k < nq) pair_load_region(q, i0 + k, c_, s_, q_);
                         for (uint32_t t = 0; t < nra[k]; ++t) {
                             const uint32_t e_ = A.pv.rends[r0[k] + t];
-                            if (e_ <= cqe[k] && e_ > cqs[k]) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
+                            if (e_ <= q_ && e_ > s_) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
                         }
                     } else {
                         for (uint32_t t = 0; t < nr[k]; ++t) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);

@@ -229,8 +229,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_pass(const uint32_t *in,
     auto top_digit = [&](uint32_t w0, uint32_t w1) { return (s_lut[min(w0, 255u)] + (w1 >> 24)) & 255u; };
     bool same;
     if (TOP == 2) {
-        if (top.flags()[1] == 0u) return;  // (only launched when the digit fits)
-        s_lut[threadIdx.x] = top.lut()[threadIdx.x];
+        s_lut[threadIdx.x] = top.lut()[threadIdx.x];  // (the host launches this pass only when the digit fits: its note says so)
         same = top.flags()[2] != 0u;
     } else {
         same = *same_byte != 0u;

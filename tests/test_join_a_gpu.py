@@ -450,8 +450,9 @@ def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert, st
 
 def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
     """AUTO: a batch of mostly wide regions -- found by a sample of the rows the host hands over, or by a first waited pass that
-    sent most regions to the exact sweep (tests/test_wide_form_gpu.py) -- runs on the wide form of the window kernel (overlap mode,
-    round 4) or on the sweep kernel (the other modes); a batch of narrow regions stays where it is."""
+    sent most regions to the exact sweep (tests/test_wide_form_gpu.py) -- runs on the mixed form of the window kernel (Overlap: round
+    4's wide form; Contained: round 5) or on the sweep kernel (ContainsRegion, inverted passes); a batch of narrow regions stays
+    where it is."""
     roots = synth.gencode_like_roots(150, seed=5, chroms=synth.SMALL2)
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
     ix = engine.TreeIndexData.from_roots(co, s, e, f)
@@ -475,7 +476,9 @@ def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
         assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)  # (host regions: a sample of the widths decides at once)
         assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)
         _, want_cc = oix.query_features(regions, 0, False)
-        assert one_pass(OverlapMode.Contained, want_cc) == (["k_join_fused" if is_wide else "k_join_pairs"], False)
+        assert one_pass(OverlapMode.Contained, want_cc) == (["k_join_pairs"], is_wide)
+        _, want_cr = oix.query_features(regions, 1, False)
+        assert one_pass(OverlapMode.ContainsRegion, want_cr) == (["k_join_fused" if is_wide else "k_join_pairs"], False)
         assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)
     b.close()
     ix.close()
