@@ -809,6 +809,17 @@ def main():
         result["wide_regions"]["root_pass"] = {"bitmap_pass_us": bmw.pass_us_one_event_pair, "kernels": kbw,
                                                "wide_form": bool(bmw.batches[0].wide_form)}
         bmw.close()
+        # ... and --contained over the same wide regions (round 5: a wide lane's run of roots filtered by their ends, no sweep kernel)
+        pwc = Pass(engine, ix, colsw, nq, 1, 0, out_flags & ~engine.OUT_SEGBASE | engine.OUT_OFFSETS, 0)
+        pairswc = pwc.size_and_warm(2)
+        kwc = pwc.kernel_us(10)
+        result["wide_regions_contained"] = roofline_obj(kwc, nq, pairswc, out_b, "the same regions, --contained, AUTO: the mixed form of k_join_pairs "
+                                                        "(round 4: the sweep kernel k_join_fused)", None, pwc.pass_us_one_event_pair, pwc.block_threads)
+        result["wide_regions_contained"]["mixed_form"] = bool(pwc.batches[0].wide_form)
+        pwc.batches[0].set_option("WIN_WIDE", 0)  # round 4's answer: the sweep kernel
+        pwc.kernel_us(10)
+        result["wide_regions_contained"]["sweep_kernel_pass_us"] = pwc.pass_us_one_event_pair
+        pwc.close()
         del colsw, regw
         # ---- a MIXED batch: the headline's regions with every tenth row replaced by an SV-sized one (width U[20 000, 2 000 000])
         # -- below the eighth at which AUTO used to leave the narrow form: the mixed form serves every region its own way
@@ -826,6 +837,16 @@ def main():
         pm.kernel_us(10)
         result["mixed_widths"]["narrow_form_pass_us"] = pm.pass_us_one_event_pair
         pm.close()
+        pmc = Pass(engine, ix, colsm, nq, 1, 0, out_flags, 0)  # --contained over the mixed batch
+        pairsmc = pmc.size_and_warm(2)
+        kmc = pmc.kernel_us(10)
+        result["mixed_widths"]["contained"] = roofline_obj(kmc, nq, pairsmc, out_b, "the mixed batch, --contained, AUTO", None, pmc.pass_us_one_event_pair,
+                                                           pmc.block_threads)
+        result["mixed_widths"]["contained"]["mixed_form"] = bool(pmc.batches[0].wide_form)
+        pmc.batches[0].set_option("WIN_WIDE", 0)
+        pmc.kernel_us(10)
+        result["mixed_widths"]["contained"]["narrow_form_pass_us"] = pmc.pass_us_one_event_pair
+        pmc.close()
         bmm = Pass(engine, ix, colsm, nq, 1, mode, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, 0)
         bmm.size_and_warm(2)
         kbm = bmm.kernel_us(10)
