@@ -119,7 +119,10 @@ constexpr uint32_t kWinMaxShift = 15;            // widest window: W + wmax + 1 
 constexpr uint32_t kWinTailMark = 0xFFFFFFFFu;   // word 3 of a line whose list continues in win_spill
 constexpr uint32_t kWinAbsent = 0x0000FFFFu;     // coordinate word of an absent entry
 constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (n = 255)
-constexpr uint32_t kWinSplit = 3;                // a split window has 2^kWinSplit sub-windows (round 4)
+#ifndef GFFX_WIN_SPLIT_LOG2
+#define GFFX_WIN_SPLIT_LOG2 3
+#endif
+constexpr uint32_t kWinSplit = GFFX_WIN_SPLIT_LOG2;  // a split window has 2^kWinSplit sub-windows (round 4; 4 and 5 measured in round 5: tools/kbench.hip -DGFFX_WIN_SPLIT_LOG2=)
 constexpr uint32_t kWaveGroup = 256;             // regions per GFFX_OUT_SEGBASE entry: 64 lanes x 4 regions, one wave's share of a round
 constexpr uint32_t kPairSumsStride = 8192;       // (= gffx_hip_batch::kMaxBlocks) k_join_roots: from a block's pair count of the pass to its accumulated one
 constexpr uint32_t kPosBits = 27;
