@@ -1003,17 +1003,27 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                 }
                 GFFX_WIN_STAMP(10);
                 if constexpr (WIDE) {
-                    // runs longer than four roots: four more words of every region's run per trip, the four regions in step,
-                    // until no lane of the wave has a word left (the cursors pd[] move on: a list tail's words follow the run)
-                    // (Contained: the run's length is nra[], its kept roots are picked by their ends again)
+                    // Runs longer than four roots (SV-sized rows keep 20 - 40): every lane walks ITS OWN long runs one after the other,
+                    // four words a trip -- ONE gather instruction per trip serves every lane's current run (with the four regions in
+                    // step it was four instructions a trip, most of their lanes idle: a gather occupies the memory path for 20 - 30
+                    // cycles however few of its lanes read; round 5).  A list tail's words follow the run: the cursors pd[] jump there.
+                    // (Contained: the run's length is nra[], its kept roots are picked by their ends again.)
                     uint32_t len[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) len[k] = CONT ? nra[k] : nr[k];
-                    const uint32_t longest = max(max(len[0], len[1]), max(len[2], len[3]));
+                    auto next_long = [&](int after) {  // (per lane) the thread's next region with a long run, or 4
+                        int r = 4;
+                        r = (len[3] > 4u && 3 > after) ? 3 : r;
+                        r = (len[2] > 4u && 2 > after) ? 2 : r;
+                        r = (len[1] > 4u && 1 > after) ? 1 : r;
+                        r = (len[0] > 4u && 0 > after) ? 0 : r;
+                        return r;
+                    };
+                    int ck = next_long(-1);
                     uint32_t cqs[4] = {0, 0, 0, 0}, cqe[4] = {0, 0, 0, 0};
-                    if (CONT && __builtin_amdgcn_ballot_w64(longest > 4)) {
+                    if (CONT && __builtin_amdgcn_ballot_w64(ck < 4)) {
                         // (Contained: a long run's ends are tested against THIS round's regions, whose registers the next round's have
-                        //  taken: read them again -- runs of more than four roots are the SV-sized rows' business)
+                        //  taken: read them again)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (i0 + k < nq) {
@@ -1021,23 +1031,39 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                                 pair_load_region(q, i0 + k, c_, cqs[k], cqe[k]);
                             }
                     }
-                    for (uint32_t t = 4; __builtin_amdgcn_ballot_w64(t < longest); t += 4) {
-                        gffx_v4u v[4], ev[4];
+                    uint32_t t = 4u, pc = win_sel(pd, ck & 3);
+                    constexpr int kTrip = CONT ? 1 : 4;  // 16-byte loads per trip and lane: what a trip costs is its round trip, not its width
+                    while (__builtin_amdgcn_ballot_w64(ck < 4)) {
+                        const bool act = ck < 4;
+                        const uint32_t r0s = win_sel(r0, ck & 3), ls = win_sel(len, ck & 3);
+                        gffx_v4u v[kTrip], ev;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int u = 0; u < kTrip; ++u) {
+                            const uint32_t tu = t + 4u * u;
+                            const uint32_t at = (act && tu < ls) ? 4u * (r0s + tu) : kWinNoLine;
                             if (POS)
-                                v[k].x = r0[k] + t, v[k].y = r0[k] + t + 1u, v[k].z = r0[k] + t + 2u, v[k].w = r0[k] + t + 3u;
+                                v[u].x = r0s + tu, v[u].y = r0s + tu + 1u, v[u].z = r0s + tu + 2u, v[u].w = r0s + tu + 3u;
                             else
-                                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, t < len[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
-                            if (CONT) ev[k] = __builtin_amdgcn_raw_buffer_load_b128(rde, t < len[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
+                                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rfd, at, 0, 0);
+                            if (CONT) ev = __builtin_amdgcn_raw_buffer_load_b128(rde, at, 0, 0);
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const uint32_t n4 = t < len[k] ? min(len[k] - t, 4u) : 0u;
-                            const uint32_t bits = CONT ? run_mask(ev[k], n4, cqs[k], cqe[k]) << 28 : (n4 ? 0xFFFFFFFFu << (32u - n4) : 0u);
-                            pair_park4(bits, pd[k], v[k].x, v[k].y, v[k].z, v[k].w);
+                        for (int u = 0; u < kTrip; ++u) {
+                            const uint32_t tu = t + 4u * u;
+                            const uint32_t n4 = (act && tu < ls) ? min(ls - tu, 4u) : 0u;
+                            const uint32_t bits = CONT ? run_mask(ev, n4, win_sel(cqs, ck & 3), win_sel(cqe, ck & 3)) << 28 : (n4 ? 0xFFFFFFFFu << (32u - n4) : 0u);
+                            pair_park4(bits, pc, v[u].x, v[u].y, v[u].z, v[u].w);
+                        }
+                        t += 4u * kTrip;
+                        if (act && t >= ls) {  // this run is done: the lane's next long run, if it has one
+                            ck = next_long(ck);
+                            t = 4u;
+                            pc = win_sel(pd, ck & 3);
                         }
                     }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)  // (where the run's words end: a list tail's / a sweep's words follow)
+                        pd[k] += 4u * (CONT ? nr[k] - (uint32_t)__popc(em0[k]) : (nr[k] > 4u ? nr[k] - 4u : 0u));
                 }
                 GFFX_WIN_STAMP(11);
                 if (__builtin_amdgcn_ballot_w64(deferred != 0)) {

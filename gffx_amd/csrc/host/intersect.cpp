@@ -793,26 +793,6 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
         (void)gffx_hip_warmup(dev[0]);
         sub.lap("  HIP runtime + context + code objects");
     }
-    const uint32_t n_seq = static_cast<uint32_t>(index_data.num_to_seqid.size());
-    const size_t chunk_rows = std::min(kChunkBytes, std::max<size_t>(text.size(), 1)) / kMinRowBytes + 16;
-    const size_t cap_rows = text.size() / kMinRowBytes + 16;
-    std::vector<Store> store(D);
-    // The region stores need a device, not the index: their pinned staging buffers (two per device, tens of MB: ~30 ms of page
-    // pinning) come up on a thread of their own while this one builds and uploads the index.
-    std::string store_err;
-    std::thread store_thread([&] {
-        for (size_t d = 0; d < D && store_err.empty(); ++d) {
-            const bool full = d == 0 && keep_store;
-            if (gffx_hip_regions_create(dev[d], full ? cap_rows : 0, chunk_rows, full ? 1 : 0, &store[d].h) != GFFX_OK)
-                store_err = std::string("gffx_hip_regions_create: ") + gffx_hip_last_error();  // (the message is this thread's)
-        }
-    });
-    struct JoinStores {  // (joined whatever throws below)
-        std::thread &t;
-        ~JoinStores() {
-            if (t.joinable()) t.join();
-        }
-    } join_stores{store_thread};
     index_data.ensure_device(dev[0]);
     std::vector<IndexClone> clones(D);
     std::vector<gffx_hip_index *> ix(D, index_data.device_index);
@@ -822,12 +802,17 @@ StreamResult stream_unique_roots(TreeIndexData &index_data, const std::string &b
         ix[d] = clones[d].h;
     }
     sub.lap("  index upload");
-    store_thread.join();
-    if (!store_err.empty()) throw Error(store_err);
+    const uint32_t n_seq = static_cast<uint32_t>(index_data.num_to_seqid.size());
+    const size_t chunk_rows = std::min(kChunkBytes, std::max<size_t>(text.size(), 1)) / kMinRowBytes + 16;
+    const size_t cap_rows = text.size() / kMinRowBytes + 16;
+    std::vector<Store> store(D);
     std::vector<Batch> batch(2 * D);
-    for (size_t d = 0; d < D; ++d)
+    for (size_t d = 0; d < D; ++d) {
+        const bool full = d == 0 && keep_store;
+        if (gffx_hip_regions_create(dev[d], full ? cap_rows : 0, chunk_rows, full ? 1 : 0, &store[d].h) != GFFX_OK) hip_fail("gffx_hip_regions_create");
         for (int k = 0; k < 2; ++k)
             if (gffx_hip_batch_create(ix[d], chunk_rows, &batch[2 * d + k].h) != GFFX_OK) hip_fail("batch_create");
+    }
     sub.lap("  region stores + batches");
     {  // the tuning knobs this run did not leave at their defaults (--stats-json "knobs")
         char ik[512] = "{}", bk[512] = "{}";
