@@ -200,9 +200,37 @@ __device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_
             : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [qs] "v"(rqs), [qe] "v"(rqe1)
             : "vcc");
     } else {
+        // Contained / ContainsRegion (round 5: SDWA as well -- the generic predicate on unpacked fields was ~10 VALU per entry and the
+        // registers to match): per entry four compares on the packed coordinates into lane masks -- overlap (start <= qe - 1, end > qs)
+        // and the mode's clause (Contained: start >= qs, end <= qe; ContainsRegion: start <= qs, end >= qe) --, the clause flipped by
+        // the invert mask, one v_addc: 5 VALU + 5 SALU.  kept = overlap && (clause != invert): intersect.rs:145-161.
         const uint32_t rqe = rqe1 + 1u;
-        m = (pair_keep<MODE>(w0 & 0xFFFFu, w0 >> 16, rqs, rqe, inv) ? 8u : 0u) | (pair_keep<MODE>(w1 & 0xFFFFu, w1 >> 16, rqs, rqe, inv) ? 4u : 0u) |
-            (pair_keep<MODE>(w2 & 0xFFFFu, w2 >> 16, rqs, rqe, inv) ? 2u : 0u) | (pair_keep<MODE>(w3 & 0xFFFFu, w3 >> 16, rqs, rqe, inv) ? 1u : 0u);
+        const uint32_t invm = (uint32_t)__builtin_amdgcn_readfirstlane(inv ? -1 : 0);  // (uniform: a pass is inverted or it is not)
+        unsigned long long t, o;
+#define GFFX_MODE_TEST1(C1, C2, W, ADDC)                                               \
+    "v_cmp_le_u32_sdwa %[t], " W ", %[qe1] src0_sel:WORD_0 src1_sel:DWORD\n\t"         \
+    "v_cmp_gt_u32_sdwa vcc, " W ", %[qs] src0_sel:WORD_1 src1_sel:DWORD\n\t"           \
+    "s_and_b64 %[o], vcc, %[t]\n\t"                                                    \
+    C1 " %[t], " W ", %[qs] src0_sel:WORD_0 src1_sel:DWORD\n\t"                        \
+    C2 " vcc, " W ", %[qe] src0_sel:WORD_1 src1_sel:DWORD\n\t"                         \
+    "s_and_b64 vcc, vcc, %[t]\n\t"                                                     \
+    "s_xor_b32 vcc_lo, vcc_lo, %[inv]\n\t"                                             \
+    "s_xor_b32 vcc_hi, vcc_hi, %[inv]\n\t"                                             \
+    "s_and_b64 vcc, vcc, %[o]\n\t" ADDC
+#define GFFX_MODE_TEST4(C1, C2)                                                                                                     \
+    asm(GFFX_MODE_TEST1(C1, C2, "%[w0]", "v_addc_co_u32 %[m], vcc, 0, 0, vcc\n\t")                                                  \
+            GFFX_MODE_TEST1(C1, C2, "%[w1]", "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t")                                        \
+                GFFX_MODE_TEST1(C1, C2, "%[w2]", "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t")                                    \
+                    GFFX_MODE_TEST1(C1, C2, "%[w3]", "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc")                                     \
+        : [m] "=&v"(m), [t] "=&s"(t), [o] "=&s"(o)                                                                                  \
+        : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [qs] "v"(rqs), [qe1] "v"(rqe1), [qe] "v"(rqe), [inv] "s"(invm)   \
+        : "vcc")
+        if (MODE == GFFX_MODE_CONTAINED)
+            GFFX_MODE_TEST4("v_cmp_ge_u32_sdwa", "v_cmp_le_u32_sdwa");
+        else
+            GFFX_MODE_TEST4("v_cmp_le_u32_sdwa", "v_cmp_ge_u32_sdwa");
+#undef GFFX_MODE_TEST4
+#undef GFFX_MODE_TEST1
     }
     return m;
 }
