@@ -176,7 +176,10 @@ __device__ __forceinline__ void pair_load_region(const QueryView &q, unsigned lo
 // unit) and one v_addc that shifts the outcome into the bit string (m = 2 m + kept): 3 VALU + 1 SALU.  One asm block per
 // line (the compiler fences every asm block with hazard nops).
 template <int MODE>
-__device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rqs, uint32_t rqe1, bool inv) {
+// has_line (the other two modes): the lane read a line -- a lane that did not (its words are zeros) carries an rqs that may have
+// wrapped, against which the packed range checks below prove nothing: its bit string is forced to 0.
+__device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rqs, uint32_t rqe1, bool inv,
+                                               bool has_line = true) {
     uint32_t m;
     if (MODE == GFFX_MODE_OVERLAP) {
         unsigned long long t;
@@ -200,37 +203,42 @@ __device__ __forceinline__ uint32_t pair_test4(uint32_t w0, uint32_t w1, uint32_
             : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [qs] "v"(rqs), [qe] "v"(rqe1)
             : "vcc");
     } else {
-        // Contained / ContainsRegion (round 5: SDWA as well -- the generic predicate on unpacked fields was ~10 VALU per entry and the
-        // registers to match): per entry four compares on the packed coordinates into lane masks -- overlap (start <= qe - 1, end > qs)
-        // and the mode's clause (Contained: start >= qs, end <= qe; ContainsRegion: start <= qs, end >= qe) --, the clause flipped by
-        // the invert mask, one v_addc: 5 VALU + 5 SALU.  kept = overlap && (clause != invert): intersect.rs:145-161.
+        // Contained / ContainsRegion (round 5): both are RANGE checks of the two packed 16-bit coordinates with per-half bounds, and an
+        // unsigned range check is one subtraction and one comparison:  lo <= x <= lo + d  <=>  (x - lo) mod 2^16 <= d.
+        //   Contained:       start in [qs, qe - 1], end in [qs + 1, qe]   (this is start >= qs && end <= qe && start < qe && end > qs;
+        //                    both spans are qe - 1 - qs)
+        //   ContainsRegion:  start in [0, qs], end in [qe, 65535]         (a line is only read for qs < qe, where the clause implies the overlap)
+        // Per entry: v_pk_sub_u16 (both halves at once), v_pk_min_u16 against the spans, v_cmp_eq (min(x, d) == x in both halves), and
+        // the v_addc that shifts the outcome into the bit string: 4 VALU, no scalar instruction (the generic predicate on unpacked
+        // fields was ~10 VALU per entry, an SDWA version with four compares 5 VALU + 5 SALU and slower than the generic one at 10 M
+        // regions: the scalar unit is shared by the CU's four SIMDs).  An absent entry (start 0xFFFF) and a line that was not read
+        // (zeros) fail the start's / the end's check.  Inverted passes (intersect.rs:161: overlap && !clause) take the overlap test
+        // as well: kept = overlap bits & ~clause bits.
         const uint32_t rqe = rqe1 + 1u;
-        const uint32_t invm = (uint32_t)__builtin_amdgcn_readfirstlane(inv ? -1 : 0);  // (uniform: a pass is inverted or it is not)
-        unsigned long long t, o;
-#define GFFX_MODE_TEST1(C1, C2, W, ADDC)                                               \
-    "v_cmp_le_u32_sdwa %[t], " W ", %[qe1] src0_sel:WORD_0 src1_sel:DWORD\n\t"         \
-    "v_cmp_gt_u32_sdwa vcc, " W ", %[qs] src0_sel:WORD_1 src1_sel:DWORD\n\t"           \
-    "s_and_b64 %[o], vcc, %[t]\n\t"                                                    \
-    C1 " %[t], " W ", %[qs] src0_sel:WORD_0 src1_sel:DWORD\n\t"                        \
-    C2 " vcc, " W ", %[qe] src0_sel:WORD_1 src1_sel:DWORD\n\t"                         \
-    "s_and_b64 vcc, vcc, %[t]\n\t"                                                     \
-    "s_xor_b32 vcc_lo, vcc_lo, %[inv]\n\t"                                             \
-    "s_xor_b32 vcc_hi, vcc_hi, %[inv]\n\t"                                             \
-    "s_and_b64 vcc, vcc, %[o]\n\t" ADDC
-#define GFFX_MODE_TEST4(C1, C2)                                                                                                     \
-    asm(GFFX_MODE_TEST1(C1, C2, "%[w0]", "v_addc_co_u32 %[m], vcc, 0, 0, vcc\n\t")                                                  \
-            GFFX_MODE_TEST1(C1, C2, "%[w1]", "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t")                                        \
-                GFFX_MODE_TEST1(C1, C2, "%[w2]", "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t")                                    \
-                    GFFX_MODE_TEST1(C1, C2, "%[w3]", "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc")                                     \
-        : [m] "=&v"(m), [t] "=&s"(t), [o] "=&s"(o)                                                                                  \
-        : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [qs] "v"(rqs), [qe1] "v"(rqe1), [qe] "v"(rqe), [inv] "s"(invm)   \
-        : "vcc")
-        if (MODE == GFFX_MODE_CONTAINED)
-            GFFX_MODE_TEST4("v_cmp_ge_u32_sdwa", "v_cmp_le_u32_sdwa");
-        else
-            GFFX_MODE_TEST4("v_cmp_le_u32_sdwa", "v_cmp_ge_u32_sdwa");
-#undef GFFX_MODE_TEST4
-#undef GFFX_MODE_TEST1
+        const uint32_t K = MODE == GFFX_MODE_CONTAINED ? (rqs | (rqs + 1u) << 16) : rqe << 16;
+        const uint32_t D = MODE == GFFX_MODE_CONTAINED ? (rqe1 - rqs) * 0x10001u : (rqs | (65535u - rqe) << 16);
+        uint32_t x, y;
+        asm("v_pk_sub_u16 %[x], %[w0], %[K]\n\t"
+            "v_pk_min_u16 %[y], %[x], %[D]\n\t"
+            "v_cmp_eq_u32 vcc, %[x], %[y]\n\t"
+            "v_addc_co_u32 %[m], vcc, 0, 0, vcc\n\t"
+            "v_pk_sub_u16 %[x], %[w1], %[K]\n\t"
+            "v_pk_min_u16 %[y], %[x], %[D]\n\t"
+            "v_cmp_eq_u32 vcc, %[x], %[y]\n\t"
+            "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t"
+            "v_pk_sub_u16 %[x], %[w2], %[K]\n\t"
+            "v_pk_min_u16 %[y], %[x], %[D]\n\t"
+            "v_cmp_eq_u32 vcc, %[x], %[y]\n\t"
+            "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t"
+            "v_pk_sub_u16 %[x], %[w3], %[K]\n\t"
+            "v_pk_min_u16 %[y], %[x], %[D]\n\t"
+            "v_cmp_eq_u32 vcc, %[x], %[y]\n\t"
+            "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc"
+            : [m] "=&v"(m), [x] "=&v"(x), [y] "=&v"(y)
+            : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [w3] "v"(w3), [K] "v"(K), [D] "v"(D)
+            : "vcc");
+        if (inv) m = pair_test4<GFFX_MODE_OVERLAP>(w0, w1, w2, w3, rqs, rqe1, false) & ~m;  // (uniform: a pass is inverted or it is not)
+        m = has_line ? m : 0u;
     }
     return m;
 }
@@ -835,7 +843,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false);
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false, off[k] != kWinNoLine);
                 if (CONT) m[k] = isw[k] ? 0u : m[k];  // (Contained: a wide lane keeps nothing of the roots that start before its region)
                 ra[k] = wf[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);  // (a narrow lane's: unused)
                 rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rel1[k]);
@@ -919,7 +927,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
+            for (int k = 0; k < 4; ++k) m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv, off[k] != kWinNoLine);
         }
         GFFX_WIN_STAMP(3);
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept words wait in
@@ -1352,7 +1360,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             uint32_t iswm = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false);
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false, off[k] != kWinNoLine);
                 if (CONT) m[k] = isw[k] ? 0u : m[k];  // (Contained: a wide lane keeps nothing of the roots that start before its region)
                 ra[k] = wf[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);  // (a narrow lane's: unused)
                 rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rel1[k]);
@@ -1431,7 +1439,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv);
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv, off[k] != kWinNoLine);
                 kept += __popc(m[k]);
             }
             {  // the rare rest: list tails and sweeps set their bits themselves

@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
     const int presort = argc > 5 ? atoi(argv[5]) : 0;  // 1: queries sorted by (chr, end) on the host (experiment)
     const uint32_t max_width = argc > 6 ? (uint32_t)atoi(argv[6]) : 10000;  // regions of width U[100, max_width)
     const uint32_t wide_every = argc > 7 ? (uint32_t)atoi(argv[7]) : 0;     // every wide_every-th region: width U[20000, 2000000) instead (0: none)
+    const int kb_mode = getenv("KB_MODE") ? atoi(getenv("KB_MODE")) : GFFX_MODE_OVERLAP;  // 0 contained, 1 contains-region, 2 overlap
     const int n_chr = sizeof(kChroms) / sizeof(kChroms[0]);
     std::mt19937_64 rng(42);
     double total_len = 0;
@@ -117,19 +118,19 @@ int main(int argc, char **argv) {
         fprintf(stderr, "batch: %s\n", gffx_hip_last_error());
         return 1;
     }
-    if (gffx_hip_batch_run(b, GFFX_MODE_OVERLAP, 0, flags, strategy) || gffx_hip_batch_wait(b)) {
+    if (gffx_hip_batch_run(b, kb_mode, 0, flags, strategy) || gffx_hip_batch_wait(b)) {
         fprintf(stderr, "run: %s\n", gffx_hip_last_error());
         return 1;
     }
     printf("nq=%llu roots=%u tiles=%u cells=%u pairs=%llu strategy=%d flags=%u\n", (unsigned long long)nq, ix->n_roots,
            ix->n_tiles, ix->n_cells, (unsigned long long)gffx_hip_batch_total_hits(b), b->strategy, flags);
-    for (int i = 0; i < 5; i++) gffx_hip_batch_run(b, GFFX_MODE_OVERLAP, 0, flags, strategy);
+    for (int i = 0; i < 5; i++) gffx_hip_batch_run(b, kb_mode, 0, flags, strategy);
     gffx_hip_batch_sync(b);
     hipEvent_t ea, eb;
     hipEventCreate(&ea);
     hipEventCreate(&eb);
     hipEventRecord(ea, b->stream);
-    for (int i = 0; i < iters; i++) gffx_hip_batch_run(b, GFFX_MODE_OVERLAP, 0, flags, strategy);
+    for (int i = 0; i < iters; i++) gffx_hip_batch_run(b, kb_mode, 0, flags, strategy);
     hipEventRecord(eb, b->stream);
     gffx_hip_batch_sync(b);
     float ms = 0;
@@ -137,7 +138,7 @@ int main(int argc, char **argv) {
     printf("pass: %.2f us (back-to-back, %d iters)\n", 1e3 * ms / iters, iters);
     gffx_hip_batch_set_profiling(b, 1);
     for (int i = 0; i < 20; i++) {
-        gffx_hip_batch_run(b, GFFX_MODE_OVERLAP, 0, flags, strategy);
+        gffx_hip_batch_run(b, kb_mode, 0, flags, strategy);
         gffx_hip_batch_sync(b);
     }
     gffx_hip_batch_set_profiling(b, 0);
@@ -154,7 +155,7 @@ int main(int argc, char **argv) {
         std::vector<unsigned long long> z(8192 * 16, 0);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z.data(), z.size() * 8);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sel), &which, sizeof(int));
-        gffx_hip_batch_run(b, GFFX_MODE_OVERLAP, 0, flags, strategy);
+        gffx_hip_batch_run(b, kb_mode, 0, flags, strategy);
         gffx_hip_batch_sync(b);
         hipMemcpyFromSymbol(z.data(), HIP_SYMBOL(g_stamps), z.size() * 8);
         unsigned long long t0 = ~0ull, t1 = 0;
@@ -193,7 +194,7 @@ int main(int argc, char **argv) {
     {
         std::vector<unsigned long long> z(8192 * 4, 0);
         hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z.data(), z.size() * 8);
-        gffx_hip_batch_run(b, GFFX_MODE_OVERLAP, 0, flags, strategy);
+        gffx_hip_batch_run(b, kb_mode, 0, flags, strategy);
         gffx_hip_batch_sync(b);
         hipMemcpyFromSymbol(z.data(), HIP_SYMBOL(g_clk), z.size() * 8);
         double sc = 0, sw = 0;
