@@ -847,6 +847,16 @@ def main():
         pmc.kernel_us(10)
         result["mixed_widths"]["contained"]["narrow_form_pass_us"] = pmc.pass_us_one_event_pair
         pmc.close()
+        pmr = Pass(engine, ix, colsm, nq, 1, 1, out_flags, 0)  # --contains-region over the mixed batch (a wide row: the roots over its first base that reach its end)
+        pairsmr = pmr.size_and_warm(2)
+        kmr = pmr.kernel_us(10)
+        result["mixed_widths"]["contains_region"] = roofline_obj(kmr, nq, pairsmr, out_b, "the mixed batch, --contains-region, AUTO", None,
+                                                                 pmr.pass_us_one_event_pair, pmr.block_threads)
+        result["mixed_widths"]["contains_region"]["mixed_form"] = bool(pmr.batches[0].wide_form)
+        pmr.batches[0].set_option("WIN_WIDE", 0)
+        pmr.kernel_us(10)
+        result["mixed_widths"]["contains_region"]["narrow_form_pass_us"] = pmr.pass_us_one_event_pair
+        pmr.close()
         bmm = Pass(engine, ix, colsm, nq, 1, mode, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, 0)
         bmm.size_and_warm(2)
         kbm = bmm.kernel_us(10)

@@ -461,13 +461,13 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
                        !(out_flags & (GFFX_OUT_FIDS | GFFX_OUT_TRIPLES | GFFX_OUT_OFFSETS | GFFX_OUT_OFFSETS32 | GFFX_OUT_SEGBASE));
     b->flags = waive ? out_flags : ((out_flags & ~(uint32_t)GFFX_OUT_NO_COUNTS) | GFFX_OUT_COUNTS);
     b->strategy = pick_strategy(b, strategy);
-    // Wide batches (AUTO: a sample of the host's rows, or a pass that sent most regions to the sweep): overlap-mode passes take
-    // the wide form of the window kernels; the other modes stay with the sweep kernel.  GFFX_HIP_WIN_WIDE: 0 = never, 2 = every
-    // eligible pass of the windows strategy (tests).
+    // Wide batches (AUTO: a sample of the host's rows, or a pass that sent most regions to the sweep): the passes take the mixed form
+    // of the window kernels.  GFFX_HIP_WIN_WIDE: 0 = never, 2 = every eligible pass of the windows strategy (tests).
     {
         const long ww = b->knobs.v[BK_WIN_WIDE];
-        // (Overlap and -- round 5 -- Contained, not inverted: a wide lane's Contained answer is its run of roots filtered by their ends)
-        const bool eligible = (mode == GFFX_MODE_OVERLAP || mode == GFFX_MODE_CONTAINED) && !invert && b->ix->win_range_ok;
+        // (every mode, inverted or not -- round 5; pair_locate_mixed has the table of what a wide lane keeps.  Overlap + invert keeps
+        //  nothing and never gets here.)
+        const bool eligible = !(mode == GFFX_MODE_OVERLAP && invert) && b->ix->win_range_ok;
         // (AUTO: some wide rows -- more than 1/128 -- and no other reason for most regions to sweep: the mixed form, which serves every
         //  region its own way; mostly wide: the same kernel, every lane the wide way)
         b->wide = eligible && ((ww == 1 && strategy == GFFX_STRATEGY_AUTO && (b->mostly_wide || (b->some_wide && !b->mostly_slow))) ||

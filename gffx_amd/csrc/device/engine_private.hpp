@@ -258,7 +258,7 @@ struct gffx_hip_batch {
     int fused_word = 2;             // ... and the one the last fused pass used
     uint64_t slow_seen_win = 0;     // windows strategy: the device's exact-sweep counter at the last wait
     uint64_t win_passes = 0;        // ... and the windows passes enqueued since
-    bool wide = false;              // this run's passes take the wide form of the window kernels (AUTO, mostly_slow, overlap mode)
+    bool wide = false;              // this run's passes take the wide form of the window kernels (AUTO: a batch with wide regions)
     bool mostly_slow = false;       // more than 1/8 of the regions are wide (a sample of the host's rows) or took the sweep in the last waited narrow pass
     bool mostly_wide = false;       // ... because of their width (the wide form answers those; dense windows and seqids without windows it does not)
     bool some_wide = false;         // more than 1/128 of the regions are wider than their seqid's lines answer: AUTO's overlap-mode passes take the MIXED form

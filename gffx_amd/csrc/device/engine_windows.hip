@@ -50,8 +50,7 @@ template <int MODE, bool ML>
 static int launch_pairs(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, bool pos, bool wide, uint32_t lds) {
 #define GFFX_P(T, O, P)                                                                                          \
     if (threads == T && offs == O && pos == P) {                                                                 \
-        if constexpr (MODE == GFFX_MODE_OVERLAP || MODE == GFFX_MODE_CONTAINED)                                  \
-            if (wide) return launch_pairs4<MODE, ML, T, O, P, true>(b, grid, a, lds);                            \
+        if (wide) return launch_pairs4<MODE, ML, T, O, P, true>(b, grid, a, lds);                                \
         return launch_pairs4<MODE, ML, T, O, P, false>(b, grid, a, lds);                                         \
     }
     GFFX_P(1024, false, false) GFFX_P(1024, true, false) GFFX_P(1024, false, true) GFFX_P(1024, true, true)
@@ -69,8 +68,7 @@ static int launch_roots3(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, ui
 }
 template <int MODE, bool ML>
 static int launch_roots(gffx_hip_batch *b, uint32_t grid, const PairArgs &a, uint32_t threads, bool wide, uint32_t lds) {
-    if constexpr (MODE == GFFX_MODE_OVERLAP || MODE == GFFX_MODE_CONTAINED)
-        if (wide) return threads == 1024 ? launch_roots3<MODE, ML, 1024, true>(b, grid, a, lds) : launch_roots3<MODE, ML, 512, true>(b, grid, a, lds);
+    if (wide) return threads == 1024 ? launch_roots3<MODE, ML, 1024, true>(b, grid, a, lds) : launch_roots3<MODE, ML, 512, true>(b, grid, a, lds);
     return threads == 1024 ? launch_roots3<MODE, ML, 1024, false>(b, grid, a, lds) : launch_roots3<MODE, ML, 512, false>(b, grid, a, lds);
 }
 

@@ -93,7 +93,7 @@ struct IndexView {
     // a region reads EXACTLY ONE line -- its window's, or the sub-line of the sub-window its last base lies in.
     const uint32_t *win_splittab;
     uint32_t win_swords;  // bitmap words (= ceil(n_win / 32)); 0 = no split level (the lists then continue in win_spill)
-    // RANKS (round 4, the WIDE form of k_join_pairs: regions of any width, overlap mode).  The roots a region [qs, qe) overlaps are
+    // RANKS (round 4, the WIDE form of k_join_pairs: regions of any width; Overlap here, the other modes: pair_locate_mixed).  The roots a region [qs, qe) overlaps are
     // the roots over its first base (what the line of qs answers for the one-base region [qs, qs + 1)) and the roots that start
     // inside it: positions rank(qs + 1) .. rank(qe) - 1 of the sorted arrays, rank(x) = the roots of the seqid and of the seqids
     // before it that start below x.  A line lists every root that starts in its (sub-)window, so

@@ -23,11 +23,12 @@
 // What the line cannot answer -- the tail of a (sub-)list still longer than 4, dense windows, regions wider than wmax,
 // qs >= qe rows (the reference keeps them), seqids without windows -- is DEFERRED: list tails are walked in line (a few
 // 16-byte records), exact sweeps (join_a_kernels.hpp) through a function call.
-// The WIDE form of both kernels (template argument WIDE; overlap mode; pair_locate_mixed below) answers regions of
+// The WIDE form of both kernels (template argument WIDE; pair_locate_mixed below) answers regions of
 // ANY width from the same index: the roots over the region's first base -- the line of qs, asked about [qs, qs + 1) -- plus the
 // roots that start inside it, a run of positions between two ranks, each rank = a stored word of a line + the line's entries
 // that start at or below the base (win_wide: the line's coordinates and its rank record side by side).  AUTO takes it for
-// batches of mostly wide regions, which otherwise went to the sweep kernel.
+// batches with wide regions, which otherwise went to the sweep kernel.  That is Overlap; the other modes and the inverted passes keep
+// a subset of the same two sets, picked by the roots' ends (the table at pair_locate_mixed).
 //
 // What bounds a pass, measured in round 4: the CU's vector memory path -- one line request per ~2.9 cycles and CU
 // for the gathers, ~10 B per cycle and CU for the region and result streams, and they add up -- and, next to it, instruction
@@ -470,11 +471,14 @@ __device__ __forceinline__ void pair_locate(const PairLds &L, uint32_t qc, uint3
 // else 0).  First line: an entry that starts at or below qs counts in le0, and is kept -- written to out[], at most `cap`
 // words -- if it ends beyond qs; second line: an entry that starts at or below qe1 = qe - 1 counts in le1.  Two records of
 // each list in flight.  Returns the kept entries.  `bits` (root passes): a kept entry sets the bit of its position there instead.
-// CONT (Contained over a wide region: the kept roots are a subset of the RUN [rank(qs), rank(qe)) -- start >= qs -- and nothing of the
-// first line's list): the first line's entries only count, those that start BELOW qs.
-template <bool POS, bool CONT = false>
+// What a wide region keeps of the FIRST line's list depends on the mode (pair_locate_mixed has the table): Overlap the entries over
+// qs; Contained none -- its first rank counts the entries that start BELOW qs --, inverted those that start below qs and reach over it;
+// ContainsRegion the entries that start at or below qs and end at or beyond qe, inverted those over qs that end before qe.  The tail's
+// records carry true coordinates: nothing to resolve here.
+template <bool POS, int MODE = GFFX_MODE_OVERLAP>
 __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t h0, uint32_t h1, uint32_t qs, uint32_t qe1, uint32_t *out,
-                                                    uint32_t cap, uint32_t &le0, uint32_t &le1, uint32_t *bits = nullptr) {
+                                                    uint32_t cap, uint32_t &le0, uint32_t &le1, uint32_t *bits = nullptr, bool inv = false) {
+    constexpr bool CONT = MODE == GFFX_MODE_CONTAINED, CREG = MODE == GFFX_MODE_CONTAINS_REGION;
     uint32_t c = 0;
     const uint32_t n0 = h0 ? (h0 & 255u) - kWinInlineTail : 0u, n1 = h1 ? (h1 & 255u) - kWinInlineTail : 0u;
     const uint4 *s0 = spill + (h0 >> 8), *s1 = spill + (h1 >> 8);
@@ -490,7 +494,9 @@ __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t
         for (uint32_t t = 0; t < 2; ++t) {
             if (CONT ? x[t].x < qs : x[t].x <= qs) {
                 ++le0;
-                if (!CONT && x[t].y > qs) {
+                const bool over = x[t].y > qs;
+                const bool keep = CONT ? inv && over : CREG ? over && ((x[t].y > qe1) != inv) : over;
+                if (keep) {
                     if (bits)
                         atomicOr(&bits[x[t].w >> 5], 1u << (x[t].w & 31));
                     else if (c < cap)
@@ -504,7 +510,20 @@ __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t
     return c;
 }
 
-// The MIXED form (round 5; template argument WIDE; overlap mode): narrow and wide regions side by side, each lane its own way.
+// ContainsRegion over a wide region: the entries `mb` (bit 3 = entry 0) of the line of qs start at or below qs and end beyond what the
+// line's 16-bit coordinates tell (they are clamped one past the line's reach).  Their true ends: the positions of the line's entries
+// (the position table's half of the same line, pos_off), then root_ends[] -- two dependent reads, for the few regions that have such an
+// entry.  Returns the entries that end at or beyond qe.
+__device__ __forceinline__ uint32_t pair_wide_resolve(__amdgpu_buffer_rsrc_t rw, __amdgpu_buffer_rsrc_t rde, uint32_t pos_off, uint32_t mb, uint32_t qe) {
+    const gffx_v4u p = __builtin_amdgcn_raw_buffer_load_b128(rw, mb ? pos_off : kWinNoLine, 0, 0);
+    const uint32_t e0 = __builtin_amdgcn_raw_buffer_load_b32(rde, (mb & 8u) ? 4u * p.x : kWinNoLine, 0, 0);
+    const uint32_t e1 = __builtin_amdgcn_raw_buffer_load_b32(rde, (mb & 4u) ? 4u * p.y : kWinNoLine, 0, 0);
+    const uint32_t e2 = __builtin_amdgcn_raw_buffer_load_b32(rde, (mb & 2u) ? 4u * p.z : kWinNoLine, 0, 0);
+    const uint32_t e3 = __builtin_amdgcn_raw_buffer_load_b32(rde, (mb & 1u) ? 4u * p.w : kWinNoLine, 0, 0);
+    return ((e0 >= qe ? 8u : 0u) | (e1 >= qe ? 4u : 0u) | (e2 >= qe ? 2u : 0u) | (e3 >= qe ? 1u : 0u)) & mb;
+}
+
+// The MIXED form (round 5; template argument WIDE): narrow and wide regions side by side, each lane its own way.
 //   * A region the lines answer (0 < qe - qs <= wmax) is served as in the narrow form: ONE line -- the line of its last base, both
 //     halves (coordinates | root_fids or positions) -- tested against [rqs, rqe1].  No coverage filter (the strips leave no room).
 //   * A wider region is its first base -- the roots over it are in the line of qs, asked about [qs, qs + 1) -- and the roots that
@@ -515,11 +534,23 @@ __device__ __forceinline__ uint32_t pair_wide_tails(const uint4 *spill, uint32_t
 // qe - 1 and qe - 1 in its coordinates (wide lanes only).  A base beyond the seqid's windows stands for the last base of the last
 // window (nothing overlaps it, every root starts at or below it); a narrow region whose last base lies there reads nothing.  A row
 // on a seqid without roots reads nothing; a seqid without windows, an empty and a reversed row take the sweep.
-// CONT (Contained): a wide lane's first rank is rank(qs) -- the roots that start BELOW qs --, so its ta is one less (unless qs lies
-// beyond the seqid's windows, where every root starts below it).
-template <bool CONT = false>
-__device__ __forceinline__ void pair_locate_mixed(const PairLds &L, uint32_t lines_base, uint32_t wide_base, uint32_t qc, uint32_t qs, uint32_t qe,
-                                                  uint32_t &off, uint32_t &ta, uint32_t &tb, uint32_t &off1, uint32_t &rel1, bool &wide, bool &swp) {
+// What a WIDE lane keeps, by mode (intersect.rs:145-161; inv = the pass is inverted: overlap && !clause):
+//   mode, inv           of the line of qs                      the run starts at            of the run
+//   Overlap             start <= qs < end                      rank(qs + 1)                 all
+//   Contained           nothing                                rank(qs)                     end <= qe
+//   Contained, inv      start < qs < end                       rank(qs)                     end > qe
+//   ContainsRegion      start <= qs, end >= qe                 (no run, no second line)
+//   ContainsRegion, inv start <= qs < end < qe                 rank(qs + 1)                 all
+// Contained: ta = qs - 1 in the line's coordinates (the rank counts the entries that start at or below ta) unless qs lies beyond the
+// seqid's windows, where every root starts below it; the inverted pass tests start <= ta, end > tb = qs.  ContainsRegion: ta = qs,
+// tb = the region's last base qe - 1 in the line's coordinates -- or, when that lies beyond what 16 bits of the line's coordinates reach
+// (ends are clamped at sat = line width + wmax + 1), sat - 1: an entry that passes then MAY contain the region (`big`: its true end
+// decides, pair_wide_resolve).
+template <int MODE = GFFX_MODE_OVERLAP>
+__device__ __forceinline__ void pair_locate_mixed(const PairLds &L, uint32_t lines_base, uint32_t wide_base, bool run_on, uint32_t qc, uint32_t qs,
+                                                  uint32_t qe, uint32_t &off, uint32_t &ta, uint32_t &tb, uint32_t &off1, uint32_t &rel1, bool &wide,
+                                                  bool &swp, bool &big) {
+    constexpr bool CONT = MODE == GFFX_MODE_CONTAINED, CREG = MODE == GFFX_MODE_CONTAINS_REGION;
     const uint4 m = L.cm[min(qc, L.n_chr)];
     const uint32_t wmax = m.z >> 8, shift = m.z & 31u, e1 = qe - 1u, wd1 = e1 - qs;
     const bool fits = wd1 < wmax;  // 0 < qe - qs <= wmax (unsigned: an empty or reversed row wraps)
@@ -527,23 +558,29 @@ __device__ __forceinline__ void pair_locate_mixed(const PairLds &L, uint32_t lin
     swp = (m.y != 0u) & ((wmax == 0u) | (qs >= qe));  // (an empty or reversed row keeps the roots that reach over both its ends: rare, the sweep)
     const bool lines = live & (wmax != 0u);
     wide = lines & !fits;
-    auto point = [&](uint32_t y, uint32_t &line, uint32_t &rel, bool &past) {
+    auto point = [&](uint32_t y, uint32_t &line, uint32_t &rel, bool &past, uint32_t &sh) {
         past = (y >> shift) >= m.y;
         const uint32_t b = past ? m.y - 1u : y >> shift, yy = past ? 0xFFFFFFFFu : y;
         const uint32_t w = m.x + b;
         const bool split = (__builtin_amdgcn_ubfe(L.sbits[min(w >> 5, L.swords)], w, 1) != 0) & L.split_on;
-        const uint32_t sh = shift - (split ? kWinSplit : 0u);
+        sh = shift - (split ? kWinSplit : 0u);
         line = split ? L.n_win + (w << kWinSplit) + __builtin_amdgcn_ubfe(yy, sh, kWinSplit) : w;
         rel = __builtin_amdgcn_ubfe(yy, 0, sh) + wmax;
     };
-    uint32_t l0, r0, l1, r1;
+    uint32_t l0, r0, l1, r1, sh0, sh1;
     bool p0, p1;
-    point(qs, l0, r0, p0);
-    point(e1, l1, r1, p1);
+    point(qs, l0, r0, p0, sh0);
+    point(e1, l1, r1, p1, sh1);
     off = !lines ? kWinNoLine : fits ? (p1 ? kWinNoLine : lines_base + l1 * kWinLineBytes) : wide_base + l0 * kWinLineBytes;
     ta = fits ? r1 - wd1 : (CONT && !p0) ? r0 - 1u : r0;  // narrow: qs relative to the line of its last base; wide: the one-base region [qs, qs + 1)
     tb = fits ? r1 : r0;
-    off1 = wide ? wide_base + l1 * kWinLineBytes : kWinNoLine;
+    big = false;
+    if (CREG) {
+        const uint32_t sat = (1u << sh0) + wmax + 1u, last = r0 + min(wd1, 0x20000u);  // (the region's last base in the line's coordinates)
+        big = wide & (last >= sat);
+        tb = fits ? r1 : min(last, sat - 1u);
+    }
+    off1 = (wide & run_on) ? wide_base + l1 * kWinLineBytes : kWinNoLine;
     rel1 = r1;
 }
 
@@ -596,12 +633,12 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 // T: threads per block (512: two blocks per CU; 1024: one, half the reservation atomics)
 // OFFS: per-region offsets are written (GFFX_OUT_OFFSETS / _OFFSETS32): each lane parks its place inside the round's segment
 // POS: the words a pass emits are index positions (table win_pos), not root_fids
-// WIDE: the mixed form (pair_locate_mixed; overlap mode, not inverted): a batch in which AUTO found wide regions -- every lane serves its
+// WIDE: the mixed form (pair_locate_mixed; every mode, inverted or not): a batch in which AUTO found wide regions -- every lane serves its
 //       region the narrow way (one line) or the wide way (two lines, two ranks) as the region's width asks
 template <int MODE, bool META_LDS, int T, bool OFFS, bool POS, bool WIDE = false>
 __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
-    static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP || MODE == GFFX_MODE_CONTAINED, "the mixed form answers Overlap and Contained");
-    constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED;  // a wide lane keeps the roots of its run that end inside the region
+    constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED;        // a wide lane keeps the roots of its run that end inside the region (inverted: beyond it)
+    constexpr bool CREG = WIDE && MODE == GFFX_MODE_CONTAINS_REGION;  // ... the roots over qs that reach the region's end (inverted: that do not, and its run)
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
     constexpr uint32_t kWaves = T / 64;
     constexpr uint32_t D = pair_depth(WIDE);
@@ -672,12 +709,13 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     const __amdgpu_buffer_rsrc_t rfd =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rfids), 0, WIDE ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rde =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rends), 0, CONT ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
-    // (Contained, a wide lane) which of up to four roots of the run, ends e, are kept: end <= qe and end > qs (start >= qs holds for
-    // the whole run; an empty interval AT qs does not overlap: tree.rs:110) -- a bit per root, the first one bit 3
-    auto run_mask = [](const gffx_v4u &e, uint32_t n4, uint32_t qs_, uint32_t qe_) {
-        return ((n4 > 0 && e.x <= qe_ && e.x > qs_) ? 8u : 0u) | ((n4 > 1 && e.y <= qe_ && e.y > qs_) ? 4u : 0u) |
-               ((n4 > 2 && e.z <= qe_ && e.z > qs_) ? 2u : 0u) | ((n4 > 3 && e.w <= qe_ && e.w > qs_) ? 1u : 0u);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rends), 0, (CONT || CREG) ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
+    const bool run_on = !(CREG && !inv);  // (uniform) a wide lane has a run of roots that start inside its region
+    // (Contained, a wide lane) which of up to four roots of the run, ends e, are kept: end <= qe (inverted: end > qe) and end > qs
+    // (start >= qs holds for the whole run; an empty interval AT qs does not overlap: tree.rs:110) -- a bit per root, the first one bit 3
+    auto run_mask = [inv](const gffx_v4u &e, uint32_t n4, uint32_t qs_, uint32_t qe_) {
+        return ((n4 > 0 && (e.x <= qe_) != inv && e.x > qs_) ? 8u : 0u) | ((n4 > 1 && (e.y <= qe_) != inv && e.y > qs_) ? 4u : 0u) |
+               ((n4 > 2 && (e.z <= qe_) != inv && e.z > qs_) ? 2u : 0u) | ((n4 > 3 && (e.w <= qe_) != inv && e.w > qs_) ? 1u : 0u);
     };
 
     // ---- what is left to do for the wave's previous D - 1 rounds once their segment bases are known (all wave-uniform;
@@ -797,16 +835,19 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         uint32_t nra[4] = {0, 0, 0, 0}, em0[4] = {0, 0, 0, 0};  // (Contained) the run's length before the test of the ends (nr: the kept ones); the first four's kept bits
         bool isw[4];                              // (mixed form) the lane serves this region the wide way
         uint32_t iswm = 0;                        // ... as a bit per region
+        bool bigr[4];                             // (ContainsRegion, a wide lane) the region ends beyond what the line's coordinates reach
+        uint32_t mb[4] = {0, 0, 0, 0};            // ... the entries whose true ends decide (pair_wide_resolve)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;  // (a partial round's rows were checked when they were loaded)
             if constexpr (WIDE) {
-                pair_locate_mixed<CONT>(L, lines_base, wide_base, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k]);
+                pair_locate_mixed<MODE>(L, lines_base, wide_base, run_on, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k],
+                                        bigr[k]);
                 iswm |= isw[k] ? 1u << k : 0u;
             } else {
                 pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
                 off1[k] = rel1[k] = r0[k] = nr[k] = 0;
-                isw[k] = false;
+                isw[k] = bigr[k] = false;
             }
         }
         GFFX_WIN_STAMP(1);
@@ -843,14 +884,31 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             bool any = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false, off[k] != kWinNoLine);
-                if (CONT) m[k] = isw[k] ? 0u : m[k];  // (Contained: a wide lane keeps nothing of the roots that start before its region)
+                // (the clause alone -- for a region that has a line it implies the overlap --, and, inverted, the overlap test beside it;
+                //  a wide lane's arguments: pair_locate_mixed's table)
+                const bool hl = off[k] != kWinNoLine;
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false, hl);
+                if constexpr (CONT) {
+                    m[k] = isw[k] ? 0u : m[k];  // (Contained: a wide lane keeps nothing of the roots that start before its region)
+                    if (inv) {
+                        const uint32_t ov = pair_test4<GFFX_MODE_OVERLAP>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, isw[k] ? rqe1[k] : rqs[k], isw[k] ? rqs[k] : rqe1[k], false, hl);
+                        m[k] = ov & ~m[k];  // (... inverted: those that start below qs and reach over it)
+                    }
+                } else if constexpr (CREG) {
+                    if (inv) {
+                        const uint32_t ov = pair_test4<GFFX_MODE_OVERLAP>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], isw[k] ? rqs[k] : rqe1[k], false, hl);
+                        mb[k] = (isw[k] && bigr[k]) ? ov & m[k] : 0u;
+                        m[k] = ov & ~m[k];
+                    } else {
+                        mb[k] = (isw[k] && bigr[k]) ? m[k] : 0u;
+                    }
+                }
                 ra[k] = wf[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);  // (a narrow lane's: unused)
                 rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rel1[k]);
                 hdr[k] = wc[k].w == kWinTailMark ? (isw[k] ? wf[k].y : wf[k].w) : 0u;
                 h1[k] = (isw[k] && wc1[k].w == kWinTailMark) ? cu1[k].y : 0u;
                 swp[k] |= ((hdr[k] & 255u) == 255u) | ((h1[k] & 255u) == 255u);
-                any |= swp[k] | ((hdr[k] | h1[k]) != 0u);
+                any |= swp[k] | ((hdr[k] | h1[k] | mb[k]) != 0u);
             }
             GFFX_WIN_STAMP(8);
             // second trip of the wide lanes, issued BEFORE the tails are walked: the kept entries' words (the other half of the line of
@@ -859,17 +917,25 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             // (the wide lanes' rank records have been used: their registers take the words; a narrow lane keeps its line's half)
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (isw[k]) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, (m[k] && !swp[k]) ? lines_base + (off[k] - wide_base) + 16 : kWinNoLine, 0, 0);
+                if (isw[k]) wf[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, ((m[k] | mb[k]) && !swp[k]) ? lines_base + (off[k] - wide_base) + 16 : kWinNoLine, 0, 0);
             if (!POS) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, (isw[k] && rb[k] != ra[k] && !swp[k]) ? 4u * ra[k] : kWinNoLine, 0, 0);
+                    rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, (run_on && isw[k] && rb[k] != ra[k] && !swp[k]) ? 4u * ra[k] : kWinNoLine, 0, 0);
             }
             if (__builtin_amdgcn_ballot_w64(any)) {  // (uniform: some lane of the wave has a list tail to walk, or a sweep)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     deferred |= (swp[k] | ((hdr[k] | h1[k]) != 0u)) ? 1u << k : 0u;
                     sweep |= swp[k] ? 1u << k : 0u;
+                }
+                if constexpr (CREG) {
+                    // ContainsRegion: the entries whose clamped ends do not tell -- their true ends decide (the regions in step: few lanes have one)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t cf = pair_wide_resolve(rw, rde, A.pv.table_bytes + (off[k] - wide_base) + 16, swp[k] ? 0u : mb[k], qe[k]);
+                        m[k] = inv ? m[k] | (mb[k] & ~cf) : (m[k] & ~mb[k]) | cf;
+                    }
                 }
                 if (deferred) {
                     n_slow += __popc(sweep);
@@ -881,11 +947,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                         uint32_t *st = s_stash + min(n_rest, kWaveStash);
                         const uint32_t cap = kWaveStash - min(n_rest, kWaveStash);
                         if (sweep >> k & 1u)
-                            c = pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), st, cap, nullptr);
+                            c = pair_sweep_call<MODE, POS>(&rare_ix(), inv, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), st, cap, nullptr);
                         else if (iswm >> k & 1u)
-                            c = pair_wide_tails<POS, CONT>(A.spill, win_sel(hdr, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, st, cap, a0, b0);
+                            c = pair_wide_tails<POS, MODE>(A.spill, win_sel(hdr, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, st, cap, a0, b0, nullptr, inv);
                         else  // a narrow lane's list tail
-                            c = pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k), st, cap);
+                            c = pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), win_sel(hdr, k), st, cap);
                         n_rest += c;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) tc[j] += k == j ? c : 0u, ra[j] += k == j ? a0 : 0u, rb[j] += k == j ? b0 : 0u;
@@ -894,7 +960,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                     if (!POS) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (moved >> k & 1u) rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, rb[k] != ra[k] ? 4u * ra[k] : kWinNoLine, 0, 0);
+                            if (moved >> k & 1u) rg[k] = __builtin_amdgcn_raw_buffer_load_b128(rfd, (run_on && rb[k] != ra[k]) ? 4u * ra[k] : kWinNoLine, 0, 0);
                     }
                 }
             }
@@ -903,7 +969,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             for (int k = 0; k < 4; ++k) {
                 m[k] = swp[k] ? 0u : m[k];
                 r0[k] = ra[k];
-                nr[k] = (swp[k] || !isw[k]) ? 0u : rb[k] - ra[k];
+                nr[k] = (swp[k] || !isw[k] || !run_on) ? 0u : rb[k] - ra[k];
                 if (POS) rg[k].x = r0[k], rg[k].y = r0[k] + 1u, rg[k].z = r0[k] + 2u, rg[k].w = r0[k] + 3u;
             }
             if constexpr (CONT) {
@@ -1116,11 +1182,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                             if constexpr (WIDE) {
                                 uint32_t a0 = 0, b0 = 0;
                                 if (sweep >> k & 1u)
-                                    (void)pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(c_, n_chr), s_, e_, e, 0xFFFFFFFFu, nullptr);
+                                    (void)pair_sweep_call<MODE, POS>(&rare_ix(), inv, min(c_, n_chr), s_, e_, e, 0xFFFFFFFFu, nullptr);
                                 else if (iswm >> k & 1u)
-                                    (void)pair_wide_tails<POS, CONT>(A.spill, win_sel(hdr, k), 0u, s_, e_ - 1u, e, 0xFFFFFFFFu, a0, b0);
+                                    (void)pair_wide_tails<POS, MODE>(A.spill, win_sel(hdr, k), 0u, s_, e_ - 1u, e, 0xFFFFFFFFu, a0, b0, nullptr, inv);
                                 else
-                                    (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
+                                    (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, 0u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
                             } else {
                                 (void)pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, sweep >> k & 1u, min(c_, n_chr), s_, e_, win_sel(hdr, k), e, 0xFFFFFFFFu);
                             }
@@ -1197,7 +1263,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                         if (nra[k] && i0 + k < nq) pair_load_region(q, i0 + k, c_, s_, q_);
                         for (uint32_t t = 0; t < nra[k]; ++t) {
                             const uint32_t e_ = A.pv.rends[r0[k] + t];
-                            if (e_ <= q_ && e_ > s_) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
+                            if ((e_ <= q_) != inv && e_ > s_) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
                         }
                     } else {
                         for (uint32_t t = 0; t < nr[k]; ++t) put(POS ? r0[k] + t : A.pv.rfids[r0[k] + t]);
@@ -1208,11 +1274,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                         uint32_t *e = out.fids + min(o, out.capacity);
                         const uint32_t cap = (uint32_t)min(out.capacity - min(o, out.capacity), 0xFFFFFFFFull);
                         if (sweep >> k & 1u)
-                            o += pair_sweep_call<MODE, POS>(&rare_ix(), 0u, min(c_, n_chr), s_, e_, e, cap, nullptr);
+                            o += pair_sweep_call<MODE, POS>(&rare_ix(), inv, min(c_, n_chr), s_, e_, e, cap, nullptr);
                         else if (iswm >> k & 1u)
-                            o += pair_wide_tails<POS, CONT>(A.spill, hdr[k], 0u, s_, e_ - 1u, e, cap, a0, b0);
+                            o += pair_wide_tails<POS, MODE>(A.spill, hdr[k], 0u, s_, e_ - 1u, e, cap, a0, b0, nullptr, inv);
                         else
-                            o += pair_rest<MODE, POS>(&rare_ix(), A.spill, false, 0u, min(c_, n_chr), s_, e_, hdr[k], e, cap);
+                            o += pair_rest<MODE, POS>(&rare_ix(), A.spill, inv, 0u, min(c_, n_chr), s_, e_, hdr[k], e, cap);
                     }
                 }
             } else if (out.fids) {
@@ -1258,8 +1324,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 // pairs (summed on the host: one same-address device atomic per wave cost 43 us per 1 M regions, per block still 5).
 template <int MODE, bool META_LDS, int T, bool WIDE = false>
 __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
-    static_assert(!WIDE || MODE == GFFX_MODE_OVERLAP || MODE == GFFX_MODE_CONTAINED, "the mixed form answers Overlap and Contained");
-    constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED;
+    constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED, CREG = WIDE && MODE == GFFX_MODE_CONTAINS_REGION;  // (as in k_join_pairs)
     constexpr uint32_t kChunk = 4u * T;
     const QueryView &q = A.q;
     const WaveOut &out = A.out;
@@ -1306,7 +1371,8 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(A.pv.all), 0, WIDE ? 3u * A.pv.table_bytes : 0u, 0x00020000);
     const uint32_t lines_base = A.pv.table_bytes, wide_base = 2u * A.pv.table_bytes;
     const __amdgpu_buffer_rsrc_t rde =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rends), 0, CONT ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rends), 0, (CONT || CREG) ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
+    const bool run_on = !(CREG && !inv);  // (uniform) a wide lane has a run of roots that start inside its region
     const uint32_t bm = lds0 + (uint32_t)(reinterpret_cast<unsigned char *>(s_bm) - smem);  // the bitmap's LDS address
     uint32_t *g_bitmap = reinterpret_cast<uint32_t *>(out.root_flags);                       // ... or the batch's bitmap (no LDS bitmap)
     auto set_global = [&](uint32_t p) {
@@ -1322,16 +1388,18 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         uint32_t off[4], rqs[4], rqe1[4];
         bool swp[4];
         uint32_t off1[4], rel1[4], r0[4], nr[4];  // (mixed form, wide lanes) the line of qe - 1, qe - 1 in its coordinates; the run of roots that start inside the region
-        bool isw[4];
+        bool isw[4], bigr[4];
+        uint32_t mb[4] = {0, 0, 0, 0};  // (ContainsRegion, wide lanes) the entries whose true ends decide
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             bad |= full && qc[k] >= n_chr;
             if constexpr (WIDE) {
-                pair_locate_mixed<CONT>(L, lines_base, wide_base, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k]);
+                pair_locate_mixed<MODE>(L, lines_base, wide_base, run_on, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], off1[k], rel1[k], isw[k], swp[k],
+                                        bigr[k]);
             } else {
                 pair_locate(L, qc[k], qs[k], qe[k], off[k], rqs[k], rqe1[k], swp[k]);
                 off1[k] = rel1[k] = r0[k] = nr[k] = 0;
-                isw[k] = false;
+                isw[k] = bigr[k] = false;
             }
         }
         gffx_v4u wc[4], wf[4];
@@ -1360,14 +1428,29 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             uint32_t iswm = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false, off[k] != kWinNoLine);
-                if (CONT) m[k] = isw[k] ? 0u : m[k];  // (Contained: a wide lane keeps nothing of the roots that start before its region)
+                const bool hl = off[k] != kWinNoLine;  // (the tests: as in k_join_pairs)
+                m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], false, hl);
+                if constexpr (CONT) {
+                    m[k] = isw[k] ? 0u : m[k];  // (Contained: a wide lane keeps nothing of the roots that start before its region)
+                    if (inv) {
+                        const uint32_t ov = pair_test4<GFFX_MODE_OVERLAP>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, isw[k] ? rqe1[k] : rqs[k], isw[k] ? rqs[k] : rqe1[k], false, hl);
+                        m[k] = ov & ~m[k];
+                    }
+                } else if constexpr (CREG) {
+                    if (inv) {
+                        const uint32_t ov = pair_test4<GFFX_MODE_OVERLAP>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], isw[k] ? rqs[k] : rqe1[k], false, hl);
+                        mb[k] = (isw[k] && bigr[k]) ? ov & m[k] : 0u;
+                        m[k] = ov & ~m[k];
+                    } else {
+                        mb[k] = (isw[k] && bigr[k]) ? m[k] : 0u;
+                    }
+                }
                 ra[k] = wf[k].x + pair_count_le4(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k]);  // (a narrow lane's: unused)
                 rb[k] = cu1[k].x + pair_count_le4(wc1[k].x, wc1[k].y, wc1[k].z, wc1[k].w, rel1[k]);
                 h0[k] = wc[k].w == kWinTailMark ? (isw[k] ? wf[k].y : wf[k].w) : 0u;
                 h1[k] = (isw[k] && wc1[k].w == kWinTailMark) ? cu1[k].y : 0u;
                 swp[k] |= ((h0[k] & 255u) == 255u) | ((h1[k] & 255u) == 255u);
-                any |= swp[k] | ((h0[k] | h1[k]) != 0u);
+                any |= swp[k] | ((h0[k] | h1[k] | mb[k]) != 0u);
                 iswm |= isw[k] ? 1u << k : 0u;
                 // the positions of the line's entries: a wide lane's come from the position table
                 wf[k].x = isw[k] ? wp[k].x : wf[k].x, wf[k].y = isw[k] ? wp[k].y : wf[k].y;
@@ -1381,19 +1464,26 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                     sweep |= swp[k] ? 1u << k : 0u;
                 }
                 n_slow += __popc(sweep);
+                if constexpr (CREG) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t cf = pair_wide_resolve(rw, rde, A.pv.table_bytes + (off[k] - wide_base) + 16, swp[k] ? 0u : mb[k], qe[k]);
+                        m[k] = inv ? m[k] | (mb[k] & ~cf) : (m[k] & ~mb[k]) | cf;
+                    }
+                }
                 uint32_t d = deferred;
                 while (d) {
                     const int k = __ffs(d) - 1;
                     d &= d - 1;
                     uint32_t c, a0 = 0, b0 = 0;
                     if (sweep >> k & 1u)
-                        c = pair_sweep_call<MODE, true>(&pair_rare_ix(), 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), nullptr, 0u,
+                        c = pair_sweep_call<MODE, true>(&pair_rare_ix(), inv, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k), nullptr, 0u,
                                                         bm_words ? s_bm : g_bitmap);
                     else if (iswm >> k & 1u)
-                        c = pair_wide_tails<true, CONT>(A.spill, win_sel(h0, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, nullptr, 0u, a0, b0,
-                                                  bm_words ? s_bm : g_bitmap);
+                        c = pair_wide_tails<true, MODE>(A.spill, win_sel(h0, k), win_sel(h1, k), win_sel(qs, k), win_sel(qe, k) - 1u, nullptr, 0u, a0, b0,
+                                                        bm_words ? s_bm : g_bitmap, inv);
                     else  // a narrow lane's list tail
-                        c = pair_rest<MODE, true>(&pair_rare_ix(), A.spill, false, 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k),
+                        c = pair_rest<MODE, true>(&pair_rare_ix(), A.spill, inv, 0u, min(win_sel(qc, k), n_chr), win_sel(qs, k), win_sel(qe, k),
                                                   win_sel(h0, k), nullptr, 0u, bm_words ? s_bm : g_bitmap);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) tc[j] += k == j ? c : 0u, ra[j] += k == j ? a0 : 0u, rb[j] += k == j ? b0 : 0u;
@@ -1403,7 +1493,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             for (int k = 0; k < 4; ++k) {
                 m[k] = swp[k] ? 0u : m[k];
                 r0[k] = ra[k];
-                nr[k] = (swp[k] || !isw[k]) ? 0u : rb[k] - ra[k];
+                nr[k] = (swp[k] || !isw[k] || !run_on) ? 0u : rb[k] - ra[k];
             }
             if constexpr (CONT) {
                 // Contained: of the run of roots that start inside the region those that also end inside it (the ends by position,
@@ -1420,7 +1510,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                         const uint32_t n4 = t < nr[k] ? min(nr[k] - t, 4u) : 0u, e4[4] = {ev[k].x, ev[k].y, ev[k].z, ev[k].w};
 #pragma unroll
                         for (uint32_t j = 0; j < 4; ++j)
-                            if (j < n4 && e4[j] <= qe[k] && e4[j] > qs[k]) {
+                            if (j < n4 && (e4[j] <= qe[k]) != inv && e4[j] > qs[k]) {
                                 const uint32_t p = r0[k] + t + j;
                                 atomicOr(&bits[p >> 5], 1u << (p & 31));
                                 ++keptr[k];

@@ -198,7 +198,7 @@ class QueryBatch:
 
     @property
     def wide_form(self) -> bool:
-        """the last run's pair passes took the wide form of the window kernel (regions of any width, overlap mode)"""
+        """the last run's pair passes took the wide form of the window kernel (regions of any width, every mode)"""
         return bool(lib().gffx_hip_batch_wide_form(self._h))
 
     def wait(self) -> None:

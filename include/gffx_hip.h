@@ -295,12 +295,13 @@ int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, i
  * index has passes in flight, 512-thread blocks (two per CU: kernels of two batches share the CUs) otherwise;
  * The knob GFFX_HIP_WIN_THREADS (512 / 1024) forces one. */
 uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *);
-/* 1 when the last run's passes took the MIXED form of the window kernels (overlap mode; round 4's "wide form" is its all-wide
- * case): every region is served its own way in one launch -- a region the index lines answer (up to 16 Ki bases by default) from ONE
+/* 1 when the last run's passes took the MIXED form of the window kernels (every mode, inverted or not; round 4's "wide form" is
+ * its all-wide Overlap case): every region is served its own way in one launch -- a region the index lines answer (up to 16 Ki bases by default) from ONE
  * line as in the narrow form, a wider one from two index lines and two rank words, no sweep.  AUTO chooses it for a batch with
  * more than one wide row in 128: found by a sample of the rows gffx_hip_batch_set_regions_host / _soa_host are given (each judged
  * against its own seqid's line width), or -- regions already on the device -- by a previous waited pass of the narrow form, which
- * counts the rows its lines did not answer; the other modes of a MOSTLY wide batch run on the sweep kernel.  The knob
+ * counts the rows its lines did not answer.  What a wide region keeps in each mode: join_pairs_kernels.hpp, pair_locate_mixed
+ * (Contained: its run of roots filtered by their ends; ContainsRegion: the roots over its first base that reach its end).  The knob
  * GFFX_HIP_WIN_WIDE (0 never / 1 AUTO / 2 every eligible pass of the windows strategy) steers it. */
 int gffx_hip_batch_wide_form(const gffx_hip_batch *);
 

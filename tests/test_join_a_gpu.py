@@ -451,8 +451,7 @@ def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert, st
 def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
     """AUTO: a batch of mostly wide regions -- found by a sample of the rows the host hands over, or by a first waited pass that
     sent most regions to the exact sweep (tests/test_wide_form_gpu.py) -- runs on the mixed form of the window kernel (Overlap: round
-    4's wide form; Contained: round 5) or on the sweep kernel (ContainsRegion, inverted passes); a batch of narrow regions stays
-    where it is."""
+    4's wide form; the other modes and the inverted passes: round 5); a batch of narrow regions stays where it is."""
     roots = synth.gencode_like_roots(150, seed=5, chroms=synth.SMALL2)
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
     ix = engine.TreeIndexData.from_roots(co, s, e, f)
@@ -461,10 +460,10 @@ def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
     narrow = synth.synth_bed(5000, seed=2, chroms=synth.SMALL2, width=(100, 5000))
     b = engine.QueryBatch(ix, 5000)
 
-    def one_pass(mode, want_c):
+    def one_pass(mode, want_c, inv=False):
         b.set_profiling(True)
         b.reset_profile()
-        b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS)  # AUTO
+        b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS)  # AUTO
         b.wait()
         b.set_profiling(False)
         assert np.array_equal(b.counts(), want_c)
@@ -478,7 +477,10 @@ def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
         _, want_cc = oix.query_features(regions, 0, False)
         assert one_pass(OverlapMode.Contained, want_cc) == (["k_join_pairs"], is_wide)
         _, want_cr = oix.query_features(regions, 1, False)
-        assert one_pass(OverlapMode.ContainsRegion, want_cr) == (["k_join_fused" if is_wide else "k_join_pairs"], False)
+        assert one_pass(OverlapMode.ContainsRegion, want_cr) == (["k_join_pairs"], is_wide)
+        for mode in (0, 1):
+            _, want_ci = oix.query_features(regions, mode, True)
+            assert one_pass(OverlapMode(mode), want_ci, True) == (["k_join_pairs"], is_wide)
         assert one_pass(OverlapMode.Overlap, want_c) == (["k_join_pairs"], is_wide)
     b.close()
     ix.close()

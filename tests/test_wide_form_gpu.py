@@ -1,4 +1,4 @@
-"""The wide form of k_join_pairs / k_join_roots (regions of any width, overlap mode) == oracle, bit for bit.
+"""The wide / mixed form of k_join_pairs / k_join_roots (regions of any width, every mode, inverted or not) == oracle, bit for bit.
 
 A region [qs, qe) overlaps the roots over its first base and the roots that start inside it (gffx_device.hpp, "ranks"):
 the kernel reads the line of qs, the line of qe - 1 and a rank word for each.  Forced on every eligible pass of the windows
@@ -37,10 +37,10 @@ def _want_pairs(regions, want_t, want_c):
     return p[np.lexsort((p[:, 1], p[:, 0]))]
 
 
-def _check_wide(roots, regions, strategy=engine.STRATEGY_WINDOWS, soa=False, OV=OV):
+def _check_wide(roots, regions, strategy=engine.STRATEGY_WINDOWS, soa=False, OV=OV, inv=False):
     co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
     oix = ob.OracleIndex.from_roots(co, s, e, f)
-    want_t, want_c = oix.query_features(regions, int(OV), False)
+    want_t, want_c = oix.query_features(regions, int(OV), inv)
     want_p = _want_pairs(regions, want_t, want_c)
     ix = engine.TreeIndexData.from_roots(co, s, e, f)
     b = engine.QueryBatch(ix, max(len(regions), 1))
@@ -49,7 +49,7 @@ def _check_wide(roots, regions, strategy=engine.STRATEGY_WINDOWS, soa=False, OV=
     else:
         b.set_regions(regions)
     # root_fids + triples + u64 offsets (the position pass and k_expand_pairs)
-    b.run(OV, False, engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_OFFSETS, strategy)
+    b.run(OV, inv, engine.OUT_FIDS | engine.OUT_TRIPLES | engine.OUT_OFFSETS, strategy)
     b.wait()
     assert b.total_hits == len(want_t)
     assert np.array_equal(b.counts(), want_c)
@@ -58,30 +58,30 @@ def _check_wide(roots, regions, strategy=engine.STRATEGY_WINDOWS, soa=False, OV=
     assert np.array_equal(b.fids(), got_t[:, 0])
     assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
     # root_fids + one base per group of 256 regions (the pass bench.py times)
-    b.run(OV, False, engine.OUT_FIDS | engine.OUT_SEGBASE, strategy)
+    b.run(OV, inv, engine.OUT_FIDS | engine.OUT_SEGBASE, strategy)
     b.wait()
     c3, f3 = b.counts(), b.fids()
     assert np.array_equal(c3, want_c) and len(f3) == len(want_t)
     assert np.array_equal(_pairs_of(regions, want_c, b.offsets_from_segbase(c3), f3), want_p)
     # u32 offsets
-    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS32, strategy)
+    b.run(OV, inv, engine.OUT_FIDS | engine.OUT_OFFSETS32, strategy)
     b.wait()
     assert np.array_equal(b.counts(), want_c)
     assert np.array_equal(_pairs_of(regions, want_c, b.offsets32(), b.fids()), want_p)
     # counts alone
-    b.run(OV, False, 0, strategy)
+    b.run(OV, inv, 0, strategy)
     b.wait()
     assert np.array_equal(b.counts(), want_c) and b.total_hits == len(want_t)
     assert b.wide_form
     # the unique roots: a root pass of its own (with and without counts: what the CLI asks for), and behind a pair pass
     want_u = np.unique(want_t[:, 0])
-    b.run(OV, False, engine.OUT_ROOT_BITMAP, strategy)
+    b.run(OV, inv, engine.OUT_ROOT_BITMAP, strategy)
     b.wait()
     assert b.wide_form and np.array_equal(b.unique_roots(), want_u) and np.array_equal(b.counts(), want_c) and b.total_hits == len(want_t)
-    b.run(OV, False, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, strategy)
+    b.run(OV, inv, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, strategy)
     b.wait()
     assert b.wide_form and np.array_equal(b.unique_roots(), want_u) and b.total_hits == len(want_t)
-    b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_ROOT_BITMAP, strategy)
+    b.run(OV, inv, engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_ROOT_BITMAP, strategy)
     b.wait()
     assert b.wide_form and np.array_equal(b.unique_roots(), want_u) and np.array_equal(b.counts(), want_c)
     assert np.array_equal(_pairs_of(regions, want_c, b.offsets()[:-1], b.fids()), want_p)
@@ -128,9 +128,17 @@ def test_wide_form_gencode_like(wide_forced):
     pairs = _check_wide(roots, regions)
     assert pairs > 1_000_000
     assert _check_wide(roots, regions, OV=OverlapMode.Contained) > 100_000  # (round 5: a wide lane's run filtered by the roots' ends)
+    # (round 5, second half: the roots over qs that reach the region's end -- by their true ends where the line's 16 bits do not tell --,
+    #  and the inverted passes)
+    assert _check_wide(roots, regions, OV=OverlapMode.ContainsRegion) > 1000
+    assert _check_wide(roots, regions, OV=OverlapMode.ContainsRegion, inv=True, soa=True) > 1_000_000
+    assert _check_wide(roots, regions, OV=OverlapMode.Contained, inv=True) > 10_000
     regions = synth.synth_bed(30_011, seed=77, width=(100, 200000), edge_frac=0.05, roots=roots)  # bench.py's wide_regions shape
     _check_wide(roots, regions, soa=True)
     _check_wide(roots, regions, OV=OverlapMode.Contained)
+    _check_wide(roots, regions, OV=OverlapMode.ContainsRegion)
+    _check_wide(roots, regions, OV=OverlapMode.ContainsRegion, inv=True)
+    _check_wide(roots, regions, OV=OverlapMode.Contained, inv=True, soa=True)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -159,6 +167,8 @@ def test_wide_form_small_indexes(wide_forced, seed):
     regions = _mixed_widths(rng, 6000 + 257 * seed, chroms, n_chr_extra=0)
     _check_wide(roots, regions, soa=bool(seed & 1))
     _check_wide(roots, regions, soa=not (seed & 1), OV=OverlapMode.Contained)
+    _check_wide(roots, regions, soa=bool(seed & 2), OV=OverlapMode.ContainsRegion, inv=bool(seed & 1))
+    _check_wide(roots, regions, soa=not (seed & 2), OV=OverlapMode.Contained if seed & 1 else OverlapMode.ContainsRegion, inv=True)
 
 
 def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
@@ -185,8 +195,8 @@ def test_wide_form_is_autos_choice_for_wide_batches(monkeypatch):
         wt, wc = oix.query_features(regions, int(mode), inv)
         b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_AUTO)
         b.wait()
-        # (Contained takes the mixed form since round 5; ContainsRegion and inverted passes stay with the sweep kernel)
-        assert b.wide_form == (mode == OverlapMode.Contained and not inv) and np.array_equal(b.counts(), wc)
+        # (every mode takes the mixed form since round 5, inverted or not)
+        assert b.wide_form and np.array_equal(b.counts(), wc)
         assert np.array_equal(_pairs_of(regions, wc, b.offsets()[:-1], b.fids()), _want_pairs(regions, wt, wc))
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_ROOT_BITMAP, engine.STRATEGY_AUTO)
     b.wait()
@@ -242,11 +252,15 @@ def test_mixed_batches_take_the_mixed_form(frac, mixed, monkeypatch):
     b.run(OverlapMode.Contained, False, engine.OUT_ROOT_BITMAP)
     b.wait()
     assert b.wide_form == mixed and np.array_equal(b.unique_roots(), np.unique(wt[:, 0])) and np.array_equal(b.counts(), wc)
-    for mode, inv in ((OverlapMode.ContainsRegion, False), (OverlapMode.Contained, True)):
+    for mode, inv in ((OverlapMode.ContainsRegion, False), (OverlapMode.Contained, True), (OverlapMode.ContainsRegion, True)):
         wt, wc = oix.query_features(regions, int(mode), inv)
         b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS)
         b.wait()
-        assert not b.wide_form and np.array_equal(b.counts(), wc)
+        assert b.wide_form == mixed and np.array_equal(b.counts(), wc)
+        assert np.array_equal(_pairs_of(regions, wc, b.offsets()[:-1], b.fids()), _want_pairs(regions, wt, wc))
+        b.run(mode, inv, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS)
+        b.wait()
+        assert b.wide_form == mixed and np.array_equal(b.unique_roots(), np.unique(wt[:, 0])) and b.total_hits == len(wt)
     # the same regions resident on the device: no sample, the first waited pass (narrow form) counts the rows its lines did not answer
     b.set_option("WIDTH_SAMPLE", 0)
     b.set_regions(regions)

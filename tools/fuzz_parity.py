@@ -81,7 +81,7 @@ for it in range(iters):
                     else:
                         b.set_option("WIN_THREADS", 0)
                 runs = [(fl, False) for fl in flag_sets]
-                if strat == engine.STRATEGY_WINDOWS and mode in (0, 2) and not inv:
+                if strat == engine.STRATEGY_WINDOWS and not (mode == 2 and inv):  # (every mode, inverted or not: round 5)
                     # the wide form of the pair and root passes (regions of any width from two lines and two ranks; AUTO's choice for wide
                     # batches), forced on these regions whatever their widths
                     runs += [(fl, True) for fl in (engine.OUT_FIDS | engine.OUT_OFFSETS, engine.OUT_TRIPLES | engine.OUT_OFFSETS, 0,
