@@ -261,6 +261,32 @@ __device__ __forceinline__ uint32_t pair_count_le4(uint32_t w0, uint32_t w1, uin
     return c;
 }
 
+// (Contained, a wide lane) which of up to four roots of a run, ends e, are kept -- a bit per root, the first one bit 3.  Kept: end <= qe
+// and end > qs (start >= qs holds for the whole run; an empty interval AT qs does not overlap: tree.rs:110), inverted: end > qe.  Both
+// are ONE unsigned range check, (e - lo - 1) < d with {lo, d} = {qs, qe - qs} or, inverted, {qe, ~qe}: per root a subtraction, a
+// compare and the v_addc that shifts the outcome into the bit string -- 3 VALU, no lane mask but vcc.  n4 = how many of the four words
+// belong to the run.
+__device__ __forceinline__ uint32_t pair_ends4(const gffx_v4u &e, uint32_t n4, uint32_t qs, uint32_t qe, bool inv) {
+    const uint32_t lo1 = (inv ? qe : qs) + 1u, d = inv ? ~qe : qe - qs;
+    uint32_t m, x;
+    asm("v_sub_u32 %[x], %[e0], %[lo]\n\t"
+        "v_cmp_lt_u32 vcc, %[x], %[d]\n\t"
+        "v_addc_co_u32 %[m], vcc, 0, 0, vcc\n\t"
+        "v_sub_u32 %[x], %[e1], %[lo]\n\t"
+        "v_cmp_lt_u32 vcc, %[x], %[d]\n\t"
+        "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t"
+        "v_sub_u32 %[x], %[e2], %[lo]\n\t"
+        "v_cmp_lt_u32 vcc, %[x], %[d]\n\t"
+        "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc\n\t"
+        "v_sub_u32 %[x], %[e3], %[lo]\n\t"
+        "v_cmp_lt_u32 vcc, %[x], %[d]\n\t"
+        "v_addc_co_u32 %[m], vcc, %[m], %[m], vcc"
+        : [m] "=&v"(m), [x] "=&v"(x)
+        : [e0] "v"(e.x), [e1] "v"(e.y), [e2] "v"(e.z), [e3] "v"(e.w), [lo] "v"(lo1), [d] "v"(d)
+        : "vcc");
+    return m & (0xF0u >> n4);
+}
+
 // Park the kept words of a line in LDS: for each of the four entries, if the top bit of x is set { LDS[pos] = word, pos += 4 },
 // x <<= 1.  Per entry: v_add_co shifts the bit into vcc, the LDS write and the advance of the cursor run under that lane mask
 // (s_and_saveexec / s_mov exec: scalar unit) -- 2 VALU + 2 SALU + the write, no position arithmetic, no branch.
@@ -711,12 +737,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     const __amdgpu_buffer_rsrc_t rde =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(A.pv.rends), 0, (CONT || CREG) ? (A.pv.n_roots + 4u) * 4u : 0u, 0x00020000);
     const bool run_on = !(CREG && !inv);  // (uniform) a wide lane has a run of roots that start inside its region
-    // (Contained, a wide lane) which of up to four roots of the run, ends e, are kept: end <= qe (inverted: end > qe) and end > qs
-    // (start >= qs holds for the whole run; an empty interval AT qs does not overlap: tree.rs:110) -- a bit per root, the first one bit 3
-    auto run_mask = [inv](const gffx_v4u &e, uint32_t n4, uint32_t qs_, uint32_t qe_) {
-        return ((n4 > 0 && (e.x <= qe_) != inv && e.x > qs_) ? 8u : 0u) | ((n4 > 1 && (e.y <= qe_) != inv && e.y > qs_) ? 4u : 0u) |
-               ((n4 > 2 && (e.z <= qe_) != inv && e.z > qs_) ? 2u : 0u) | ((n4 > 3 && (e.w <= qe_) != inv && e.w > qs_) ? 1u : 0u);
-    };
+    auto run_mask = [inv](const gffx_v4u &e, uint32_t n4, uint32_t qs_, uint32_t qe_) { return pair_ends4(e, n4, qs_, qe_, inv); };
 
     // ---- what is left to do for the wave's previous D - 1 rounds once their segment bases are known (all wave-uniform;
     // entry 0 = the latest round)
@@ -832,7 +853,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         uint32_t off[4], rqs[4], rqe1[4];  // the line's byte offset; the region in the line's coordinates (rqe1 = its last base)
         bool swp[4];  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
         uint32_t off1[4], rel1[4], r0[4], nr[4];  // (mixed form, wide lanes) the line of qe - 1 and qe - 1 in its coordinates; the run of roots starting inside
-        uint32_t nra[4] = {0, 0, 0, 0}, em0[4] = {0, 0, 0, 0};  // (Contained) the run's length before the test of the ends (nr: the kept ones); the first four's kept bits
+        uint32_t nra[4] = {0, 0, 0, 0}, em0[4] = {0, 0, 0, 0};  // (Contained) the run's length before the test of the ends (nr: the kept ones); the kept bits of its first 32 roots (root 0 = bit 31)
         bool isw[4];                              // (mixed form) the lane serves this region the wide way
         uint32_t iswm = 0;                        // ... as a bit per region
         bool bigr[4];                             // (ContainsRegion, a wide lane) the region ends beyond what the line's coordinates reach
@@ -974,21 +995,52 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             }
             if constexpr (CONT) {
                 // Contained: the run [rank(qs), rank(qe)) holds the roots that START inside the region; kept are those that also END
-                // inside it -- the ends by position, sixteen bytes a trip, the four regions in step: counted here (the reservation
-                // needs the number), read again when the words are parked
-                uint32_t longest = 0;
+                // inside it (inverted: beyond it) -- the ends by position.  Counted here (the reservation needs the number); the kept bits
+                // of a run's first 32 roots stay in a register for the parking (em0: root 0 = bit 31).  First the four regions in step,
+                // four roots each (most runs end there); then every lane walks the REST of its own runs one after the other, sixteen
+                // roots a trip (four 16-byte loads in flight).
 #pragma unroll
-                for (int k = 0; k < 4; ++k) nra[k] = nr[k], nr[k] = 0u, longest = max(longest, nra[k]);
-                for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < longest); t += 4) {
+                for (int k = 0; k < 4; ++k) nra[k] = nr[k], nr[k] = 0u;
+                constexpr uint32_t kFirst = 4u;  // roots of every run tested in step
+                {
                     gffx_v4u ev[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) ev[k] = __builtin_amdgcn_raw_buffer_load_b128(rde, t < nra[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
+                    for (int k = 0; k < 4; ++k) ev[k] = __builtin_amdgcn_raw_buffer_load_b128(rde, nra[k] ? 4u * r0[k] : kWinNoLine, 0, 0);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const uint32_t msk = run_mask(ev[k], t < nra[k] ? min(nra[k] - t, 4u) : 0u, qs[k], qe[k]);
-                        nr[k] += __popc(msk);
-                        em0[k] = t == 0 ? msk : em0[k];
+                        const uint32_t msk = run_mask(ev[k], min(nra[k], 4u), qs[k], qe[k]);
+                        nr[k] = __popc(msk);
+                        em0[k] = msk << 28;
                     }
+                }
+                auto next_run = [&](int after) {  // (per lane) the thread's next region with a run longer than kFirst, or 4
+                    int r = 4;
+                    r = (nra[3] > kFirst && 3 > after) ? 3 : r;
+                    r = (nra[2] > kFirst && 2 > after) ? 2 : r;
+                    r = (nra[1] > kFirst && 1 > after) ? 1 : r;
+                    r = (nra[0] > kFirst && 0 > after) ? 0 : r;
+                    return r;
+                };
+                int ck = next_run(-1);
+                uint32_t t = kFirst;
+                while (__builtin_amdgcn_ballot_w64(ck < 4)) {
+                    const bool act = ck < 4;
+                    const uint32_t r0s = win_sel(r0, ck & 3), ls = win_sel(nra, ck & 3), qs_ = win_sel(qs, ck & 3), qe_ = win_sel(qe, ck & 3);
+                    gffx_v4u ev[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u)
+                        ev[u] = __builtin_amdgcn_raw_buffer_load_b128(rde, (act && t + 4u * u < ls) ? 4u * (r0s + t + 4u * u) : kWinNoLine, 0, 0);
+                    uint32_t m16 = 0;  // the trip's kept bits, root t = bit 15
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t tu = t + 4u * u;
+                        m16 = m16 << 4 | run_mask(ev[u], (act && tu < ls) ? min(ls - tu, 4u) : 0u, qs_, qe_);
+                    }
+                    const uint32_t c16 = __popc(m16), e32 = t < 32u ? (m16 << 16) >> t : 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nr[j] += ck == j ? c16 : 0u, em0[j] |= ck == j ? e32 : 0u;
+                    t += 16u;
+                    if (act && t >= ls) ck = next_run(ck), t = kFirst;
                 }
             }
         } else {
@@ -1095,7 +1147,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                     uint32_t pos = pb;
                     pair_park4(m[k] << 28, pos, wf[k].x, wf[k].y, wf[k].z, wf[k].w);
                     if constexpr (CONT) {
-                        pair_park4(em0[k] << 28, pos, rg[k].x, rg[k].y, rg[k].z, rg[k].w);
+                        pair_park4(em0[k], pos, rg[k].x, rg[k].y, rg[k].z, rg[k].w);  // (its top four bits: the run's first four roots)
                     } else if constexpr (WIDE) {
                         const uint32_t n4 = min(nr[k], 4u);
                         pair_park4(n4 ? 0xFFFFFFFFu << (32u - n4) : 0u, pos, rg[k].x, rg[k].y, rg[k].z, rg[k].w);
@@ -1123,9 +1175,10 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                     };
                     int ck = next_long(-1);
                     uint32_t cqs[4] = {0, 0, 0, 0}, cqe[4] = {0, 0, 0, 0};
-                    if (CONT && __builtin_amdgcn_ballot_w64(ck < 4)) {
-                        // (Contained: a long run's ends are tested against THIS round's regions, whose registers the next round's have
-                        //  taken: read them again)
+                    constexpr uint32_t kEm = 32u;  // roots of a run whose kept bits em0 holds
+                    if (CONT && __builtin_amdgcn_ballot_w64(max(max(len[0], len[1]), max(len[2], len[3])) > max(kEm, 4u))) {
+                        // (Contained: beyond a run's first 32 roots -- whose kept bits the count left in em0 -- the ends are tested again,
+                        //  against THIS round's regions, whose registers the next round's have taken: read them again)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (i0 + k < nq) {
@@ -1134,11 +1187,12 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                             }
                     }
                     uint32_t t = 4u, pc = win_sel(pd, ck & 3);
-                    constexpr int kTrip = CONT ? 1 : 4;  // 16-byte loads per trip and lane: what a trip costs is its round trip, not its width
+                    constexpr int kTrip = CONT ? 2 : 4;  // 16-byte loads of root_fids per trip and lane: what a trip costs is its round trip, not its width
                     while (__builtin_amdgcn_ballot_w64(ck < 4)) {
                         const bool act = ck < 4;
                         const uint32_t r0s = win_sel(r0, ck & 3), ls = win_sel(len, ck & 3);
-                        gffx_v4u v[kTrip], ev;
+                        gffx_v4u v[kTrip], ev[kTrip];
+                        const uint32_t ems = CONT ? win_sel(em0, ck & 3) : 0u;
 #pragma unroll
                         for (int u = 0; u < kTrip; ++u) {
                             const uint32_t tu = t + 4u * u;
@@ -1147,13 +1201,14 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                                 v[u].x = r0s + tu, v[u].y = r0s + tu + 1u, v[u].z = r0s + tu + 2u, v[u].w = r0s + tu + 3u;
                             else
                                 v[u] = __builtin_amdgcn_raw_buffer_load_b128(rfd, at, 0, 0);
-                            if (CONT) ev = __builtin_amdgcn_raw_buffer_load_b128(rde, at, 0, 0);
+                            if (CONT) ev[u] = __builtin_amdgcn_raw_buffer_load_b128(rde, tu >= kEm ? at : kWinNoLine, 0, 0);  // (a lane that does not read is free)
                         }
 #pragma unroll
                         for (int u = 0; u < kTrip; ++u) {
                             const uint32_t tu = t + 4u * u;
                             const uint32_t n4 = (act && tu < ls) ? min(ls - tu, 4u) : 0u;
-                            const uint32_t bits = CONT ? run_mask(ev, n4, win_sel(cqs, ck & 3), win_sel(cqe, ck & 3)) << 28 : (n4 ? 0xFFFFFFFFu << (32u - n4) : 0u);
+                            uint32_t bits = n4 ? 0xFFFFFFFFu << (32u - n4) : 0u;
+                            if (CONT) bits = tu < kEm ? (act ? ems << tu : 0u) : run_mask(ev[u], n4, win_sel(cqs, ck & 3), win_sel(cqe, ck & 3)) << 28;
                             pair_park4(bits, pc, v[u].x, v[u].y, v[u].z, v[u].w);
                         }
                         t += 4u * kTrip;
@@ -1165,7 +1220,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k)  // (where the run's words end: a list tail's / a sweep's words follow)
-                        pd[k] += 4u * (CONT ? nr[k] - (uint32_t)__popc(em0[k]) : (nr[k] > 4u ? nr[k] - 4u : 0u));
+                        pd[k] += 4u * (CONT ? nr[k] - (uint32_t)__popc(em0[k] >> 28) : (nr[k] > 4u ? nr[k] - 4u : 0u));
                 }
                 GFFX_WIN_STAMP(11);
                 if (__builtin_amdgcn_ballot_w64(deferred != 0)) {
@@ -1496,26 +1551,58 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 nr[k] = (swp[k] || !isw[k] || !run_on) ? 0u : rb[k] - ra[k];
             }
             if constexpr (CONT) {
-                // Contained: of the run of roots that start inside the region those that also end inside it (the ends by position,
-                // sixteen bytes a trip, the four regions in step): their bits are set here, one by one
+                // Contained: of the run of roots that start inside the region those that also end inside it (inverted: beyond it) --
+                // the ends by position, as in k_join_pairs: the four regions in step for the runs' first four roots, then every lane the
+                // rest of its own runs one after the other, sixteen roots a trip.  The kept roots' bits are consecutive positions: one
+                // or two ORs per trip.
                 uint32_t *bits = bm_words ? s_bm : g_bitmap;
-                const uint32_t longest = max(max(nr[0], nr[1]), max(nr[2], nr[3]));
                 uint32_t keptr[4] = {0, 0, 0, 0};
-                for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(t < longest); t += 4) {
+                auto set_bits = [&](uint32_t p, uint32_t mask /* root p = bit 0 */) {
+                    const uint32_t sh = p & 31u, lo = mask << sh, hi = sh ? mask >> (32u - sh) : 0u;
+                    if (lo) atomicOr(&bits[p >> 5], lo);
+                    if (hi) atomicOr(&bits[(p >> 5) + 1u], hi);
+                };
+                constexpr uint32_t kFirst = 4u;
+                {
                     gffx_v4u ev[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) ev[k] = __builtin_amdgcn_raw_buffer_load_b128(rde, t < nr[k] ? 4u * (r0[k] + t) : kWinNoLine, 0, 0);
+                    for (int k = 0; k < 4; ++k) ev[k] = __builtin_amdgcn_raw_buffer_load_b128(rde, nr[k] ? 4u * r0[k] : kWinNoLine, 0, 0);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const uint32_t n4 = t < nr[k] ? min(nr[k] - t, 4u) : 0u, e4[4] = {ev[k].x, ev[k].y, ev[k].z, ev[k].w};
-#pragma unroll
-                        for (uint32_t j = 0; j < 4; ++j)
-                            if (j < n4 && (e4[j] <= qe[k]) != inv && e4[j] > qs[k]) {
-                                const uint32_t p = r0[k] + t + j;
-                                atomicOr(&bits[p >> 5], 1u << (p & 31));
-                                ++keptr[k];
-                            }
+                        const uint32_t msk = pair_ends4(ev[k], min(nr[k], 4u), qs[k], qe[k], inv);
+                        set_bits(r0[k], __brev(msk) >> 28);
+                        keptr[k] = __popc(msk);
                     }
+                }
+                auto next_run = [&](int after) {
+                    int r = 4;
+                    r = (nr[3] > kFirst && 3 > after) ? 3 : r;
+                    r = (nr[2] > kFirst && 2 > after) ? 2 : r;
+                    r = (nr[1] > kFirst && 1 > after) ? 1 : r;
+                    r = (nr[0] > kFirst && 0 > after) ? 0 : r;
+                    return r;
+                };
+                int ck = next_run(-1);
+                uint32_t t = kFirst;
+                while (__builtin_amdgcn_ballot_w64(ck < 4)) {
+                    const bool act = ck < 4;
+                    const uint32_t r0s = win_sel(r0, ck & 3), ls = win_sel(nr, ck & 3), qs_ = win_sel(qs, ck & 3), qe_ = win_sel(qe, ck & 3);
+                    gffx_v4u ev[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u)
+                        ev[u] = __builtin_amdgcn_raw_buffer_load_b128(rde, (act && t + 4u * u < ls) ? 4u * (r0s + t + 4u * u) : kWinNoLine, 0, 0);
+                    uint32_t m16 = 0;  // root t = bit 15
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        const uint32_t tu = t + 4u * u;
+                        m16 = m16 << 4 | pair_ends4(ev[u], (act && tu < ls) ? min(ls - tu, 4u) : 0u, qs_, qe_, inv);
+                    }
+                    set_bits(r0s + t, __brev(m16) >> 16);
+                    const uint32_t c16 = __popc(m16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) keptr[j] += ck == j ? c16 : 0u;
+                    t += 16u;
+                    if (act && t >= ls) ck = next_run(ck), t = kFirst;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) nr[k] = 0u, tc[k] += keptr[k];  // (nothing is left for the range-OR below)
