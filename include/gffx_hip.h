@@ -291,7 +291,7 @@ int gffx_hip_batch_timed_runs(gffx_hip_batch *, int mode, int invert, uint32_t o
 int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
                            int strategy, uint64_t n_passes);
 /* Threads per block of the last windows-strategy pair pass of this batch (512 or 1024; 0: none ran).  The engine takes
- * 1024-thread blocks (one per CU, rounds of 4096 regions) for a batch of 0.5-2.5 M regions while NO other batch of the
+ * 1024-thread blocks (one per CU, rounds of 4096 regions) for a batch of 500 000 regions or more while NO other batch of the
  * index has passes in flight, 512-thread blocks (two per CU: kernels of two batches share the CUs) otherwise;
  * The knob GFFX_HIP_WIN_THREADS (512 / 1024) forces one. */
 uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *);

@@ -76,7 +76,7 @@ for it in range(iters):
                 if strat == engine.STRATEGY_WINDOWS:  # u32 offsets next to the u64 ones; the CLI's bitmap-only pass
                     flag_sets += [engine.OUT_FIDS | engine.OUT_OFFSETS | engine.OUT_OFFSETS32, engine.OUT_ROOT_BITMAP,
                                   engine.OUT_FIDS | engine.OUT_SEGBASE]  # (the pass bench.py times: one base per 256 regions)
-                    if it % 3 == 0:  # the 1024-thread variant of the pair pass (the engine takes it for 0.5-2.5 M regions alone)
+                    if it % 3 == 0:  # the 1024-thread variant of the pair pass (the engine takes it for batches of 500 000 regions or more that run alone)
                         b.set_option("WIN_THREADS", 1024)
                     else:
                         b.set_option("WIN_THREADS", 0)
