@@ -267,7 +267,7 @@ class Pass:
 
     def kernel_us(self, n_prof, block_threads=None):
         """HIP-event durations per kernel: serial launches back to back on batch 0's stream.  block_threads: the block width
-        the measured passes must use (the engine takes 1024-thread blocks for a 0.5-2.5 M-region pass that runs ALONE and
+        the measured passes must use (the engine takes 1024-thread blocks for a pass of 500 000 regions or more that runs ALONE and
         512-thread blocks while another batch is in flight: serial passes measured for a timed region with two batches in
         flight have to be told which kernel that region ran)."""
         b0 = self.batches[0]
@@ -751,7 +751,7 @@ def main():
         result["serial"] = {"ms_per_step": 1e3 * el / args.steps, "us_per_pass": 1e6 * el / n_passes, "value": nq * n_passes / el, "unit": "queries/s",
                             "batches_in_flight": 1,
                             "roofline": roofline_obj(ks, nq, pairs, out_b, "one batch, passes strictly one after the other: the engine "
-                                                     "takes 1024-thread blocks (one per CU) for a 0.5-2.5 M-region pass that runs alone",
+                                                     "takes 1024-thread blocks (one per CU) for a pass of 500 000 regions or more that runs alone",
                                                      None, ser.pass_us_one_event_pair, ser.block_threads)}
         ser.close()
     if world == 1 and not args.quick:
