@@ -2,8 +2,9 @@
 // line format of join_pairs_kernels.hpp): random indexes (seqids of 1 Kbp .. 4 Gbp, nested / empty / long roots), random regions that the
 // lines answer, all three modes.  Restates the kernel's use of a line on the CPU -- window of the region's last base,
 // 16-bit relative coordinates, the four inline tests, the list tail from win_spill -- and compares the kept root_fids with
-// a brute-force scan of the roots; then the WIDE form's reading (two lines and two rank words per region of any width, overlap
-// mode) against the same scan.  Runs without a GPU (tests/test_window_index_cpu.py); built by the Makefile of
+// a brute-force scan of the roots; then the WIDE form's reading (two lines and two rank words per region of any width; every mode,
+// inverted or not: what a wide lane keeps of the line of qs and of its run, the true ends where the lines' clamped ones do not tell)
+// against the same scan.  Runs without a GPU (tests/test_window_index_cpu.py); built by the Makefile of
 // gffx_amd/csrc into gffx_amd/bin/win_index_check.     usage: win_index_check [seed]
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -148,60 +149,94 @@ int main(int argc, char **argv) {
             const uint64_t wd = kind == 0 ? 1 + rng() % 3 : kind == 1 ? 1 + rng() % 50000 : kind == 2 ? 1 + rng() % 5000000 : 1 + rng() % 4000000000ull;
             const uint32_t qe = (uint32_t)std::min<uint64_t>((uint64_t)qs + wd, 0xFFFFFFFFull);
             if (qe <= qs) continue;
-            std::multiset<uint32_t> want, got;
-            for (uint32_t i = co[c]; i < co[c + 1]; i++)
-                if (keep(2, start[i], aux[i].x, qs, qe)) want.insert(aux[i].w);
-            bool marked = false;
-            uint32_t r[2];
-            for (int side = 0; side < 2; side++) {
-                uint32_t y = side ? qe - 1 : qs;
-                const bool past = (y >> m.z) >= m.y;
-                const uint32_t b = past ? m.y - 1 : y >> m.z;
-                if (past) y = 0xFFFFFFFFu;
-                const size_t w = (size_t)m.x + b;
-                const bool split = !sbits.empty() && (sbits[w >> 5] >> (w & 31) & 1u);
-                const uint32_t sh = m.z - (split ? gffx::kWinSplit : 0u);
-                static const uint32_t kZero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                const uint32_t *l = ww + 8 * w;
-                size_t line = w;
-                if (split) {
-                    line = n_win + (w << gffx::kWinSplit) + ((y >> sh) & ((1u << gffx::kWinSplit) - 1));
-                    const auto it = sub_of.find((uint32_t)line);
-                    l = it == sub_of.end() ? kZero : (const uint32_t *)&sub_lines[2 * it->second];
-                }
-                n_wide_reads++;
-                const uint32_t rel = (y & ((1u << sh) - 1)) + m.w;
-                uint32_t le = 0;
-                for (int j = 0; j < 4; j++) le += (l[j] & 0xFFFFu) <= rel;
-                if (side == 0)
-                    for (int j = 0; j < 4; j++)
-                        if (keep(2, l[j] & 0xFFFF, l[j] >> 16, rel, rel + 1)) got.insert(l[4 + j]);
-                if (l[3] == 0xFFFFFFFFu) {  // the list continues in win_spill: the header comes with the rank record
-                    const uint32_t hdr = rank[line].y;
-                    if (hdr != l[7]) { printf("RANK HEADER MISMATCH iter %d line %zu\n", iter, line); return 1; }
-                    if ((hdr & 255u) == 255u) { marked = true; break; }  // dense: the sweep
-                    const uint32_t base = side ? qe - 1 : qs;  // (absolute coordinates: the real base, also beyond the windows)
-                    for (uint32_t j = 3; j < (hdr & 255u); j++) {
-                        const uint4 x = spill[(hdr >> 8) + j - 3];
-                        if (x.x <= base) {
-                            le++;
-                            if (side == 0 && x.y > base) got.insert(x.z);
+            // what a wide lane keeps in each mode (join_pairs_kernels.hpp, pair_locate_mixed): {mode, inverted}
+            static const int kForms[5][2] = {{2, 0}, {0, 0}, {0, 1}, {1, 0}, {1, 1}};
+            const uint32_t *wpp = (const uint32_t *)wpos.data();
+            for (int form = 0; form < 5; form++) {
+                const int mode = kForms[form][0];
+                const bool inv = kForms[form][1] != 0, cont = mode == 0, creg = mode == 1, run_on = !(creg && !inv);
+                std::multiset<uint32_t> want, got;
+                for (uint32_t i = co[c]; i < co[c + 1]; i++)
+                    if (start[i] < qe && aux[i].x > qs && keep(mode, start[i], aux[i].x, qs, qe) != inv) want.insert(aux[i].w);
+                bool marked = false;
+                uint32_t r[2] = {0, 0};
+                for (int side = 0; side < (run_on ? 2 : 1); side++) {
+                    uint32_t y = side ? qe - 1 : qs;
+                    const bool past = (y >> m.z) >= m.y;
+                    const uint32_t b = past ? m.y - 1 : y >> m.z;
+                    if (past) y = 0xFFFFFFFFu;
+                    const size_t w = (size_t)m.x + b;
+                    const bool split = !sbits.empty() && (sbits[w >> 5] >> (w & 31) & 1u);
+                    const uint32_t sh = m.z - (split ? gffx::kWinSplit : 0u);
+                    static const uint32_t kZero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const uint32_t *l = ww + 8 * w, *lp = wpp + 8 * w;
+                    size_t line = w;
+                    if (split) {
+                        line = n_win + (w << gffx::kWinSplit) + ((y >> sh) & ((1u << gffx::kWinSplit) - 1));
+                        const auto it = sub_of.find((uint32_t)line);
+                        l = it == sub_of.end() ? kZero : (const uint32_t *)&sub_lines[2 * it->second];
+                        lp = it == sub_of.end() ? kZero : (const uint32_t *)&sub_lines_pos[2 * it->second];
+                    }
+                    if (form == 0) n_wide_reads++;
+                    const uint32_t rel = (y & ((1u << sh) - 1)) + m.w;
+                    // the rank counts the entries that start at or below ta: qs (Contained: qs - 1, unless qs lies beyond the windows)
+                    const uint32_t ta = (side == 0 && cont && !past) ? rel - 1 : rel;
+                    uint32_t le = 0;
+                    for (int j = 0; j < 4; j++) le += (l[j] & 0xFFFFu) <= ta;
+                    if (side == 0) {
+                        // ends are clamped at sat: beyond it the true end decides (pair_wide_resolve: positions, then the end column)
+                        const uint64_t sat = (1ull << sh) + m.w + 1, rqe = (uint64_t)rel + ((uint64_t)qe - qs);
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t sj = l[j] & 0xFFFFu, ej = l[j] >> 16;
+                            if (l[3] == 0xFFFFFFFFu && j == 3) break;
+                            const bool over = sj <= rel && ej > rel;
+                            bool k;
+                            if (cont) {
+                                k = inv && sj <= ta && ej > rel && (!past);
+                                if (past) k = inv && over;
+                            } else if (creg) {
+                                bool clause = sj <= rel && ej >= std::min(rqe, sat);
+                                if (clause && rqe > sat) clause = aux[lp[4 + j]].x >= qe;
+                                k = inv ? over && !clause : clause;
+                            } else {
+                                k = over;
+                            }
+                            if (k) got.insert(l[4 + j]);
                         }
                     }
-                    n_wide_tails++;
-                } else if (rank[line].y) { printf("RANK HEADER on an unmarked line, iter %d line %zu\n", iter, line); return 1; }
-                r[side] = rank[line].x + le;
-            }
-            if (marked) continue;  // a dense window: the kernel takes the sweep
-            if (r[1] < r[0] || r[1] > co[c + 1] || r[0] < co[c]) {
-                printf("RANK MISMATCH iter %d chr %u q [%u,%u): ranks %u %u outside [%u, %u]\n", iter, c, qs, qe, r[0], r[1], co[c], co[c + 1]);
-                return 1;
-            }
-            for (uint32_t i = r[0]; i < r[1]; i++) got.insert(aux[i].w);
-            n_wide++;
-            if (want != got) {
-                printf("WIDE MISMATCH iter %d chr %u q [%u,%u) want %zu got %zu (ranks %u %u) shift %u wmax %u\n", iter, c, qs, qe, want.size(), got.size(), r[0], r[1], m.z, m.w);
-                return 1;
+                    if (l[3] == 0xFFFFFFFFu) {  // the list continues in win_spill: the header comes with the rank record
+                        const uint32_t hdr = rank[line].y;
+                        if (hdr != l[7]) { printf("RANK HEADER MISMATCH iter %d line %zu\n", iter, line); return 1; }
+                        if ((hdr & 255u) == 255u) { marked = true; break; }  // dense: the sweep
+                        const uint32_t base = side ? qe - 1 : qs;  // (absolute coordinates: the real base, also beyond the windows)
+                        for (uint32_t j = 3; j < (hdr & 255u); j++) {
+                            const uint4 x = spill[(hdr >> 8) + j - 3];
+                            if ((side == 0 && cont) ? x.x < base : x.x <= base) {
+                                le++;
+                                const bool over = x.y > base;
+                                const bool k = cont ? inv && over : creg ? over && ((x.y > qe - 1) != inv) : over;
+                                if (side == 0 && k) got.insert(x.z);
+                            }
+                        }
+                        if (form == 0) n_wide_tails++;
+                    } else if (rank[line].y) { printf("RANK HEADER on an unmarked line, iter %d line %zu\n", iter, line); return 1; }
+                    r[side] = rank[line].x + le;
+                }
+                if (marked) break;  // a dense window: the kernel takes the sweep
+                if (run_on) {
+                    if (r[1] < r[0] || r[1] > co[c + 1] || r[0] < co[c]) {
+                        printf("RANK MISMATCH iter %d chr %u q [%u,%u) form %d: ranks %u %u outside [%u, %u]\n", iter, c, qs, qe, form, r[0], r[1], co[c], co[c + 1]);
+                        return 1;
+                    }
+                    for (uint32_t i = r[0]; i < r[1]; i++)
+                        if (!cont || ((aux[i].x <= qe) != inv && aux[i].x > qs)) got.insert(aux[i].w);
+                }
+                if (form == 0) n_wide++;
+                if (want != got) {
+                    printf("WIDE MISMATCH iter %d chr %u q [%u,%u) mode %d invert %d want %zu got %zu (ranks %u %u) shift %u wmax %u\n", iter, c, qs, qe, mode, (int)inv,
+                           want.size(), got.size(), r[0], r[1], m.z, m.w);
+                    return 1;
+                }
             }
         }
     }
