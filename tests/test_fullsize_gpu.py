@@ -34,12 +34,12 @@ def gencode():
     return roots, engine.TreeIndexData.from_roots(co, s, e, f), ob.OracleIndex.from_roots(co, s, e, f)
 
 
-def _full_parity(ix, oix, regions, mode, batch=None):
+def _full_parity(ix, oix, regions, mode, batch=None, inv=False):
     """counts, sorted root_fid multiset, per-region segments (via the offsets) and the unique roots of ALL regions"""
-    want_t, want_c = oix.query_features(regions, int(mode), False)
+    want_t, want_c = oix.query_features(regions, int(mode), inv)
     b = batch or engine.QueryBatch(ix, len(regions))
     b.set_regions(regions)
-    b.run(mode, False, engine.OUT_FIDS | engine.OUT_OFFSETS)  # AUTO
+    b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS)  # AUTO
     b.wait()
     assert b.total_hits == len(want_t)
     assert np.array_equal(b.counts(), want_c)
@@ -53,7 +53,7 @@ def _full_parity(ix, oix, regions, mode, batch=None):
     by_chr = np.argsort(regions[:, 0], kind="stable")  # the oracle walks seqid after seqid, regions in input order
     want = (np.repeat(by_chr, wc[by_chr]).astype(np.int64) << 32) | want_t[:, 0].astype(np.int64)
     assert np.array_equal(np.sort(got), np.sort(want))
-    b.run(mode, False, engine.OUT_ROOT_BITMAP)  # the pass the CLI runs
+    b.run(mode, inv, engine.OUT_ROOT_BITMAP)  # the pass the CLI runs
     b.wait()
     assert np.array_equal(b.unique_roots(), np.unique(want_t[:, 0]))
     if batch is None:
@@ -67,6 +67,23 @@ def test_config2_join_a_10m_all_modes_full_parity(gencode):
     b = engine.QueryBatch(ix, len(regions))
     for mode in OverlapMode:
         assert _full_parity(ix, oix, regions, mode, batch=b) > 0
+    b.close()
+
+
+def test_config2_10m_regions_with_sv_sized_rows_every_mode_full_parity(gencode):
+    """configs[2]'s 10 M regions with every tenth row widened to U[20 k, 2 M] bases (bench.py's mixed_widths shape): AUTO takes the
+    MIXED form of the window kernels (round 5) -- narrow and wide regions lane by lane in one launch -- in every mode, inverted or
+    not; every count, every region's segment and the unique roots against the whole oracle."""
+    roots, ix, oix = gencode
+    regions = synth.synth_bed(10_000_000, seed=1002)
+    rng = np.random.default_rng(77)
+    wide = np.arange(0, len(regions), 10)
+    regions[wide, 2] = np.minimum(regions[wide, 1].astype(np.int64) + rng.integers(20_000, 2_000_000, len(wide)), 0xFFFFFFF0).astype(np.uint32)
+    b = engine.QueryBatch(ix, len(regions))
+    for mode, inv in ((OverlapMode.Overlap, False), (OverlapMode.Contained, False), (OverlapMode.ContainsRegion, False),
+                      (OverlapMode.Contained, True), (OverlapMode.ContainsRegion, True)):
+        assert _full_parity(ix, oix, regions, mode, batch=b, inv=inv) > 0
+        assert b.wide_form
     b.close()
 
 

@@ -300,10 +300,28 @@ def test_wide_form_full_size_properties(wide_forced, monkeypatch):
     wt, wc = oix.query_features(regions[pick], OV, False)
     assert np.array_equal(c[pick], wc)
     assert np.array_equal(_pairs_of(regions[pick], wc, off[:-1][pick], f), _want_pairs(regions[pick], wt, wc))
+    # the other modes at full size, through properties that need no oracle (intersect.rs:145-161): a mode's pass and its inverted
+    # pass split the overlap pass's pairs between them, region by region -- counts, and the sorted root_fids of the sample's regions;
+    # the sample itself against the oracle
+    fs = np.sort(f)
+    for mode in (OverlapMode.Contained, OverlapMode.ContainsRegion):
+        got = []
+        for inv in (False, True):
+            b.run(mode, inv, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_WINDOWS)
+            b.wait()
+            assert b.wide_form
+            cm, om, fm = b.counts(), b.offsets(), b.fids()
+            assert int(cm.sum()) == b.total_hits == len(fm)
+            wt, wc = oix.query_features(regions[pick], int(mode), inv)
+            assert np.array_equal(cm[pick], wc)
+            assert np.array_equal(_pairs_of(regions[pick], wc, om[:-1][pick], fm), _want_pairs(regions[pick], wt, wc))
+            got.append((cm, fm))
+        assert np.array_equal(got[0][0] + got[1][0], c)
+        assert np.array_equal(np.sort(np.concatenate([got[0][1], got[1][1]])), fs)
     b.set_option("WIN_WIDE", 0)  # (a batch reads its knobs from the environment once, when it is created; later: set_option)
     b.run(OV, False, engine.OUT_FIDS | engine.OUT_OFFSETS, engine.STRATEGY_FUSED)
     b.wait()
-    assert not b.wide_form and np.array_equal(b.counts(), c) and np.array_equal(np.sort(b.fids()), np.sort(f))
+    assert not b.wide_form and np.array_equal(b.counts(), c) and np.array_equal(fs, np.sort(b.fids()))
     b.close()
     ix.close()
 
