@@ -265,19 +265,24 @@ class Pass:
             bb.wait()
             assert bb.total_hits == pairs, (bb.total_hits, pairs)
 
-    def kernel_us(self, n_prof, block_threads=None):
+    def kernel_us(self, n_prof, block_threads=None, blocks=None):
         """HIP-event durations per kernel: serial launches back to back on batch 0's stream.  block_threads: the block width
         the measured passes must use (the engine takes 1024-thread blocks for a pass of 500 000 regions or more that runs ALONE and
         512-thread blocks while another batch is in flight: serial passes measured for a timed region with two batches in
-        flight have to be told which kernel that region ran)."""
+        flight have to be told which kernel that region ran).  blocks: likewise the grid (one 512-thread block per CU from the
+        third batch in flight on)."""
         b0 = self.batches[0]
         before = b0.options().get("GFFX_HIP_WIN_THREADS", 0)
+        before_blocks = b0.options().get("GFFX_HIP_FUSED_BLOCKS", 0)
         if block_threads:
             b0.set_option("WIN_THREADS", block_threads)
+        if blocks:
+            b0.set_option("FUSED_BLOCKS", blocks)
         try:
             return self._kernel_us(n_prof)
         finally:
             b0.set_option("WIN_THREADS", before)
+            b0.set_option("FUSED_BLOCKS", before_blocks)
 
     def _kernel_us(self, n_prof):
         b0 = self.batches[0]
@@ -295,6 +300,7 @@ class Pass:
         # the same passes between ONE event pair: launch-to-launch average without the ~3 us an event pair per launch adds
         self.pass_us_one_event_pair = b0.timed_runs(self.mode, False, self.flags, self.strategy, max(n_prof, 20))
         self.block_threads = b0.block_threads
+        self.block_count = b0.block_count
         return kern
 
     def close(self):
@@ -302,7 +308,7 @@ class Pass:
             bb.close()
 
 
-def roofline_obj(kern, nq, pairs, out_b, note, traffic=None, one_pair_us=None, block_threads=None):
+def roofline_obj(kern, nq, pairs, out_b, note, traffic=None, one_pair_us=None, block_threads=None, blocks=None):
     h_bar = pairs / max(nq, 1)
     bytes_per_query = 12.0 + 4.0 + out_b * h_bar  # regions in, count out, pairs out
     per_launch_us = sum(k["avg_us"] * k["launches_per_step"] for k in kern.values())
@@ -315,10 +321,10 @@ def roofline_obj(kern, nq, pairs, out_b, note, traffic=None, one_pair_us=None, b
             "frac_of_copy_ceiling": achieved / 6300.0, "traffic": traffic, "dominant_kernel": dominant,
             "regions_per_launch": nq, "pairs_per_region": h_bar, "algorithmic_bytes_per_pass": bytes_per_query * nq,
             "pass_kernel_us": pass_us, "pass_kernel_us_event_pair_per_launch": per_launch_us, "kernels": kern,
-            "block_threads": block_threads, "note": note}
+            "block_threads": block_threads, "blocks": blocks, "note": note}
 
 
-def measure_traffic(args, block_threads=None):
+def measure_traffic(args, block_threads=None, blocks=None):
     """roofline.traffic, measured by THIS run: HBM bytes per launch of the dominant kernel from the L2's fabric counters,
     collected as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --kernel-trace --pmc`
     passes (never combined with other trace domains), per-dispatch averages, FETCH_SIZE doubled (gfx950 reports half the
@@ -342,6 +348,8 @@ def measure_traffic(args, block_threads=None):
                 env = dict(os.environ, TMPDIR="/tmp")
                 if block_threads:  # (the child's serial passes must run the kernel variant of the timed region)
                     env["GFFX_HIP_WIN_THREADS"] = str(block_threads)
+                if blocks:
+                    env["GFFX_HIP_FUSED_BLOCKS"] = str(blocks)
                 r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=240)
             except Exception as exc:
                 return {"error": repr(exc)[:200]}
@@ -668,7 +676,8 @@ def main():
         # the kernel variant the timed region ran (the last pass of batch 0 in it): the serial passes measured for `roofline`
         # and the PMC child are forced to the same block width
         timed_threads = run.batches[0].block_threads or None
-        kern = run.kernel_us(max(5, min(args.steps, 30)), timed_threads)
+        timed_blocks = run.batches[0].block_count or None
+        kern = run.kernel_us(max(5, min(args.steps, 30)), timed_threads, timed_blocks)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if world > 1:
@@ -683,7 +692,7 @@ def main():
             except Exception:
                 traffic = None
         if world == 1 and not args.no_traffic and not args.quick:
-            live = measure_traffic(args, timed_threads)
+            live = measure_traffic(args, timed_threads, timed_blocks)
             if live and "error" not in live:
                 traffic = live
             elif live and traffic is not None:
@@ -735,11 +744,13 @@ def main():
             "roofline": roofline_obj(kern, nq, pairs, out_b,
                                      "achieved = (12 B region + 4 B count + 4 B x pairs/region) x regions / summed HIP-event "
                                      "duration of a pass: serial launches back to back between one pair of HIP events on the engine's "
-                                     "stream (rank 0), forced to the block width of the timed region's launches (block_threads); "
+                                     "stream (rank 0), forced to the block width and the grid of the timed region's launches (block_threads, "
+                                     "blocks: with three batches in flight the engine launches ONE 512-thread block per CU, so that two "
+                                     "batches' kernels are resident side by side -- alone, as measured here, such a launch uses half the slots); "
                                      "kernels{} = the same with an event pair per launch.  The resident batch is re-read by every "
                                      "pass: at 1 M regions (12 MB) the input stream is served by the 256 MB Infinity Cache, not by HBM "
                                      "(immaterial at this fraction of the roofline, but it is not a cold-HBM figure)", traffic,
-                                     run.pass_us_one_event_pair, timed_threads),
+                                     run.pass_us_one_event_pair, timed_threads, timed_blocks),
         }
     if world == 1:
         # ---- strictly serial passes (one batch, one stream): what the committed rocprofv3 kernel stats show

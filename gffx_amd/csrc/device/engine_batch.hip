@@ -485,7 +485,8 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     b->ran = true;
     b->waited = false;
     b->total = 0;
-    b->others_busy = b->ix->busy_batches.v.load(std::memory_order_relaxed) - (b->busy ? 1 : 0) > 0;
+    b->others = (int)b->ix->busy_batches.v.load(std::memory_order_relaxed) - (b->busy ? 1 : 0);
+    b->others_busy = b->others > 0;
     if (!b->busy) {
         b->busy = true;
         b->ix->busy_batches.v.fetch_add(1, std::memory_order_relaxed);
@@ -802,6 +803,7 @@ extern "C" int gffx_hip_batch_kernel_ms(gffx_hip_batch *b, int kernel_id, double
 // n passes back to back on the batch's stream between ONE pair of HIP events: the average launch-to-launch duration without
 // the cost of an event pair per launch (which adds ~3 us to a ~18 us kernel)
 extern "C" uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *b) { return b ? b->win_threads : 0; }
+extern "C" uint32_t gffx_hip_batch_block_count(const gffx_hip_batch *b) { return b ? b->win_blocks : 0; }
 extern "C" int gffx_hip_batch_wide_form(const gffx_hip_batch *b) { return b && b->wide ? 1 : 0; }
 
 extern "C" int gffx_hip_batch_timed_runs(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags, int strategy, uint32_t n,

@@ -269,6 +269,8 @@ struct gffx_hip_batch {
     uint64_t chunk = 0;
     bool ran = false, waited = false;
     uint32_t win_threads = 0;  // block width of the last windows pair pass (gffx_hip_batch_block_threads)
+    uint32_t win_blocks = 0;   // ... and its grid (gffx_hip_batch_block_count)
+    int others = 0;            // at the last run: how many OTHER batches of the index had passes in flight
     bool others_busy = false;  // at the last run: another batch of the index had passes in flight (co-resident kernels)
     bool busy = false;  // counted in ix->busy_batches: a pass was enqueued since the last stream synchronisation
     uint64_t total = 0;

@@ -138,7 +138,14 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     if (!roots) b->win_threads = threads;
     const uint64_t rounds = (b->nq + 4ull * threads - 1) / (4ull * threads);
     const long blocks_knob = b->knobs.v[roots ? BK_BITMAP_BLOCKS : BK_FUSED_BLOCKS];
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)(blocks_knob ? blocks_knob : (threads == 1024 ? 256 : 512)));
+    // Blocks per launch: every slot of the 256 CUs (one 1024-thread block or two 512-thread blocks each) -- but ONE 512-thread block
+    // per CU for a pair pass launched while two or more other batches of the index have passes in flight: kernels of different
+    // streams only run side by side when each leaves slots free, and three batches of 256 blocks keep two kernels resident at all
+    // times (1 M regions, three in flight: 8.5 us per pass against 9.4 with 512 blocks; with ONE other batch in flight 512 blocks
+    // are better, 9.6 against 10.4: profiles/r05_blocks_in_flight.txt).  The root passes were not measured that way and keep 512.
+    const uint32_t slots = threads == 1024 ? 256u : (!roots && b->others >= 2) ? 256u : 512u;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)(blocks_knob ? blocks_knob : slots));
+    if (!roots) b->win_blocks = grid;
     if (roots && !second) {
         b->roots_blocks = grid;
         o.sums_valid = b->sums_valid;  // (the kept pairs of a run of GFFX_OUT_BITMAP_KEEP passes add up per block: gffx_hip_batch_kept_pairs_accumulated)

@@ -197,6 +197,11 @@ class QueryBatch:
         return int(lib().gffx_hip_batch_block_threads(self._h))
 
     @property
+    def block_count(self) -> int:
+        """blocks of that launch (one 512-thread block per CU when two or more other batches of the index were in flight)"""
+        return int(lib().gffx_hip_batch_block_count(self._h))
+
+    @property
     def wide_form(self) -> bool:
         """the last run's pair passes took the wide form of the window kernel (regions of any width, every mode)"""
         return bool(lib().gffx_hip_batch_wide_form(self._h))

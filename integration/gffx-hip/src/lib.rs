@@ -72,6 +72,7 @@ extern "C" {
     pub fn gffx_hip_batch_wait(b: *mut gffx_hip_batch) -> c_int;
     pub fn gffx_hip_batch_sync(b: *mut gffx_hip_batch) -> c_int;
     pub fn gffx_hip_batch_block_threads(b: *const gffx_hip_batch) -> u32;
+    pub fn gffx_hip_batch_block_count(b: *const gffx_hip_batch) -> u32;
     pub fn gffx_hip_batch_wide_form(b: *const gffx_hip_batch) -> c_int; // (round 5: the MIXED form -- narrow and wide regions lane by lane)
     // round 5: tuning knobs (read from the environment once per object; changed through set_option), the non-default ones as JSON;
     // the kept pairs of all root passes since the last pass without GFFX_OUT_BITMAP_KEEP (a streaming caller's per-device hit count)

@@ -2,11 +2,12 @@
 # Round 5's evidence, made on the GPU box in one gpurun call (from the repo root):
 #   tools/profile_r05.sh            -> gpurun_out/r05_*  (copy what is to be judged into profiles/)
 # kernel-trace stats + PMC counters (separate passes, tools/profile_pmc.sh; one kernel variant and one batch size per file) of the
-# pair kernel at 1 M regions in the timed region's 512-thread form and alone (1024 threads), at 10 M regions, of the mixed form on
+# pair kernel at 1 M regions in the timed region's form (512 threads x 256 blocks; and x 489, two batches in flight) and alone (1024 threads), at 10 M regions, of the mixed form on
 # wide regions and on a batch with every tenth row SV-sized, every kernel of a full bench.py run, Join B's kernels, and the bench line.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 GFFX_HIP_WIN_THREADS=512 bash tools/profile_pmc.sh r05_joinA_pairs_1m_512
+GFFX_HIP_WIN_THREADS=512 GFFX_HIP_FUSED_BLOCKS=256 bash tools/profile_pmc.sh r05_joinA_pairs_1m_512x256  # the timed region's launches: one 512-thread block per CU (three batches in flight)
 bash tools/profile_pmc.sh r05_joinA_pairs_1m
 bash tools/profile_pmc.sh r05_joinA_pairs_10m --queries-per-gpu 10000000
 bash tools/profile_pmc.sh r05_joinA_wide_1m --region-width 100 200000 --offsets u64
