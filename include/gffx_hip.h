@@ -296,8 +296,8 @@ int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, i
  * The knob GFFX_HIP_WIN_THREADS (512 / 1024) forces one. */
 uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *);
 /* Blocks of that launch: as many as the device has slots for (256 blocks of 1024 threads, 512 of 512 threads), fewer for a small
- * batch (a block per round of 4 x threads regions) -- and 256 blocks of 512 threads (one per CU) for a pair pass launched while TWO OR
- * MORE other batches of the index have passes in flight: kernels of different streams run side by side only when each leaves
+ * batch (a block per round of 4 x threads regions) -- and 256 blocks of 512 threads (one per CU) for a pair pass over at most ~2 M
+ * regions launched while TWO OR MORE other batches of the index have passes in flight: kernels of different streams run side by side only when each leaves
  * slots free, and that is where three batches in flight gain (measured; with one other batch in flight the full grid is better).
  * The knob GFFX_HIP_FUSED_BLOCKS forces a count (GFFX_HIP_BITMAP_BLOCKS: the root passes'). */
 uint32_t gffx_hip_batch_block_count(const gffx_hip_batch *);
