@@ -144,8 +144,9 @@ static int run_windows_pass(gffx_hip_batch *b, int kind, bool second) {
     // times (1 M regions, three in flight: 8.5 us per pass against 9.4 with 512 blocks; with ONE other batch in flight 512 blocks
     // are better, 9.6 against 10.4: profiles/r05_blocks_in_flight.txt).  Only for batches of up to ~2 M regions (1024 rounds): a larger
     // one gains nothing from overlapping its ramp and drain, and would run on half the slots whenever the other batches' passes are
-    // long finished but not yet synchronised with.  The root passes were not measured that way and keep 512.
-    const uint32_t slots = threads == 1024 ? 256u : (!roots && b->others >= 2 && rounds <= 1024) ? 256u : 512u;
+    // long finished but not yet synchronised with.  A ROOT pass takes one block per CU as soon as ONE other batch is in flight: 9.3 us
+    // per pass against 10.1 with two batches in flight, 7.9 against 10.0 with three, 9.7 against 11.1 with four.
+    const uint32_t slots = threads == 1024 ? 256u : (b->others >= (roots ? 1 : 2) && rounds <= 1024) ? 256u : 512u;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(rounds, (uint64_t)(blocks_knob ? blocks_knob : slots));
     if (!roots) b->win_blocks = grid;
     if (roots && !second) {

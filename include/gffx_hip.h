@@ -299,6 +299,7 @@ uint32_t gffx_hip_batch_block_threads(const gffx_hip_batch *);
  * batch (a block per round of 4 x threads regions) -- and 256 blocks of 512 threads (one per CU) for a pair pass over at most ~2 M
  * regions launched while TWO OR MORE other batches of the index have passes in flight: kernels of different streams run side by side only when each leaves
  * slots free, and that is where three batches in flight gain (measured; with one other batch in flight the full grid is better).
+ * A root pass (GFFX_OUT_ROOT_BITMAP alone) takes one block per CU as soon as ONE other batch is in flight (measured likewise).
  * The knob GFFX_HIP_FUSED_BLOCKS forces a count (GFFX_HIP_BITMAP_BLOCKS: the root passes'). */
 uint32_t gffx_hip_batch_block_count(const gffx_hip_batch *);
 /* 1 when the last run's passes took the MIXED form of the window kernels (every mode, inverted or not; round 4's "wide form" is
