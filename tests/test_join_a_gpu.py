@@ -448,6 +448,39 @@ def test_slots_wide_empty_and_dense_regions_take_the_exact_lane(mode, invert, st
         _check(roots2, regions, mode, invert, soa=bool(nq & 1), strategy=strategy)
 
 
+def test_launch_grid_follows_the_batches_in_flight():
+    """(round 5) Block width and grid of a pair pass follow what else is in flight on the index: alone 1024-thread blocks, one per
+    round; with ONE other batch in flight 512-thread blocks, a block per slot; from the third batch on ONE 512-thread block per CU
+    (256), so that two batches' kernels are resident side by side (include/gffx_hip.h, gffx_hip_batch_block_count).  The results do
+    not depend on any of it."""
+    roots = synth.gencode_like_roots(20000, seed=6)
+    co, s, e, f = roots["chr_offsets"], roots["start"], roots["end"], roots["fid"]
+    ix = engine.TreeIndexData.from_roots(co, s, e, f)
+    oix = ob.OracleIndex.from_roots(co, s, e, f)
+    regions = synth.synth_bed(600_000, seed=21, edge_frac=0.01, roots=roots)
+    _, want_c = oix.query_features(regions, 2, False)
+    bs = [engine.QueryBatch(ix, len(regions)) for _ in range(3)]
+    for b in bs:
+        b.set_regions(regions)
+    flags = engine.OUT_FIDS | engine.OUT_SEGBASE
+    bs[0].run(OverlapMode.Overlap, False, flags)
+    bs[0].wait()
+    assert (bs[0].block_threads, bs[0].block_count) == (1024, (len(regions) + 4095) // 4096)
+    for b in bs:  # nobody waits in between: the second launch sees one busy batch, the third two
+        b.run(OverlapMode.Overlap, False, flags)
+    assert (bs[0].block_threads, bs[1].block_threads, bs[2].block_threads) == (1024, 512, 512)
+    assert (bs[1].block_count, bs[2].block_count) == ((len(regions) + 2047) // 2048, 256)
+    for b in bs:
+        b.wait()
+        assert np.array_equal(b.counts(), want_c)
+    bs[1].run(OverlapMode.Overlap, False, flags)  # everything was waited for: alone again
+    bs[1].wait()
+    assert bs[1].block_threads == 1024 and np.array_equal(bs[1].counts(), want_c)
+    for b in bs:
+        b.close()
+    ix.close()
+
+
 def test_auto_moves_a_batch_of_wide_regions_off_the_narrow_form():
     """AUTO: a batch of mostly wide regions -- found by a sample of the rows the host hands over, or by a first waited pass that
     sent most regions to the exact sweep (tests/test_wide_form_gpu.py) -- runs on the mixed form of the window kernel (Overlap: round
