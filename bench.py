@@ -84,7 +84,7 @@ def parse_args():
     ap.add_argument("--offsets", default="seg", choices=["seg", "u32", "u64", "none"],
                     help="where the pairs of a region are: seg = one u64 base per group of 256 regions (GFFX_OUT_SEGBASE, windows "
                          "strategy / auto); u32 / u64 = a segment start per region")
-    ap.add_argument("--presort", default="none", choices=["none", "chr_end"],
+    ap.add_argument("--presort", default="none", choices=["none", "chr_end", "chr_start"],
                     help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
     ap.add_argument("--exchange", default=None, choices=["final", "final-timed", "per-step"])
     ap.add_argument("--inflight", type=int, default=3,
@@ -601,6 +601,8 @@ def main():
                                             args.region_width, args.wide_every)
     if args.presort == "chr_end":
         regions = np.ascontiguousarray(regions[np.lexsort((regions[:, 2], regions[:, 0]))])
+    elif args.presort == "chr_start":  # (as BED files usually are; the `sorted_bed` leg's order)
+        regions = np.ascontiguousarray(regions[np.lexsort((regions[:, 1], regions[:, 0]))])
     nq = len(regions)
 
     ix = engine.TreeIndexData.from_roots(roots["chr_offsets"], roots["start"], roots["end"], roots["fid"],

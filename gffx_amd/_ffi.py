@@ -76,6 +76,8 @@ SIGNATURES = {
     "gffx_hip_batch_block_count": (C.c_uint32, [vp]),
     "gffx_hip_batch_wide_form": (C.c_int, [vp]),
     "gffx_hip_batches_run_n": (C.c_int, [C.POINTER(vp), C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint64]),
+    "gffx_hip_batches_timed_runs": (C.c_int, [C.POINTER(vp), C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32,
+                                    C.POINTER(C.c_double), u32p]),
     "gffx_hip_batch_timed_runs": (C.c_int, [vp, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]),
     "gffx_hip_query_features": (C.c_int, [vp, u32p, C.c_uint64, C.c_int, C.c_int, C.POINTER(u32p), u64p]),
     "gffx_hip_free_host": (None, [vp]),

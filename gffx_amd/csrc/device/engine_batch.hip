@@ -22,11 +22,12 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(GFFX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     if ((rc = dev_alloc(&b->d_counts, max_queries)) || (rc = dev_alloc(&b->d_block_sums, 2 * gffx_hip_batch::kMaxBlocks)) ||
-        (rc = dev_alloc(&b->d_status, gffx_hip_batch::kStatusWords))) {
+        (rc = dev_alloc(&b->d_status, gffx_hip_batch::kStatusWords)) || (rc = dev_alloc(&b->d_ticket, 64))) {
         gffx_hip_batch_destroy(b.release());
         return rc;
     }
     GFFX_HIP_TRY(hipMemset(b->d_status, 0, gffx_hip_batch::kStatusWords * sizeof(unsigned long long)));
+    GFFX_HIP_TRY(hipMemset(b->d_ticket, 0, 64 * sizeof(uint32_t)));
     GFFX_HIP_TRY(hipDeviceSynchronize());  // NULL-stream memset vs the batch's non-blocking stream
     e = hipHostMalloc((void **)&b->h_status, (1 + gffx_hip_batch::kMaxBlocks) * sizeof(unsigned long long),
                       hipHostMallocDefault);
@@ -41,7 +42,9 @@ extern "C" int gffx_hip_batch_create(const gffx_hip_index *ix, uint64_t max_quer
 extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->ix->device);
+    if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->join_ev) (void)hipEventDestroy(b->join_ev);
     if (b->busy) b->ix->busy_batches.v.fetch_sub(1, std::memory_order_relaxed);
     for (auto &p : b->pending) {
         (void)hipEventDestroy(p.a);
@@ -52,6 +55,7 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     (void)hipFree(b->d_counts);
     (void)hipFree(b->d_block_sums);
     (void)hipFree(b->d_status);
+    (void)hipFree(b->d_ticket);
     (void)hipFree(b->d_fids);
     (void)hipFree(b->d_triples);
     (void)hipFree(b->d_bitmap);
@@ -66,6 +70,20 @@ extern "C" void gffx_hip_batch_destroy(gffx_hip_batch *b) {
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
+
+// Stream `s` behind the batch's newest work (which may be on another stream: a launch that served several batches); the batch's
+// newest work is on `s` from now on.  No call into the runtime when it already is.
+int gffx::batch_join_stream(gffx_hip_batch *b, hipStream_t s) {
+    const hipStream_t newest = b->last_stream ? b->last_stream : b->stream;
+    if (newest != s) {
+        if (!b->join_ev) GFFX_HIP_TRY(hipEventCreateWithFlags(&b->join_ev, hipEventDisableTiming));
+        GFFX_HIP_TRY(hipEventRecord(b->join_ev, newest));
+        GFFX_HIP_TRY(hipStreamWaitEvent(s, b->join_ev, 0));
+    }
+    b->last_stream = s == b->stream ? nullptr : s;
+    return GFFX_OK;
+}
+int gffx::batch_own_stream(gffx_hip_batch *b) { return b->last_stream ? batch_join_stream(b, b->stream) : GFFX_OK; }
 
 int gffx::batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who) {
     if (!b) return fail(GFFX_E_INVALID, "%s: batch is NULL", who);
@@ -103,6 +121,7 @@ extern "C" int gffx_hip_batch_set_regions_host(gffx_hip_batch *b, const uint32_t
     if (nq && !regions) return fail(GFFX_E_INVALID, "set_regions_host: regions is NULL");
     GFFX_HIP_TRY(hipSetDevice(b->ix->device));
     if (!b->d_regions && (rc = dev_alloc(&b->d_regions, 3 * b->max_q))) return rc;
+    if ((rc = batch_own_stream(b))) return rc;
     if (nq)
         GFFX_HIP_TRY(hipMemcpyAsync(b->d_regions, regions, nq * 12, hipMemcpyHostToDevice, b->stream));
     b->q = QueryView{b->d_regions, nullptr, nullptr, nullptr};
@@ -121,6 +140,7 @@ extern "C" int gffx_hip_batch_set_regions_soa_host(gffx_hip_batch *b, const uint
     if (nq && (!chr || !start || !end)) return fail(GFFX_E_INVALID, "set_regions_soa_host: NULL array");
     GFFX_HIP_TRY(hipSetDevice(b->ix->device));
     if (!b->d_soa && (rc = dev_alloc(&b->d_soa, 3 * b->max_q))) return rc;
+    if ((rc = batch_own_stream(b))) return rc;
     uint32_t *dc = b->d_soa, *ds = b->d_soa + b->max_q, *de = b->d_soa + 2 * b->max_q;
     if (nq) {
         GFFX_HIP_TRY(hipMemcpyAsync(dc, chr, nq * 4, hipMemcpyHostToDevice, b->stream));
@@ -442,8 +462,10 @@ static int pick_strategy(const gffx_hip_batch *b, int strategy) {
     return b->mostly_slow ? GFFX_STRATEGY_FUSED : GFFX_STRATEGY_WINDOWS;
 }
 
-extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags,
-                                  int strategy) {
+// Everything of a run before its kernels: arguments, AUTO's choice of strategy and form, the output buffers.  *launch = false: the
+// run is complete without a kernel of the strategies (an empty batch).  What it enqueues goes to the batch's own stream.
+static int batch_prepare_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags, int strategy, bool *launch) {
+    *launch = false;
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: batch is NULL");
     if (!b->have_regions) return fail(GFFX_E_STATE, "gffx_hip_batch_run: no regions set");
     if (mode < 0 || mode > 2) return fail(GFFX_E_INVALID, "gffx_hip_batch_run: bad mode %d", mode);
@@ -493,6 +515,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     }
     const uint64_t nq = b->nq;
     int rc;
+    if (nq == 0 && (rc = batch_own_stream(b))) return rc;
     if (b->flags & GFFX_OUT_OFFSETS) {
         if (!b->d_offsets && (rc = dev_alloc(&b->d_offsets, b->max_q + 1))) return rc;
         if (nq == 0) GFFX_HIP_TRY(hipMemsetAsync(b->d_offsets, 0, sizeof(unsigned long long), b->stream));
@@ -501,6 +524,7 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     if ((b->flags & GFFX_OUT_SEGBASE) && !b->d_segbase && (rc = dev_alloc(&b->d_segbase, b->max_q / kWaveGroup + 2))) return rc;
     if ((b->flags & GFFX_OUT_ROOT_BITMAP) && !b->d_bitmap) {
         if ((rc = dev_alloc(&b->d_bitmap, ((size_t)b->ix->n_roots + 31) / 32 + 1))) return rc;
+        if ((rc = batch_own_stream(b))) return rc;
         GFFX_HIP_TRY(hipMemsetAsync(b->d_bitmap, 0, ((size_t)b->ix->n_roots + 31) / 32 * 4 + 4, b->stream));  // (GFFX_OUT_BITMAP_KEEP on a first pass)
     }
     // A new set of roots (no GFFX_OUT_BITMAP_KEEP) starts from nothing WHATEVER strategy serves it: the slabs an earlier, unwaited
@@ -517,11 +541,24 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
         b->n_blocks = 0;
         return GFFX_OK;
     }
+    *launch = true;
     if (b->strategy != GFFX_STRATEGY_DIRECT) {
         const uint64_t want = std::max<uint64_t>(b->reserve ? b->reserve : 2 * nq, 1024);
-        if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want && (rc = grow(&b->d_fids, &b->cap_fids, want, 1))) return rc;
-        if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want && (rc = grow(&b->d_triples, &b->cap_triples, want, 3)))
-            return rc;
+        if (((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want) || ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want)) {
+            GFFX_HIP_TRY(hipStreamSynchronize(b->last_stream ? b->last_stream : b->stream));  // (an earlier pass may still write the old buffers)
+            if ((b->flags & GFFX_OUT_FIDS) && b->cap_fids < want && (rc = grow(&b->d_fids, &b->cap_fids, want, 1))) return rc;
+            if ((b->flags & GFFX_OUT_TRIPLES) && b->cap_triples < want && (rc = grow(&b->d_triples, &b->cap_triples, want, 3))) return rc;
+        }
+    }
+    return GFFX_OK;
+}
+
+// ... and its kernels, on the batch's own stream
+static int batch_launch_run(gffx_hip_batch *b) {
+    int rc = batch_own_stream(b);
+    if (rc) return rc;
+    const uint64_t nq = b->nq;
+    if (b->strategy != GFFX_STRATEGY_DIRECT) {
         return b->strategy == GFFX_STRATEGY_SORTED    ? run_partitioned(b)
                : b->strategy == GFFX_STRATEGY_WINDOWS ? run_windows(b)
                                                       : run_fused(b);
@@ -553,9 +590,19 @@ extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint3
     return GFFX_OK;
 }
 
+extern "C" int gffx_hip_batch_run(gffx_hip_batch *b, int mode, int invert, uint32_t out_flags, int strategy) {
+    bool launch = false;
+    const int rc = batch_prepare_run(b, mode, invert, out_flags, strategy, &launch);
+    return (rc || !launch) ? rc : batch_launch_run(b);
+}
+
 extern "C" int gffx_hip_batch_sync(gffx_hip_batch *b) {
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_sync: batch is NULL");
     GFFX_HIP_TRY(hipSetDevice(b->ix->device));
+    if (b->last_stream) {  // (the batch's newest work ran in a launch that served several batches)
+        GFFX_HIP_TRY(hipStreamSynchronize(b->last_stream));
+        b->last_stream = nullptr;
+    }
     GFFX_HIP_TRY(hipStreamSynchronize(b->stream));
     if (b->busy) {
         b->busy = false;
@@ -568,8 +615,9 @@ extern "C" int gffx_hip_batch_sync(gffx_hip_batch *b) {
 extern "C" int gffx_hip_batch_wait(gffx_hip_batch *b) {
     if (!b) return fail(GFFX_E_INVALID, "gffx_hip_batch_wait: batch is NULL");
     if (!b->ran) return fail(GFFX_E_STATE, "gffx_hip_batch_wait: nothing was run");
-    int rc = windows_pack_roots(b);  // (the root flags of the windows strategy's passes -> the bitmap, behind them on the stream)
+    int rc = batch_own_stream(b);
     if (rc) return rc;
+    if ((rc = windows_pack_roots(b))) return rc;  // (the root flags of the windows strategy's passes -> the bitmap, behind them on the stream)
     rc = gffx_hip_batch_sync(b);
     if (rc) return rc;
     if (b->nq == 0) {
@@ -828,14 +876,94 @@ extern "C" int gffx_hip_batch_timed_runs(gffx_hip_batch *b, int mode, int invert
     return rc;
 }
 
+// n_passes passes, pass i over batches[i % n_batches].  Round 6: consecutive passes over DISTINCT batches of one index are handed to
+// the windows strategy TOGETHER -- one launch per group of up to kPairMaxSubs batches (engine_windows.hip: run_windows_group) --
+// whenever every batch of the group resolves to the same kernel; anything else runs pass by pass as before.  With four batches or
+// more the groups are halves that alternate between the index's two group streams, so that one group's drain overlaps the next
+// one's ramp.  GFFX_HIP_GROUP=0 (a knob of batches[0]): pass by pass; =1: one group stream only.
+static int run_group(gffx_hip_batch *const *bs, uint32_t n, int mode, int invert, uint32_t out_flags, int strategy, int which_stream) {
+    bool launch[kPairMaxSubs];
+    bool all = n >= 2;
+    for (uint32_t t = 0; t < n; ++t) {
+        const int rc = batch_prepare_run(bs[t], mode, invert, out_flags, strategy, &launch[t]);
+        if (rc) return rc;
+        all = all && launch[t];
+    }
+    if (all && windows_groupable(bs, n)) return run_windows_group(bs, n, which_stream);
+    for (uint32_t t = 0; t < n; ++t)
+        if (launch[t]) {
+            const int rc = batch_launch_run(bs[t]);
+            if (rc) return rc;
+        }
+    return GFFX_OK;
+}
+static uint32_t group_size(gffx_hip_batch *const *batches, uint32_t n_batches, int *n_streams) {
+    *n_streams = 1;
+    if (n_batches < 2 || !batches[0]) return 1;
+    const long g = batches[0]->knobs.v[BK_GROUP];
+    if (g == 0) return 1;
+    for (uint32_t i = 0; i < n_batches; ++i) {  // distinct batches of one index
+        if (!batches[i] || batches[i]->ix != batches[0]->ix) return 1;
+        for (uint32_t j = 0; j < i; ++j)
+            if (batches[i] == batches[j]) return 1;
+    }
+    uint32_t size = n_batches;
+    if (g >= 2 && n_batches >= 2 * (uint32_t)g) {
+        size = (n_batches + (uint32_t)g - 1) / (uint32_t)g;
+        *n_streams = (int)g;
+    }
+    return std::min(size, kPairMaxSubs);
+}
 extern "C" int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
                                       int strategy, uint64_t n_passes) {
     if (!batches || !n_batches) return fail(GFFX_E_INVALID, "gffx_hip_batches_run_n: no batches");
-    for (uint64_t i = 0; i < n_passes; ++i) {
-        const int rc = gffx_hip_batch_run(batches[i % n_batches], mode, invert, out_flags, strategy);
+    int n_streams = 1;
+    const uint32_t gs = group_size(batches, n_batches, &n_streams);
+    if (gs < 2) {
+        for (uint64_t i = 0; i < n_passes; ++i) {
+            const int rc = gffx_hip_batch_run(batches[i % n_batches], mode, invert, out_flags, strategy);
+            if (rc) return rc;
+        }
+        return GFFX_OK;
+    }
+    uint64_t chunk = 0;
+    for (uint64_t i = 0; i < n_passes; ++chunk) {
+        gffx_hip_batch *bs[kPairMaxSubs];
+        const uint32_t n = (uint32_t)std::min<uint64_t>(gs, n_passes - i);
+        for (uint32_t t = 0; t < n; ++t) bs[t] = batches[(i + t) % n_batches];
+        const int rc = run_group(bs, n, mode, invert, out_flags, strategy, (int)(chunk % (uint64_t)n_streams));
         if (rc) return rc;
+        i += n;
     }
     return GFFX_OK;
+}
+// n_launches launches, each ONE pass over every batch (a group of n_batches <= 8), back to back on one group stream between one
+// pair of HIP events: the duration of the launch that gffx_hip_batches_run_n issues for such a group (bench.py's roofline)
+extern "C" int gffx_hip_batches_timed_runs(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
+                                           int strategy, uint32_t n_launches, double *total_ms, uint32_t *grouped) {
+    if (!batches || !n_batches || n_batches > kPairMaxSubs || !total_ms || !n_launches)
+        return fail(GFFX_E_INVALID, "gffx_hip_batches_timed_runs: bad argument");
+    int rc = run_group(batches, n_batches, mode, invert, out_flags, strategy, 0);  // (sizes the buffers; not timed)
+    for (uint32_t t = 0; t < n_batches && !rc; ++t) rc = gffx_hip_batch_sync(batches[t]);
+    if (rc) return rc;
+    GFFX_HIP_TRY(hipSetDevice(batches[0]->ix->device));
+    hipEvent_t a, z;
+    GFFX_HIP_TRY(hipEventCreate(&a));
+    GFFX_HIP_TRY(hipEventCreate(&z));
+    rc = run_group(batches, n_batches, mode, invert, out_flags, strategy, 0);  // (moves every batch to the group stream, if they group)
+    const hipStream_t s = batches[0]->last_stream ? batches[0]->last_stream : batches[0]->stream;
+    if (grouped) *grouped = batches[0]->last_stream ? 1u : 0u;
+    if (!rc) {
+        (void)hipEventRecord(a, s);
+        for (uint32_t i = 0; i < n_launches && !rc; ++i) rc = run_group(batches, n_batches, mode, invert, out_flags, strategy, 0);
+        (void)hipEventRecord(z, s);
+        for (uint32_t t = 0; t < n_batches && !rc; ++t) rc = gffx_hip_batch_sync(batches[t]);
+        float ms = 0.f;
+        if (!rc && hipEventElapsedTime(&ms, a, z) == hipSuccess) *total_ms = ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(z);
+    return rc;
 }
 
 extern "C" int gffx_hip_batch_reset_profile(gffx_hip_batch *b) {

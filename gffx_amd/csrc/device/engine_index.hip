@@ -659,6 +659,11 @@ extern "C" int gffx_hip_index_clone(const gffx_hip_index *src, int device, gffx_
 extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
+    for (hipStream_t &gs : ix->group.s)
+        if (gs) {
+            (void)hipStreamSynchronize(gs);
+            (void)hipStreamDestroy(gs);
+        }
     (void)hipFree(ix->d_start);
     (void)hipFree(ix->d_aux);
     (void)hipFree(ix->d_chr_meta);

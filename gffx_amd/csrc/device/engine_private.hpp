@@ -56,13 +56,14 @@ constexpr KnobDef kIndexKnobs[IK__COUNT] = {{"GFFX_HIP_WIN_PER_ENTRY", 2, 1, 16}
                                             {"GFFX_HIP_WIN_FILTER_KB", 24, 0, 120},         {"GFFX_HIP_BINS_PER_ENTRY", 2, 1, 64}};
 enum BatchKnob {
     BK_AUTO_STRATEGY, BK_FUSED_BLOCKS, BK_BITMAP_BLOCKS, BK_JOIN_BLOCKS, BK_MAX_BLOCKS, BK_PARTITION_BUDGET_MB, BK_WIDTH_SAMPLE, BK_WIN_THREADS,
-    BK_WIN_WIDE, BK__COUNT
+    BK_WIN_WIDE, BK_GROUP, BK_TICKETS, BK__COUNT
 };
 constexpr KnobDef kBatchKnobs[BK__COUNT] = {{"GFFX_HIP_AUTO_STRATEGY", 0, 0, 5},   {"GFFX_HIP_FUSED_BLOCKS", 0, 0, 65535},
                                             {"GFFX_HIP_BITMAP_BLOCKS", 0, 0, 8192}, {"GFFX_HIP_JOIN_BLOCKS", 512, 1, 65535},
                                             {"GFFX_HIP_MAX_BLOCKS", 2048, 1, 8192}, {"GFFX_HIP_PARTITION_BUDGET_MB", 12 * 1024, 1, 256 * 1024},
                                             {"GFFX_HIP_WIDTH_SAMPLE", 1, 0, 1},     {"GFFX_HIP_WIN_THREADS", 0, 0, 1024},
-                                            {"GFFX_HIP_WIN_WIDE", 1, 0, 2}};
+                                            {"GFFX_HIP_WIN_WIDE", 1, 0, 2},          {"GFFX_HIP_GROUP", 2, 0, 3},
+                                            {"GFFX_HIP_TICKETS", 1, 0, 3}};
 template <int N>
 struct Knobs {
     long v[N];
@@ -163,6 +164,17 @@ struct gffx_hip_index {
     uint32_t n_cells = 0, n_tiles = 0, cshift = 0;
     bool partition_ok = false;  // the tile plan exists (n_chr <= kMaxCells)
     mutable BusyCount busy_batches;  // batches of this index with passes that nobody synchronised with yet
+    // streams of the launches that serve several batches at once (gffx_hip_batches_run_n, engine_windows.hip): created on first use,
+    // owned by the index (a batch that ran in such a launch remembers the stream: gffx_hip_batch::last_stream)
+    struct GroupStreams {
+        std::mutex mu;
+        hipStream_t s[3] = {nullptr, nullptr, nullptr};
+        uint64_t launches = 0;
+        GroupStreams() = default;
+        GroupStreams(const GroupStreams &) {}
+        GroupStreams &operator=(const GroupStreams &) { return *this; }
+    };
+    mutable GroupStreams group;
     std::vector<uint32_t> h_sorted_fids;
     std::vector<size_t> array_bytes;  // of arrays(), in order (gffx_hip_index_clone)
 
@@ -220,6 +232,13 @@ struct gffx_hip_batch {
     const gffx_hip_index *ix = nullptr;
     Knobs<BK__COUNT> knobs{};  // GFFX_HIP_* of the passes, as read when the batch was created (gffx_hip_batch_set_option changes them)
     hipStream_t stream = nullptr;
+    // the stream the batch's NEWEST work was enqueued on when that is not its own: a launch that serves several batches runs on a
+    // stream of the index (ix->group).  Whoever enqueues on the batch's own stream next, or synchronises with the batch, joins the two
+    // first (batch_own_stream / gffx_hip_batch_sync); nullptr: the own stream
+    hipStream_t last_stream = nullptr;
+    hipEvent_t join_ev = nullptr;  // (created on first use)
+    uint32_t *d_ticket = nullptr;  // windows strategy: the passes' ticket words (PairSub::ticket), 64 of them, alternating like the pair cursors
+    int tick_phase[2] = {0, 0};    // ... which word the next pass / the next second pass (a root pass behind a pair pass) takes
     uint64_t max_q = 0, nq = 0;
     // inputs
     uint32_t *d_regions = nullptr;  // owned AoS upload buffer (3*max_q)
@@ -303,7 +322,13 @@ struct WidthSample {
 void sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride,
                    const std::vector<uint32_t> &h_wmax);
 int run_windows(gffx_hip_batch *b);  // engine_windows.hip
+// one launch per pass kind for ALL the batches (same index, mode, invert, flags, form; every one with regions; prepared by
+// batch_prepare_run), on a stream of the index
+int run_windows_group(gffx_hip_batch *const *bs, uint32_t n, int which_stream);
+bool windows_groupable(gffx_hip_batch *const *bs, uint32_t n);
 int windows_pack_roots(gffx_hip_batch *b);
+int batch_own_stream(gffx_hip_batch *b);       // engine_batch.hip: the batch's own stream, behind whatever ran for the batch elsewhere
+int batch_join_stream(gffx_hip_batch *b, hipStream_t s);  // ... stream s behind the batch's newest work; the batch's newest work is on s from now on
 int batch_check_nq(gffx_hip_batch *b, uint64_t nq, const char *who);  // engine_batch.hip
 int need_input_order(gffx_hip_batch *b);
 

@@ -100,6 +100,7 @@ extern "C" int gffx_hip_batch_set_regions_store(gffx_hip_batch *b, const gffx_hi
     if (R->device != b->ix->device) return fail(GFFX_E_INVALID, "gffx_hip_batch_set_regions_store: store and batch on different devices");
     if (first + n_rows > R->last_n[k]) return fail(GFFX_E_INVALID, "gffx_hip_batch_set_regions_store: rows beyond the last append");
     GFFX_HIP_TRY(hipSetDevice(R->device));
+    if ((rc = batch_own_stream(b))) return rc;
     GFFX_HIP_TRY(hipStreamWaitEvent(b->stream, R->copied[k], 0));
     b->q = QueryView{R->d + 3 * (R->last_first[k] + first), nullptr, nullptr, nullptr};
     b->nq = n_rows;

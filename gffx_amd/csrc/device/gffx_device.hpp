@@ -125,6 +125,7 @@ constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (
 constexpr uint32_t kWinSplit = GFFX_WIN_SPLIT_LOG2;  // a split window has 2^kWinSplit sub-windows (round 4; 4 and 5 measured in round 5: tools/kbench.hip -DGFFX_WIN_SPLIT_LOG2=)
 constexpr uint32_t kWaveGroup = 256;             // regions per GFFX_OUT_SEGBASE entry: 64 lanes x 4 regions, one wave's share of a round
 constexpr uint32_t kPairSumsStride = 8192;       // (= gffx_hip_batch::kMaxBlocks) k_join_roots: from a block's pair count of the pass to its accumulated one
+constexpr uint32_t kPairMaxSubs = 8;             // batches one launch of the window kernels serves (join_pairs_kernels.hpp: PairSub)
 constexpr uint32_t kPosBits = 27;
 constexpr uint32_t kPosMask = (1u << kPosBits) - 1;
 constexpr uint32_t kCntSat = 31;

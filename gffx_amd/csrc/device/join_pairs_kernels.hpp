@@ -94,7 +94,7 @@ __device__ __forceinline__ uint32_t win_sel(const uint32_t (&a)[4], int k) {
 }
 
 constexpr uint32_t kWaveDepth = 3;     // strips per wave: a round's words wait kWaveDepth - 1 rounds for their place
-constexpr uint32_t kWaveHdrBytes = 64; // arrival words, posted bases, post sequence numbers (kWaveDepth of each)
+constexpr uint32_t kWaveHdrBytes = 128; // arrival words, posted bases, post sequence numbers (kWaveDepth of each); the ticket words (PairTickets, at byte 64)
 constexpr uint32_t kWaveStash = 2;     // per thread: kept words of deferred regions wait here (LDS) for the parking
 // words a wave parks in LDS per round (a strip): 2 kept pairs per region at 1024 threads, 1.5 at 512 (two blocks share a CU's
 // LDS); a fuller round -- gene-dense stretches of a sorted BED file -- takes all kWaveDepth strips, beyond that the synchronous path
@@ -139,21 +139,76 @@ struct WaveOut {
     unsigned long long capacity;
 };
 
-// The kernels' one argument.  The main path reads `pv`, `q`, `out` and the scalars; `ix` is never touched by value: the rare
-// paths read it where it already lies, in the kernarg segment, through a pointer made inside the rare block (as by-value
-// arguments used inside the loop its twenty-odd pointers would be loaded once and held -- i.e. spilled -- across the loop).
-struct PairArgs {
-    PairView pv;
+// One BATCH of a launch (round 6).  A launch serves up to kPairMaxSubs batches of one index in the same mode (a caller with several
+// batches in flight -- gffx_hip_batches_run_n -- hands them over together: the index lines are fetched into the L2s once per launch,
+// ramp and drain are paid once, and the blocks run several rounds each, so the reservation's round trip is hidden).  The blocks
+// [first_block, first_block + n_blocks) belong to this batch for the whole launch.  The batch's rounds below n_static are walked
+// with a stride of n_blocks (block b: b, b + n_blocks, ...: n_static is a multiple of n_blocks); the rounds from n_static on -- the
+// launch's tail, between one and two per block -- are TAKEN from the batch's ticket word (round n_static + ticket): the blocks that
+// got through their share faster -- lighter rounds, a luckier CU -- take more of the tail (a static stride all the way left the
+// launch waiting for its slowest block: 10 M regions, mean block life 82 us, longest 94; tickets for EVERY round cost more than
+// they balance: a returning device atomic in front of the taker's gathers, every round).
+struct PairSub {
     QueryView q;
     unsigned long long nq;
     WaveOut out;
     int vec_ok;
+    uint32_t first_block, n_blocks;
+    unsigned long long n_static;  // (>= n_blocks when the batch has that many rounds: a block's first round is always its own number)
+    uint32_t *ticket;       // zero on entry
+    uint32_t *ticket_next;  // the other ticket word: zeroed here for the batch's next pass
+};
+
+// The kernels' one argument.  The main path reads `pv`, the block's `sub` record and the scalars; `ix` is never touched by value: the rare
+// paths read it where it already lies, in the kernarg segment, through a pointer made inside the rare block (as by-value
+// arguments used inside the loop its twenty-odd pointers would be loaded once and held -- i.e. spilled -- across the loop).
+struct PairArgs {
+    PairView pv;
+    uint32_t n_subs;          // batches of this launch
     uint32_t invert;          // intersect.rs:161 (never set with Overlap)
     uint32_t fwords, swords;  // filter / split-bitmap words staged in LDS (0: that table did not fit, or does not exist)
     const uint4 *spill;       // IndexView::win_spill (list tails: the one rare path that is walked in line)
-    uint32_t grid;            // blocks of the launch (read from the dispatch packet it would be a scalar load per round)
     IndexView ix;
+    PairSub sub[kPairMaxSubs];
 };
+
+// Rounds by ticket (both kernels).  LDS words of a block, zero before its barrier.  k = the block's rounds whose SUCCESSOR is taken by
+// ticket, counted (0, 1, ...).  In such a round the FIRST
+// wave to reach the round's top -- cnt[k % 4] counts the waves that did: it sees (k / 4) x waves -- takes the ticket of round k + 1
+// with one returning device atomic (issued before the round's gathers: its answer is back when they are) and posts the round
+// number right after its tests; every wave reads it where it requests the next round's regions.  A slot is used again four rounds
+// later: by then every wave has read it (a wave that is in round k + 1 - 4 or beyond has; the poster checks cnt of that slot).
+struct PairTickets {
+    uint32_t cnt[4], val[4], seq[4];
+};
+__device__ __forceinline__ bool pair_ticket_first(PairTickets *tk, uint32_t k, uint32_t waves, int lane) {
+    uint32_t old = 0;
+    if (lane == 0) old = atomicAdd(&tk->cnt[k & 3u], 1u);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)old) == (k >> 2) * waves;
+}
+template <bool CHECK_SLOT>
+__device__ __forceinline__ void pair_ticket_post(PairTickets *tk, uint32_t k /* the round that ends */, uint32_t waves, int lane, uint32_t next) {
+    const uint32_t s = (k + 1u) & 3u;
+    if (CHECK_SLOT && k + 1u >= 4u)
+        while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tk->cnt[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < ((k + 1u) >> 2) * waves)
+            __builtin_amdgcn_s_sleep(1);
+    if (lane == 0) {
+        tk->val[s] = next;
+        __hip_atomic_store(&tk->seq[s], k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+__device__ __forceinline__ uint32_t pair_ticket_await(PairTickets *tk, uint32_t k) {
+    const uint32_t s = (k + 1u) & 3u;
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tk->seq[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != k + 1u)
+        __builtin_amdgcn_s_sleep(1);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)tk->val[s]);
+}
+// the block's batch: the last record whose first block is not beyond this block (uniform; the records lie in the kernarg segment)
+__device__ __forceinline__ uint32_t pair_sub_of_block(const PairArgs &A) {
+    uint32_t j = 0;
+    for (uint32_t t = 1; t < A.n_subs; ++t) j = blockIdx.x >= A.sub[t].first_block ? t : j;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+}
 
 __device__ __forceinline__ const IndexView &pair_rare_ix() {
     typedef const unsigned char __attribute__((address_space(4))) * KernargBytes;
@@ -671,9 +726,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     constexpr uint32_t keep_words = OFFS ? 2u : 0u;
     constexpr uint32_t kStage = pair_stage_words(T, WIDE);  // words a wave parks per round
     auto rare_ix = [&]() -> const IndexView & { return pair_rare_ix(); };
-    const QueryView &q = A.q;
-    const WaveOut &out = A.out;
-    const unsigned long long nq = A.nq;
+    const PairSub &S = A.sub[pair_sub_of_block(A)];  // this block's batch
+    const QueryView &q = S.q;
+    const WaveOut &out = S.out;
+    const unsigned long long nq = S.nq;
+    const uint32_t lb = blockIdx.x - S.first_block;  // the block's number inside its batch
     const uint32_t fwords = A.fwords, swords = A.swords, n_chr = A.pv.n_chr;
     const bool inv = A.invert != 0;
     GFFX_WIN_STAMP(13);
@@ -689,6 +746,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     unsigned long long *s_arrive = reinterpret_cast<unsigned long long *>(s_work);              // [D] arrivals << 56 | pairs so far
     unsigned long long *s_post_base = reinterpret_cast<unsigned long long *>(s_work + 8 * D);   // [D] the round's segment base
     uint32_t *s_post_seq = reinterpret_cast<uint32_t *>(s_work + 16 * D);                       // [D] block round + 1 it belongs to
+    PairTickets *s_tick = reinterpret_cast<PairTickets *>(s_work + 64);                         // rounds by ticket
     uint32_t *s_stage_all = reinterpret_cast<uint32_t *>(s_work + kWaveHdrBytes);               // waves x D x kStage
     uint32_t *s_keep_all = s_stage_all + kWaves * D * kStage;                                   // T x D x keep_words
     uint32_t *s_stash = s_keep_all + (size_t)T * D * keep_words + kWaveStash * threadIdx.x;     // this thread's kWaveStash words
@@ -700,9 +758,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 
     uint32_t qc[4], qs[4], qe[4];  // the round's 4 consecutive regions of the thread
     bool bad = false;              // a region's seqid is out of range
-    auto load_round = [&](unsigned long long r) { pair_load_round<kChunk>(q, nq, A.vec_ok, n_chr, r, t4, qc, qs, qe, bad); };
+    auto load_round = [&](unsigned long long r) { pair_load_round<kChunk>(q, nq, S.vec_ok, n_chr, r, t4, qc, qs, qe, bad); };
     const unsigned long long n_rounds = (nq + kChunk - 1) / kChunk;
-    if (blockIdx.x < n_rounds) load_round(blockIdx.x);  // in flight while the tables are staged
+    if (lb < n_rounds) load_round(lb);  // in flight while the tables are staged
     const uint4 *cm;
     if (META_LDS) {
         for (uint32_t i = tid; i <= n_chr; i += T) s_meta[i] = A.pv.meta[i];
@@ -718,9 +776,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         s_arrive[tid] = 0ull;
         s_post_seq[tid] = 0u;
     }
-    win_barrier();  // the ONLY block barrier: tables staged, arrival words zero
-    if (blockIdx.x == 0 && tid == 0) {
+    if (tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
+    win_barrier();  // the ONLY block barrier: tables staged, arrival and ticket words zero
+    if (lb == 0 && tid == 0) {
         *out.pair_cursor_next = 0ull;
+        *S.ticket_next = 0u;
         if (lds0 != 0) atomicOr(out.err, 2u);  // (the filter lookups assume the dynamic LDS starts at LDS address 0)
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -839,16 +899,21 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         p_valid[i] = false;
     };
     uint32_t k_round = 0, slot_now = 0;  // the block's rounds, counted; k_round % D
+    uint32_t k_tick = 0;                 // ... those whose successor was taken by ticket
     // The first round's regions are waited for HERE, once: pending at the loop's entry (with possibly nothing issued after them)
     // they would turn the wait at the top of EVERY round into s_waitcnt vmcnt(0) -- a drain of the previous round's stores
     // and of its reservation atomic -- because the compiler merges the entry's state with the back edge's.
 #pragma unroll
     for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(qc[k]), "+v"(qs[k]), "+v"(qe[k]));
-    for (unsigned long long r = blockIdx.x; r < n_rounds; r += A.grid, ++k_round) {
+    for (unsigned long long r = lb; r < n_rounds; ++k_round) {
         const unsigned long long base = r * kChunk;  // (uniform) first region of the round
         const unsigned long long i0 = base + t4;     // this thread's 4 consecutive regions
         const bool full = base + kChunk <= nq;       // (uniform) every thread has its 4 regions
         GFFX_WIN_STAMP(0);
+        // (the block's next round: its own stride while that stays below n_static, else by ticket -- the first wave of the block to
+        //  get here takes it: PairTickets)
+        const bool by_ticket = r + S.n_blocks >= S.n_static;  // (uniform, the same for every wave of the block)
+        const bool t_first = by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
         // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
         uint32_t off[4], rqs[4], rqe1[4];  // the line's byte offset; the region in the line's coordinates (rqe1 = its last base)
         bool swp[4];  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
@@ -872,6 +937,10 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             }
         }
         GFFX_WIN_STAMP(1);
+        // the next round's ticket: older than the round's gathers (its answer is back when they are), younger than the wait for the
+        // round's regions (a conditional memory operation younger than loads that are still waited for makes that wait a drain)
+        uint32_t t_got = 0;
+        if (t_first && lane == 0) t_got = atomicAdd(S.ticket, 1u);
         gffx_v4u wc[4], wf[4];  // the line's halves: coordinates | root_fids (or positions); a wide lane's second half: {rank, list-tail header, 0, 0}
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1048,6 +1117,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             for (int k = 0; k < 4; ++k) m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv, off[k] != kWinNoLine);
         }
         GFFX_WIN_STAMP(3);
+        uint32_t r_next = 0;
+        if (t_first) {  // (uniform) this wave took the next round's ticket: it is back with the gathers; posted before anything rare
+            r_next = (uint32_t)S.n_static + (uint32_t)__builtin_amdgcn_readfirstlane((int)t_got);
+            pair_ticket_post<false>(s_tick, k_tick, kWaves, lane, r_next);
+        }
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept words wait in
         // the thread's LDS strip)
         if constexpr (!WIDE) {
@@ -1116,7 +1190,12 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(6);
         finish(P - 1);
         GFFX_WIN_STAMP(7);
-        load_round(r + A.grid);
+        if (!by_ticket)
+            r_next = (uint32_t)r + S.n_blocks;
+        else if (!t_first)
+            r_next = pair_ticket_await(s_tick, k_tick);
+        k_tick += by_ticket ? 1u : 0u;
+        load_round(r_next);
         const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         const uint32_t inc = win_wave_scan(mine);
         const uint32_t wtotal = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);  // (uniform) the wave's kept pairs
@@ -1351,6 +1430,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): as above (rare path at the end of a round)
         }
         slot_now = slot_now + 1 == D ? 0u : slot_now + 1;
+        r = r_next;
     }
     GFFX_WIN_STAMP(14);
     post_pending();
@@ -1381,9 +1461,12 @@ template <int MODE, bool META_LDS, int T, bool WIDE = false>
 __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED, CREG = WIDE && MODE == GFFX_MODE_CONTAINS_REGION;  // (as in k_join_pairs)
     constexpr uint32_t kChunk = 4u * T;
-    const QueryView &q = A.q;
-    const WaveOut &out = A.out;
-    const unsigned long long nq = A.nq;
+    constexpr uint32_t kWaves = T / 64;
+    const PairSub &S = A.sub[pair_sub_of_block(A)];  // this block's batch
+    const QueryView &q = S.q;
+    const WaveOut &out = S.out;
+    const unsigned long long nq = S.nq;
+    const uint32_t lb = blockIdx.x - S.first_block;  // the block's number inside its batch
     const uint32_t fwords = A.fwords, swords = A.swords, n_chr = A.pv.n_chr;
     const bool inv = A.invert != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1392,16 +1475,17 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     uint32_t *s_sbits = s_filter + fwords;
     uint4 *s_meta = reinterpret_cast<uint4 *>(s_sbits + sw4);
     unsigned long long *s_total = reinterpret_cast<unsigned long long *>(s_meta + (META_LDS ? n_chr + 1 : 0));  // the block's kept pairs (16 bytes)
-    uint32_t *s_bm = reinterpret_cast<uint32_t *>(s_total + 2);  // bm_words: the block's root bitmap
+    PairTickets *s_tick = reinterpret_cast<PairTickets *>(s_total + 2);                                          // rounds by ticket (48 bytes)
+    uint32_t *s_bm = reinterpret_cast<uint32_t *>(s_tick + 1);  // bm_words: the block's root bitmap
     const uint32_t bm_words = (uint32_t)out.capacity;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
     const uint32_t tid = threadIdx.x, t4 = 4u * tid;
     const int lane = tid & 63;
     uint32_t qc[4], qs[4], qe[4];
     bool bad = false;
-    auto load_round = [&](unsigned long long r) { pair_load_round<kChunk>(q, nq, A.vec_ok, n_chr, r, t4, qc, qs, qe, bad); };
+    auto load_round = [&](unsigned long long r) { pair_load_round<kChunk>(q, nq, S.vec_ok, n_chr, r, t4, qc, qs, qe, bad); };
     const unsigned long long n_rounds = (nq + kChunk - 1) / kChunk;
-    if (blockIdx.x < n_rounds) load_round(blockIdx.x);
+    if (lb < n_rounds) load_round(lb);
     const uint4 *cm;
     if (META_LDS) {
         for (uint32_t i = tid; i <= n_chr; i += T) s_meta[i] = A.pv.meta[i];
@@ -1415,9 +1499,11 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         reinterpret_cast<uint4 *>(s_sbits)[x] = reinterpret_cast<const uint4 *>(A.pv.splittab)[x];
     for (uint32_t x = tid; x < bm_words; x += T) s_bm[x] = 0u;
     if (tid == 0) s_total[0] = 0ull;
+    if (tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
     win_barrier();
-    if (blockIdx.x == 0 && tid == 0) {
+    if (lb == 0 && tid == 0) {
         *out.pair_cursor_next = 0ull;
+        *S.ticket_next = 0u;
         if (lds0 != 0) atomicOr(out.err, 2u);
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1437,9 +1523,12 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     uint32_t n_slow = 0, kept = 0;  // (n_slow: as in k_join_pairs)
 #pragma unroll
     for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(qc[k]), "+v"(qs[k]), "+v"(qe[k]));
-    for (unsigned long long r = blockIdx.x; r < n_rounds; r += A.grid) {
+    uint32_t k_tick = 0;  // the block's rounds whose successor was taken by ticket, counted
+    for (unsigned long long r = lb; r < n_rounds;) {
         const unsigned long long base = r * kChunk;
         const bool full = base + kChunk <= nq;
+        const bool by_ticket = r + S.n_blocks >= S.n_static;  // (as in k_join_pairs: the tail's rounds are taken by ticket)
+        const bool t_first = by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
         uint32_t off[4], rqs[4], rqe1[4];
         bool swp[4];
         uint32_t off1[4], rel1[4], r0[4], nr[4];  // (mixed form, wide lanes) the line of qe - 1, qe - 1 in its coordinates; the run of roots that start inside the region
@@ -1457,6 +1546,8 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 isw[k] = bigr[k] = false;
             }
         }
+        uint32_t t_got = 0;  // (as in k_join_pairs: older than the gathers, younger than the wait for the regions)
+        if (t_first && lane == 0) t_got = atomicAdd(S.ticket, 1u);
         gffx_v4u wc[4], wf[4];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1653,6 +1744,16 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 }
             }
         }
+        uint32_t r_next;
+        if (!by_ticket) {
+            r_next = (uint32_t)r + S.n_blocks;
+        } else if (t_first) {  // (uniform) the ticket is back with the gathers; nothing bounds how far this kernel's waves drift apart: the slot is checked
+            r_next = (uint32_t)S.n_static + (uint32_t)__builtin_amdgcn_readfirstlane((int)t_got);
+            pair_ticket_post<true>(s_tick, k_tick, kWaves, lane, r_next);
+        } else {
+            r_next = pair_ticket_await(s_tick, k_tick);
+        }
+        k_tick += by_ticket ? 1u : 0u;
         if (out.counts) {  // (uniform) per-region counts, unless the caller waived them (GFFX_OUT_NO_COUNTS); older than the prefetch below
             const unsigned long long left = nq - base;
             const uint32_t rows = (uint32_t)min(left, (unsigned long long)kChunk);
@@ -1662,7 +1763,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         }
         // the regions are done with: the next round's take their registers; then the flags (stores younger than every load
         // that is waited for)
-        load_round(r + A.grid);
+        load_round(r_next);
         if constexpr (WIDE) {  // the runs: up to 32 bits per step
             uint32_t *bits = bm_words ? s_bm : g_bitmap;
 #pragma unroll
@@ -1686,6 +1787,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 if (m[k] & 1u) set_global(wf[k].w);
             }
         }
+        r = r_next;
     }
     uint32_t n_wide = n_slow >> 16;
     n_slow &= 0xFFFFu;
@@ -1694,14 +1796,14 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     if (lane == 0 && kept) atomicAdd(s_total, (unsigned long long)kept);
     win_barrier();
     if (bm_words) {  // the block's bitmap into the block's slab
-        uint32_t *slab = out.fids + (size_t)blockIdx.x * bm_words;
-        const bool merge = blockIdx.x < (uint32_t)(uintptr_t)out.segbase;
+        uint32_t *slab = out.fids + (size_t)lb * bm_words;
+        const bool merge = lb < (uint32_t)(uintptr_t)out.segbase;
         for (uint32_t x = tid; x < bm_words; x += T) slab[x] = merge ? (slab[x] | s_bm[x]) : s_bm[x];
     }
     if (tid == 0 && out.block_sums) {
-        out.block_sums[blockIdx.x] = s_total[0];
-        unsigned long long *acc = out.block_sums + kPairSumsStride + blockIdx.x;  // (this block's own word: plain load and store)
-        *acc = (blockIdx.x < out.sums_valid ? *acc : 0ull) + s_total[0];
+        out.block_sums[lb] = s_total[0];
+        unsigned long long *acc = out.block_sums + kPairSumsStride + lb;  // (this block's own word: plain load and store)
+        *acc = (lb < out.sums_valid ? *acc : 0ull) + s_total[0];
     }
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);
     if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow | ((unsigned long long)n_wide << 32));

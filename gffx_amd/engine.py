@@ -441,6 +441,26 @@ def segments_covered(seg_seq, seg_start, seg_end, regions, n_seq: int, device: i
     return out[: len(q)]
 
 
+def run_batches(batches: Sequence["QueryBatch"], mode: int = OverlapMode.Overlap, invert: bool = False, out_flags: int = OUT_FIDS,
+                strategy: int = STRATEGY_AUTO, n_passes: Optional[int] = None) -> None:
+    """gffx_hip_batches_run_n: pass i over batches[i % len(batches)], enqueued by ONE call.  Distinct batches of one index that
+    resolve to the same pass of the windows strategy are served by ONE launch per group of up to 8 (knob GFFX_HIP_GROUP of
+    batches[0]); results are those of single `run` calls."""
+    arr = (C.c_void_p * len(batches))(*[b._h for b in batches])
+    check(lib().gffx_hip_batches_run_n(arr, len(batches), int(mode), int(bool(invert)), int(out_flags), int(strategy),
+                                       int(len(batches) if n_passes is None else n_passes)))
+
+
+def timed_group_runs(batches: Sequence["QueryBatch"], mode: int, invert: bool, out_flags: int, strategy: int, n: int):
+    """n launches, each one pass over every batch (a group of <= 8), back to back between one pair of HIP events.
+    Returns (microseconds per launch, grouped: the passes ran as one launch)."""
+    arr = (C.c_void_p * len(batches))(*[b._h for b in batches])
+    ms, grouped = C.c_double(0.0), C.c_uint32(0)
+    check(lib().gffx_hip_batches_timed_runs(arr, len(batches), int(mode), int(bool(invert)), int(out_flags), int(strategy), int(n),
+                                            C.byref(ms), C.byref(grouped)))
+    return 1e3 * ms.value / n, bool(grouped.value)
+
+
 def warmup(device: int = 0) -> None:
     """Pay the process's one-off HIP costs now (gffx_hip_warmup); optional."""
     check(lib().gffx_hip_warmup(int(device)))

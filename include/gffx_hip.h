@@ -58,6 +58,8 @@
  *   GFFX_HIP_WIN_WIDE=0|1|2         the mixed form of the window kernels: never / AUTO's choice for batches with wide rows (default) /
  *                                   every eligible pass of the windows strategy
  *   GFFX_HIP_WIDTH_SAMPLE=0         no width sample of the rows the host hands over (AUTO then learns from a first waited pass)
+ *   GFFX_HIP_GROUP=0|1|2            gffx_hip_batches_run_n: one launch for a group of batches (2, default: halves of four or more batches
+ *                                   alternate between two streams; 1: one group, one stream; 0: pass by pass)
  *   GFFX_HIP_AUTO_STRATEGY=n        what GFFX_STRATEGY_AUTO resolves to (0: the engine's choice)
  *   launch sizes (0 = the engine's choice): GFFX_HIP_FUSED_BLOCKS, GFFX_HIP_BITMAP_BLOCKS; GFFX_HIP_JOIN_BLOCKS, GFFX_HIP_MAX_BLOCKS;
  *   GFFX_HIP_PARTITION_BUDGET_MB (record buffers of the partitioned strategy)
@@ -287,9 +289,22 @@ int gffx_hip_batch_reset_profile(gffx_hip_batch *);
 int gffx_hip_batch_timed_runs(gffx_hip_batch *, int mode, int invert, uint32_t out_flags, int strategy, uint32_t n,
                               double *total_ms);
 /* n_passes passes enqueued round-robin over n_batches batches (batch i % n_batches takes pass i) in one call: a host that
- * keeps several batches in flight pays one FFI crossing for the lot (bench.py's timed region: the launch loop runs in C). */
+ * keeps several batches in flight pays one FFI crossing for the lot (bench.py's timed region: the launch loop runs in C).
+ * Round 6: consecutive passes over DISTINCT batches of one index that resolve to the same pass of the windows strategy are served
+ * by ONE launch per group of up to 8 batches (every batch a share of the launch's blocks, its rounds handed out by ticket): the
+ * index lines are fetched into the L2s once per launch instead of once per batch, ramp and drain are paid once.  The launch runs on
+ * a stream of the index; a batch's own stream joins it whenever the batch is used on its own again (_run, _wait, _sync, a new set of
+ * regions): per-batch order is what it always was.  With four batches or more the groups are halves that alternate between two such
+ * streams.  Results are exactly those of n_passes single _run calls.  Knob GFFX_HIP_GROUP of batches[0]: 0 = pass by pass (round
+ * 5's behaviour), 1 = one group, one stream, 2 (default) = as described. */
 int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
                            int strategy, uint64_t n_passes);
+/* n_launches times ONE pass over each of the n_batches (<= 8) batches -- the launch _batches_run_n issues for such a group --, back
+ * to back between one pair of HIP events on the stream they run on (blocking): total_ms / n_launches = the duration of the launch.
+ * *grouped (may be NULL) = 1 when the passes ran as one launch, 0 when they did not group (then: pass after pass on batches[0]'s
+ * stream is NOT what was timed -- the figure is meaningless). */
+int gffx_hip_batches_timed_runs(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
+                                int strategy, uint32_t n_launches, double *total_ms, uint32_t *grouped);
 /* Threads per block of the last windows-strategy pair pass of this batch (512 or 1024; 0: none ran).  The engine takes
  * 1024-thread blocks (one per CU, rounds of 4096 regions) for a batch of 500 000 regions or more while NO other batch of the
  * index has passes in flight, 512-thread blocks (two per CU: kernels of two batches share the CUs) otherwise;

@@ -5,6 +5,7 @@
 //   tools/_kb/kbench [nq] [strategy 0..5] [flags] [iters] [presort] [max region width] [every n-th region SV-sized]
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <random>
@@ -136,6 +137,36 @@ int main(int argc, char **argv) {
     float ms = 0;
     hipEventElapsedTime(&ms, ea, eb);
     printf("pass: %.2f us (back-to-back, %d iters)\n", 1e3 * ms / iters, iters);
+    if (getenv("KB_GROUP")) {
+        // round 6: n batches over the same regions handed over together (gffx_hip_batches_run_n: one launch per group)
+        const int ng = atoi(getenv("KB_GROUP"));
+        std::vector<gffx_hip_batch *> bb(ng, nullptr);
+        bb[0] = b;
+        for (int i = 1; i < ng; i++) {
+            if (gffx_hip_batch_create(ix, nq, &bb[i]) || gffx_hip_batch_set_regions_soa_host(bb[i], qc.data(), qs.data(), qe.data(), nq)) return 1;
+            gffx_hip_batch_reserve_hits(bb[i], gffx_hip_batch_total_hits(b) + 4096);
+            if (gffx_hip_batch_run(bb[i], kb_mode, 0, flags, strategy) || gffx_hip_batch_wait(bb[i])) return 1;
+        }
+        for (int rep = 0; rep < 3; rep++) {
+            const int passes = iters * ng;
+            if (gffx_hip_batches_run_n(bb.data(), ng, kb_mode, 0, flags, strategy, 2 * ng)) { fprintf(stderr, "group: %s\n", gffx_hip_last_error()); return 1; }
+            for (auto *x : bb) gffx_hip_batch_sync(x);
+            const auto t0 = std::chrono::steady_clock::now();
+            if (gffx_hip_batches_run_n(bb.data(), ng, kb_mode, 0, flags, strategy, passes)) { fprintf(stderr, "group: %s\n", gffx_hip_last_error()); return 1; }
+            for (auto *x : bb) gffx_hip_batch_sync(x);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            printf("group of %d: %.2f us per pass (wall, %d passes), %.1f G regions/s; blocks %u x %u threads\n", ng, us / passes, passes, nq * 1e-3 * passes / us, bb[0]->win_blocks, bb[0]->win_threads);
+        }
+        double ms = 0;
+        uint32_t grouped = 0;
+        if (ng <= 8 && !gffx_hip_batches_timed_runs(bb.data(), ng, kb_mode, 0, flags, strategy, 20, &ms, &grouped))
+            printf("group launch: %.2f us per launch of %d batches = %.2f us per pass (HIP events, serial launches, grouped=%u)\n", 1e3 * ms / 20, ng, 1e3 * ms / 20 / ng, grouped);
+        for (auto *x : bb) {
+            if (gffx_hip_batch_wait(x)) { fprintf(stderr, "wait: %s\n", gffx_hip_last_error()); return 1; }
+            if (gffx_hip_batch_total_hits(x) != gffx_hip_batch_total_hits(b)) printf("MISMATCH: %llu pairs\n", (unsigned long long)gffx_hip_batch_total_hits(x));
+        }
+        for (int i = 1; i < ng; i++) gffx_hip_batch_destroy(bb[i]);
+    }
     gffx_hip_batch_set_profiling(b, 1);
     for (int i = 0; i < 20; i++) {
         gffx_hip_batch_run(b, kb_mode, 0, flags, strategy);
@@ -188,8 +219,95 @@ int main(int argc, char **argv) {
             if (n) printf(" [%d]%.2f/%.2f", k, m / n, mx);
         }
         printf("\n");
+        if (which == 4 && nb) {
+            // round 6: per-block lives against what the block's rounds held.  A block's life = stamp 15 - stamp 13; the rounds it
+            // ran are blockIdx, blockIdx + grid, ...; the kept pairs of a round come from the counts (input order).
+            const uint32_t T = b->win_threads ? b->win_threads : 1024, grid = b->win_blocks ? b->win_blocks : (uint32_t)nb;
+            const uint64_t chunk = 4ull * T;
+            std::vector<uint32_t> cnt(nq);
+            gffx_hip_batch_wait(b);
+            gffx_hip_batch_copy_counts(b, cnt.data());
+            std::vector<double> life(nb), endt(nb);
+            std::vector<uint64_t> bp(nb, 0), bmaxw(nb, 0);
+            for (int blk = 0; blk < nb; blk++) {
+                life[blk] = (double)(z[blk * 16 + 15] - z[blk * 16 + 13]) * 0.01;
+                endt[blk] = (double)(z[blk * 16 + 15] - t0) * 0.01;
+                for (uint64_t r = blk; r * chunk < nq; r += grid)
+                    for (uint64_t w0 = r * chunk; w0 < std::min<uint64_t>(nq, (r + 1) * chunk); w0 += 256) {
+                        uint64_t wp = 0;
+                        for (uint64_t i = w0; i < std::min<uint64_t>(nq, w0 + 256); i++) wp += cnt[i];
+                        bp[blk] += wp;
+                        bmaxw[blk] = std::max(bmaxw[blk], wp);
+                    }
+            }
+            std::vector<int> o(nb);
+            for (int i = 0; i < nb; i++) o[i] = i;
+            std::sort(o.begin(), o.end(), [&](int a, int c) { return life[a] > life[c]; });
+            double ml = 0, me = 0;
+            for (int i = 0; i < nb; i++) ml += life[i], me += endt[i];
+            printf("  blocks: T=%u grid=%u mean life %.2f us, mean end %.2f, p50 life %.2f, p90 %.2f, max %.2f\n", T, grid, ml / nb, me / nb, life[o[nb / 2]],
+                   life[o[nb / 10]], life[o[0]]);
+            printf("  slowest blocks (block: life us, end us, kept pairs of its rounds, fullest wave round):");
+            for (int i = 0; i < std::min(nb, 8); i++) printf(" %d: %.2f %.2f %llu %llu;", o[i], life[o[i]], endt[o[i]], (unsigned long long)bp[o[i]], (unsigned long long)bmaxw[o[i]]);
+            {   // block b runs on XCD b % 8 (observed, MI355X_MICROARCH.md): lives by XCD
+                double xs[8] = {0}, xm[8] = {0};
+                int xn[8] = {0};
+                for (int i = 0; i < nb; i++) xs[i % 8] += life[i], xm[i % 8] = std::max(xm[i % 8], life[i]), xn[i % 8]++;
+                printf("\n  mean / max life by block %% 8:");
+                for (int x = 0; x < 8; x++) printf(" %.2f/%.2f", xs[x] / std::max(xn[x], 1), xm[x]);
+            }
+            printf("\n  fastest:");
+            for (int i = nb - 4; i < nb; i++) if (i >= 0) printf(" %d: %.2f %.2f %llu %llu;", o[i], life[o[i]], endt[o[i]], (unsigned long long)bp[o[i]], (unsigned long long)bmaxw[o[i]]);
+            printf("\n");
+            // wave rounds by kept pairs: how many take all strips (> strip words) or the synchronous path (> 3 strips)
+            const uint32_t strip = T == 1024 ? 512 : 384;
+            uint64_t nw = 0, big = 0, sync = 0;
+            for (uint64_t w0 = 0; w0 < nq; w0 += 256) {
+                uint64_t wp = 0;
+                for (uint64_t i = w0; i < std::min<uint64_t>(nq, w0 + 256); i++) wp += cnt[i];
+                nw++, big += wp > strip, sync += wp > 3 * strip;
+            }
+            printf("  wave rounds: %llu, kept pairs > one strip (%u): %llu, > three strips: %llu\n", (unsigned long long)nw, strip, (unsigned long long)big, (unsigned long long)sync);
+        }
     }
 #endif
+    {
+        // round 6: distinct 128-byte lines of the line table a gather instruction touches (instruction k of a wave round reads the
+        // line of region base + 4 lane + k for its 64 lanes), first-level lines only, and the span of a wave round in lines
+        std::vector<uint4> wm(n_chr + 1);
+        hipMemcpy(wm.data(), ix->d_win_meta, (n_chr + 1) * sizeof(uint4), hipMemcpyDeviceToHost);
+        double dl = 0, span = 0;
+        uint64_t ni = 0, nwv = 0, in32 = 0, in64 = 0, tot = 0;
+        for (uint64_t w0 = 0; w0 + 256 <= nq; w0 += 256) {
+            uint32_t lo = ~0u, hi = 0, base_line = 0;
+            for (int k = 0; k < 4; k++) {
+                std::vector<uint32_t> l;
+                for (int lane = 0; lane < 64; lane++) {
+                    const uint64_t i = w0 + 4 * lane + k;
+                    const uint4 m = wm[qc[i]];
+                    const uint32_t line = m.x + ((qe[i] - 1) >> (m.z & 31u));
+                    l.push_back(line / 4);
+                    lo = std::min(lo, line), hi = std::max(hi, line);
+                }
+                std::sort(l.begin(), l.end());
+                dl += (double)(std::unique(l.begin(), l.end()) - l.begin());
+                ni++;
+            }
+            {   // the staging rule: base = the smaller of the lines of the wave's first and last regions' STARTS
+                const uint4 m0 = wm[qc[w0]], m1 = wm[qc[w0 + 255]];
+                base_line = std::min(m0.x + (qs[w0] >> (m0.z & 31u)), m1.x + (qs[w0 + 255] >> (m1.z & 31u)));
+                for (uint64_t i = w0; i < w0 + 256; i++) {
+                    const uint4 m = wm[qc[i]];
+                    const uint32_t line = m.x + ((qe[i] - 1) >> (m.z & 31u));
+                    in32 += line >= base_line && line < base_line + 32, in64 += line >= base_line && line < base_line + 64, tot++;
+                }
+            }
+            span += hi - lo + 1;
+            nwv++;
+        }
+        if (ni) printf("gathers: %.1f distinct 128-byte lines per instruction; a wave round spans %.1f lines (mean); regions within 32 / 64 lines of the wave's base: %.3f / %.3f\n",
+                       dl / ni, span / nwv, (double)in32 / tot, (double)in64 / tot);
+    }
 #if GFFX_CLKCHECK
     {
         std::vector<unsigned long long> z(8192 * 4, 0);
