@@ -878,9 +878,8 @@ extern "C" int gffx_hip_batch_timed_runs(gffx_hip_batch *b, int mode, int invert
 
 // n_passes passes, pass i over batches[i % n_batches].  Round 6: consecutive passes over DISTINCT batches of one index are handed to
 // the windows strategy TOGETHER -- one launch per group of up to kPairMaxSubs batches (engine_windows.hip: run_windows_group) --
-// whenever every batch of the group resolves to the same kernel; anything else runs pass by pass as before.  With four batches or
-// more the groups are halves that alternate between the index's two group streams, so that one group's drain overlaps the next
-// one's ramp.  GFFX_HIP_GROUP=0 (a knob of batches[0]): pass by pass; =1: one group stream only.
+// whenever every batch of the group resolves to the same kernel; anything else runs pass by pass as before (plan_groups below says
+// how the passes are cut into groups).
 static int run_group(gffx_hip_batch *const *bs, uint32_t n, int mode, int invert, uint32_t out_flags, int strategy, int which_stream) {
     bool launch[kPairMaxSubs];
     bool all = n >= 2;
@@ -897,29 +896,38 @@ static int run_group(gffx_hip_batch *const *bs, uint32_t n, int mode, int invert
         }
     return GFFX_OK;
 }
-static uint32_t group_size(gffx_hip_batch *const *batches, uint32_t n_batches, int *n_streams) {
-    *n_streams = 1;
-    if (n_batches < 2 || !batches[0]) return 1;
+// How _batches_run_n cuts its round-robin passes into launches: `cycle` groups per walk over the batches (sizes that differ by at
+// most one, every group <= kPairMaxSubs), group c on stream c % streams -- a batch is always in the same group and on the same
+// stream.  Measured (kbench, 1 M regions per batch, G regions/s; profiles/r06_groups.txt): pass by pass (round 5's launches in
+// flight) 2: 97, 3: 110, 4: 86, 6: 108; ONE group 2: 78, 3: 91, 4: 93, 8: 121; halves on two streams 4: 117, 6: 125, 8: 130, 12: 134,
+// 16: 142; thirds on three streams 6: 126, 9: 130, 12: 138, 16: 125.  So: up to three batches pass by pass, from four on halves on two
+// streams.  GFFX_HIP_GROUP (batches[0]'s knob): 0 = always pass by pass, 1 = one stream, 2 = two (default), 3 = three.
+struct GroupPlan {
+    uint32_t cycle = 0, streams = 1;  // cycle == 0: pass by pass
+    uint32_t size[64];
+};
+static GroupPlan plan_groups(gffx_hip_batch *const *batches, uint32_t n_batches) {
+    GroupPlan p;
+    if (n_batches < 2 || !batches[0]) return p;
     const long g = batches[0]->knobs.v[BK_GROUP];
-    if (g == 0) return 1;
+    if (g == 0 || (g >= 2 && n_batches < 4) || n_batches > 64 * kPairMaxSubs) return p;
     for (uint32_t i = 0; i < n_batches; ++i) {  // distinct batches of one index
-        if (!batches[i] || batches[i]->ix != batches[0]->ix) return 1;
+        if (!batches[i] || batches[i]->ix != batches[0]->ix) return p;
         for (uint32_t j = 0; j < i; ++j)
-            if (batches[i] == batches[j]) return 1;
+            if (batches[i] == batches[j]) return p;
     }
-    uint32_t size = n_batches;
-    if (g >= 2 && n_batches >= 2 * (uint32_t)g) {
-        size = (n_batches + (uint32_t)g - 1) / (uint32_t)g;
-        *n_streams = (int)g;
-    }
-    return std::min(size, kPairMaxSubs);
+    p.streams = (uint32_t)g;
+    p.cycle = (n_batches + kPairMaxSubs - 1) / kPairMaxSubs;
+    if (g >= 2) p.cycle = std::max<uint32_t>((p.cycle + p.streams - 1) / p.streams * p.streams, p.streams);
+    p.cycle = std::min(p.cycle, n_batches);
+    for (uint32_t c = 0; c < p.cycle; ++c) p.size[c] = n_batches / p.cycle + (c < n_batches % p.cycle ? 1u : 0u);
+    return p;
 }
 extern "C" int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
                                       int strategy, uint64_t n_passes) {
     if (!batches || !n_batches) return fail(GFFX_E_INVALID, "gffx_hip_batches_run_n: no batches");
-    int n_streams = 1;
-    const uint32_t gs = group_size(batches, n_batches, &n_streams);
-    if (gs < 2) {
+    const GroupPlan plan = plan_groups(batches, n_batches);
+    if (!plan.cycle) {
         for (uint64_t i = 0; i < n_passes; ++i) {
             const int rc = gffx_hip_batch_run(batches[i % n_batches], mode, invert, out_flags, strategy);
             if (rc) return rc;
@@ -929,9 +937,10 @@ extern "C" int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n
     uint64_t chunk = 0;
     for (uint64_t i = 0; i < n_passes; ++chunk) {
         gffx_hip_batch *bs[kPairMaxSubs];
-        const uint32_t n = (uint32_t)std::min<uint64_t>(gs, n_passes - i);
+        const uint32_t c = (uint32_t)(chunk % plan.cycle);
+        const uint32_t n = (uint32_t)std::min<uint64_t>(plan.size[c], n_passes - i);
         for (uint32_t t = 0; t < n; ++t) bs[t] = batches[(i + t) % n_batches];
-        const int rc = run_group(bs, n, mode, invert, out_flags, strategy, (int)(chunk % (uint64_t)n_streams));
+        const int rc = run_group(bs, n, mode, invert, out_flags, strategy, (int)(c % plan.streams));
         if (rc) return rc;
         i += n;
     }

@@ -63,7 +63,7 @@ constexpr KnobDef kBatchKnobs[BK__COUNT] = {{"GFFX_HIP_AUTO_STRATEGY", 0, 0, 5},
                                             {"GFFX_HIP_MAX_BLOCKS", 2048, 1, 8192}, {"GFFX_HIP_PARTITION_BUDGET_MB", 12 * 1024, 1, 256 * 1024},
                                             {"GFFX_HIP_WIDTH_SAMPLE", 1, 0, 1},     {"GFFX_HIP_WIN_THREADS", 0, 0, 1024},
                                             {"GFFX_HIP_WIN_WIDE", 1, 0, 2},          {"GFFX_HIP_GROUP", 2, 0, 3},
-                                            {"GFFX_HIP_TICKETS", 1, 0, 3}};
+                                            {"GFFX_HIP_TICKETS", 4, 0, 4}};
 template <int N>
 struct Knobs {
     long v[N];

@@ -187,13 +187,20 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
             for (uint32_t t = 0; t < n && given < want_grid; ++t)
                 if (share[t] < rounds[t]) ++share[t], ++given, moved = true;
         }
-        // GFFX_HIP_TICKETS: 0 = every round by stride, 1 (default) = the tail by ticket (the last one to two rounds per block), 2 = every
-        // round but a block's first by ticket
-        const long tk = b0->knobs.v[BK_TICKETS];
+        // GFFX_HIP_TICKETS: 0 = every round by stride, 1 = the tail by ticket (the last one to two rounds per block), 2 = every round but
+        // a block's first by ticket, 3 = only the rounds beyond the last full stride, 4 (default) = the engine's choice: the tail by
+        // ticket for a launch that serves ONE batch with eight or more rounds per block, strides otherwise.  Measured (kbench, us per
+        // launch, random / sorted regions; profiles/r06_tickets.txt): 4 M regions (3.8 rounds per block) 0: 39.4 / 36.9, 1: 40.3 / 39.8,
+        // 3: 39.1 / 39.5; 10 M (9.5) 0: 84.1 / 74.4, 1: 80.0 / 64.7, 3: 80.3 / 70.0, 2: 82.6 / 68.3; eight batches of 1 M in one launch
+        // (7.7 per block and batch) 0: 63.7, 1: 64.7, 3: 64.5, 2: 66.1.  A ticket is a returning device atomic in front of the taker's
+        // gathers and couples the block's waves to the taker once a round; it pays where blocks have drifted apart by a good part
+        // of a round when the tail begins.
+        long tk = b0->knobs.v[BK_TICKETS];
         for (uint32_t t = 0; t < n; ++t) {
             a.sub[t].first_block = grid;
             a.sub[t].n_blocks = share[t];
             const uint64_t per_block = rounds[t] / share[t];
+            if (b0->knobs.v[BK_TICKETS] == 4) tk = (n == 1 && per_block >= 8) ? 1 : 0;
             a.sub[t].n_static = tk == 0 ? UINT64_MAX / 2 : tk == 2 ? share[t] : (uint64_t)share[t] * std::max<uint64_t>(1, tk == 3 ? per_block : per_block - 1);
             if (a.sub[t].n_static >= rounds[t]) a.sub[t].n_static = UINT64_MAX / 2;  // (no round is left to take: nobody asks)
             grid += share[t];

@@ -58,8 +58,11 @@
  *   GFFX_HIP_WIN_WIDE=0|1|2         the mixed form of the window kernels: never / AUTO's choice for batches with wide rows (default) /
  *                                   every eligible pass of the windows strategy
  *   GFFX_HIP_WIDTH_SAMPLE=0         no width sample of the rows the host hands over (AUTO then learns from a first waited pass)
- *   GFFX_HIP_GROUP=0|1|2            gffx_hip_batches_run_n: one launch for a group of batches (2, default: halves of four or more batches
- *                                   alternate between two streams; 1: one group, one stream; 0: pass by pass)
+ *   GFFX_HIP_GROUP=0|1|2|3          gffx_hip_batches_run_n with four batches or more: one launch per GROUP of batches, the groups on 1 / 2
+ *                                   (default) / 3 streams of the index; 0: always pass by pass; 1 also groups two or three batches
+ *   GFFX_HIP_TICKETS=0..4           how a launch's blocks get their rounds: 0 a fixed stride, 1 the launch's tail by ticket, 2 every round by
+ *                                   ticket, 3 only the rounds beyond the last full stride, 4 (default) the engine's choice (1 for a launch that
+ *                                   serves one batch with eight or more rounds per block, else 0)
  *   GFFX_HIP_AUTO_STRATEGY=n        what GFFX_STRATEGY_AUTO resolves to (0: the engine's choice)
  *   launch sizes (0 = the engine's choice): GFFX_HIP_FUSED_BLOCKS, GFFX_HIP_BITMAP_BLOCKS; GFFX_HIP_JOIN_BLOCKS, GFFX_HIP_MAX_BLOCKS;
  *   GFFX_HIP_PARTITION_BUDGET_MB (record buffers of the partitioned strategy)
@@ -294,9 +297,10 @@ int gffx_hip_batch_timed_runs(gffx_hip_batch *, int mode, int invert, uint32_t o
  * by ONE launch per group of up to 8 batches (every batch a share of the launch's blocks, its rounds handed out by ticket): the
  * index lines are fetched into the L2s once per launch instead of once per batch, ramp and drain are paid once.  The launch runs on
  * a stream of the index; a batch's own stream joins it whenever the batch is used on its own again (_run, _wait, _sync, a new set of
- * regions): per-batch order is what it always was.  With four batches or more the groups are halves that alternate between two such
- * streams.  Results are exactly those of n_passes single _run calls.  Knob GFFX_HIP_GROUP of batches[0]: 0 = pass by pass (round
- * 5's behaviour), 1 = one group, one stream, 2 (default) = as described. */
+ * regions): per-batch order is what it always was.  Up to three batches run pass by pass (their launches share the chip as in round
+ * 5); from four on the batches are cut into groups of equal size (<= 8), half of them on each of two such streams, so that one group's
+ * drain overlaps the next one's ramp.  Results are exactly those of n_passes single _run calls.  Knob GFFX_HIP_GROUP of batches[0]
+ * ("Tuning knobs" above). */
 int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
                            int strategy, uint64_t n_passes);
 /* n_launches times ONE pass over each of the n_batches (<= 8) batches -- the launch _batches_run_n issues for such a group --, back
