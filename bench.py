@@ -87,8 +87,10 @@ def parse_args():
     ap.add_argument("--presort", default="none", choices=["none", "chr_end", "chr_start"],
                     help="EXPERIMENT ONLY: reorder the synthetic regions on the host before upload")
     ap.add_argument("--exchange", default=None, choices=["final", "final-timed", "per-step"])
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="batches in flight in the timed region (own stream and result buffers each): 3 measured 2.4 %% above 2, 4 below both")
+    ap.add_argument("--inflight", type=int, default=16,
+                    help="batches in flight in the timed region (own result buffers each).  The engine serves four or more with ONE launch "
+                         "per group of up to 8 (gffx_hip_batches_run_n: 16 = two groups of 8 alternating between two streams); up to "
+                         "three run pass by pass as in round 5")
     ap.add_argument("--quick", action="store_true", help="headline + roofline + cpu_baseline only (skip the extra legs)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not measure roofline.traffic live (two child runs of this script under rocprofv3 --pmc, ~20 s)")
@@ -324,7 +326,7 @@ def roofline_obj(kern, nq, pairs, out_b, note, traffic=None, one_pair_us=None, b
             "block_threads": block_threads, "blocks": blocks, "note": note}
 
 
-def measure_traffic(args, block_threads=None, blocks=None):
+def measure_traffic(args, block_threads=None, blocks=None, group=1):
     """roofline.traffic, measured by THIS run: HBM bytes per launch of the dominant kernel from the L2's fabric counters,
     collected as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE in SEPARATE `rocprofv3 --kernel-trace --pmc`
     passes (never combined with other trace domains), per-dispatch averages, FETCH_SIZE doubled (gfx950 reports half the
@@ -341,11 +343,11 @@ def measure_traffic(args, block_threads=None, blocks=None):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", out, "-o", "run", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--traffic-child", "--mode", args.mode, "--strategy", args.strategy,
-                   "--out", args.out, "--offsets", args.offsets, "--queries-per-gpu", str(args.queries_per_gpu)]
+                   "--out", args.out, "--offsets", args.offsets, "--queries-per-gpu", str(args.queries_per_gpu), "--inflight", str(group)]
             if args.region_width:
                 cmd += ["--region-width", str(args.region_width[0]), str(args.region_width[1])]
             try:
-                env = dict(os.environ, TMPDIR="/tmp")
+                env = dict(os.environ, TMPDIR="/tmp", GFFX_HIP_GROUP="1")  # (the child's launches: one group of `group` batches, serial)
                 if block_threads:  # (the child's serial passes must run the kernel variant of the timed region)
                     env["GFFX_HIP_WIN_THREADS"] = str(block_threads)
                 if blocks:
@@ -615,11 +617,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.traffic_child:  # (under rocprofv3 --pmc: the workload, 12 serial passes, nothing else)
-        one = Pass(engine, ix, cols, nq, 1, mode, out_flags, strategy)
+    if args.traffic_child:  # (under rocprofv3 --pmc: the workload, 12 serial launches, nothing else)
+        # --inflight here = the batches ONE launch of the timed region serves (the parent passes the group's size and GFFX_HIP_GROUP=1:
+        # one group, one stream, launch after launch)
+        one = Pass(engine, ix, cols, nq, args.inflight, mode, out_flags, strategy)
         one.size_and_warm(0)
-        for _ in range(12):
-            one.step()
+        one.run_n(12 * len(one.batches))
         one.sync()
         one.close()
         return
@@ -679,7 +682,26 @@ def main():
         # and the PMC child are forced to the same block width
         timed_threads = run.batches[0].block_threads or None
         timed_blocks = run.batches[0].block_count or None
-        kern = run.kernel_us(max(5, min(args.steps, 30)), timed_threads, timed_blocks)
+        plan_groups, plan_largest, plan_streams = engine.batches_plan(run.batches)
+        group_launch = None
+        if plan_groups:
+            # the timed region's launches serve `plan_largest` batches each: THAT launch is what the roofline is quoted for -- serial
+            # launches of one group, back to back between one pair of HIP events on the stream they run on
+            gb = run.batches[:plan_largest]
+            for bb in gb:
+                bb.set_option("WIN_THREADS", timed_threads or 0)
+            us_launch, grouped = engine.timed_group_runs(gb, mode, False, out_flags, strategy, max(5, min(args.steps, 30)))
+            for bb in gb:
+                bb.set_option("WIN_THREADS", 0)
+            kern = {"k_join_pairs": {"avg_us": us_launch, "launches_per_step": args.passes_per_step / plan_largest}}
+            run.pass_us_one_event_pair = us_launch
+            group_launch = {"batches_per_launch": plan_largest, "groups": plan_groups, "streams": plan_streams, "grouped": grouped,
+                            "launch_us": us_launch, "us_per_pass_inside_the_launch": us_launch / plan_largest,
+                            "launches_per_step": args.passes_per_step / plan_largest,
+                            "launch_us_x_launches_per_step_ms": 1e-3 * us_launch * args.passes_per_step / plan_largest,
+                            "note": "ms_per_step below launch_us x launches_per_step = what two streams buy: one group's drain under the next one's ramp"}
+        else:
+            kern = run.kernel_us(max(5, min(args.steps, 30)), timed_threads, timed_blocks)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if world > 1:
@@ -694,7 +716,7 @@ def main():
             except Exception:
                 traffic = None
         if world == 1 and not args.no_traffic and not args.quick:
-            live = measure_traffic(args, timed_threads, timed_blocks)
+            live = measure_traffic(args, timed_threads, None if plan_groups else timed_blocks, plan_largest if plan_groups else 1)
             if live and "error" not in live:
                 traffic = live
             elif live and traffic is not None:
@@ -743,16 +765,16 @@ def main():
                 # batches read them when they were created
                 "knobs": {**ix.options(), **run.batches[0].options()},
             },
-            "roofline": roofline_obj(kern, nq, pairs, out_b,
-                                     "achieved = (12 B region + 4 B count + 4 B x pairs/region) x regions / summed HIP-event "
-                                     "duration of a pass: serial launches back to back between one pair of HIP events on the engine's "
-                                     "stream (rank 0), forced to the block width and the grid of the timed region's launches (block_threads, "
-                                     "blocks: with three batches in flight the engine launches ONE 512-thread block per CU, so that two "
-                                     "batches' kernels are resident side by side -- alone, as measured here, such a launch uses half the slots); "
-                                     "kernels{} = the same with an event pair per launch.  The resident batch is re-read by every "
-                                     "pass: at 1 M regions (12 MB) the input stream is served by the 256 MB Infinity Cache, not by HBM "
-                                     "(immaterial at this fraction of the roofline, but it is not a cold-HBM figure)", traffic,
+            "roofline": roofline_obj(kern, nq * (plan_largest if plan_groups else 1), pairs * (plan_largest if plan_groups else 1), out_b,
+                                     "achieved = (12 B region + 4 B count + 4 B x pairs/region) x the regions of ONE LAUNCH of the timed region / "
+                                     "its duration: serial launches back to back between one pair of HIP events on the stream they run on "
+                                     "(rank 0), at the block width of the timed region's launches.  With four batches or more in flight a launch "
+                                     "serves a group of batches (group_launch: regions_per_launch = batches_per_launch x the batch; traffic "
+                                     "is per launch as well); with fewer, one batch (round 5's launches in flight: forced to that region's grid).  "
+                                     "The resident batch is re-read by every pass: at 1 M regions (12 MB) the input stream is served by the 256 MB "
+                                     "Infinity Cache, not by HBM (immaterial at this fraction of the roofline, but it is not a cold-HBM figure)", traffic,
                                      run.pass_us_one_event_pair, timed_threads, timed_blocks),
+            "group_launch": group_launch,
         }
     if world == 1:
         # ---- strictly serial passes (one batch, one stream): what the committed rocprofv3 kernel stats show

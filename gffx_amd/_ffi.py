@@ -76,6 +76,7 @@ SIGNATURES = {
     "gffx_hip_batch_block_count": (C.c_uint32, [vp]),
     "gffx_hip_batch_wide_form": (C.c_int, [vp]),
     "gffx_hip_batches_run_n": (C.c_int, [C.POINTER(vp), C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint64]),
+    "gffx_hip_batches_plan": (C.c_int, [C.POINTER(vp), C.c_uint32, u32p, u32p, u32p]),
     "gffx_hip_batches_timed_runs": (C.c_int, [C.POINTER(vp), C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32,
                                     C.POINTER(C.c_double), u32p]),
     "gffx_hip_batch_timed_runs": (C.c_int, [vp, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(C.c_double)]),

@@ -496,6 +496,10 @@ static int batch_prepare_run(gffx_hip_batch *b, int mode, int invert, uint32_t o
                                (ww == 2 && b->strategy == GFFX_STRATEGY_WINDOWS));
         if (b->wide) b->strategy = GFFX_STRATEGY_WINDOWS;
     }
+    // A root pass of its own with the counts waived is what a STREAMING caller runs, chunk after chunk, with GFFX_OUT_BITMAP_KEEP from the
+    // second chunk on -- which only the windows strategy serves: AUTO takes it for the first chunk as well, or that chunk's kept pairs
+    // would be missing from gffx_hip_batch_kept_pairs_accumulated (the sweep kernel does not feed the per-block sums; round 5's advisor)
+    if (waive && strategy == GFFX_STRATEGY_AUTO) b->strategy = GFFX_STRATEGY_WINDOWS;
     if (waive && b->strategy != GFFX_STRATEGY_WINDOWS) b->flags = (b->flags & ~(uint32_t)GFFX_OUT_NO_COUNTS) | GFFX_OUT_COUNTS;
     if ((out_flags & GFFX_OUT_SEGBASE) && (out_flags & GFFX_OUT_TRIPLES))
         return fail(GFFX_E_INVALID, "gffx_hip_batch_run: GFFX_OUT_SEGBASE is an output of the root_fid passes, not of GFFX_OUT_TRIPLES");
@@ -944,6 +948,16 @@ extern "C" int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n
         if (rc) return rc;
         i += n;
     }
+    return GFFX_OK;
+}
+// how _batches_run_n would cut passes over these batches into launches: groups per walk over the batches (0: pass by pass), the
+// largest group, the streams the groups alternate between
+extern "C" int gffx_hip_batches_plan(gffx_hip_batch *const *batches, uint32_t n_batches, uint32_t *groups, uint32_t *largest, uint32_t *streams) {
+    if (!batches || !n_batches) return fail(GFFX_E_INVALID, "gffx_hip_batches_plan: no batches");
+    const GroupPlan p = plan_groups(batches, n_batches);
+    if (groups) *groups = p.cycle;
+    if (largest) *largest = p.cycle ? p.size[0] : 1u;
+    if (streams) *streams = p.cycle ? p.streams : 0u;
     return GFFX_OK;
 }
 // n_launches launches, each ONE pass over every batch (a group of n_batches <= 8), back to back on one group stream between one

@@ -686,7 +686,11 @@ extern "C" void gffx_hip_index_destroy(gffx_hip_index *ix) {
 
 extern "C" uint32_t gffx_hip_index_n_chr(const gffx_hip_index *ix) { return ix ? ix->n_chr : 0; }
 extern "C" int gffx_hip_index_options(const gffx_hip_index *ix, char *buf, size_t cap) {
-    return copy_out(ix ? ix->knobs.json(kIndexKnobs) : std::string("{}"), buf, cap);
+    // (+ "mixed_form": 0 when the index has no mixed form of the window kernels -- an interval that ends before it starts, or line
+    //  tables beyond the 2^31 bytes one buffer descriptor addresses: every wide region then takes the exact sweep; round 5's advisor)
+    std::string s = ix ? ix->knobs.json(kIndexKnobs) : std::string("{}");
+    if (ix && !ix->win_range_ok) s.insert(s.size() - 1, std::string(s.size() > 2 ? ", " : "") + "\"mixed_form\": 0");
+    return copy_out(s, buf, cap);
 }
 extern "C" uint64_t gffx_hip_index_n_roots(const gffx_hip_index *ix) { return ix ? ix->n_roots : 0; }
 extern "C" int gffx_hip_index_device(const gffx_hip_index *ix) { return ix ? ix->device : -1; }

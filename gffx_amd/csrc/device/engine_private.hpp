@@ -318,7 +318,7 @@ struct WidthSample {
     // 19.1 + 1.0 per % / 12.5 + 1.0 per %: 0.6 % / 0.9 % -- one row in 128 (32 of the sample's 4096)
     bool some_wide() const { return 128 * wide > n; }
 };
-// (chr may be nullptr: then every row is measured against `wmax_all`; with chr, against its seqid's own limit h_wmax[chr])
+// (every row is measured against its seqid's own limit h_wmax[chr]; chr, start and end are read with the same stride -- none may be NULL)
 void sample_widths(WidthSample &w, uint64_t rows, uint64_t step, const uint32_t *chr, const uint32_t *start, const uint32_t *end, size_t stride,
                    const std::vector<uint32_t> &h_wmax);
 int run_windows(gffx_hip_batch *b);  // engine_windows.hip

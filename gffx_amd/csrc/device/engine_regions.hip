@@ -74,14 +74,18 @@ extern "C" int gffx_hip_regions_append_parts(gffx_hip_regions *R, int k, uint32_
     uint64_t at = first;
     // (the rows are still in the staging buffer: ~4096 of them will say whether the chunk is mostly wide regions)
     std::vector<std::pair<uint32_t, uint32_t>> &sample = R->last_sample[k];
+    std::vector<uint64_t> &sample_row = R->last_sample_row[k];
     sample.clear();
+    sample_row.clear();
     const uint64_t step = std::max<uint64_t>(1, n_rows / 4096);
     for (uint32_t p = 0; p < n_parts; ++p) {
         if (part_rows[p]) {
             const uint32_t *rows = R->h_stage[k] + 3 * stage_first[p];
             GFFX_HIP_TRY(hipMemcpyAsync(R->d + 3 * at, rows, part_rows[p] * 12, hipMemcpyHostToDevice, R->stream));
-            for (uint64_t i = 0; i < part_rows[p]; i += step)
+            for (uint64_t i = 0; i < part_rows[p]; i += step) {
                 sample.emplace_back(rows[3 * i], rows[3 * i + 2] > rows[3 * i + 1] ? rows[3 * i + 2] - rows[3 * i + 1] : 0u);
+                sample_row.push_back(at - first + i);
+            }
         }
         at += part_rows[p];
     }
@@ -108,7 +112,10 @@ extern "C" int gffx_hip_batch_set_regions_store(gffx_hip_batch *b, const gffx_hi
     {
         WidthSample ws;
         if (b->knobs.v[BK_WIDTH_SAMPLE])
-            for (const auto &row : R->last_sample[k]) {
+            for (size_t i = 0; i < R->last_sample[k].size(); ++i) {  // (only the sampled rows the batch takes: [first, first + n_rows) of the chunk)
+                const auto &row = R->last_sample[k][i];
+                const uint64_t at = R->last_sample_row[k][i];
+                if (at < first || at >= first + n_rows) continue;
                 const uint32_t wmax = row.first < b->ix->h_win_wmax.size() ? b->ix->h_win_wmax[row.first] : 0u;
                 ws.n++, ws.wide += (wmax && row.second > wmax) ? 1 : 0;
             }

@@ -26,7 +26,7 @@ static uint32_t pairs_lds_bytes(const gffx_hip_index *ix, uint32_t threads, bool
     const uint32_t tables = 4 * fwords + 4 * sw4 + (ml ? (ix->n_chr + 1) * 16 : 0);
     if (roots) return tables + 16 + (uint32_t)sizeof(PairTickets) + 4 * bm_words;  // (+ the block's pair count, the ticket words)
     return tables + kWaveHdrBytes + 4 * (threads / 64) * pair_depth(wide) * pair_stage_words(threads, wide) +
-           4 * threads * pair_depth(wide) * keep_words + 4 * kWaveStash * threads;
+           4 * threads * pair_depth(wide) * keep_words + 4 * pair_stash_words(threads) * threads;
 }
 
 // Threads per block.  The waves of a pass are independent, so the block width only sets how many regions share one
@@ -347,7 +347,7 @@ bool gffx::windows_groupable(gffx_hip_batch *const *bs, uint32_t n) {
         if (b->strategy != GFFX_STRATEGY_WINDOWS || b->nq == 0 || b->ix != bs[0]->ix || b->mode != bs[0]->mode || b->invert != bs[0]->invert ||
             b->flags != bs[0]->flags || b->wide != bs[0]->wide || b->profiling)
             return false;
-        for (int k : {BK_WIN_THREADS, BK_FUSED_BLOCKS, BK_BITMAP_BLOCKS})
+        for (int k : {BK_WIN_THREADS, BK_FUSED_BLOCKS, BK_BITMAP_BLOCKS, BK_TICKETS})
             if (b->knobs.v[k] != bs[0]->knobs.v[k]) return false;
     }
     return true;

@@ -95,7 +95,11 @@ __device__ __forceinline__ uint32_t win_sel(const uint32_t (&a)[4], int k) {
 
 constexpr uint32_t kWaveDepth = 3;     // strips per wave: a round's words wait kWaveDepth - 1 rounds for their place
 constexpr uint32_t kWaveHdrBytes = 128; // arrival words, posted bases, post sequence numbers (kWaveDepth of each); the ticket words (PairTickets, at byte 64)
-constexpr uint32_t kWaveStash = 2;     // per thread: kept words of deferred regions wait here (LDS) for the parking
+#ifndef GFFX_STASH_1024
+#define GFFX_STASH_1024 2
+#endif
+// per thread: kept words of deferred regions wait here (LDS) for the parking
+__host__ __device__ constexpr uint32_t pair_stash_words(uint32_t threads) { return threads == 1024 ? GFFX_STASH_1024 : 2u; }
 // words a wave parks in LDS per round (a strip): 2 kept pairs per region at 1024 threads, 1.5 at 512 (two blocks share a CU's
 // LDS); a fuller round -- gene-dense stretches of a sorted BED file -- takes all kWaveDepth strips, beyond that the synchronous path
 // The wide form keeps several pairs per region (2.6 at bench.py's wide shape: 600 .. 800 a round): strips of 3.75 pairs per
@@ -749,6 +753,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     PairTickets *s_tick = reinterpret_cast<PairTickets *>(s_work + 64);                         // rounds by ticket
     uint32_t *s_stage_all = reinterpret_cast<uint32_t *>(s_work + kWaveHdrBytes);               // waves x D x kStage
     uint32_t *s_keep_all = s_stage_all + kWaves * D * kStage;                                   // T x D x keep_words
+    constexpr uint32_t kWaveStash = pair_stash_words(T);
     uint32_t *s_stash = s_keep_all + (size_t)T * D * keep_words + kWaveStash * threadIdx.x;     // this thread's kWaveStash words
     // (where the dynamic LDS starts, as an LDS address: what ds_write takes)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;

@@ -409,7 +409,7 @@ struct DeviceSort {
                 unsigned long long word = 0;
                 while (!(posted = (uint32_t)((word = __atomic_load_n(reinterpret_cast<unsigned long long *>(top_note), __ATOMIC_ACQUIRE)) >> 32) == top_seq) &&
                        std::chrono::steady_clock::now() - t0 < std::chrono::seconds(2))
-                    std::this_thread::yield();
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));  // (a queued stream would otherwise burn a quota CPU: as in lines_run)
                 ok = posted && (uint32_t)word != 0u;
                 if (!posted) {
                     uint32_t h_ok = 0;

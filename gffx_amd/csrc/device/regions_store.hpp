@@ -15,5 +15,6 @@ struct gffx_hip_regions {
     uint64_t last_first[2] = {0, 0}, last_n[2] = {0, 0};  // where the last append from buffer k went
     std::vector<std::pair<uint32_t, uint32_t>> last_sample[2];  // ... and {seqid, width} of ~4096 of its rows (AUTO's prior: judged against the
                                                                 // index's per-seqid line widths when a batch takes the rows: the store knows no index)
+    std::vector<uint64_t> last_sample_row[2];     // ... the row of the appended chunk every sampled entry is (a batch that takes a sub-range counts its own only)
     hipStream_t stream = nullptr;                 // copies
 };

@@ -451,6 +451,14 @@ def run_batches(batches: Sequence["QueryBatch"], mode: int = OverlapMode.Overlap
                                        int(len(batches) if n_passes is None else n_passes)))
 
 
+def batches_plan(batches: Sequence["QueryBatch"]):
+    """(groups per walk over the batches -- 0: pass by pass --, largest group, streams) of run_batches for these batches"""
+    arr = (C.c_void_p * len(batches))(*[b._h for b in batches])
+    g, m, st = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    check(lib().gffx_hip_batches_plan(arr, len(batches), C.byref(g), C.byref(m), C.byref(st)))
+    return int(g.value), int(m.value), int(st.value)
+
+
 def timed_group_runs(batches: Sequence["QueryBatch"], mode: int, invert: bool, out_flags: int, strategy: int, n: int):
     """n launches, each one pass over every batch (a group of <= 8), back to back between one pair of HIP events.
     Returns (microseconds per launch, grouped: the passes ran as one launch)."""

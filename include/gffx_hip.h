@@ -303,6 +303,9 @@ int gffx_hip_batch_timed_runs(gffx_hip_batch *, int mode, int invert, uint32_t o
  * ("Tuning knobs" above). */
 int gffx_hip_batches_run_n(gffx_hip_batch *const *batches, uint32_t n_batches, int mode, int invert, uint32_t out_flags,
                            int strategy, uint64_t n_passes);
+/* How _batches_run_n cuts passes over these batches into launches: *groups per walk over the batches (0: pass by pass), the *largest
+ * group's size, the *streams the groups alternate between (any pointer may be NULL). */
+int gffx_hip_batches_plan(gffx_hip_batch *const *batches, uint32_t n_batches, uint32_t *groups, uint32_t *largest, uint32_t *streams);
 /* n_launches times ONE pass over each of the n_batches (<= 8) batches -- the launch _batches_run_n issues for such a group --, back
  * to back between one pair of HIP events on the stream they run on (blocking): total_ms / n_launches = the duration of the launch.
  * *grouped (may be NULL) = 1 when the passes ran as one launch, 0 when they did not group (then: pass after pass on batches[0]'s
