@@ -742,7 +742,8 @@ def main():
             "config": {
                 "workload": "BASELINE %s: %d synthetic BED regions %s (seed %d) x GENCODE/GRCh38-shaped index (25 seqids, %d root "
                             "genes, seed 42), --%s, regions resident in HBM as u32 SoA; one step = %d passes over the resident batch "
-                            "(one kernel launch per pass)"
+                            "(a pass = the kernel's work over the batch's regions into one of the result buffers in flight; from four "
+                            "buffers on ONE launch serves a group of them: group_launch)"
                             % (cfg, nq_global if strong else args.queries_per_gpu, "in total" if strong else "per GPU", 1003 if strong else 1001,
                                ix.n_roots, args.mode, args.passes_per_step),
                 "regions_total": nq_total,

@@ -95,11 +95,9 @@ __device__ __forceinline__ uint32_t win_sel(const uint32_t (&a)[4], int k) {
 
 constexpr uint32_t kWaveDepth = 3;     // strips per wave: a round's words wait kWaveDepth - 1 rounds for their place
 constexpr uint32_t kWaveHdrBytes = 128; // arrival words, posted bases, post sequence numbers (kWaveDepth of each); the ticket words (PairTickets, at byte 64)
-#ifndef GFFX_STASH_1024
-#define GFFX_STASH_1024 2
-#endif
-// per thread: kept words of deferred regions wait here (LDS) for the parking
-__host__ __device__ constexpr uint32_t pair_stash_words(uint32_t threads) { return threads == 1024 ? GFFX_STASH_1024 : 2u; }
+// per thread: kept words of deferred regions wait here (LDS) for the parking (round 6: 4 or 6 words at 1024 threads change nothing,
+// sorted batches included: profiles/r06_staging_and_stride_ab.txt)
+__host__ __device__ constexpr uint32_t pair_stash_words(uint32_t) { return 2u; }
 // words a wave parks in LDS per round (a strip): 2 kept pairs per region at 1024 threads, 1.5 at 512 (two blocks share a CU's
 // LDS); a fuller round -- gene-dense stretches of a sorted BED file -- takes all kWaveDepth strips, beyond that the synchronous path
 // The wide form keeps several pairs per region (2.6 at bench.py's wide shape: 600 .. 800 a round): strips of 3.75 pairs per

@@ -155,13 +155,19 @@ void write_segments(const uint8_t *base, const std::vector<std::pair<uint64_t, u
     // Large outputs: buffered pwrite()s to ONE file serialise on its inode lock (8 threads reached 2 GB/s), stores through a
     // shared mapping do not.  The space is reserved first (posix_fallocate reports a full disk as an error; a store into a
     // hole would raise SIGBUS instead); anything that does not work here falls back to the pwrite path below.
-    if (total >= (32u << 20) && threads > 1 && ::posix_fallocate(fd, 0, static_cast<off_t>(total)) == 0) {
+    const char *wm = std::getenv("GFFX_WRITE_MODE");  // (experiments: "pwrite" = no mapping; "populate" = the mapping's pages are made in bulk first)
+    const bool no_map = wm && std::strcmp(wm, "pwrite") == 0, populate = wm && std::strcmp(wm, "populate") == 0;
+    if (!no_map && total >= (32u << 20) && threads > 1 && ::posix_fallocate(fd, 0, static_cast<off_t>(total)) == 0) {
         void *m = ::mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         if (m != MAP_FAILED) {
             uint8_t *out = static_cast<uint8_t *>(m);
             const size_t W = std::max<size_t>(1, std::min<size_t>(threads, 32));
             auto copy = [&](size_t t) {  // thread t takes the segments whose first byte lies in its share of the output
                 const uint64_t lo = total * t / W, hi = total * (t + 1) / W;
+                if (populate) {
+                    const uint64_t plo = lo & ~4095ull, phi = t + 1 == W ? total : hi & ~4095ull;
+                    if (phi > plo) (void)::madvise(out + plo, phi - plo, 23 /* MADV_POPULATE_WRITE */);
+                }
                 size_t i = static_cast<size_t>(std::lower_bound(dst.begin(), dst.end() - 1, lo) - dst.begin());
                 for (; i < seg.size() && dst[i] < hi; ++i) std::memcpy(out + dst[i], base + seg[i].first, static_cast<size_t>(seg[i].second));
             };
@@ -174,7 +180,7 @@ void write_segments(const uint8_t *base, const std::vector<std::pair<uint64_t, u
             return;
         }
     }
-    const size_t T = total < (32u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(threads, 8));
+    const size_t T = total < (32u << 20) ? 1 : std::max<size_t>(1, std::min<size_t>(threads, no_map ? 32 : 8));
     std::atomic<bool> failed{false};
     auto work = [&](size_t t) {
         // thread t takes the segments whose first byte lies in its share of the output

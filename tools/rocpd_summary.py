@@ -57,6 +57,35 @@ def main(path):
         print("\n## concurrency: %d kernels over a span of %.1f us; summed kernel time %.1f us; %d launches start before the "
               "previous kernel ended (%.1f us of pairwise overlap); span / launches = %.2f us per launch"
               % (len(iv), (span1 - span0) / 1e3, busy / 1e3, n_over, overlap / 1e3, (span1 - span0) / 1e3 / len(iv)))
+    # the same per kernel VARIANT (name x grid x block): how many of its launches run while another kernel is still running, and the
+    # steady-state distance between its launches (round 6: the timed region's launches serve a group of batches each and alternate
+    # between two streams -- this is where the trace shows what overlaps)
+    try:
+        kv = cur.execute("select name, grid_x, workgroup_x, start, end from kernels order by start").fetchall()
+    except sqlite3.Error:
+        kv = []
+    if len(kv) > 1:
+        import statistics
+        groups = {}
+        run_end = 0  # the latest end of any kernel that started earlier
+        for i, (name, gx, wx, a, b) in enumerate(kv):
+            g = groups.setdefault((name, gx, wx), {"n": 0, "dur": [], "over_n": 0, "over": [], "starts": []})
+            g["n"] += 1
+            g["dur"].append(b - a)
+            g["starts"].append(a)
+            if i and run_end > a:
+                g["over_n"] += 1
+                g["over"].append(min(run_end, b) - a)
+            run_end = max(run_end, b)
+        print("\n## overlap by kernel variant (launches >= 20 only): launches | avg us | launches that start while an earlier kernel still runs "
+              "(mean us of such overlap) | median distance between consecutive launches of the variant, us")
+        for (name, gx, wx), g in sorted(groups.items(), key=lambda kv_: -sum(kv_[1]["dur"])):
+            if g["n"] < 20:
+                continue
+            d = [y - x for x, y in zip(g["starts"], g["starts"][1:])]
+            print("%-6d %9.2f   %5d (%.2f)   %9.2f | grid %s x %s | %s" % (
+                g["n"], statistics.mean(g["dur"]) / 1e3, g["over_n"], (statistics.mean(g["over"]) / 1e3) if g["over"] else 0.0,
+                statistics.median(d) / 1e3 if d else 0.0, gx, wx, name[:110]))
     try:
         mc = cur.execute("select count(*), sum(size), avg(duration) from memory_copies").fetchone()
         if mc and mc[0]:
