@@ -214,9 +214,12 @@ class Pass:
     def __init__(self, engine, ix, dev_cols, nq, inflight, mode, out_flags, strategy):
         self.engine, self.mode, self.flags, self.strategy = engine, mode, out_flags, strategy
         self.batches = []
-        for _ in range(max(1, inflight)):
+        for i in range(max(1, inflight)):
             bb = engine.QueryBatch(ix, max(nq, 1))
-            bb.set_regions_device(dev_cols[0].data_ptr(), dev_cols[1].data_ptr(), dev_cols[2].data_ptr(), nq, keep=dev_cols)
+            # every batch in flight reads its OWN copy of the regions (round 6: a launch that serves eight batches would otherwise find
+            # seven of its eight region streams in the L2 -- a caller's batches in flight hold different regions)
+            cols = dev_cols if i == 0 else tuple(c.clone() for c in dev_cols)
+            bb.set_regions_device(cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), nq, keep=cols)
             self.batches.append(bb)
         self.issued = 0
 
@@ -743,7 +746,7 @@ def main():
                 "workload": "BASELINE %s: %d synthetic BED regions %s (seed %d) x GENCODE/GRCh38-shaped index (25 seqids, %d root "
                             "genes, seed 42), --%s, regions resident in HBM as u32 SoA; one step = %d passes over the resident batch "
                             "(a pass = the kernel's work over the batch's regions into one of the result buffers in flight; from four "
-                            "buffers on ONE launch serves a group of them: group_launch)"
+                            "buffers on ONE launch serves a group of them: group_launch; every buffer in flight has its own copy of the regions)"
                             % (cfg, nq_global if strong else args.queries_per_gpu, "in total" if strong else "per GPU", 1003 if strong else 1001,
                                ix.n_roots, args.mode, args.passes_per_step),
                 "regions_total": nq_total,
