@@ -365,17 +365,20 @@ def measure_traffic(args, block_threads=None, blocks=None, group=1):
                         db = os.path.join(dirpath, f)
             if r.returncode != 0 or db is None:
                 return {"error": "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-200:])}
+            # per kernel AND grid: the child's first launches serve one batch each (they size the buffers), the measured ones a group
+            # of `group` batches -- a different grid of the same kernel; the variant that moves the most bytes in all is the measured one
             rows = sqlite3.connect(db).execute(
-                "select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name",
-                (counter,)).fetchall()
+                "select kernel_name, count(*), avg(value), grid_size_x from counters_collection where counter_name = ? "
+                "group by kernel_name, grid_size_x", (counter,)).fetchall()
             rows = [x for x in rows if "k_join_" in x[0] or "k_tile_join" in x[0] or "k_partition" in x[0]]
             if not rows:
                 return {"error": "no dispatch of a join kernel in the %s pass" % counter}
-            name, n, avg = max(rows, key=lambda x: x[1] * x[2])
-            kib[counter] = {"kernel": name.split("<")[0].replace("void ", ""), "dispatches": n, "avg_KiB": avg}
+            name, n, avg, grid_x = max(rows, key=lambda x: x[1] * x[2])
+            kib[counter] = {"kernel": name.split("<")[0].replace("void ", ""), "dispatches": n, "avg_KiB": avg, "grid_threads": grid_x}
     b = 2.0 * kib["FETCH_SIZE"]["avg_KiB"] * 1024 + kib["WRITE_SIZE"]["avg_KiB"] * 1024
     return {"hbm_bytes_per_launch": b, "kernel": kib["FETCH_SIZE"]["kernel"], "FETCH_SIZE_KiB": kib["FETCH_SIZE"]["avg_KiB"],
-            "WRITE_SIZE_KiB": kib["WRITE_SIZE"]["avg_KiB"], "dispatches": kib["FETCH_SIZE"]["dispatches"],
+            "WRITE_SIZE_KiB": kib["WRITE_SIZE"]["avg_KiB"], "dispatches": kib["FETCH_SIZE"]["dispatches"], "grid_threads": kib["FETCH_SIZE"]["grid_threads"],
+            "batches_per_launch": group,
             "source": "measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate child "
                       "passes; bytes = 2 x FETCH_SIZE + WRITE_SIZE (the doubling is calibrated for wide streaming reads: an "
                       "upper bound for this kernel's 16-byte index gathers)"}

@@ -80,6 +80,11 @@ extern "C" {
     pub fn gffx_hip_batch_options(b: *const gffx_hip_batch, buf: *mut std::os::raw::c_char, cap: usize) -> c_int;
     pub fn gffx_hip_index_options(ix: *const gffx_hip_index, buf: *mut std::os::raw::c_char, cap: usize) -> c_int;
     pub fn gffx_hip_batch_kept_pairs_accumulated(b: *mut gffx_hip_batch, out: *mut u64) -> c_int;
+    // round 6: passes over several batches handed over together -- from four batches on ONE launch serves a group of up to 8 of them
+    // (results exactly those of single gffx_hip_batch_run calls); how the passes would be cut into launches
+    pub fn gffx_hip_batches_run_n(batches: *const *mut gffx_hip_batch, n_batches: u32, mode: c_int, invert: c_int, out_flags: u32,
+                                  strategy: c_int, n_passes: u64) -> c_int;
+    pub fn gffx_hip_batches_plan(batches: *const *mut gffx_hip_batch, n_batches: u32, groups: *mut u32, largest: *mut u32, streams: *mut u32) -> c_int;
     // streaming BED ingestion through pinned staging buffers, several GPUs
     pub fn gffx_hip_regions_create(device: c_int, capacity_rows: u64, chunk_rows: u64, keep_all: c_int, out: *mut *mut gffx_hip_regions) -> c_int;
     pub fn gffx_hip_regions_destroy(r: *mut gffx_hip_regions);

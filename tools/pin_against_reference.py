@@ -91,6 +91,13 @@ def make_cases(work: str):
         wbed = os.path.join(work, name + ".wide.bed")
         synth.write_bed(wbed, wide, [c for c, _ in synth.SMALL2])
         cases.append((name + "_wide", gff, wbed, None, []))
+        # ... and the plain BED sorted by (seqid, start), as real files mostly are (round 6: ordered input -- the same rows, so the
+        # outputs must be the unsorted case's row sets; the reference walks a seqid's rows in input order, intersect.rs:139-141)
+        import numpy as np
+        srt = rows[np.lexsort((rows[:, 1], rows[:, 0]))]
+        sbed = os.path.join(work, name + ".sorted.bed")
+        synth.write_bed(sbed, srt, [c for c, _ in synth.SMALL2])
+        cases.append((name + "_sorted", gff, sbed, None, []))
     return cases
 
 

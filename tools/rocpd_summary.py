@@ -26,11 +26,18 @@ def main(path):
         print("%-8d %10.1f %9.2f %9.2f %9.2f %6.2f | %4s %4s %4s %6s %7s | %9s %5s | %s" % (
             n, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot, vg, ag, sg, lds, scr, gx, wx, name))
     try:
+        # (per kernel and GRID: round 6's launches that serve a group of batches are the same kernel on another grid)
         prow = cur.execute(
-            "select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
-            "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
+            "select kernel_name || '  [grid ' || grid_size_x || ' x ' || workgroup_size_x || ']', counter_name, count(*), avg(value), sum(value) "
+            "from counters_collection group by kernel_name, grid_size_x, workgroup_size_x, counter_name "
+            "order by kernel_name, grid_size_x, counter_name").fetchall()
     except sqlite3.Error:
-        prow = []
+        try:
+            prow = cur.execute(
+                "select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+                "group by kernel_name, counter_name order by kernel_name, counter_name").fetchall()
+        except sqlite3.Error:
+            prow = []
     if prow:
         print("\n## PMC counters (per dispatch average; summed over all instances of the counter's block)")
         last = None

@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 6, call 14: round 5's kernels (kb5) against today's (kb6) on one box: pair pass (258) and root pass (520), 1 M / 10 M, random / sorted, both block widths; tickets off / auto
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+O=$R/gpurun_out/r6_14.txt
+: > $O
+for nq in 1000000 10000000; do for ps in 0 2; do for fl in 258 520; do for th in 0 512; do
+  echo "== nq=$nq presort=$ps flags=$fl WIN_THREADS=$th: kb5 | kb6 TICKETS=0 | kb6 (auto)" >> $O
+  GFFX_HIP_WIN_THREADS=$th timeout 120 tools/_kb/kb5 $nq 5 $fl 40 $ps 2>&1 | grep "pass:" >> $O
+  GFFX_HIP_TICKETS=0 GFFX_HIP_WIN_THREADS=$th timeout 120 tools/_kb/kb6 $nq 5 $fl 40 $ps 2>&1 | grep "pass:" >> $O
+  GFFX_HIP_WIN_THREADS=$th timeout 120 tools/_kb/kb6 $nq 5 $fl 40 $ps 2>&1 | grep "pass:" >> $O
+done; done; done; done
+cat $O
