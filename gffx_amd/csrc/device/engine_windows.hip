@@ -38,20 +38,22 @@ static uint32_t pair_threads(const gffx_hip_batch *b, uint64_t nq_launch, bool o
     return (!others_busy && nq_launch >= 500000) ? 1024u : 512u;
 }
 
-template <int MODE, bool ML, int T, bool OFFS, bool POS, bool WIDE>
+template <int MODE, bool ML, int T, bool OFFS, bool POS, bool WIDE, bool DYN>
 static int launch_pairs4(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t lds) {
-    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_pairs<MODE, ML, T, OFFS, POS, WIDE>), device, lds,
+    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_pairs<MODE, ML, T, OFFS, POS, WIDE, DYN>), device, lds,
                               T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_join_pairs<MODE, ML, T, OFFS, POS, WIDE>), dim3(grid), dim3(T), lds, stream, a);
+    hipLaunchKernelGGL((k_join_pairs<MODE, ML, T, OFFS, POS, WIDE, DYN>), dim3(grid), dim3(T), lds, stream, a);
     return GFFX_OK;
 }
 template <int MODE, bool ML>
-static int launch_pairs(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, bool pos, bool wide, uint32_t lds) {
+static int launch_pairs(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, bool pos, bool wide, bool dyn, uint32_t lds) {
 #define GFFX_P(T, O, P)                                                                                          \
     if (threads == T && offs == O && pos == P) {                                                                 \
-        if (wide) return launch_pairs4<MODE, ML, T, O, P, true>(device, stream, grid, a, lds);                   \
-        return launch_pairs4<MODE, ML, T, O, P, false>(device, stream, grid, a, lds);                            \
+        if (wide) return dyn ? launch_pairs4<MODE, ML, T, O, P, true, true>(device, stream, grid, a, lds)        \
+                             : launch_pairs4<MODE, ML, T, O, P, true, false>(device, stream, grid, a, lds);      \
+        return dyn ? launch_pairs4<MODE, ML, T, O, P, false, true>(device, stream, grid, a, lds)                 \
+                   : launch_pairs4<MODE, ML, T, O, P, false, false>(device, stream, grid, a, lds);               \
     }
     GFFX_P(1024, false, false) GFFX_P(1024, true, false) GFFX_P(1024, false, true) GFFX_P(1024, true, true)
     GFFX_P(512, false, false) GFFX_P(512, true, false) GFFX_P(512, false, true) GFFX_P(512, true, true)
@@ -59,17 +61,21 @@ static int launch_pairs(int device, hipStream_t stream, uint32_t grid, const Pai
 
     return GFFX_OK;
 }
-template <int MODE, bool ML, int T, bool WIDE>
+template <int MODE, bool ML, int T, bool WIDE, bool DYN>
 static int launch_roots3(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t lds) {
-    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_roots<MODE, ML, T, WIDE>), device, lds, T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
+    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_roots<MODE, ML, T, WIDE, DYN>), device, lds, T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_join_roots<MODE, ML, T, WIDE>), dim3(grid), dim3(T), lds, stream, a);
+    hipLaunchKernelGGL((k_join_roots<MODE, ML, T, WIDE, DYN>), dim3(grid), dim3(T), lds, stream, a);
     return GFFX_OK;
 }
+template <int MODE, bool ML, bool WIDE, bool DYN>
+static int launch_roots2(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t threads, uint32_t lds) {
+    return threads == 1024 ? launch_roots3<MODE, ML, 1024, WIDE, DYN>(device, stream, grid, a, lds) : launch_roots3<MODE, ML, 512, WIDE, DYN>(device, stream, grid, a, lds);
+}
 template <int MODE, bool ML>
-static int launch_roots(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t threads, bool wide, uint32_t lds) {
-    if (wide) return threads == 1024 ? launch_roots3<MODE, ML, 1024, true>(device, stream, grid, a, lds) : launch_roots3<MODE, ML, 512, true>(device, stream, grid, a, lds);
-    return threads == 1024 ? launch_roots3<MODE, ML, 1024, false>(device, stream, grid, a, lds) : launch_roots3<MODE, ML, 512, false>(device, stream, grid, a, lds);
+static int launch_roots(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t threads, bool wide, bool dyn, uint32_t lds) {
+    if (wide) return dyn ? launch_roots2<MODE, ML, true, true>(device, stream, grid, a, threads, lds) : launch_roots2<MODE, ML, true, false>(device, stream, grid, a, threads, lds);
+    return dyn ? launch_roots2<MODE, ML, false, true>(device, stream, grid, a, threads, lds) : launch_roots2<MODE, ML, false, false>(device, stream, grid, a, threads, lds);
 }
 
 // One launch of the windows strategy for the n batches bs[] (same index, mode, invert, flags and form: windows_groupable), on
@@ -175,6 +181,7 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
     const uint32_t want_grid = (uint32_t)std::min<uint64_t>(total_rounds, (uint64_t)(blocks_knob ? blocks_knob : slots));
     // every batch's share of the blocks: in proportion to its rounds, at least one, at most a block per round
     uint32_t grid = 0;
+    bool dyn = n > 1;  // the kernels' DYN instantiation: several batches, or rounds by ticket
     {
         uint32_t share[kPairMaxSubs];
         uint64_t given = 0;
@@ -200,9 +207,10 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
             a.sub[t].first_block = grid;
             a.sub[t].n_blocks = share[t];
             const uint64_t per_block = rounds[t] / share[t];
-            if (b0->knobs.v[BK_TICKETS] == 4) tk = (n == 1 && per_block >= 8) ? 1 : 0;
+            if (b0->knobs.v[BK_TICKETS] == 4) tk = (n == 1 && per_block >= 8 && !roots) ? 1 : 0;  // (pair passes only: the root kernel's waves are not coupled otherwise, tickets cost it 3-8 % on random regions)
             a.sub[t].n_static = tk == 0 ? UINT64_MAX / 2 : tk == 2 ? share[t] : (uint64_t)share[t] * std::max<uint64_t>(1, tk == 3 ? per_block : per_block - 1);
             if (a.sub[t].n_static >= rounds[t]) a.sub[t].n_static = UINT64_MAX / 2;  // (no round is left to take: nobody asks)
+            dyn = dyn || a.sub[t].n_static < UINT64_MAX / 2;
             grid += share[t];
         }
     }
@@ -267,8 +275,8 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
     if (n == 1) prof_begin(b0, roots ? GFFX_K_WINDOWS : GFFX_K_WAVE, &pe);
 #define GFFX_CASE(M, L)                                                                                                  \
     if (b0->mode == M && ml == L)                                                                                        \
-        lrc = roots ? launch_roots<M, L>(ix->device, stream, grid, a, threads, wide, lds)                                \
-                    : launch_pairs<M, L>(ix->device, stream, grid, a, threads, offs, pos, wide, lds);
+        lrc = roots ? launch_roots<M, L>(ix->device, stream, grid, a, threads, wide, dyn, lds)                           \
+                    : launch_pairs<M, L>(ix->device, stream, grid, a, threads, offs, pos, wide, dyn, lds);
     GFFX_CASE(0, true) GFFX_CASE(0, false) GFFX_CASE(1, true) GFFX_CASE(1, false) GFFX_CASE(2, true) GFFX_CASE(2, false)
 #undef GFFX_CASE
     if (n == 1) prof_end(b0, &pe);

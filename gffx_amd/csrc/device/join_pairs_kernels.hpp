@@ -718,7 +718,11 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 // POS: the words a pass emits are index positions (table win_pos), not root_fids
 // WIDE: the mixed form (pair_locate_mixed; every mode, inverted or not): a batch in which AUTO found wide regions -- every lane serves its
 //       region the narrow way (one line) or the wide way (two lines, two ranks) as the region's width asks
-template <int MODE, bool META_LDS, int T, bool OFFS, bool POS, bool WIDE = false>
+// DYN: the launch serves several batches and / or hands rounds out by ticket (section "PairSub" above).  The plain launch -- one batch,
+//      every round by stride -- is an instantiation of its own: behind a run-time record index and next to the ticket code the
+//      compiler re-loads the record's fields from the kernarg segment in the loop (the root kernel 12 -> 42 scalar loads, each one an
+//      s_waitcnt lgkmcnt(0)): +2 % per pair pass, +5-10 % per root pass (profiles/r06_single_batch_regression.txt)
+template <int MODE, bool META_LDS, int T, bool OFFS, bool POS, bool WIDE = false, bool DYN = false>
 __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED;        // a wide lane keeps the roots of its run that end inside the region (inverted: beyond it)
     constexpr bool CREG = WIDE && MODE == GFFX_MODE_CONTAINS_REGION;  // ... the roots over qs that reach the region's end (inverted: that do not, and its run)
@@ -728,11 +732,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
     constexpr uint32_t keep_words = OFFS ? 2u : 0u;
     constexpr uint32_t kStage = pair_stage_words(T, WIDE);  // words a wave parks per round
     auto rare_ix = [&]() -> const IndexView & { return pair_rare_ix(); };
-    const PairSub &S = A.sub[pair_sub_of_block(A)];  // this block's batch
+    const PairSub &S = A.sub[DYN ? pair_sub_of_block(A) : 0u];  // this block's batch
     const QueryView &q = S.q;
     const WaveOut &out = S.out;
     const unsigned long long nq = S.nq;
-    const uint32_t lb = blockIdx.x - S.first_block;  // the block's number inside its batch
+    const uint32_t lb = DYN ? blockIdx.x - S.first_block : blockIdx.x;  // the block's number inside its batch
     const uint32_t fwords = A.fwords, swords = A.swords, n_chr = A.pv.n_chr;
     const bool inv = A.invert != 0;
     GFFX_WIN_STAMP(13);
@@ -779,11 +783,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         s_arrive[tid] = 0ull;
         s_post_seq[tid] = 0u;
     }
-    if (tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
+    if (DYN && tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
     win_barrier();  // the ONLY block barrier: tables staged, arrival and ticket words zero
     if (lb == 0 && tid == 0) {
         *out.pair_cursor_next = 0ull;
-        *S.ticket_next = 0u;
+        if (DYN) *S.ticket_next = 0u;
         if (lds0 != 0) atomicOr(out.err, 2u);  // (the filter lookups assume the dynamic LDS starts at LDS address 0)
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -915,8 +919,8 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(0);
         // (the block's next round: its own stride while that stays below n_static, else by ticket -- the first wave of the block to
         //  get here takes it: PairTickets)
-        const bool by_ticket = r + S.n_blocks >= S.n_static;  // (uniform, the same for every wave of the block)
-        const bool t_first = by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
+        const bool by_ticket = DYN && r + S.n_blocks >= S.n_static;  // (uniform, the same for every wave of the block)
+        const bool t_first = DYN && by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
         // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
         uint32_t off[4], rqs[4], rqe1[4];  // the line's byte offset; the region in the line's coordinates (rqe1 = its last base)
         bool swp[4];  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
@@ -943,7 +947,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         // the next round's ticket: older than the round's gathers (its answer is back when they are), younger than the wait for the
         // round's regions (a conditional memory operation younger than loads that are still waited for makes that wait a drain)
         uint32_t t_got = 0;
-        if (t_first && lane == 0) t_got = atomicAdd(S.ticket, 1u);
+        if constexpr (DYN) {
+            if (t_first && lane == 0) t_got = atomicAdd(S.ticket, 1u);
+        }
         gffx_v4u wc[4], wf[4];  // the line's halves: coordinates | root_fids (or positions); a wide lane's second half: {rank, list-tail header, 0, 0}
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1121,9 +1127,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         }
         GFFX_WIN_STAMP(3);
         uint32_t r_next = 0;
-        if (t_first) {  // (uniform) this wave took the next round's ticket: it is back with the gathers; posted before anything rare
-            r_next = (uint32_t)S.n_static + (uint32_t)__builtin_amdgcn_readfirstlane((int)t_got);
-            pair_ticket_post<false>(s_tick, k_tick, kWaves, lane, r_next);
+        if constexpr (DYN) {
+            if (t_first) {  // (uniform) this wave took the next round's ticket: it is back with the gathers; posted before anything rare
+                r_next = (uint32_t)S.n_static + (uint32_t)__builtin_amdgcn_readfirstlane((int)t_got);
+                pair_ticket_post<false>(s_tick, k_tick, kWaves, lane, r_next);
+            }
         }
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept words wait in
         // the thread's LDS strip)
@@ -1193,11 +1201,15 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(6);
         finish(P - 1);
         GFFX_WIN_STAMP(7);
-        if (!by_ticket)
+        if constexpr (DYN) {
+            if (!by_ticket)
+                r_next = (uint32_t)r + S.n_blocks;
+            else if (!t_first)
+                r_next = pair_ticket_await(s_tick, k_tick);
+            k_tick += by_ticket ? 1u : 0u;
+        } else {
             r_next = (uint32_t)r + S.n_blocks;
-        else if (!t_first)
-            r_next = pair_ticket_await(s_tick, k_tick);
-        k_tick += by_ticket ? 1u : 0u;
+        }
         load_round(r_next);
         const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         const uint32_t inc = win_wave_scan(mine);
@@ -1460,16 +1472,16 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 // out.fids = the slabs (grid x bm_words words); out.capacity = bm_words (0: no LDS bitmap); out.segbase (as a number) = how many
 // slabs hold something to OR with (GFFX_OUT_BITMAP_KEEP), the others are overwritten.  out.block_sums[block] = the block's kept
 // pairs (summed on the host: one same-address device atomic per wave cost 43 us per 1 M regions, per block still 5).
-template <int MODE, bool META_LDS, int T, bool WIDE = false>
+template <int MODE, bool META_LDS, int T, bool WIDE = false, bool DYN = false>
 __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED, CREG = WIDE && MODE == GFFX_MODE_CONTAINS_REGION;  // (as in k_join_pairs)
     constexpr uint32_t kChunk = 4u * T;
     constexpr uint32_t kWaves = T / 64;
-    const PairSub &S = A.sub[pair_sub_of_block(A)];  // this block's batch
+    const PairSub &S = A.sub[DYN ? pair_sub_of_block(A) : 0u];  // this block's batch (DYN: as in k_join_pairs)
     const QueryView &q = S.q;
     const WaveOut &out = S.out;
     const unsigned long long nq = S.nq;
-    const uint32_t lb = blockIdx.x - S.first_block;  // the block's number inside its batch
+    const uint32_t lb = DYN ? blockIdx.x - S.first_block : blockIdx.x;  // the block's number inside its batch
     const uint32_t fwords = A.fwords, swords = A.swords, n_chr = A.pv.n_chr;
     const bool inv = A.invert != 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1502,11 +1514,11 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         reinterpret_cast<uint4 *>(s_sbits)[x] = reinterpret_cast<const uint4 *>(A.pv.splittab)[x];
     for (uint32_t x = tid; x < bm_words; x += T) s_bm[x] = 0u;
     if (tid == 0) s_total[0] = 0ull;
-    if (tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
+    if (DYN && tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
     win_barrier();
     if (lb == 0 && tid == 0) {
         *out.pair_cursor_next = 0ull;
-        *S.ticket_next = 0u;
+        if (DYN) *S.ticket_next = 0u;
         if (lds0 != 0) atomicOr(out.err, 2u);
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1530,8 +1542,8 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     for (unsigned long long r = lb; r < n_rounds;) {
         const unsigned long long base = r * kChunk;
         const bool full = base + kChunk <= nq;
-        const bool by_ticket = r + S.n_blocks >= S.n_static;  // (as in k_join_pairs: the tail's rounds are taken by ticket)
-        const bool t_first = by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
+        const bool by_ticket = DYN && r + S.n_blocks >= S.n_static;  // (as in k_join_pairs: the tail's rounds are taken by ticket)
+        const bool t_first = DYN && by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
         uint32_t off[4], rqs[4], rqe1[4];
         bool swp[4];
         uint32_t off1[4], rel1[4], r0[4], nr[4];  // (mixed form, wide lanes) the line of qe - 1, qe - 1 in its coordinates; the run of roots that start inside the region
@@ -1550,7 +1562,9 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             }
         }
         uint32_t t_got = 0;  // (as in k_join_pairs: older than the gathers, younger than the wait for the regions)
-        if (t_first && lane == 0) t_got = atomicAdd(S.ticket, 1u);
+        if constexpr (DYN) {
+            if (t_first && lane == 0) t_got = atomicAdd(S.ticket, 1u);
+        }
         gffx_v4u wc[4], wf[4];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1748,7 +1762,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             }
         }
         uint32_t r_next;
-        if (!by_ticket) {
+        if (!DYN || !by_ticket) {
             r_next = (uint32_t)r + S.n_blocks;
         } else if (t_first) {  // (uniform) the ticket is back with the gathers; nothing bounds how far this kernel's waves drift apart: the slot is checked
             r_next = (uint32_t)S.n_static + (uint32_t)__builtin_amdgcn_readfirstlane((int)t_got);

@@ -12,7 +12,7 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 STRATS = [engine.STRATEGY_DIRECT, engine.STRATEGY_SORTED, engine.STRATEGY_FUSED, engine.STRATEGY_WINDOWS]
 t0 = time.time()
-n_checks = n_wide = 0
+n_checks = n_wide = n_group = 0
 for it in range(iters):
     n_chr = int(rng.choice([1, 2, 3, 7, 40, 300]))
     span = int(rng.choice([200, 5_000, 1_000_000, 250_000_000, 0xFFFFFF00]))
@@ -127,6 +127,60 @@ for it in range(iters):
                         print("MISMATCH iteration", it, "strategy", strat, "mode", mode, "invert", inv, "flags", flags, "wide form", wide,
                               "n_chr", n_chr, "R", R, "nq", nq, "shape", shape, "span", span, flush=True)
                         sys.exit(1)
+    # round 6: the same index, 2-6 batches of slices / shuffles / sorted copies of the regions handed over TOGETHER (one launch per
+    # group: engine.run_batches), pair passes, triples + roots and root passes, the narrow and the forced mixed form -- every batch
+    # against the oracle on ITS regions
+    ng = int(rng.choice([2, 3, 4, 6]))
+    gsets = []
+    for g in range(ng):
+        kind_g = g % 3
+        sub = regions[rng.permutation(nq)[: max(1, int(rng.integers(1, nq + 1)))]]
+        if kind_g == 1:
+            sub = sub[np.lexsort((sub[:, 1], sub[:, 0]))]  # sorted by (seqid, start)
+        gsets.append(np.ascontiguousarray(sub))
+    gb = []
+    for r_ in gsets:
+        bb = engine.QueryBatch(ix, len(r_))
+        bb.set_regions(r_)
+        gb.append(bb)
+    gb[0].set_option("GROUP", int(rng.choice([1, 2, 3])))
+    for mode in (0, 1, 2):
+        inv = bool(rng.integers(0, 2)) and mode != 2
+        for flags, wide in ((engine.OUT_FIDS | engine.OUT_OFFSETS, False), (engine.OUT_FIDS | engine.OUT_SEGBASE, True),
+                            (engine.OUT_TRIPLES | engine.OUT_ROOT_BITMAP | engine.OUT_OFFSETS, False), (engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, bool(it & 1))):
+            for bb in gb:
+                bb.set_option("WIN_WIDE", 2 if wide else 1)
+            engine.run_batches(gb, mode, inv, flags, engine.STRATEGY_WINDOWS, n_passes=2 * ng + 1)
+            for bb, r_ in zip(gb, gsets):
+                bb.wait()
+                wt, wcn = oix.query_features(r_, mode, inv)
+                ok = bb.total_hits == len(wt)
+                if not (flags & engine.OUT_NO_COUNTS):
+                    ok = ok and np.array_equal(bb.counts(), wcn)
+                if ok and (flags & engine.OUT_ROOT_BITMAP):
+                    ok = np.array_equal(bb.unique_roots(), np.unique(wt[:, 0]))
+                if ok and (flags & engine.OUT_FIDS):
+                    c_ = wcn.astype(np.int64)
+                    off = (bb.offsets_from_segbase(bb.counts()) if flags & engine.OUT_SEGBASE else bb.offsets()[:-1]).astype(np.int64)
+                    qid_ = np.repeat(np.arange(len(r_), dtype=np.int64), c_)
+                    within_ = np.arange(len(qid_), dtype=np.int64) - np.repeat(np.cumsum(c_) - c_, c_)
+                    got = np.stack([qid_, bb.fids()[off[qid_] + within_].astype(np.int64)], axis=1)
+                    bc = np.argsort(r_[:, 0], kind="stable")
+                    want = np.stack([np.repeat(bc, c_[bc]), wt[:, 0].astype(np.int64)], axis=1)
+                    ok = np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want[np.lexsort((want[:, 1], want[:, 0]))])
+                if ok and (flags & engine.OUT_TRIPLES):
+                    srt = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]  # noqa: E731
+                    ok = np.array_equal(srt(bb.triples()), srt(wt))
+                n_checks += 1
+                n_group += 1
+                if not ok:
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.savez("gpurun_out/fuzz_fail.npz", co=co, s=s, e=e, f=f, regions=r_)
+                    print("MISMATCH (batches in one launch) iteration", it, "mode", mode, "invert", inv, "flags", flags, "wide form", wide, "batches", ng,
+                          "n_chr", n_chr, "R", R, "nq", len(r_), flush=True)
+                    sys.exit(1)
+    for bb in gb:
+        bb.close()
     b.close()
     ix.close()
-print("fuzz ok: %d iterations, %d passes checked (%d of them in the wide form), %.0f s" % (iters, n_checks, n_wide, time.time() - t0))
+print("fuzz ok: %d iterations, %d passes checked (%d of them in the wide form, %d of batches served in groups), %.0f s" % (iters, n_checks, n_wide, n_group, time.time() - t0))
