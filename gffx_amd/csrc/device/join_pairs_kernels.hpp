@@ -60,6 +60,9 @@ typedef const __attribute__((address_space(3))) uint32_t *LdsWords;  // an LDS a
     do {                     \
     } while (0)
 #endif
+#ifndef GFFX_EXP_NOTICK
+#define GFFX_EXP_NOTICK 0
+#endif
 
 // Block barrier that orders LDS traffic only (__syncthreads() also drains every outstanding global load and store).
 __device__ __forceinline__ void win_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -919,8 +922,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(0);
         // (the block's next round: its own stride while that stays below n_static, else by ticket -- the first wave of the block to
         //  get here takes it: PairTickets)
-        const bool by_ticket = DYN && r + S.n_blocks >= S.n_static;  // (uniform, the same for every wave of the block)
-        const bool t_first = DYN && by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
+        constexpr bool TICK = DYN && !GFFX_EXP_NOTICK;
+        const bool by_ticket = TICK && r + S.n_blocks >= S.n_static;  // (uniform, the same for every wave of the block)
+        const bool t_first = TICK && by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
         // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
         uint32_t off[4], rqs[4], rqe1[4];  // the line's byte offset; the region in the line's coordinates (rqe1 = its last base)
         bool swp[4];  // regions only the exact sweep answers: wider than wmax, empty width (dense windows join below)
@@ -947,7 +951,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         // the next round's ticket: older than the round's gathers (its answer is back when they are), younger than the wait for the
         // round's regions (a conditional memory operation younger than loads that are still waited for makes that wait a drain)
         uint32_t t_got = 0;
-        if constexpr (DYN) {
+        if constexpr (TICK) {
             if (t_first && lane == 0) t_got = atomicAdd(S.ticket, 1u);
         }
         gffx_v4u wc[4], wf[4];  // the line's halves: coordinates | root_fids (or positions); a wide lane's second half: {rank, list-tail header, 0, 0}
@@ -1127,7 +1131,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         }
         GFFX_WIN_STAMP(3);
         uint32_t r_next = 0;
-        if constexpr (DYN) {
+        if constexpr (TICK) {
             if (t_first) {  // (uniform) this wave took the next round's ticket: it is back with the gathers; posted before anything rare
                 r_next = (uint32_t)S.n_static + (uint32_t)__builtin_amdgcn_readfirstlane((int)t_got);
                 pair_ticket_post<false>(s_tick, k_tick, kWaves, lane, r_next);
@@ -1201,7 +1205,7 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(6);
         finish(P - 1);
         GFFX_WIN_STAMP(7);
-        if constexpr (DYN) {
+        if constexpr (TICK) {
             if (!by_ticket)
                 r_next = (uint32_t)r + S.n_blocks;
             else if (!t_first)
