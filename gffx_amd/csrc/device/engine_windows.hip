@@ -1,12 +1,11 @@
 // engine_windows.hip -- the windows strategy (AUTO's choice): k_join_pairs for the pair passes (counts, root_fids or positions,
 // segment bases / offsets), k_join_roots for the root passes, k_expand_pairs for triples (join_pairs_kernels.hpp).
-#include "engine_private.hpp"
-#include "join_pairs_kernels.hpp"
+#include "windows_launch.hpp"
 
 // Beyond the default 64 KB of dynamic LDS a kernel has to opt in (hipFuncSetAttribute) -- per FUNCTION and per DEVICE: a
 // clone of the index on another GPU (gffx_hip_index_clone) needs its own call, and host threads of several devices launch
 // concurrently (gffx depth --gpus N).  One table for all kernels: {function, device} pairs that have opted in.
-static int lds_opt_in(const void *func, int device, uint32_t lds, uint32_t max_lds) {
+int gffx::lds_opt_in(const void *func, int device, uint32_t lds, uint32_t max_lds) {
     if (lds <= 64 * 1024) return GFFX_OK;
     static std::mutex mu;
     static std::vector<std::pair<const void *, int>> done;
@@ -17,6 +16,46 @@ static int lds_opt_in(const void *func, int device, uint32_t lds, uint32_t max_l
     done.emplace_back(func, device);
     return GFFX_OK;
 }
+
+namespace gffx {
+
+// the blocks' slabs -> ORed into the batch's root bitmap: block x takes 64 words, its 16 rows of threads a sixteenth of the slabs each
+__global__ void k_bitmap_fold(const uint32_t *slabs, uint32_t n_slabs, uint32_t words, uint32_t *bitmap) {
+    __shared__ uint32_t part[16][64];
+    const uint32_t w = blockIdx.x * 64 + (threadIdx.x & 63), row = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    if (w < words)
+        for (uint32_t s = row; s < n_slabs; s += 16) acc |= slabs[(size_t)s * words + w];
+    part[row][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (row == 0 && w < words) {
+#pragma unroll
+        for (int r = 1; r < 16; ++r) acc |= part[r][threadIdx.x];
+        // OR, not overwrite: a pass whose bitmap did not fit LDS sets its bits in `bitmap` directly, and the slabs of a sequence
+        // may be folded more than once (the bitmap is cleared where a new sequence starts: run_windows)
+        if (acc) bitmap[w] |= acc;
+    }
+}
+
+// triples passes: a position pass, then every pair's (root_fid, start, end) -- the reference's Vec<(u32,u32,u32)>,
+// intersect.rs:163 -- from the index arrays by position (coalesced over the pairs; the arrays are L2-resident).
+// words[i] = position of pair i on entry; on exit its root_fid when `fids_too`.
+__global__ void k_expand_pairs(const uint32_t *start, const uint4 *aux, uint32_t *words, uint32_t *triples, const unsigned long long *n_pairs,
+                               unsigned long long capacity, int fids_too) {
+    const unsigned long long n = min(*n_pairs, capacity);
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t p = words[i];
+        const uint4 a = aux[p];
+        if (triples) {
+            triples[3 * i] = a.w;
+            triples[3 * i + 1] = start[p];
+            triples[3 * i + 2] = a.x;
+        }
+        if (fids_too) words[i] = a.w;
+    }
+}
+
+}  // namespace gffx
 
 // dynamic LDS: coverage filter + split bitmap + seqid records, and for the pair passes header + strips + parked offsets +
 // per-thread strips
@@ -36,46 +75,6 @@ static uint32_t pair_threads(const gffx_hip_batch *b, uint64_t nq_launch, bool o
     const long forced = b->knobs.v[BK_WIN_THREADS];
     if (forced == 512 || forced == 1024) return (uint32_t)forced;
     return (!others_busy && nq_launch >= 500000) ? 1024u : 512u;
-}
-
-template <int MODE, bool ML, int T, bool OFFS, bool POS, bool WIDE, bool DYN>
-static int launch_pairs4(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t lds) {
-    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_pairs<MODE, ML, T, OFFS, POS, WIDE, DYN>), device, lds,
-                              T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_join_pairs<MODE, ML, T, OFFS, POS, WIDE, DYN>), dim3(grid), dim3(T), lds, stream, a);
-    return GFFX_OK;
-}
-template <int MODE, bool ML>
-static int launch_pairs(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t threads, bool offs, bool pos, bool wide, bool dyn, uint32_t lds) {
-#define GFFX_P(T, O, P)                                                                                          \
-    if (threads == T && offs == O && pos == P) {                                                                 \
-        if (wide) return dyn ? launch_pairs4<MODE, ML, T, O, P, true, true>(device, stream, grid, a, lds)        \
-                             : launch_pairs4<MODE, ML, T, O, P, true, false>(device, stream, grid, a, lds);      \
-        return dyn ? launch_pairs4<MODE, ML, T, O, P, false, true>(device, stream, grid, a, lds)                 \
-                   : launch_pairs4<MODE, ML, T, O, P, false, false>(device, stream, grid, a, lds);               \
-    }
-    GFFX_P(1024, false, false) GFFX_P(1024, true, false) GFFX_P(1024, false, true) GFFX_P(1024, true, true)
-    GFFX_P(512, false, false) GFFX_P(512, true, false) GFFX_P(512, false, true) GFFX_P(512, true, true)
-#undef GFFX_P
-
-    return GFFX_OK;
-}
-template <int MODE, bool ML, int T, bool WIDE, bool DYN>
-static int launch_roots3(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t lds) {
-    const int rc = lds_opt_in(reinterpret_cast<const void *>(&k_join_roots<MODE, ML, T, WIDE, DYN>), device, lds, T == 1024 ? 2 * kWinMaxLds : kWinMaxLds);
-    if (rc) return rc;
-    hipLaunchKernelGGL((k_join_roots<MODE, ML, T, WIDE, DYN>), dim3(grid), dim3(T), lds, stream, a);
-    return GFFX_OK;
-}
-template <int MODE, bool ML, bool WIDE, bool DYN>
-static int launch_roots2(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t threads, uint32_t lds) {
-    return threads == 1024 ? launch_roots3<MODE, ML, 1024, WIDE, DYN>(device, stream, grid, a, lds) : launch_roots3<MODE, ML, 512, WIDE, DYN>(device, stream, grid, a, lds);
-}
-template <int MODE, bool ML>
-static int launch_roots(int device, hipStream_t stream, uint32_t grid, const PairArgs &a, uint32_t threads, bool wide, bool dyn, uint32_t lds) {
-    if (wide) return dyn ? launch_roots2<MODE, ML, true, true>(device, stream, grid, a, threads, lds) : launch_roots2<MODE, ML, true, false>(device, stream, grid, a, threads, lds);
-    return dyn ? launch_roots2<MODE, ML, false, true>(device, stream, grid, a, threads, lds) : launch_roots2<MODE, ML, false, false>(device, stream, grid, a, threads, lds);
 }
 
 // One launch of the windows strategy for the n batches bs[] (same index, mode, invert, flags and form: windows_groupable), on
@@ -181,7 +180,7 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
     const uint32_t want_grid = (uint32_t)std::min<uint64_t>(total_rounds, (uint64_t)(blocks_knob ? blocks_knob : slots));
     // every batch's share of the blocks: in proportion to its rounds, at least one, at most a block per round
     uint32_t grid = 0;
-    bool dyn = n > 1;  // the kernels' DYN instantiation: several batches, or rounds by ticket
+    int lkind = n > 1 ? kLaunchGroup : kLaunchPlain;  // the kernels' instantiation: plain, a group of batches, or one batch with its tail by ticket
     {
         uint32_t share[kPairMaxSubs];
         uint64_t given = 0;
@@ -207,10 +206,11 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
             a.sub[t].first_block = grid;
             a.sub[t].n_blocks = share[t];
             const uint64_t per_block = rounds[t] / share[t];
-            if (b0->knobs.v[BK_TICKETS] == 4) tk = (n == 1 && per_block >= 8 && !roots) ? 1 : 0;  // (pair passes only: the root kernel's waves are not coupled otherwise, tickets cost it 3-8 % on random regions)
+            if (b0->knobs.v[BK_TICKETS] == 4) tk = (per_block >= 8 && !roots) ? 1 : 0;  // (pair passes only: the root kernel's waves are not coupled otherwise, tickets cost it 3-8 % on random regions)
+            if (n > 1) tk = 0;  // (a launch that serves a group walks by stride: tickets measured slower there, and its instantiation has no ticket code)
             a.sub[t].n_static = tk == 0 ? UINT64_MAX / 2 : tk == 2 ? share[t] : (uint64_t)share[t] * std::max<uint64_t>(1, tk == 3 ? per_block : per_block - 1);
             if (a.sub[t].n_static >= rounds[t]) a.sub[t].n_static = UINT64_MAX / 2;  // (no round is left to take: nobody asks)
-            dyn = dyn || a.sub[t].n_static < UINT64_MAX / 2;
+            if (n == 1 && a.sub[t].n_static < UINT64_MAX / 2) lkind = kLaunchTickets;
             grid += share[t];
         }
     }
@@ -273,12 +273,8 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
     ProfEvent pe;
     int lrc = GFFX_OK;
     if (n == 1) prof_begin(b0, roots ? GFFX_K_WINDOWS : GFFX_K_WAVE, &pe);
-#define GFFX_CASE(M, L)                                                                                                  \
-    if (b0->mode == M && ml == L)                                                                                        \
-        lrc = roots ? launch_roots<M, L>(ix->device, stream, grid, a, threads, wide, dyn, lds)                           \
-                    : launch_pairs<M, L>(ix->device, stream, grid, a, threads, offs, pos, wide, dyn, lds);
-    GFFX_CASE(0, true) GFFX_CASE(0, false) GFFX_CASE(1, true) GFFX_CASE(1, false) GFFX_CASE(2, true) GFFX_CASE(2, false)
-#undef GFFX_CASE
+    const WindowsLaunch L{ix->device, stream, grid, threads, lds, roots, offs, pos, wide, ml, b0->mode, &a};
+    lrc = lkind == kLaunchGroup ? launch_windows_kind<kLaunchGroup>(L) : lkind == kLaunchTickets ? launch_windows_kind<kLaunchTickets>(L) : launch_windows_kind<kLaunchPlain>(L);
     if (n == 1) prof_end(b0, &pe);
     if (lrc) return lrc;
     GFFX_HIP_TRY(hipGetLastError());

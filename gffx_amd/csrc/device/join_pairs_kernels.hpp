@@ -60,9 +60,10 @@ typedef const __attribute__((address_space(3))) uint32_t *LdsWords;  // an LDS a
     do {                     \
     } while (0)
 #endif
-#ifndef GFFX_EXP_NOTICK
-#define GFFX_EXP_NOTICK 0
-#endif
+// the three kinds of launch the two kernels are instantiated for (template argument KIND)
+constexpr int kLaunchPlain = 0;    // one batch, every round by stride: the record at index 0, no ticket code
+constexpr int kLaunchGroup = 1;    // several batches: a block finds its record (PairSub); rounds by stride
+constexpr int kLaunchTickets = 2;  // one batch, the launch's tail by ticket (PairTickets)
 
 // Block barrier that orders LDS traffic only (__syncthreads() also drains every outstanding global load and store).
 __device__ __forceinline__ void win_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -721,12 +722,13 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 // POS: the words a pass emits are index positions (table win_pos), not root_fids
 // WIDE: the mixed form (pair_locate_mixed; every mode, inverted or not): a batch in which AUTO found wide regions -- every lane serves its
 //       region the narrow way (one line) or the wide way (two lines, two ranks) as the region's width asks
-// DYN: the launch serves several batches and / or hands rounds out by ticket (section "PairSub" above).  The plain launch -- one batch,
-//      every round by stride -- is an instantiation of its own: behind a run-time record index and next to the ticket code the
-//      compiler re-loads the record's fields from the kernarg segment in the loop (the root kernel 12 -> 42 scalar loads, each one an
-//      s_waitcnt lgkmcnt(0)): +2 % per pair pass, +5-10 % per root pass (profiles/r06_single_batch_regression.txt)
-template <int MODE, bool META_LDS, int T, bool OFFS, bool POS, bool WIDE = false, bool DYN = false>
+// KIND: kLaunchPlain / kLaunchGroup / kLaunchTickets.  Three instantiations because each feature costs the launches that do not use
+//      it: behind a run-time record index and next to the ticket code's control flow the compiler re-loads the record's fields from
+//      the kernarg segment in the loop (the root kernel 12 -> 42 scalar loads, each one an s_waitcnt lgkmcnt(0)): +2 % per pair pass,
+//      +5-10 % per root pass for the plain launch, +1-2 % for a launch that serves a group (profiles/r06_single_batch_regression.txt)
+template <int MODE, bool META_LDS, int T, bool OFFS, bool POS, bool WIDE = false, int KIND = kLaunchPlain>
 __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
+    constexpr bool DYN = KIND == kLaunchGroup, TICK = KIND == kLaunchTickets;
     constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED;        // a wide lane keeps the roots of its run that end inside the region (inverted: beyond it)
     constexpr bool CREG = WIDE && MODE == GFFX_MODE_CONTAINS_REGION;  // ... the roots over qs that reach the region's end (inverted: that do not, and its run)
     constexpr uint32_t kChunk = 4u * T;  // regions per round: one uint4 of every region column per thread
@@ -786,11 +788,11 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         s_arrive[tid] = 0ull;
         s_post_seq[tid] = 0u;
     }
-    if (DYN && tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
+    if (TICK && tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
     win_barrier();  // the ONLY block barrier: tables staged, arrival and ticket words zero
     if (lb == 0 && tid == 0) {
         *out.pair_cursor_next = 0ull;
-        if (DYN) *S.ticket_next = 0u;
+        if (TICK) *S.ticket_next = 0u;
         if (lds0 != 0) atomicOr(out.err, 2u);  // (the filter lookups assume the dynamic LDS starts at LDS address 0)
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -922,7 +924,6 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         GFFX_WIN_STAMP(0);
         // (the block's next round: its own stride while that stays below n_static, else by ticket -- the first wave of the block to
         //  get here takes it: PairTickets)
-        constexpr bool TICK = DYN && !GFFX_EXP_NOTICK;
         const bool by_ticket = TICK && r + S.n_blocks >= S.n_static;  // (uniform, the same for every wave of the block)
         const bool t_first = TICK && by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
         // ---- one index line per region: 2 x 16 bytes, the loads of all four regions in flight together; no branches
@@ -1476,8 +1477,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
 // out.fids = the slabs (grid x bm_words words); out.capacity = bm_words (0: no LDS bitmap); out.segbase (as a number) = how many
 // slabs hold something to OR with (GFFX_OUT_BITMAP_KEEP), the others are overwritten.  out.block_sums[block] = the block's kept
 // pairs (summed on the host: one same-address device atomic per wave cost 43 us per 1 M regions, per block still 5).
-template <int MODE, bool META_LDS, int T, bool WIDE = false, bool DYN = false>
+template <int MODE, bool META_LDS, int T, bool WIDE = false, int KIND = kLaunchPlain>
 __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
+    constexpr bool DYN = KIND == kLaunchGroup, TICK = KIND == kLaunchTickets;
     constexpr bool CONT = WIDE && MODE == GFFX_MODE_CONTAINED, CREG = WIDE && MODE == GFFX_MODE_CONTAINS_REGION;  // (as in k_join_pairs)
     constexpr uint32_t kChunk = 4u * T;
     constexpr uint32_t kWaves = T / 64;
@@ -1518,11 +1520,11 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
         reinterpret_cast<uint4 *>(s_sbits)[x] = reinterpret_cast<const uint4 *>(A.pv.splittab)[x];
     for (uint32_t x = tid; x < bm_words; x += T) s_bm[x] = 0u;
     if (tid == 0) s_total[0] = 0ull;
-    if (DYN && tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
+    if (TICK && tid < sizeof(PairTickets) / 4) reinterpret_cast<uint32_t *>(s_tick)[tid] = 0u;
     win_barrier();
     if (lb == 0 && tid == 0) {
         *out.pair_cursor_next = 0ull;
-        if (DYN) *S.ticket_next = 0u;
+        if (TICK) *S.ticket_next = 0u;
         if (lds0 != 0) atomicOr(out.err, 2u);
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -1546,8 +1548,8 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     for (unsigned long long r = lb; r < n_rounds;) {
         const unsigned long long base = r * kChunk;
         const bool full = base + kChunk <= nq;
-        const bool by_ticket = DYN && r + S.n_blocks >= S.n_static;  // (as in k_join_pairs: the tail's rounds are taken by ticket)
-        const bool t_first = DYN && by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
+        const bool by_ticket = TICK && r + S.n_blocks >= S.n_static;  // (as in k_join_pairs: the tail's rounds are taken by ticket)
+        const bool t_first = TICK && by_ticket && pair_ticket_first(s_tick, k_tick, kWaves, lane);
         uint32_t off[4], rqs[4], rqe1[4];
         bool swp[4];
         uint32_t off1[4], rel1[4], r0[4], nr[4];  // (mixed form, wide lanes) the line of qe - 1, qe - 1 in its coordinates; the run of roots that start inside the region
@@ -1566,7 +1568,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             }
         }
         uint32_t t_got = 0;  // (as in k_join_pairs: older than the gathers, younger than the wait for the regions)
-        if constexpr (DYN) {
+        if constexpr (TICK) {
             if (t_first && lane == 0) t_got = atomicAdd(S.ticket, 1u);
         }
         gffx_v4u wc[4], wf[4];
@@ -1766,7 +1768,7 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
             }
         }
         uint32_t r_next;
-        if (!DYN || !by_ticket) {
+        if (!TICK || !by_ticket) {
             r_next = (uint32_t)r + S.n_blocks;
         } else if (t_first) {  // (uniform) the ticket is back with the gathers; nothing bounds how far this kernel's waves drift apart: the slot is checked
             r_next = (uint32_t)S.n_static + (uint32_t)__builtin_amdgcn_readfirstlane((int)t_got);
@@ -1828,42 +1830,6 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
     }
     if (__builtin_amdgcn_ballot_w64(bad) && lane == 0) atomicOr(out.err, 1u);
     if (lane == 0 && n_slow) atomicAdd(out.slow, (unsigned long long)n_slow | ((unsigned long long)n_wide << 32));
-}
-
-// the blocks' slabs -> ORed into the batch's root bitmap: block x takes 64 words, its 16 rows of threads a sixteenth of the slabs each
-__global__ void k_bitmap_fold(const uint32_t *slabs, uint32_t n_slabs, uint32_t words, uint32_t *bitmap) {
-    __shared__ uint32_t part[16][64];
-    const uint32_t w = blockIdx.x * 64 + (threadIdx.x & 63), row = threadIdx.x >> 6;
-    uint32_t acc = 0;
-    if (w < words)
-        for (uint32_t s = row; s < n_slabs; s += 16) acc |= slabs[(size_t)s * words + w];
-    part[row][threadIdx.x & 63] = acc;
-    __syncthreads();
-    if (row == 0 && w < words) {
-#pragma unroll
-        for (int r = 1; r < 16; ++r) acc |= part[r][threadIdx.x];
-        // OR, not overwrite: a pass whose bitmap did not fit LDS sets its bits in `bitmap` directly, and the slabs of a sequence
-        // may be folded more than once (the bitmap is cleared where a new sequence starts: run_windows)
-        if (acc) bitmap[w] |= acc;
-    }
-}
-
-// triples passes: a position pass, then every pair's (root_fid, start, end) -- the reference's Vec<(u32,u32,u32)>,
-// intersect.rs:163 -- from the index arrays by position (coalesced over the pairs; the arrays are L2-resident).
-// words[i] = position of pair i on entry; on exit its root_fid when `fids_too`.
-__global__ void k_expand_pairs(const uint32_t *start, const uint4 *aux, uint32_t *words, uint32_t *triples, const unsigned long long *n_pairs,
-                               unsigned long long capacity, int fids_too) {
-    const unsigned long long n = min(*n_pairs, capacity);
-    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t p = words[i];
-        const uint4 a = aux[p];
-        if (triples) {
-            triples[3 * i] = a.w;
-            triples[3 * i + 1] = start[p];
-            triples[3 * i + 2] = a.x;
-        }
-        if (fids_too) words[i] = a.w;
-    }
 }
 
 }  // namespace gffx
