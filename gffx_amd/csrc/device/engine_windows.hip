@@ -110,12 +110,7 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
             o.pair_cursor_next = b->d_status + 2 + (b->fused_phase ^ 1);
             b->fused_phase ^= 1;
         }
-        {   // the pass's ticket word (zero: the batch's previous pass of this kind zeroed it) and the one it zeroes for the next
-            int &ph = b->tick_phase[second ? 1 : 0];
-            S.ticket = b->d_ticket + (second ? 16 : 0) + 32 * ph;
-            S.ticket_next = b->d_ticket + (second ? 16 : 0) + 32 * (ph ^ 1);
-            ph ^= 1;
-        }
+        S.ticket = S.ticket_next = nullptr;  // (set below, for a launch of the ticket kind only)
         if (roots) {
             o.root_flags = reinterpret_cast<uint8_t *>(b->d_bitmap);  // (only written when the bitmap does not fit LDS)
             o.block_sums = second ? nullptr : b->d_block_sums;       // (a pass of its own: its kept pairs are the pass's total)
@@ -210,7 +205,15 @@ static int run_windows_pass(gffx_hip_batch *const *bs, uint32_t n, hipStream_t s
             if (n > 1) tk = 0;  // (a launch that serves a group walks by stride: tickets measured slower there, and its instantiation has no ticket code)
             a.sub[t].n_static = tk == 0 ? UINT64_MAX / 2 : tk == 2 ? share[t] : (uint64_t)share[t] * std::max<uint64_t>(1, tk == 3 ? per_block : per_block - 1);
             if (a.sub[t].n_static >= rounds[t]) a.sub[t].n_static = UINT64_MAX / 2;  // (no round is left to take: nobody asks)
-            if (n == 1 && a.sub[t].n_static < UINT64_MAX / 2) lkind = kLaunchTickets;
+            if (n == 1 && a.sub[t].n_static < UINT64_MAX / 2) {
+                // the pass's ticket word (zero: the batch's previous launch of THIS kind zeroed it) and the one it zeroes for the next
+                // (only launches of the ticket kind touch the words, so only they alternate)
+                lkind = kLaunchTickets;
+                int &ph = bs[t]->tick_phase[second ? 1 : 0];
+                a.sub[t].ticket = bs[t]->d_ticket + (second ? 16 : 0) + 32 * ph;
+                a.sub[t].ticket_next = bs[t]->d_ticket + (second ? 16 : 0) + 32 * (ph ^ 1);
+                ph ^= 1;
+            }
             grid += share[t];
         }
     }

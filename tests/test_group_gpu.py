@@ -217,3 +217,36 @@ def test_grouped_capacity_replay_and_timed_runs():
     for b in bs:
         b.close()
     ix.close()
+
+
+@pytest.mark.parametrize("tickets", [1, 2, 3, 4])
+@pytest.mark.parametrize("threads,blocks", [(512, 3), (1024, 5), (512, 16)])
+def test_rounds_by_ticket_on_small_grids(tickets, threads, blocks):
+    """the launch's tail (or every round) handed out by ticket, forced on grids of a few blocks so that every block takes many rounds
+    by ticket; ticket-kind launches alternate with plain ones (a root pass takes no tickets) on ONE batch: the ticket words must be
+    zero whenever a launch of the ticket kind starts (round 6: they alternate per KIND of launch, not per pass)"""
+    roots = _roots()
+    oix, ix = _oracle(roots), _index(roots)
+    regions = synth.synth_bed(150_000, seed=7000 + tickets, edge_frac=0.02, roots=roots)
+    srt = np.ascontiguousarray(regions[np.lexsort((regions[:, 1], regions[:, 0]))])
+    for regs in (regions, srt):
+        b = engine.QueryBatch(ix, len(regs))
+        b.set_option("TICKETS", tickets)
+        b.set_option("WIN_THREADS", threads)
+        b.set_option("FUSED_BLOCKS", blocks)
+        b.set_regions(regs)
+        want, wc, wt = _want_pairs(oix, regs, OverlapMode.Overlap, False)
+        for rep in range(3):
+            b.run(OverlapMode.Overlap, False, engine.OUT_FIDS | engine.OUT_SEGBASE, engine.STRATEGY_WINDOWS)
+            b.wait()
+            c = b.counts()
+            assert np.array_equal(c, wc) and b.total_hits == len(want), (rep, b.total_hits, len(want))
+            assert np.array_equal(_pairs_of(b, regs, c, b.offsets_from_segbase(c)), want)
+            b.run(OverlapMode.Overlap, False, engine.OUT_ROOT_BITMAP | engine.OUT_NO_COUNTS, engine.STRATEGY_WINDOWS)  # (a plain launch in between)
+            b.wait()
+            assert np.array_equal(b.unique_roots(), np.unique(wt[:, 0]))
+            b.run(OverlapMode.Overlap, False, engine.OUT_TRIPLES | engine.OUT_OFFSETS | engine.OUT_ROOT_BITMAP, engine.STRATEGY_WINDOWS)
+            b.wait()
+            assert np.array_equal(b.counts(), wc) and b.total_hits == len(want)
+        b.close()
+    ix.close()
