@@ -24,6 +24,21 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// Continuation lines (gffx_device.hpp): the three records {coordinates x 4 | root_fids x 4 | positions x 4} in front of a short list's
+// tail records.  win_cont_begin appends them (all entries absent) when the list has one and returns where the tail records start.
+static size_t win_cont_begin(std::vector<uint4> &spill, uint32_t n) {
+    if (win_cont_records(n)) {
+        spill.push_back(make_uint4(kWinAbsent, kWinAbsent, kWinAbsent, kWinAbsent));
+        spill.push_back(make_uint4(0u, 0u, 0u, 0u));
+        spill.push_back(make_uint4(0u, 0u, 0u, 0u));
+    }
+    return spill.size();
+}
+static void win_cont_put(std::vector<uint4> &spill, size_t tail_at, uint32_t slot, uint32_t coords, uint32_t root_fid, uint32_t position) {
+    uint32_t *c = reinterpret_cast<uint32_t *>(&spill[tail_at - kWinContRecs]);
+    c[slot] = coords, c[4 + slot] = root_fid, c[8 + slot] = position;
+}
+
 // Window index (gffx_device.hpp, join_pairs_kernels.hpp): per seqid ~GFFX_HIP_WIN_PER_ENTRY windows per root (a power of
 // two wide, at most 2^15 bp: the lines hold 16-bit coordinates relative to the window); the line of window b lists, by
 // ascending start, the roots with start < (b+1) << shift and end + wmax > b << shift.  `start` / `aux` are the sorted
@@ -92,11 +107,11 @@ static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, co
         for (uint64_t b = 0; b < ns; b++) {
             uint32_t n = len[b];
             uint64_t off = 0;
-            if (n > kWinMaxList || (n > kWinInline && spill.size() + (n - kWinInlineTail) >= (1ull << 24))) {
+            if (n > kWinMaxList || (n > kWinInline && spill.size() + win_cont_records(n) + (n - kWinInlineTail) >= (1ull << 24))) {
                 n = 255;  // dense window (or the 24-bit spill offsets are used up): exact sweep
             } else if (n > kWinInline) {
-                off = spill.size();
-                spill.resize(spill.size() + (n - kWinInlineTail));
+                off = win_cont_begin(spill, n);  // (a short list's continuation line in front of its tail records)
+                spill.resize(off + (n - kWinInlineTail));
             }
             uint32_t *l = ww + 8 * ((size_t)base + b), *lp = wp + 8 * ((size_t)base + b);
             for (int j = 0; j < 4; j++) l[j] = lp[j] = kWinAbsent, l[4 + j] = lp[4 + j] = 0;
@@ -120,6 +135,12 @@ static int build_window_index_at(uint32_t n_chr, const uint32_t *chr_offsets, co
                     lp[4 + j] = i;
                 } else {
                     spill[(l[7] >> 8) + j - kWinInlineTail] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
+                    if (win_cont_records(l[7] & 255u)) {
+                        const int64_t org = (int64_t)(b * W) - (int64_t)wmax;
+                        const int64_t rs = std::max<int64_t>((int64_t)h_start[i] - org, 0);
+                        const int64_t re = std::min<int64_t>((int64_t)h_aux[i].x - org, (int64_t)(W + wmax + 1));
+                        win_cont_put(spill, l[7] >> 8, j - kWinInlineTail, (uint32_t)rs | ((uint32_t)re << 16), h_aux[i].w, i);
+                    }
                 }
             }
         }
@@ -169,7 +190,7 @@ static void build_window_splits(uint32_t n_chr, const std::vector<uint32_t> &h_s
             if (l[3] != kWinTailMark) continue;
             const uint32_t n = l[7] & 255u;
             if (n == 255u) continue;  // dense: the sweep
-            if (spill.size() + (size_t)(n << kWinSplit) >= (1ull << 24)) continue;  // (24-bit spill offsets)
+            if (spill.size() + (size_t)((n + kWinContRecs) << kWinSplit) >= (1ull << 24)) continue;  // (24-bit spill offsets)
             list.clear();
             for (uint32_t j = 0; j < kWinInlineTail; j++) list.push_back(l[4 + j]);  // positions of entries 0..2
             for (uint32_t j = kWinInlineTail; j < n; j++) list.push_back(spill[(l[7] >> 8) + j - kWinInlineTail].w);
@@ -181,7 +202,7 @@ static void build_window_splits(uint32_t n_chr, const std::vector<uint32_t> &h_s
                 for (uint32_t i : list)
                     if (((uint64_t)h_start[i] >> sshift) <= g && g <= (((uint64_t)h_aux[i].x + wmax - 1) >> sshift)) cnt++;
                 const bool over = cnt > kWinInline;
-                const size_t sp0 = spill.size();
+                const size_t sp0 = over ? win_cont_begin(spill, cnt) : spill.size();  // (a short sub-list's continuation line first)
                 if (over) spill.resize(sp0 + cnt - kWinInlineTail);
                 const int64_t org = (int64_t)(g << sshift) - (int64_t)wmax;
                 uint32_t k = 0;
@@ -196,6 +217,11 @@ static void build_window_splits(uint32_t n_chr, const std::vector<uint32_t> &h_s
                         tp[4 + k] = i;
                     } else {
                         spill[sp0 + k - kWinInlineTail] = make_uint4(h_start[i], h_aux[i].x, h_aux[i].w, i);
+                        if (win_cont_records(cnt)) {
+                            const int64_t rs = std::max<int64_t>((int64_t)h_start[i] - org, 0);
+                            const int64_t re = std::min<int64_t>((int64_t)h_aux[i].x - org, (int64_t)(Ws + wmax + 1));
+                            win_cont_put(spill, sp0, k - kWinInlineTail, (uint32_t)rs | ((uint32_t)re << 16), h_aux[i].w, i);
+                        }
                     }
                     k++;
                 }

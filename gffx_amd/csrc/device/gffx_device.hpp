@@ -71,6 +71,10 @@ struct IndexView {
     // clamped to 16 bits; win_pos is a copy with index positions in place of the root_fids (root-bitmap and triples
     // passes).  A longer list keeps 3 entries in the line, word 3 = 0xFFFFFFFF, word 7 = n | spill << 8 (n = 255: dense
     // window, take the sweep) and win_spill[spill + j - 3] = {start, end, root_fid, position} of entry j >= 3.
+    // CONTINUATION LINES (round 6): a list of 5 .. kWinContMax entries has its entries 3 .. n - 1 once more IN THE LINE'S OWN FORMAT,
+    // in the three records in front of its tail: win_spill[spill - 3 .. spill - 1] = {start_rel | end_rel << 16 x 4 (absent: kWinAbsent),
+    // root_fid x 4, position x 4}, same origin and clamping as the line.  k_join_pairs / k_join_roots test it with the line's four
+    // packed tests, all four regions of a thread in step, instead of walking the records one region at a time (join_pairs_kernels.hpp).
     // A seqid with meta {0, 1, 31, 0} has no windows: every region on it takes the exact sweep.
     //   win_meta[seqid] = {first window, windows, shift | wmax << 8, first filter bit}
     const uint4 *win_meta;
@@ -119,6 +123,9 @@ constexpr uint32_t kWinMaxShift = 15;            // widest window: W + wmax + 1 
 constexpr uint32_t kWinTailMark = 0xFFFFFFFFu;   // word 3 of a line whose list continues in win_spill
 constexpr uint32_t kWinAbsent = 0x0000FFFFu;     // coordinate word of an absent entry
 constexpr uint32_t kWinMaxList = 32;             // longer lists: dense window (n = 255)
+constexpr uint32_t kWinContMax = kWinInlineTail + 4;  // lists up to this long (3 in the line + 4) have a continuation line ...
+constexpr uint32_t kWinContRecs = 3;             // ... of three 16-byte records in front of their tail records in win_spill
+__host__ __device__ inline uint32_t win_cont_records(uint32_t n) { return (n > kWinInline && n <= kWinContMax) ? kWinContRecs : 0u; }
 #ifndef GFFX_WIN_SPLIT_LOG2
 #define GFFX_WIN_SPLIT_LOG2 3
 #endif

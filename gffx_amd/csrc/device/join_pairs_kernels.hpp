@@ -16,6 +16,8 @@
 //       words 4..7    root_fid of entries 0..3  (the "pos" copy of the table carries index positions instead)
 //   a list longer than 4 keeps entries 0..2 in the line; word 3 = 0xFFFFFFFF marks it and word 7 = n | spill << 8: entries
 //   3.. are 16-byte records {start, end, root_fid, position} (absolute) at win_spill[spill ...]; n = 255: dense window.
+//   A list of 5 .. kWinContMax roots also has a CONTINUATION LINE (round 6): its entries 3 .. n - 1 in the line's own packed format,
+//   in the three records in front of the tail (gffx_device.hpp) -- see pair_cont_*.
 // SPLIT windows (round 4): such a window is cut into 2^kWinSplit sub-windows, each with a line of its own (same format,
 // relative to the sub-window) in a sparse second level of the same table, and a one-bit-per-window table in LDS says which
 // windows those are BEFORE anything is read: every region reads exactly ONE line -- two 16-byte loads from one cache line,
@@ -60,6 +62,11 @@ typedef const __attribute__((address_space(3))) uint32_t *LdsWords;  // an LDS a
     do {                     \
     } while (0)
 #endif
+#ifndef GFFX_WIN_NOTE  // (a value instead of a time: the largest over the wave's lanes)
+#define GFFX_WIN_NOTE(slot, value) \
+    do {                           \
+    } while (0)
+#endif
 // the three kinds of launch the two kernels are instantiated for (template argument KIND)
 constexpr int kLaunchPlain = 0;    // one batch, every round by stride: the record at index 0, no ticket code
 constexpr int kLaunchGroup = 1;    // several batches: a block finds its record (PairSub); rounds by stride
@@ -95,6 +102,10 @@ constexpr uint32_t kWinNoLine = 0x80000000u;  // byte offset beyond every window
 // a[k] for a per-lane k without making `a` addressable (an indexed private array would live in scratch memory)
 __device__ __forceinline__ uint32_t win_sel(const uint32_t (&a)[4], int k) {
     return (a[0] & (k == 0 ? ~0u : 0u)) | (a[1] & (k == 1 ? ~0u : 0u)) | (a[2] & (k == 2 ? ~0u : 0u)) | (a[3] & (k == 3 ? ~0u : 0u));
+}
+__device__ __forceinline__ uint32_t win_sel4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, int k) {
+    const uint32_t a[4] = {a0, a1, a2, a3};
+    return win_sel(a, k);
 }
 
 constexpr uint32_t kWaveDepth = 3;     // strips per wave: a round's words wait kWaveDepth - 1 rounds for their place
@@ -481,6 +492,26 @@ __device__ __forceinline__ uint32_t pair_rest(const IndexView *ix, const uint4 *
     return c;
 }
 
+// CONTINUATION LINES (round 6).  Walking list tails one region at a time (pair_rest) cost a pair pass 8 % of its time on random
+// regions and 20-30 % on a BED sorted by position -- where the four regions of a lane all wait for a tail, four walks one after
+// another, and again when the words are placed (the ablation in profiles/r06_continuation_lines.txt).  Most tails are short: a list
+// of 5 .. kWinContMax roots has its entries 3 .. n - 1 once more in the line's own format (gffx_device.hpp).  All four regions of a
+// thread are served IN STEP, like the lines themselves: one 16-byte load per region for the coordinates and one for the words
+// (a region without such a list reads nothing: the offset beyond the table), the line's four packed tests, a 4-bit string per region;
+// the kept words are parked from registers by the same pair_park4 that parks the line's -- no walk, no second walk, no stash.
+__device__ __forceinline__ bool pair_cont_has(uint32_t coords3, uint32_t word7) {  // the line's words 3 and 7
+    return coords3 == kWinTailMark && (word7 & 255u) <= kWinContMax;
+}
+template <bool POS>
+__device__ __forceinline__ void pair_cont_load(__amdgpu_buffer_rsrc_t rsp, bool has, uint32_t word7, gffx_v4u &coords, gffx_v4u &words) {
+    const uint32_t o = has ? ((word7 >> 8) - kWinContRecs) * 16u : kWinNoLine;
+    coords = __builtin_amdgcn_raw_buffer_load_b128(rsp, o, 0, 0);
+    words = __builtin_amdgcn_raw_buffer_load_b128(rsp, has ? o + (POS ? 32u : 16u) : kWinNoLine, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pair_cont_rsrc(const uint4 *spill) {  // (24-bit record offsets: < 2^28 bytes; kWinNoLine is beyond it)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(spill), 0, kWinNoLine, 0x00020000);
+}
+
 // every kept pair of ONE region, generic walk over the window's own line (the synchronous path of an overfull round and
 // nothing else): f(word)
 template <int MODE, bool POS, typename F>
@@ -674,7 +705,7 @@ __device__ __forceinline__ void pair_locate_mixed(const PairLds &L, uint32_t lin
 // a round's regions: buffer loads from a descriptor of exactly the round's rows (scalar work), 16 bytes per thread and column
 // at a fixed offset -- straight-line code: no per-thread bounds, and a round beyond the batch (the prefetch of the last
 // rounds) reads zeros without touching memory.  Only the batch's last, partial round and unaligned columns take the
-// element-wise path afterwards (uniform branch); a row beyond the batch becomes the "no region" row {n_chr, 0, 0}: the seqid
+// element-wise path afterwards (uniform branch); a row beyond the batch becomes the "no region" row {n_chr, 0, 1}: the seqid
 // table's extra record has no windows, so it reads nothing and keeps nothing; a real row with a seqid out of range is flagged
 // there and becomes the same row (the round loops flag rows of full rounds only).
 template <uint32_t kChunk>
@@ -707,7 +738,8 @@ __device__ __forceinline__ void pair_load_round(const QueryView &q, unsigned lon
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             qc[k] = n_chr;
-            qs[k] = qe[k] = 0;
+            qs[k] = 0, qe[k] = 1;  // (one base wide: it "fits"; as {n_chr, 0, 0} the 3520 rows that pad a 1 M batch to whole rounds took the sweep call
+                                   //  for empty rows -- 2.4 us of the last block's life -- and were counted in the pass's slow regions)
             if (i0 + k < nq) {
                 pair_load_region(q, i0 + k, qc[k], qs[k], qe[k]);
                 bad |= qc[k] >= n_chr;
@@ -972,6 +1004,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         gffx_v4u rg[4];  // (wide form) the first four words of the run
         uint32_t tc[4] = {0, 0, 0, 0}, hdr[4] = {0, 0, 0, 0};
         uint32_t deferred = 0, sweep = 0, n_rest = 0;
+        uint32_t tm = 0;                          // (narrow form) continuation lines: the kept bits, four per region (entry 3 = bit 3 of the nibble)
+        bool cont_step = false;                   // ... (uniform) served in step (their words in cf[0 .. 3]) or one per lane (in cf[0])
+        gffx_v4u cf[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // ... and their words, kept for the parking
         if constexpr (WIDE) {
             // wide lanes: the second line's coordinates and rank record (in flight with the first line's halves), then the roots over qs
             // (the one-base region) and the two ranks; narrow lanes: the line's four tests.  A line whose list continues in win_spill
@@ -1141,17 +1176,54 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
         // ---- the rare rest, one region at a time: list tails and exact sweeps (count; the first kept words wait in
         // the thread's LDS strip)
         if constexpr (!WIDE) {
-            bool dfr[4];
+            bool dfr[4], cl[4];
             bool any = false;
+            uint32_t clm = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                dfr[k] = swp[k] || wc[k].w == kWinTailMark;
+                cl[k] = pair_cont_has(wc[k].w, wf[k].w);
+                clm |= cl[k] ? 1u << k : 0u;
+            }
+#ifdef GFFX_ABL_NO_DEFERRED  // (tools/kbench.hip, timing only: the continuation lines are not read either)
+            clm = 0;
+#endif
+            if (__builtin_amdgcn_ballot_w64(clm != 0u)) {  // (uniform) continuation lines (pair_cont_*)
+                const __amdgpu_buffer_rsrc_t rsp = pair_cont_rsrc(A.spill);
+                cont_step = __builtin_amdgcn_ballot_w64((clm & (clm - 1u)) != 0u) != 0ull;  // (uniform) some lane has two or more
+                if (cont_step) {  // the four regions in step: eight gathers, no selection
+                    gffx_v4u cc[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pair_cont_load<POS>(rsp, cl[k], wf[k].w, cc[k], cf[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t m2 = pair_test4<MODE>(cc[k].x, cc[k].y, cc[k].z, cc[k].w, rqs[k], rqe1[k], inv, cl[k]);
+                        tm |= m2 << (4 * k);
+                        tc[k] += __popc(m2);
+                    }
+                } else {  // at most one per lane (random regions): the lane's one region picked, two gathers; its words wait in cf[0]
+                    const int k1 = (__ffs(clm) - 1) & 3;
+                    const uint32_t w7 = win_sel4(wf[0].w, wf[1].w, wf[2].w, wf[3].w, k1);
+                    gffx_v4u cc;
+                    pair_cont_load<POS>(rsp, clm != 0u, w7, cc, cf[0]);
+                    const uint32_t m2 = pair_test4<MODE>(cc.x, cc.y, cc.z, cc.w, win_sel(rqs, k1), win_sel(rqe1, k1), inv, clm != 0u);
+                    tm = m2 << (4 * k1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) tc[k] += k1 == k ? __popc(m2) : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dfr[k] = swp[k] || (wc[k].w == kWinTailMark && !cl[k]);
                 any |= dfr[k];
             }
+
+#ifdef GFFX_ABL_NO_DEFERRED  // (tools/kbench.hip, timing only: what the deferred walks cost at most -- the pass's results are wrong)
+            any = false;
+#endif
             if (__builtin_amdgcn_ballot_w64(any)) {  // (uniform: some lane of the wave has deferred work)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const bool tail = wc[k].w == kWinTailMark;
+                    const bool tail = wc[k].w == kWinTailMark && !cl[k];
                     hdr[k] = tail ? wf[k].w : 0u;
                     const bool sw = swp[k] || (hdr[k] & 255u) == 255u;
                     deferred |= dfr[k] ? 1u << k : 0u;
@@ -1165,6 +1237,9 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                             n_slow += (swp[k] && qe[k] > qs[k] && (cm[min(qc[k], n_chr)].z >> 8) != 0u) ? 0x10000u : 0u;
                     }
                     uint32_t d = deferred;
+                    GFFX_WIN_NOTE(8, __popc(sweep & deferred));
+                    GFFX_WIN_NOTE(9, ((deferred & ~sweep & 1u) ? hdr[0] & 255u : 0u) + ((deferred & ~sweep & 2u) ? hdr[1] & 255u : 0u) +
+                                         ((deferred & ~sweep & 4u) ? hdr[2] & 255u : 0u) + ((deferred & ~sweep & 8u) ? hdr[3] & 255u : 0u));
                     while (d) {
                         const int k = __ffs(d) - 1;
                         d &= d - 1;
@@ -1253,6 +1328,18 @@ __global__ __launch_bounds__(T, 4) void k_join_pairs(PairArgs A) {
                     }
                     pd[k] = pos;
                     pb += 4u * cnt[k];
+                }
+                if constexpr (!WIDE) {
+                    if (__builtin_amdgcn_ballot_w64(tm != 0u)) {  // (uniform) the continuation lines' kept words follow the line's
+                        if (cont_step) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) pair_park4((tm >> (4 * k)) << 28, pd[k], cf[k].x, cf[k].y, cf[k].z, cf[k].w);
+                        } else {
+                            const int k1 = ((__ffs(tm) - 1) >> 2) & 3;
+                            uint32_t pos = win_sel(pd, k1);  // (the region has no other deferred words: its cursor is not needed again)
+                            pair_park4((tm >> (4 * k1)) << 28, pos, cf[0].x, cf[0].y, cf[0].z, cf[0].w);
+                        }
+                    }
                 }
                 GFFX_WIN_STAMP(10);
                 if constexpr (WIDE) {
@@ -1733,15 +1820,58 @@ __global__ __launch_bounds__(T, 4) void k_join_roots(PairArgs A) {
                 m[k] = pair_test4<MODE>(wc[k].x, wc[k].y, wc[k].z, wc[k].w, rqs[k], rqe1[k], inv, off[k] != kWinNoLine);
                 kept += __popc(m[k]);
             }
-            {  // the rare rest: list tails and sweeps set their bits themselves
+            {  // continuation lines (pair_cont_*, as in k_join_pairs); their kept entries' bits are set at once
+                bool cl[4];
+                uint32_t clm = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    cl[k] = pair_cont_has(wc[k].w, wf[k].w);
+                    clm |= cl[k] ? 1u << k : 0u;
+                }
+                auto flag = [&](uint32_t m2, const gffx_v4u &cp) {
+                    if (bm_words) {  // (uniform)
+                        pair_flag4(m2 << 28, bm, cp.x, cp.y, cp.z, cp.w);
+                    } else {
+                        if (m2 & 8u) set_global(cp.x);
+                        if (m2 & 4u) set_global(cp.y);
+                        if (m2 & 2u) set_global(cp.z);
+                        if (m2 & 1u) set_global(cp.w);
+                    }
+                };
+                if (__builtin_amdgcn_ballot_w64(clm != 0u)) {
+                    const __amdgpu_buffer_rsrc_t rsp = pair_cont_rsrc(A.spill);
+                    if (__builtin_amdgcn_ballot_w64((clm & (clm - 1u)) != 0u)) {  // (uniform) some lane has two or more: the four regions in step
+                        gffx_v4u cc[4], cp[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) pair_cont_load<true>(rsp, cl[k], wf[k].w, cc[k], cp[k]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t m2 = pair_test4<MODE>(cc[k].x, cc[k].y, cc[k].z, cc[k].w, rqs[k], rqe1[k], inv, cl[k]);
+                            kept += __popc(m2);
+                            tc[k] += __popc(m2);
+                            flag(m2, cp[k]);
+                        }
+                    } else {  // at most one per lane: that region picked, two gathers
+                        const int k1 = (__ffs(clm) - 1) & 3;
+                        const uint32_t w7 = win_sel4(wf[0].w, wf[1].w, wf[2].w, wf[3].w, k1);
+                        gffx_v4u cc, cp;
+                        pair_cont_load<true>(rsp, clm != 0u, w7, cc, cp);
+                        const uint32_t m2 = pair_test4<MODE>(cc.x, cc.y, cc.z, cc.w, win_sel(rqs, k1), win_sel(rqe1, k1), inv, clm != 0u);
+                        kept += __popc(m2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) tc[k] += k1 == k ? __popc(m2) : 0u;
+                        flag(m2, cp);
+                    }
+                }
+                // the rare rest: longer list tails and sweeps set their bits themselves
                 bool any = false;
                 uint32_t deferred = 0, sweep = 0, hdr[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) any |= swp[k] || wc[k].w == kWinTailMark;
+                for (int k = 0; k < 4; ++k) any |= swp[k] || (wc[k].w == kWinTailMark && !cl[k]);
                 if (__builtin_amdgcn_ballot_w64(any)) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const bool tail = wc[k].w == kWinTailMark;
+                        const bool tail = wc[k].w == kWinTailMark && !cl[k];
                         hdr[k] = tail ? wf[k].w : 0u;
                         deferred |= (swp[k] || tail) ? 1u << k : 0u;
                         sweep |= (swp[k] || (hdr[k] & 255u) == 255u) ? 1u << k : 0u;

@@ -24,6 +24,17 @@ __device__ int g_stamp_sel;
 #if GFFX_STAMPS
 #define GFFX_WIN_STAMP(slot) GFFX_STAMP(4, slot)  // the pair kernel's phase stamps (slots 13 / 14 / 15: entry, loop done, end)
 #endif
+#if GFFX_WAVE_STAMPS  // round 6: the same stamps from EVERY wave's lane 0 (one launch of <= 1024 blocks): which wave of a block is the slow one, and where
+__device__ unsigned long long g_wstamps[1024 * 16 * 16];
+#define GFFX_WIN_STAMP(slot)                                                                                          \
+    do {                                                                                                              \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); \
+    } while (0)
+#define GFFX_WIN_NOTE(slot, value)                                                                                    \
+    do {                                                                                                              \
+        if (blockIdx.x < 1024) atomicMax(&g_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (slot)], (unsigned long long)(value)); \
+    } while (0)
+#endif
 
 #if GFFX_CLKCHECK  // shader clocks (clock64) against the 100 MHz wall clock over a block's life: the CU's effective frequency
 __device__ unsigned long long g_clk[8192 * 4];
@@ -125,6 +136,8 @@ int main(int argc, char **argv) {
     }
     printf("nq=%llu roots=%u tiles=%u cells=%u pairs=%llu strategy=%d flags=%u\n", (unsigned long long)nq, ix->n_roots,
            ix->n_tiles, ix->n_cells, (unsigned long long)gffx_hip_batch_total_hits(b), b->strategy, flags);
+    printf("regions that took the exact sweep in that pass: %llu (because of their width: %llu)\n", (unsigned long long)(b->slow_seen_win & 0xFFFFFFFFull),
+           (unsigned long long)(b->slow_seen_win >> 32));
     for (int i = 0; i < 5; i++) gffx_hip_batch_run(b, kb_mode, 0, flags, strategy);
     gffx_hip_batch_sync(b);
     hipEvent_t ea, eb;
@@ -256,6 +269,12 @@ int main(int argc, char **argv) {
                 printf("\n  mean / max life by block %% 8:");
                 for (int x = 0; x < 8; x++) printf(" %.2f/%.2f", xs[x] / std::max(xn[x], 1), xm[x]);
             }
+            printf("\n  phase stamps of the three slowest blocks and the median one (us since the block's entry; slots 0-12, 14, 15):");
+            for (int pick : {o[0], o[1], o[2], o[nb / 2]}) {
+                printf("\n    block %d:", pick);
+                for (int k : {0, 1, 2, 3, 4, 5, 6, 7, 10, 11, 12, 14, 15})
+                    if (z[pick * 16 + k]) printf(" [%d]%.2f", k, (double)(z[pick * 16 + k] - z[pick * 16 + 13]) * 0.01);
+            }
             printf("\n  fastest:");
             for (int i = nb - 4; i < nb; i++) if (i >= 0) printf(" %d: %.2f %.2f %llu %llu;", o[i], life[o[i]], endt[o[i]], (unsigned long long)bp[o[i]], (unsigned long long)bmaxw[o[i]]);
             printf("\n");
@@ -308,6 +327,40 @@ int main(int argc, char **argv) {
         if (ni) printf("gathers: %.1f distinct 128-byte lines per instruction; a wave round spans %.1f lines (mean); regions within 32 / 64 lines of the wave's base: %.3f / %.3f\n",
                        dl / ni, span / nwv, (double)in32 / tot, (double)in64 / tot);
     }
+#if GFFX_WAVE_STAMPS
+    {
+        std::vector<unsigned long long> z(1024 * 16 * 16, 0);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_wstamps), z.data(), z.size() * 8);
+        gffx_hip_batch_run(b, kb_mode, 0, flags, strategy);
+        gffx_hip_batch_sync(b);
+        hipMemcpyFromSymbol(z.data(), HIP_SYMBOL(g_wstamps), z.size() * 8);
+        const int nw = b->win_threads / 64, nb = (int)std::min<uint32_t>(b->win_blocks, 1024);
+        // per block: the wave that leaves the loop last (slot 14), and the block's end (max of slot 15)
+        std::vector<std::pair<double, int>> ends;
+        unsigned long long t0 = ~0ull;
+        for (int blk = 0; blk < nb; blk++)
+            for (int w = 0; w < nw; w++)
+                if (z[(blk * 16 + w) * 16 + 13]) t0 = std::min(t0, z[(blk * 16 + w) * 16 + 13]);
+        for (int blk = 0; blk < nb; blk++) {
+            unsigned long long e = 0;
+            for (int w = 0; w < nw; w++) e = std::max(e, z[(blk * 16 + w) * 16 + 15]);
+            ends.push_back({(double)(e - t0) * 0.01, blk});
+        }
+        std::sort(ends.begin(), ends.end());
+        printf("wave stamps (us since the launch's first entry), T=%u grid=%d: block ends median %.2f, p90 %.2f, max %.2f\n", b->win_threads, nb, ends[nb / 2].first,
+               ends[nb * 9 / 10].first, ends.back().first);
+        for (int pick : {ends.back().second, ends[nb - 2].second, ends[nb / 2].second}) {
+            printf("  block %d (ends %.2f): per wave [3 tested] [4 deferred done] [7 flushed] [10 parked] [12 tails placed] [14 loop left] [15 end]\n", pick,
+                   (double)0 + 0.0);
+            for (int w = 0; w < nw; w++) {
+                const unsigned long long *q = &z[(pick * 16 + w) * 16];
+                printf("    wave %2d:", w);
+                for (int k : {0, 3, 4, 7, 10, 12, 14, 15}) printf(" [%d]%6.2f", k, q[k] ? (double)(q[k] - t0) * 0.01 : -1.0);
+                printf("  sweeps of one lane <= %llu, list entries of one lane <= %llu\n", q[8], q[9]);
+            }
+        }
+    }
+#endif
 #if GFFX_CLKCHECK
     {
         std::vector<unsigned long long> z(8192 * 4, 0);

@@ -22,7 +22,7 @@ static bool keep(int mode, uint32_t s, uint32_t e, uint32_t qs, uint32_t qe) {
 }
 int main(int argc, char **argv) {
     uint64_t seed = argc > 1 ? atoll(argv[1]) : 1;
-    unsigned long long n_checked = 0, n_split_reads = 0, n_wide = 0, n_wide_reads = 0, n_wide_tails = 0;
+    unsigned long long n_checked = 0, n_split_reads = 0, n_wide = 0, n_wide_reads = 0, n_wide_tails = 0, n_cont = 0;
     std::mt19937_64 rng(seed);
     for (int iter = 0; iter < 200; iter++) {
         uint32_t n_chr = 1 + rng() % 4;
@@ -126,6 +126,29 @@ int main(int argc, char **argv) {
                         uint32_t n = l[7] & 255, sp = l[7] >> 8;
                         if (n == 255) skip = true;
                         else for (uint32_t j = 3; j < n; j++) { uint4 x = spill[sp + j - 3]; if (keep(mode, x.x, x.y, qs, qe)) got.insert(x.z); }
+                        // the continuation line of a short list (gffx_device.hpp): the same entries in the line's format -- the packed
+                        // tests keep what the records' exact tests keep, root_fids and positions agree with the records
+                        if (n != 255 && gffx::win_cont_records(n)) {
+                            const uint32_t *cl = (const uint32_t *)&spill[sp - gffx::kWinContRecs];
+                            std::set<uint32_t> rec, con;
+                            for (uint32_t j = 3; j < n; j++) { uint4 x = spill[sp + j - 3]; if (keep(mode, x.x, x.y, qs, qe)) rec.insert(x.z); }
+                            for (uint32_t j = 0; j < 4; j++) {
+                                const bool there = j + 3 < n;
+                                if (there != (cl[j] != 0x0000FFFFu) || (there && (cl[4 + j] != spill[sp + j].z || cl[8 + j] != spill[sp + j].w))) {
+                                    printf("CONT LINE MISMATCH iter %d entry %u of %u\n", iter, j + 3, n);
+                                    return 1;
+                                }
+                                if (keep(mode, cl[j] & 0xFFFF, cl[j] >> 16, rqs, rqe)) con.insert(cl[4 + j]);
+                            }
+                            n_cont++;
+                            if (rec != con) {
+                                printf("CONT TEST MISMATCH iter %d chr %u q [%u,%u) mode %d: records keep %zu, the continuation line %zu\n", iter, c, qs, qe, mode, rec.size(), con.size());
+                                return 1;
+                            }
+                        } else if (n != 255 && n <= gffx::kWinContMax) {
+                            printf("CONT LINE MISSING iter %d n %u\n", iter, n);
+                            return 1;
+                        }
                     }
                 }
                 if (!skip && want != got) {
@@ -240,6 +263,6 @@ int main(int argc, char **argv) {
             }
         }
     }
-    printf("ok (%llu line reads checked, %llu of them sub-lines of split windows; wide form: %llu regions, %llu line reads, %llu list tails)\n", n_checked, n_split_reads, n_wide, n_wide_reads, n_wide_tails);
+    printf("ok (%llu line reads checked, %llu of them sub-lines of split windows, %llu continuation lines; wide form: %llu regions, %llu line reads, %llu list tails)\n", n_checked, n_split_reads, n_cont, n_wide, n_wide_reads, n_wide_tails);
     return 0;
 }
