@@ -3,7 +3,8 @@
 #   tools/profile_r06.sh            -> gpurun_out/r06_*  (copy what is to be judged into profiles/)
 # kernel-trace stats + PMC counters (separate passes, tools/profile_pmc.sh; one kernel variant and one batch size per file) of
 #   * the launch the timed region runs: ONE launch for a group of 8 batches of 1 M regions (512-thread blocks: two groups alternate),
-#   * a lone 1 M-region launch, a 10 M-region launch, the mixed form on wide regions and on a batch with every tenth row SV-sized,
+#   * a lone 1 M-region launch, a 10 M-region launch, the same two sorted by (seqid, start), the mixed form on wide regions and on a
+#     batch with every tenth row SV-sized,
 # the kernel trace of the DEFAULT bench.py timed region (16 batches in flight: two groups of 8 on two streams) with its concurrency line,
 # the sweep over batches in flight, and the bench line.
 set -u
@@ -11,6 +12,8 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 GFFX_HIP_GROUP=1 GFFX_HIP_WIN_THREADS=512 bash tools/profile_pmc.sh r06_joinA_group8_1m --inflight 8 --passes-per-step 8
 bash tools/profile_pmc.sh r06_joinA_pairs_1m
 bash tools/profile_pmc.sh r06_joinA_pairs_10m --queries-per-gpu 10000000
+bash tools/profile_pmc.sh r06_joinA_sorted_1m --presort chr_start
+bash tools/profile_pmc.sh r06_joinA_sorted_10m --presort chr_start --queries-per-gpu 10000000
 bash tools/profile_pmc.sh r06_joinA_wide_1m --region-width 100 200000 --offsets u64
 bash tools/profile_pmc.sh r06_joinA_mixed_1m --wide-every 10
 # the timed configuration: the program itself after `--`, default arguments but the legs that are not the timed region
