@@ -1,8 +1,10 @@
-"""Ordered input (round 6): a wave whose regions need consecutive index lines copies that range of the line table into LDS and reads
-its lines from there ("LDS-staged lines", join_pairs_kernels.hpp); lanes whose line lies outside the range gather it as before.
-Whatever the order of the batch -- sorted by (seqid, start), by end, reversed, sorted per seqid only, half sorted, clustered on
-gene-dense stretches, a few strays among sorted rows -- every region's pairs and the unique roots equal the oracle's, bit for bit,
-in every mode, for the pair passes and for the root passes.  Reference: utils/tree.rs:98-121, commands/intersect.rs:139-165.
+"""Ordered input (round 6).  A BED file is usually sorted by position: the four consecutive regions of a thread then sit in the same
+windows, a gene-dense stretch lands on one wave, rounds overflow their strip, list tails cluster (the continuation lines' in-step path,
+DESIGN 4.0f), and a launch's tail is taken by ticket.  Whatever the order of the batch -- sorted by (seqid, start), by end, reversed,
+sorted per seqid only, half sorted, clustered on gene-dense stretches, a few strays among sorted rows -- every region's pairs and the
+unique roots equal the oracle's, bit for bit, in every mode, for the pair passes and for the root passes.  (The file was written for the
+LDS-staged lines of the round's first experiment, which lost and are gone: DESIGN 10.1; the orders it checks stayed.)
+Reference: utils/tree.rs:98-121, commands/intersect.rs:139-165.
 """
 import numpy as np
 import pytest
@@ -73,8 +75,8 @@ def test_ordered_batches_on_the_gencode_shaped_index(mode, invert, threads):
     oix = ob.OracleIndex.from_roots(co, s, e, f)
     ix = engine.TreeIndexData.from_roots(co, s, e, f)
     rng = np.random.default_rng(61)
-    # 300 k regions: a sorted wave round spans ~80 lines (partly staged); 60 k regions on three seqids: ~30 lines (all staged);
-    # widths up to 20 k: some rows are wider than the lines answer and take the sweep from inside a staged round
+    # 300 k regions: a sorted wave round spans ~80 lines; 60 k regions on three seqids: ~30 lines (every lane of a wave in a few windows);
+    # widths up to 20 k: some rows are wider than the lines answer and take the sweep from inside such a round
     big = synth.synth_bed(300_000, seed=6100, edge_frac=0.01, roots=roots, width=(1, 20_000))
     dense = synth.synth_bed(60_000, seed=6101, edge_frac=0.3, roots=roots, width=(10, 3000))
     dense = dense[dense[:, 0] < 3]
@@ -85,8 +87,8 @@ def test_ordered_batches_on_the_gencode_shaped_index(mode, invert, threads):
 
 @pytest.mark.parametrize("seed", range(4))
 def test_ordered_batches_on_small_dense_indexes(seed):
-    """tiny coordinate ranges: split windows everywhere (a sorted wave's lowest line is a SUB-line: the staged range lies in the
-    second level), list tails, dense windows, empty and reversed rows inside staged rounds"""
+    """tiny coordinate ranges: split windows everywhere (a sorted wave's lines are SUB-lines), list tails of every length (continuation
+    lines in step, walked lists, dense windows), empty and reversed rows inside such rounds"""
     rng = np.random.default_rng(700 + seed)
     n_chr = int(rng.integers(1, 4))
     span = int(rng.choice([3000, 200_000, 5_000_000]))
