@@ -136,3 +136,23 @@ def test_lists_of_five_to_seven_roots_in_a_group_launch():
     for b in batches:
         b.close()
     ix.close()
+
+
+@pytest.mark.parametrize("mode,invert", [(OverlapMode.Overlap, False), (OverlapMode.Contained, True), (OverlapMode.ContainsRegion, False)])
+def test_windows_without_a_split_level(mode, invert, monkeypatch):
+    """GFFX_HIP_WIN_SPLIT=0: the windows' OWN lists continue in win_spill (no sub-lines), so their continuation lines -- built by
+    build_window_index_at, not by build_window_splits -- are what the kernels read; also with a small LDS filter"""
+    monkeypatch.setenv("GFFX_HIP_WIN_SPLIT", "0")
+    monkeypatch.setenv("GFFX_HIP_WIN_FILTER_KB", "8")
+    rng = np.random.default_rng(6580 + int(mode))
+    co, start, end, fid = _clustered_roots(rng, n_chr=2, clusters=900)
+    oix = ob.OracleIndex.from_roots(co, start, end, fid)
+    ix = engine.TreeIndexData.from_roots(co, start, end, fid)
+    monkeypatch.delenv("GFFX_HIP_WIN_SPLIT")
+    monkeypatch.delenv("GFFX_HIP_WIN_FILTER_KB")
+    assert ix.options() == {"GFFX_HIP_WIN_SPLIT": 0, "GFFX_HIP_WIN_FILTER_KB": 8}
+    regions = _regions_on_clusters(rng, co, start, end, 60_000)
+    by_start = np.lexsort((regions[:, 1], regions[:, 0]))
+    for regs in (regions, np.ascontiguousarray(regions[by_start])):
+        _check(oix, ix, regs, mode, invert, 1024)
+    ix.close()
