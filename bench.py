@@ -914,6 +914,36 @@ def main():
         result["sorted_bed"] = roofline_obj(ks_, nq, pairss, out_b, "the headline's regions sorted by (seqid, start)", None,
                                             ps.pass_us_one_event_pair, ps.block_threads)
         ps.close()
+        if group_launch and group_launch.get("grouped"):
+            # ... and the headline's configuration on sorted batches (every batch its own copy): the launch that serves a group, alone, at both
+            # block widths; then as many batches in flight as the timed region has, one timed region
+            try:
+                n_sg = group_launch["batches_per_launch"]
+                pg = Pass(engine, ix, colss, nq, len(run.batches), mode, out_flags, strategy)
+                pg.size_and_warm(1)
+                alg_sg = n_sg * (12.0 * nq + 4.0 * nq + out_b * pairss)
+                sg = {"batches_per_launch": n_sg, "algorithmic_bytes_per_launch": alg_sg}
+                for th in (512, 1024):
+                    for bb in pg.batches[:n_sg]:
+                        bb.set_option("WIN_THREADS", th)
+                    us_sg, grouped_sg = engine.timed_group_runs(pg.batches[:n_sg], mode, False, out_flags, strategy, 20)
+                    sg["launch_us_%d_threads" % th] = us_sg
+                    sg["frac_%d_threads" % th] = alg_sg / (us_sg * 1e-6) / 8e12
+                    sg["grouped"] = bool(grouped_sg)
+                for bb in pg.batches:
+                    bb.set_option("WIN_THREADS", 0)
+                n_passes = args.steps * args.passes_per_step
+                dt = pg.timed(n_passes, lambda: None, torch)
+                pg.check(pairss)
+                sg["in_flight"] = {"batches_in_flight": len(pg.batches), "passes": n_passes, "timed_region_ms": 1e3 * dt,
+                                   "value": nq * n_passes / dt, "unit": "queries/s", "block_threads": pg.batches[0].block_threads}
+                sg["note"] = ("serial launches, each serving this many sorted batches, back to back between one pair of HIP events, at 512-thread blocks "
+                              "(what the timed region's launches use: two groups co-resident) and at 1024; in_flight: the headline's timed region on sorted "
+                              "batches, one repeat")
+                result["sorted_bed"]["group_launch"] = sg
+                pg.close()
+            except Exception as exc:  # (an auxiliary leg)
+                result["sorted_bed"]["group_launch"] = {"error": repr(exc)[:300]}
         del colss, regs
         # ---- transfers included, and the product CLI end to end
         result["t_xfer"] = xfer_leg(engine, torch, ix, regions, mode, pairs)

@@ -89,6 +89,17 @@ int main(int argc, char **argv) {
         co.push_back((uint32_t)s.size());
     }
     std::vector<uint32_t> qc(nq), qs(nq), qe(nq);
+    std::vector<uint32_t> file_regions;
+    if (getenv("KB_DATA")) {  // roots and regions from a file instead ({n_chr, n_roots, n_regions}, chr_offsets, starts, ends, region triples: u32) -- bench.py's data
+        FILE *fp = fopen(getenv("KB_DATA"), "rb");
+        uint32_t h[3];
+        if (!fp || fread(h, 4, 3, fp) != 3 || (int)h[0] != n_chr) { fprintf(stderr, "KB_DATA: cannot read %s\n", getenv("KB_DATA")); return 1; }
+        co.resize(h[0] + 1), s.resize(h[1]), e.resize(h[1]), f.resize(h[1]), file_regions.resize(3 * (size_t)h[2]);
+        if (fread(co.data(), 4, co.size(), fp) != co.size() || fread(s.data(), 4, s.size(), fp) != s.size() || fread(e.data(), 4, e.size(), fp) != e.size() ||
+            fread(file_regions.data(), 4, file_regions.size(), fp) != file_regions.size()) return 1;
+        for (size_t i = 0; i < f.size(); i++) f[i] = (uint32_t)i * 54;
+        fclose(fp);
+    }
     std::vector<double> cum(n_chr);
     double acc = 0;
     for (int c = 0; c < n_chr; c++) cum[c] = (acc += kChroms[c].len / total_len);
@@ -103,6 +114,10 @@ int main(int argc, char **argv) {
         qc[i] = c;
         qs[i] = st;
         qe[i] = st + w;
+        if (!file_regions.empty()) {
+            const size_t j = (size_t)(i % (file_regions.size() / 3));
+            qc[i] = file_regions[3 * j], qs[i] = file_regions[3 * j + 1], qe[i] = file_regions[3 * j + 2];
+        }
     }
     if (presort) {
         std::vector<uint32_t> o(nq);
