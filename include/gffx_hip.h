@@ -54,7 +54,9 @@
  * (`gffx ... --stats-json` and bench.py's `config.knobs` carry it).
  *   passes (batch):
  *   GFFX_HIP_WIN_THREADS=0|512|1024 block width of the window kernels (0 = the engine's choice: 1024 for a pass of >= 500 000 regions
- *                                   that runs alone, 512 otherwise)
+ *                                   that runs alone, 512 otherwise).  Batches sorted by position handed over in groups on ONE stream
+ *                                   (GFFX_HIP_GROUP=1) are 25 % faster at 1024: their gene-dense wave rounds overflow the 512-thread
+ *                                   kernel's smaller strips (on two streams: 1.5 %; profiles/r06_block_width_on_sorted_batches.txt)
  *   GFFX_HIP_WIN_WIDE=0|1|2         the mixed form of the window kernels: never / AUTO's choice for batches with wide rows (default) /
  *                                   every eligible pass of the windows strategy
  *   GFFX_HIP_WIDTH_SAMPLE=0         no width sample of the rows the host hands over (AUTO then learns from a first waited pass)
