@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call 38: the whole GPU suite on the round's final tree (235 tests), smoke()
+# round 6, call 38: the whole GPU suite on the round's final tree (238 tests), smoke()
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=$R/gpurun_out/r6_38.txt
