@@ -495,10 +495,14 @@ __device__ __forceinline__ uint32_t pair_rest(const IndexView *ix, const uint4 *
 // CONTINUATION LINES (round 6).  Walking list tails one region at a time (pair_rest) cost a pair pass 8 % of its time on random
 // regions and 20-30 % on a BED sorted by position -- where the four regions of a lane all wait for a tail, four walks one after
 // another, and again when the words are placed (the ablation in profiles/r06_continuation_lines.txt).  Most tails are short: a list
-// of 5 .. kWinContMax roots has its entries 3 .. n - 1 once more in the line's own format (gffx_device.hpp).  All four regions of a
-// thread are served IN STEP, like the lines themselves: one 16-byte load per region for the coordinates and one for the words
-// (a region without such a list reads nothing: the offset beyond the table), the line's four packed tests, a 4-bit string per region;
-// the kept words are parked from registers by the same pair_park4 that parks the line's -- no walk, no second walk, no stash.
+// of 5 .. kWinContMax roots has its entries 3 .. n - 1 once more in the line's own format (gffx_device.hpp).  When some lane of the
+// wave has two such lists or more (ordered input), all four regions of a thread are served IN STEP, like the lines themselves: one
+// 16-byte load per region for the coordinates and one for the words (a region without such a list reads nothing: the offset beyond
+// the table), the line's four packed tests, a 4-bit string per region; the kept words are parked from registers by the same
+// pair_park4 that parks the line's -- no walk, no second walk, no stash.  Otherwise (shuffled input: at most one per lane) the
+// lane's one region is picked and TWO gathers serve the wave: eight gathers per wave round cost shuffled input 2-4 %.  Measured and
+// dropped on top of it (same file): the words re-read at the parking instead of held in registers, one walk per list shared by a
+// lane's regions, lists of 8 .. 32 roots by the whole wave.
 __device__ __forceinline__ bool pair_cont_has(uint32_t coords3, uint32_t word7) {  // the line's words 3 and 7
     return coords3 == kWinTailMark && (word7 & 255u) <= kWinContMax;
 }
